@@ -1,0 +1,185 @@
+/*
+ * lins_ieskf.h — C ABI of the MI355X-native LINS IESKF update path.
+ *
+ * This is the drop-in boundary for the one hot path of the reference
+ * (ChaoqinRobotics/LINS---LiDAR-inertial-SLAM):
+ *
+ *     StateEstimator::performIESKF()              lins/include/StateEstimator.hpp:465-600
+ *       findCorrespondingSurfFeatures()           lins/include/StateEstimator.hpp:829-953
+ *       findCorrespondingCornerFeatures()         lins/include/StateEstimator.hpp:955-1063
+ *       transformToStart()                        lins/include/StateEstimator.hpp:1066-1080
+ *       H / residual assembly, gain, boxPlus      lins/include/StateEstimator.hpp:507-580
+ *       Joseph covariance update                  lins/include/StateEstimator.hpp:594-598
+ *
+ * Everything crossing the boundary is a plain pointer, a size or a POD; no
+ * C++/torch types.  Host pointers unless a parameter says "device".
+ *
+ * Conventions
+ *   - lins_point mirrors pcl::PointXYZI (lins/include/parameters.h:52) without
+ *     PCL's 16-byte padding lanes: x,y,z,intensity as four f32 = 16 B.
+ *     `intensity` carries  ring + SCAN_PERIOD*relTime  (StateEstimator.hpp:649-650).
+ *   - state vector (19 f64) mirrors filter::GlobalState (KalmanFilter.hpp:35-116):
+ *       [0..2] rn_  [3..5] vn_  [6..9] qbn_ as (w,x,y,z)  [10..12] ba_
+ *       [13..15] bw_  [16..18] gn_
+ *   - covariance: 18x18 f64 row-major, error-state order pos,vel,att,acc,gyr,gra
+ *     (KalmanFilter.hpp:40-45).
+ *   - return value 0 = ok, negative = API / HIP error (lins_strerror()).
+ *     Numerical divergence of the filter is NOT an error: it is reported in
+ *     lins_result.diverged, exactly as the reference handles it internally
+ *     (StateEstimator.hpp:552-570, 585-592).
+ *   - a lins_ctx is not thread-safe (one HIP stream inside); distinct contexts
+ *     may be driven from distinct threads / processes / GPUs.
+ */
+#ifndef LINS_IESKF_H_
+#define LINS_IESKF_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LINS_STATE_DIM 19  /* GlobalState as stored: p,v,q(wxyz),ba,bw,g           */
+#define LINS_ERR_DIM 18    /* GlobalState::DIM_OF_STATE_ (KalmanFilter.hpp:39)     */
+#define LINS_MAX_QUERY 1024  /* per cloud; reference caps: 192 sharp / 144 flat    */
+#define LINS_MAX_RING 64     /* int(intensity) must lie in [0, LINS_MAX_RING)      */
+
+/* error codes */
+#define LINS_OK 0
+#define LINS_E_ARG (-1)       /* bad argument (null pointer, negative size, ...)   */
+#define LINS_E_HIP (-2)       /* HIP runtime error; see lins_last_hip_error()      */
+#define LINS_E_CAPACITY (-3)  /* batch / cloud larger than the context was sized   */
+#define LINS_E_INPUT (-4)     /* cloud violates the input contract (NaN, ring id)  */
+#define LINS_E_NODEVICE (-5)  /* no usable gfx950 device                           */
+#define LINS_E_STATE (-6)     /* call sequence error (run before upload, ...)      */
+
+typedef struct lins_point {
+  float x, y, z, intensity;
+} lins_point;
+
+/* Parameters read on the path (parameters.h / exp_port.yaml:11-20).           */
+typedef struct lins_params {
+  int32_t num_iter;        /* NUM_ITER                    (yaml: 30)  SE:475    */
+  int32_t icp_freq;        /* ICP_FREQ                    (yaml: 1)   SE:844,935*/
+  int32_t fixed_iters;     /* 0 = reference semantics (stop on ||dx||<=1e-2,
+                              SE:575-578).  1 = throughput mode: run exactly
+                              num_iter iterations unless the filter diverges
+                              (BASELINE.json configs[0]: "10 ESKF iterations") */
+  int32_t reserved;
+  double lidar_std;        /* LIDAR_STD                   (yaml: 0.01) SE:537   */
+  double lidar_scale;      /* LIDAR_SCALE                 (yaml: 1)    SE:524   */
+  double nearest_sq_dist;  /* NEAREST_FEATURE_SEARCH_SQ_DIST (yaml: 25) SE:851  */
+  double scan_period;      /* SCAN_PERIOD                 (yaml: 0.1)  SE:1067  */
+} lins_params;
+
+/* One IESKF problem = what performIESKF() reads:
+ * queries from scan_new_, targets from scan_last_, filter state + covariance. */
+typedef struct lins_scan_pair {
+  const lins_point* surf_flat;          /* scan_new_->surfPointsFlat_           */
+  const lins_point* corner_sharp;       /* scan_new_->cornerPointsSharp_        */
+  const lins_point* surf_less_flat_last;    /* scan_last_->surfPointsLessFlat_  */
+  const lins_point* corner_less_sharp_last; /* scan_last_->cornerPointsLessSharp_ */
+  int32_t n_surf_flat;
+  int32_t n_corner_sharp;
+  int32_t n_surf_last;
+  int32_t n_corner_last;
+  double state[LINS_STATE_DIM];         /* filter_->state_                      */
+  double cov[LINS_ERR_DIM * LINS_ERR_DIM]; /* filter_->covariance_              */
+} lins_scan_pair;
+
+/* What performIESKF() leaves behind (linState_, Pk_) + the flags the
+ * reference keeps in locals (SE:471-474). When diverged != 0, `state`/`cov`
+ * hold the un-updated filter state / covariance (SE:585-592 passes Pk_
+ * un-updated) and the caller must run the ICP fallback
+ * (lins_host_perform_ieskf() in lins_host.h does exactly that).                */
+typedef struct lins_result {
+  double state[LINS_STATE_DIM];
+  double cov[LINS_ERR_DIM * LINS_ERR_DIM];
+  double residual_norm;   /* ||residual_|| of the last executed iteration       */
+  double update_norm;     /* ||updateVec_|| of the last executed iteration      */
+  int32_t iters;          /* iterations executed (incl. the diverging one)      */
+  int32_t converged;
+  int32_t diverged;       /* 1 = residual blow-up (SE:566), 2 = NaN (SE:552)    */
+  int32_t m_surf;         /* accepted surf rows in the last iteration           */
+  int32_t m_corner;       /* accepted corner rows in the last iteration         */
+  int32_t reserved[3];
+} lins_result;
+
+/* Fixed-size pose record used for the multi-GPU gather:
+ * 19 f64 + 5 i32 + pad = 192 B.                                                */
+typedef struct lins_pose_record {
+  double state[LINS_STATE_DIM];
+  double residual_norm;
+  int32_t iters, converged, diverged, m_surf, m_corner, scan_id;
+  int32_t pad[2];
+} lins_pose_record;
+
+/* Per-query output of one correspondence pass (A2/A3 of SURVEY.md §8a): what
+ * the reference keeps in pointSearch{Surf,Corner}Ind{1,2,3} (SE:205-211) and
+ * pushes to jacobianCoff{Surfs,Corns} (SE:943-949, 1053-1059).                 */
+typedef struct lins_corr {
+  int32_t ind1, ind2, ind3; /* closest / second / third target index, -1 = none
+                               (corner rows: ind3 is always -1)                 */
+  int32_t accepted;         /* 1 iff a row was pushed (s > 0.1 && res != 0)     */
+  float coeff[4];           /* (s*jac.x, s*jac.y, s*jac.z, s*res) as f32        */
+  float sel[4];             /* pointSel = transformToStart(query), f32          */
+} lins_corr;
+
+typedef struct lins_ctx lins_ctx;
+
+/* --- lifetime ------------------------------------------------------------ */
+/* max_batch scans, each with at most max_targets points per target cloud.    */
+int lins_create(const lins_params* params, int device, int max_batch,
+                int max_targets, lins_ctx** out);
+void lins_destroy(lins_ctx* ctx);
+const char* lins_strerror(int code);
+const char* lins_last_hip_error(const lins_ctx* ctx);
+/* "brute" (exact all-pairs search) or "binned" (exact pruned search).         */
+int lins_set_search(lins_ctx* ctx, const char* mode);
+
+/* --- replaces StateEstimator::performIESKF() (SE:465-600) ----------------- */
+/* synchronous, host buffers in and out                                        */
+int lins_ieskf_update(lins_ctx* ctx, const lins_scan_pair* in, lins_result* out);
+int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in,
+                            lins_result* out);
+
+/* --- staged (device-resident) form of the same call, for batches ---------- */
+int lins_batch_upload(lins_ctx* ctx, int n, const lins_scan_pair* in);
+/* Runs the full IESKF loop for the uploaded batch on the context's stream.
+ * d_poses: optional DEVICE pointer to n lins_pose_record (e.g. a torch tensor
+ * that RCCL gathers afterwards); may be NULL. Asynchronous; lins_sync() waits. */
+int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base);
+int lins_sync(lins_ctx* ctx);
+int lins_batch_download(lins_ctx* ctx, int n, lins_result* out);
+/* HIP-event time (ms) of the IESKF kernel(s) of the last lins_batch_run().    */
+int lins_last_kernel_ms(lins_ctx* ctx, float* ms);
+/* Algorithmic bytes of one iteration summed over the uploaded batch
+ * (16*(Nsharp+Nflat+Nls+Nlf) + 8*19 + 8*28 per scan).          */
+int lins_batch_bytes_per_iter(lins_ctx* ctx, uint64_t* bytes);
+/* Total iterations executed by the last run (sum over scans).                 */
+int lins_batch_total_iters(lins_ctx* ctx, uint64_t* iters);
+
+/* --- one correspondence + residual/Jacobian pass (A2+A3) ------------------ */
+/* Replaces findCorrespondingSurfFeatures / findCorrespondingCornerFeatures for
+ * a given linearisation state (19 f64) and iteration counter. `surf` has
+ * in->n_surf_flat entries, `corner` in->n_corner_sharp. Used by the host-side
+ * solve of BASELINE.json configs[1] and by the ICP fallback (SE:1163-1196).
+ * iter only selects the robust weight (iter >= icp_freq) — a fresh search is
+ * always performed.                                                            */
+int lins_correspondences(lins_ctx* ctx, const lins_scan_pair* in,
+                         const double* lin_state, int iter, lins_corr* surf,
+                         lins_corr* corner);
+/* Same pass followed by the on-device reduction: 28 f64 sums
+ *   [0..5]  A_pp (upper tri, row-major: 00 01 02 11 12 22)
+ *   [6..14] A_pu (3x3 row-major)     [15..20] A_uu (upper tri)
+ *   [21..23] g_p  [24..26] g_u  [27] sum r^2
+ *  and the accepted-row counts.                          */
+int lins_reduce_pass(lins_ctx* ctx, const lins_scan_pair* in,
+                     const double* lin_state, int iter, double* sums28,
+                     int32_t* m_surf, int32_t* m_corner);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LINS_IESKF_H_ */
