@@ -1,0 +1,112 @@
+/*
+ * lins_host.h — host-side (CPU, C++ behind a C ABI) pieces that sit either
+ * side of the IESKF hot path.  None of this touches the GPU except
+ * lins_host_perform_ieskf(), which drives liblins_ieskf.so.
+ *
+ *   lins_filter_*            mirrors filter::StatePredictor
+ *                            (lins/include/KalmanFilter.hpp:118-380): IMU
+ *                            propagation + reset(1); produces the prior (x,P)
+ *                            performIESKF() starts from.
+ *   lins_frontend_*          mirrors image_projection_node's projection /
+ *                            ground / segmentation (lins/src/image_projection_node.cpp:191-415)
+ *                            and StateEstimator's feature front-end
+ *                            (StateEstimator.hpp:619-827); produces the four
+ *                            feature clouds performIESKF() reads.
+ *   lins_transform_to_end    StateEstimator::transformToEnd (SE:1083-1101), the
+ *                            re-projection updatePointCloud() applies to make
+ *                            the next scan's target clouds (SE:1116-1139).
+ *   lins_synth_*             seeded synthetic VLP-16 scan pairs.
+ *   lins_host_perform_ieskf  StateEstimator::performIESKF() as the node sees it
+ *                            (SE:465-600): GPU IESKF loop, and on divergence the
+ *                            ICP fallback estimateTransform (SE:585-592,
+ *                            1163-1320) with GPU correspondences + host 6x6 GN.
+ */
+#ifndef LINS_HOST_H_
+#define LINS_HOST_H_
+
+#include "lins_ieskf.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LINS_LINE_NUM 16   /* LINE_NUM  (exp_port.yaml:9)  */
+#define LINS_SCAN_NUM 1800 /* SCAN_NUM  (exp_port.yaml:10) */
+#define LINS_CLOUD_MAX (LINS_LINE_NUM * LINS_SCAN_NUM)
+
+/* ---- StatePredictor ------------------------------------------------------ */
+typedef struct lins_filter_params {
+  double acc_n, gyr_n, acc_w, gyr_w;                   /* yaml:29-32           */
+  double init_pos_std[3], init_vel_std[3], init_att_std[3]; /* yaml:34-50      */
+  double init_acc_std[3], init_gyr_std[3];             /* yaml:52-62           */
+} lins_filter_params;
+
+typedef struct lins_filter {
+  double state[LINS_STATE_DIM];
+  double cov[LINS_ERR_DIM * LINS_ERR_DIM];
+  double noise[12 * 12];
+  double acc_last[3], gyr_last[3];
+  double time;
+  int32_t has_imu;
+  int32_t pad;
+  lins_filter_params prm;
+} lins_filter;
+
+void lins_filter_default_params(lins_filter_params* p);           /* exp_port.yaml */
+/* StatePredictor::initialization-like start: identity state with given v, ba,
+ * bw, gravity (0,0,-9.81), covariance = initializeCovariance(0) (KF:247-311).  */
+void lins_filter_init(lins_filter* f, const lins_filter_params* p, const double* vn,
+                      const double* ba, const double* bw);
+void lins_filter_predict(lins_filter* f, double dt, const double* acc,
+                         const double* gyr);                      /* KF:125-186  */
+void lins_filter_reset1(lins_filter* f);                          /* KF:320-352  */
+
+/* ---- front-end ------------------------------------------------------------ */
+typedef struct lins_features {
+  lins_point* corner_sharp;      int32_t n_corner_sharp;      /* cap 192  */
+  lins_point* corner_less_sharp; int32_t n_corner_less_sharp; /* cap 1920 */
+  lins_point* surf_flat;         int32_t n_surf_flat;         /* cap 1024 */
+  lins_point* surf_less_flat;    int32_t n_surf_less_flat;    /* cap LINS_CLOUD_MAX */
+  int32_t n_segmented;           /* size of the segmented cloud              */
+  int32_t n_outlier;
+} lins_features;
+
+/* raw: unorganised cloud in firing order (what /velodyne_points carries).
+ * Caller allocates the four output arrays with the capacities noted above.   */
+int lins_frontend_extract(const lins_point* raw, int n_raw, double scan_period,
+                          lins_features* out);
+
+/* transformToEnd for every point, with the scan's final relative pose
+ * (t = linState_.rn_, q = linState_.qbn_ as w,x,y,z). In-place allowed.       */
+void lins_transform_to_end(const double* t, const double* q_wxyz, double scan_period,
+                           const lins_point* in, int n, lins_point* out);
+
+/* ---- synthetic scan pairs -------------------------------------------------- */
+typedef struct lins_synth_pair {
+  /* caller-allocated, capacities as in lins_features */
+  lins_point* surf_flat;      int32_t n_surf_flat;
+  lins_point* corner_sharp;   int32_t n_corner_sharp;
+  lins_point* surf_last;      int32_t n_surf_last;
+  lins_point* corner_last;    int32_t n_corner_last;
+  double state[LINS_STATE_DIM];            /* prior x for performIESKF          */
+  double cov[LINS_ERR_DIM * LINS_ERR_DIM]; /* prior P                            */
+  double true_t[3], true_q[4];             /* ground-truth relative pose (w,x,y,z) */
+  double speed, yaw_rate;
+  int32_t n_raw_last, n_raw_new;
+} lins_synth_pair;
+
+#define LINS_SYNTH_SEED 0x4C494E53u /* "LINS" */
+int lins_synth_generate(uint32_t seed, uint32_t scan_index, lins_synth_pair* out);
+/* raw distorted cloud of one synthetic scan (k = 0 or 1), firing order        */
+int lins_synth_raw_scan(uint32_t seed, uint32_t scan_index, int k, lins_point* out,
+                        int cap);
+
+/* ---- performIESKF as the node sees it -------------------------------------- */
+int lins_host_perform_ieskf(lins_ctx* ctx, const lins_params* prm,
+                            const lins_scan_pair* in, lins_result* out,
+                            int32_t* used_icp_fallback);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

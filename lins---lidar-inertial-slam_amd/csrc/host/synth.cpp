@@ -1,0 +1,270 @@
+// synth.cpp — seeded synthetic VLP-16 scan pairs + canned IMU.
+//
+// There is no dataset in the reference tree (the sample rosbag is an external
+// link, README.md:55) and no network, so the workload is manufactured: a
+// parametric scene is ray-cast on the 16 x 1800 VLP-16 firing grid from a moving
+// sensor, the raw (motion-distorted) clouds go through the restated front-end
+// (frontend.cpp) to become the four feature clouds performIESKF() reads, and 40
+// IMU samples at 400 Hz go through the restated StatePredictor
+// (state_predictor.cpp) to become its prior (x, P).
+//
+// Scene: ground z=-1.8 m, 40 x 30 m room with 6 m walls, 24 poles r=0.15 m,
+// 8 boxes 2x2x2 m.  Sensor: rings -15..+15 deg step 2 deg (parameters.h:82-84),
+// 1800 firings of 0.2 deg, clockwise, range noise N(0, 0.02 m), max 100 m.
+// Motion: planar, constant forward speed U(0,10) m/s and yaw rate U(-0.5,0.5).
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../../include/lins_host.h"
+#include "../lins_math.h"
+
+using namespace lins;
+
+namespace {
+
+struct Rng {  // splitmix64
+  uint64_t s;
+  explicit Rng(uint64_t seed) : s(seed) {}
+  uint64_t next() {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  double uni() { return (next() >> 11) * (1.0 / 9007199254740992.0); }
+  double uni(double a, double b) { return a + (b - a) * uni(); }
+  double gauss() {
+    double u1 = uni(), u2 = uni();
+    if (u1 < 1e-300) u1 = 1e-300;
+    return std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * M_PI * u2);
+  }
+};
+
+constexpr double kGroundZ = -1.8, kWallTop = 4.2, kHalfX = 20.0, kHalfY = 15.0;
+constexpr double kPoleR = 0.15, kBoxHalf = 1.0, kMaxRange = 100.0, kMinRange = 0.5;
+constexpr double kScanPeriod = 0.1;
+constexpr int kPoles = 24, kBoxes = 8, kImuPerScan = 40;
+
+struct Scene {
+  double pole[kPoles][2];
+  double box[kBoxes][2];
+  double x0, y0, yaw0, speed, yaw_rate;
+};
+
+Scene make_scene(uint32_t seed, uint32_t scan_index) {
+  Rng r(((uint64_t)seed << 32) ^ (uint64_t)scan_index * 0x9E3779B1u ^ 0xA5A5A5A5ull);
+  Scene s;
+  s.x0 = r.uni(-5, 5);
+  s.y0 = r.uni(-4, 4);
+  s.yaw0 = r.uni(-M_PI, M_PI);
+  s.speed = r.uni(0, 10);
+  s.yaw_rate = r.uni(-0.5, 0.5);
+  auto place = [&](double* xy, double margin) {
+    for (;;) {
+      double x = r.uni(-kHalfX + margin, kHalfX - margin), y = r.uni(-kHalfY + margin, kHalfY - margin);
+      double dx = x - s.x0, dy = y - s.y0;
+      if (dx * dx + dy * dy < 4.5 * 4.5) continue;  // keep the sensor's 0.2 s path clear
+      xy[0] = x, xy[1] = y;
+      return;
+    }
+  };
+  for (auto& p : s.pole) place(p, 1.0);
+  for (auto& b : s.box) place(b, 2.0);
+  return s;
+}
+
+// planar pose of the sensor at absolute time tau (since the start of scan 0)
+void pose_at(const Scene& s, double tau, double& x, double& y, double& yaw) {
+  double w = s.yaw_rate, v = s.speed;
+  yaw = s.yaw0 + w * tau;
+  double lx, ly;  // displacement in the frame of tau = 0
+  if (std::fabs(w) < 1e-9) {
+    lx = v * tau, ly = 0;
+  } else {
+    lx = v / w * std::sin(w * tau), ly = v / w * (1 - std::cos(w * tau));
+  }
+  x = s.x0 + std::cos(s.yaw0) * lx - std::sin(s.yaw0) * ly;
+  y = s.y0 + std::sin(s.yaw0) * lx + std::cos(s.yaw0) * ly;
+}
+
+// nearest hit distance of the ray o + r d (|d| = 1), or +inf
+double cast(const Scene& s, const double o[3], const double d[3]) {
+  double best = INFINITY;
+  auto consider = [&](double t) {
+    if (t > 1e-6 && t < best) best = t;
+  };
+  if (d[2] < -1e-12) consider((kGroundZ - o[2]) / d[2]);
+  // walls (bounded in the other horizontal axis and in z)
+  for (int sgn = -1; sgn <= 1; sgn += 2) {
+    if (std::fabs(d[0]) > 1e-12) {
+      double t = (sgn * kHalfX - o[0]) / d[0];
+      if (t > 0) {
+        double y = o[1] + t * d[1], z = o[2] + t * d[2];
+        if (std::fabs(y) <= kHalfY && z >= kGroundZ && z <= kWallTop) consider(t);
+      }
+    }
+    if (std::fabs(d[1]) > 1e-12) {
+      double t = (sgn * kHalfY - o[1]) / d[1];
+      if (t > 0) {
+        double x = o[0] + t * d[0], z = o[2] + t * d[2];
+        if (std::fabs(x) <= kHalfX && z >= kGroundZ && z <= kWallTop) consider(t);
+      }
+    }
+  }
+  // poles: vertical cylinders
+  double a = d[0] * d[0] + d[1] * d[1];
+  if (a > 1e-12)
+    for (auto& p : s.pole) {
+      double fx = o[0] - p[0], fy = o[1] - p[1];
+      double b = fx * d[0] + fy * d[1], c = fx * fx + fy * fy - kPoleR * kPoleR;
+      double disc = b * b - a * c;
+      if (disc < 0) continue;
+      double t = (-b - std::sqrt(disc)) / a;
+      if (t <= 0) continue;
+      double z = o[2] + t * d[2];
+      if (z >= kGroundZ && z <= kWallTop) consider(t);
+    }
+  // boxes: axis-aligned, on the ground
+  for (auto& bx : s.box) {
+    double lo[3] = {bx[0] - kBoxHalf, bx[1] - kBoxHalf, kGroundZ};
+    double hi[3] = {bx[0] + kBoxHalf, bx[1] + kBoxHalf, kGroundZ + 2 * kBoxHalf};
+    double t0 = 0, t1 = INFINITY;
+    bool miss = false;
+    for (int k = 0; k < 3 && !miss; ++k) {
+      if (std::fabs(d[k]) < 1e-12) {
+        if (o[k] < lo[k] || o[k] > hi[k]) miss = true;
+      } else {
+        double ta = (lo[k] - o[k]) / d[k], tb = (hi[k] - o[k]) / d[k];
+        if (ta > tb) std::swap(ta, tb);
+        t0 = std::max(t0, ta), t1 = std::min(t1, tb);
+        if (t0 > t1) miss = true;
+      }
+    }
+    if (!miss) consider(t0);
+  }
+  return best;
+}
+
+// raw distorted cloud of scan k (k-th 0.1 s interval), firing order
+int raw_scan(const Scene& s, uint32_t seed, uint32_t scan_index, int k, lins_point* out, int cap) {
+  Rng noise(((uint64_t)seed << 32) ^ ((uint64_t)scan_index << 8) ^ (uint64_t)(k + 1) * 0xD1B54A32D192ED03ull);
+  int n = 0;
+  for (int f = 0; f < LINS_SCAN_NUM; ++f) {
+    double tau = k * kScanPeriod + kScanPeriod * f / LINS_SCAN_NUM;
+    double sx, sy, yaw;
+    pose_at(s, tau, sx, sy, yaw);
+    double az = M_PI - (f + 0.5) * (2 * M_PI / LINS_SCAN_NUM);  // clockwise from -x
+    for (int l = 0; l < LINS_LINE_NUM; ++l) {
+      double el = (-15.0 + 2.0 * l) * M_PI / 180.0;
+      double ds[3] = {std::cos(el) * std::cos(az), std::cos(el) * std::sin(az), std::sin(el)};
+      double dw[3] = {std::cos(yaw) * ds[0] - std::sin(yaw) * ds[1], std::sin(yaw) * ds[0] + std::cos(yaw) * ds[1], ds[2]};
+      double o[3] = {sx, sy, 0.0};
+      double r = cast(s, o, dw);
+      double nz = noise.gauss();  // always drawn: keeps streams aligned across hits/misses
+      if (!(r < kMaxRange) || r < kMinRange) continue;
+      r += 0.02 * nz;
+      if (n >= cap) return -1;
+      out[n++] = {(float)(r * ds[0]), (float)(r * ds[1]), (float)(r * ds[2]), 0.f};
+    }
+  }
+  return n;
+}
+
+struct FeatBuf {
+  std::vector<lins_point> cs, cls, sf, slf;
+  lins_features f;
+  FeatBuf() : cs(192), cls(1920), sf(LINS_MAX_QUERY), slf(LINS_CLOUD_MAX) {
+    f.corner_sharp = cs.data(), f.corner_less_sharp = cls.data();
+    f.surf_flat = sf.data(), f.surf_less_flat = slf.data();
+    f.n_corner_sharp = f.n_corner_less_sharp = f.n_surf_flat = f.n_surf_less_flat = 0;
+    f.n_segmented = f.n_outlier = 0;
+  }
+};
+
+// relative pose over one scan interval: end frame expressed in the start frame
+void rel_pose(const Scene& s, double t[3], double q[4]) {
+  double w = s.yaw_rate, v = s.speed, T = kScanPeriod;
+  double psi = w * T;
+  if (std::fabs(w) < 1e-9) {
+    t[0] = v * T, t[1] = 0;
+  } else {
+    t[0] = v / w * std::sin(psi), t[1] = v / w * (1 - std::cos(psi));
+  }
+  t[2] = 0;
+  q[0] = std::cos(psi / 2), q[1] = 0, q[2] = 0, q[3] = std::sin(psi / 2);
+}
+
+}  // namespace
+
+extern "C" {
+
+int lins_synth_raw_scan(uint32_t seed, uint32_t scan_index, int k, lins_point* out, int cap) {
+  if (!out || k < 0) return LINS_E_ARG;
+  Scene s = make_scene(seed, scan_index);
+  int n = raw_scan(s, seed, scan_index, k, out, cap);
+  return n < 0 ? LINS_E_CAPACITY : n;
+}
+
+int lins_synth_generate(uint32_t seed, uint32_t scan_index, lins_synth_pair* out) {
+  if (!out || !out->surf_flat || !out->corner_sharp || !out->surf_last || !out->corner_last)
+    return LINS_E_ARG;
+  Scene s = make_scene(seed, scan_index);
+  std::vector<lins_point> raw(LINS_CLOUD_MAX);
+  FeatBuf last, cur;
+  int n0 = raw_scan(s, seed, scan_index, 0, raw.data(), LINS_CLOUD_MAX);
+  if (n0 < 2) return LINS_E_INPUT;
+  int rc = lins_frontend_extract(raw.data(), n0, kScanPeriod, &last.f);
+  if (rc) return rc;
+  int n1 = raw_scan(s, seed, scan_index, 1, raw.data(), LINS_CLOUD_MAX);
+  if (n1 < 2) return LINS_E_INPUT;
+  rc = lins_frontend_extract(raw.data(), n1, kScanPeriod, &cur.f);
+  if (rc) return rc;
+  out->n_raw_last = n0, out->n_raw_new = n1;
+
+  // targets: previous scan's less-sharp / less-flat clouds re-projected to its end
+  // with the true motion — what updatePointCloud() leaves after a converged update
+  double t[3], q[4];
+  rel_pose(s, t, q);
+  lins_transform_to_end(t, q, kScanPeriod, last.f.corner_less_sharp, last.f.n_corner_less_sharp, out->corner_last);
+  lins_transform_to_end(t, q, kScanPeriod, last.f.surf_less_flat, last.f.n_surf_less_flat, out->surf_last);
+  out->n_corner_last = last.f.n_corner_less_sharp;
+  out->n_surf_last = last.f.n_surf_less_flat;
+  std::memcpy(out->corner_sharp, cur.f.corner_sharp, sizeof(lins_point) * cur.f.n_corner_sharp);
+  std::memcpy(out->surf_flat, cur.f.surf_flat, sizeof(lins_point) * cur.f.n_surf_flat);
+  out->n_corner_sharp = cur.f.n_corner_sharp;
+  out->n_surf_flat = cur.f.n_surf_flat;
+  std::memcpy(out->true_t, t, sizeof t);
+  std::memcpy(out->true_q, q, sizeof q);
+  out->speed = s.speed, out->yaw_rate = s.yaw_rate;
+
+  // prior: StatePredictor over scan 0's IMU, reset(1), then scan 1's 40 samples
+  Rng r(((uint64_t)seed << 32) ^ (uint64_t)scan_index * 0x85EBCA6Bu ^ 0x5EEDull);
+  const double ba0[3] = {-0.015774, 0.143237, -0.0263845};       // INIT_BA yaml:65-69
+  const double bw0[3] = {-0.00275058, -0.000165954, 0.00262913}; // INIT_BW yaml:71-75
+  double ba_true[3], bw_true[3];
+  for (int i = 0; i < 3; ++i) ba_true[i] = ba0[i] + 0.01 * r.gauss(), bw_true[i] = bw0[i] + 0.0005 * r.gauss();
+  lins_filter_params fp;
+  lins_filter_default_params(&fp);
+  lins_filter filt;
+  double v_body[3] = {s.speed + 0.05 * r.gauss(), 0.05 * r.gauss(), 0.02 * r.gauss()};
+  lins_filter_init(&filt, &fp, v_body, ba0, bw0);
+  const double dt = kScanPeriod / kImuPerScan;
+  for (int scan = 0; scan < 2; ++scan) {
+    for (int i = 0; i < kImuPerScan; ++i) {
+      // specific force / angular rate of the planar constant-twist motion
+      double acc[3] = {0 + ba_true[0] + 0.05 * r.gauss(), s.speed * s.yaw_rate + ba_true[1] + 0.05 * r.gauss(),
+                       9.81 + ba_true[2] + 0.05 * r.gauss()};
+      double gyr[3] = {bw_true[0] + 0.002 * r.gauss(), bw_true[1] + 0.002 * r.gauss(),
+                       s.yaw_rate + bw_true[2] + 0.002 * r.gauss()};
+      lins_filter_predict(&filt, dt, acc, gyr);
+    }
+    if (scan == 0) lins_filter_reset1(&filt);
+  }
+  std::memcpy(out->state, filt.state, sizeof filt.state);
+  std::memcpy(out->cov, filt.cov, sizeof filt.cov);
+  return LINS_OK;
+}
+
+}  // extern "C"

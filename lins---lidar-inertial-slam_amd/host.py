@@ -1,0 +1,148 @@
+"""Bindings for liblins_host.so (pure-CPU host pieces, include/lins_host.h):
+StatePredictor mirror, feature front-end, transformToEnd, synthetic scan pairs.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._ctypes_defs import (CLOUD_MAX, ERR_DIM, MAX_QUERY, STATE_DIM, Point, ScanPair)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SYNTH_SEED = 0x4C494E53  # "LINS"
+
+
+class FilterParams(C.Structure):
+    _fields_ = [
+        ("acc_n", C.c_double), ("gyr_n", C.c_double), ("acc_w", C.c_double), ("gyr_w", C.c_double),
+        ("init_pos_std", C.c_double * 3), ("init_vel_std", C.c_double * 3), ("init_att_std", C.c_double * 3),
+        ("init_acc_std", C.c_double * 3), ("init_gyr_std", C.c_double * 3),
+    ]
+
+
+class Filter(C.Structure):
+    _fields_ = [
+        ("state", C.c_double * STATE_DIM),
+        ("cov", C.c_double * (ERR_DIM * ERR_DIM)),
+        ("noise", C.c_double * 144),
+        ("acc_last", C.c_double * 3), ("gyr_last", C.c_double * 3),
+        ("time", C.c_double),
+        ("has_imu", C.c_int32), ("pad", C.c_int32),
+        ("prm", FilterParams),
+    ]
+
+
+class Features(C.Structure):
+    _fields_ = [
+        ("corner_sharp", C.POINTER(Point)), ("n_corner_sharp", C.c_int32),
+        ("corner_less_sharp", C.POINTER(Point)), ("n_corner_less_sharp", C.c_int32),
+        ("surf_flat", C.POINTER(Point)), ("n_surf_flat", C.c_int32),
+        ("surf_less_flat", C.POINTER(Point)), ("n_surf_less_flat", C.c_int32),
+        ("n_segmented", C.c_int32), ("n_outlier", C.c_int32),
+    ]
+
+
+class SynthPairC(C.Structure):
+    _fields_ = [
+        ("surf_flat", C.POINTER(Point)), ("n_surf_flat", C.c_int32),
+        ("corner_sharp", C.POINTER(Point)), ("n_corner_sharp", C.c_int32),
+        ("surf_last", C.POINTER(Point)), ("n_surf_last", C.c_int32),
+        ("corner_last", C.POINTER(Point)), ("n_corner_last", C.c_int32),
+        ("state", C.c_double * STATE_DIM),
+        ("cov", C.c_double * (ERR_DIM * ERR_DIM)),
+        ("true_t", C.c_double * 3), ("true_q", C.c_double * 4),
+        ("speed", C.c_double), ("yaw_rate", C.c_double),
+        ("n_raw_last", C.c_int32), ("n_raw_new", C.c_int32),
+    ]
+
+
+def lib_path():
+    return os.path.join(_HERE, "liblins_host.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise RuntimeError(f"{p} is missing — run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(p)
+        L.lins_synth_generate.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(SynthPairC)]
+        L.lins_synth_generate.restype = C.c_int
+        L.lins_synth_raw_scan.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(Point), C.c_int]
+        L.lins_synth_raw_scan.restype = C.c_int
+        L.lins_frontend_extract.argtypes = [C.POINTER(Point), C.c_int, C.c_double, C.POINTER(Features)]
+        L.lins_frontend_extract.restype = C.c_int
+        L.lins_transform_to_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
+                                            C.POINTER(Point), C.c_int, C.POINTER(Point)]
+        L.lins_transform_to_end.restype = None
+        L.lins_filter_default_params.argtypes = [C.POINTER(FilterParams)]
+        L.lins_filter_init.argtypes = [C.POINTER(Filter), C.POINTER(FilterParams)] + [C.POINTER(C.c_double)] * 3
+        L.lins_filter_predict.argtypes = [C.POINTER(Filter), C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.lins_filter_reset1.argtypes = [C.POINTER(Filter)]
+        for f in (L.lins_filter_default_params, L.lins_filter_init, L.lins_filter_predict, L.lins_filter_reset1):
+            f.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _buf(n):
+    a = np.zeros((n, 4), dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(Point))
+
+
+def synth_pair(index, seed=SYNTH_SEED):
+    """Seeded synthetic scan pair `index` as a ScanPair."""
+    sf, psf = _buf(MAX_QUERY)
+    cs, pcs = _buf(MAX_QUERY)
+    sl, psl = _buf(CLOUD_MAX)
+    cl, pcl = _buf(1920)
+    sp = SynthPairC()
+    sp.surf_flat, sp.corner_sharp, sp.surf_last, sp.corner_last = psf, pcs, psl, pcl
+    rc = lib().lins_synth_generate(seed, index, C.byref(sp))
+    if rc != 0:
+        raise RuntimeError(f"lins_synth_generate failed: {rc}")
+    meta = dict(true_t=np.array(sp.true_t[:]), true_q=np.array(sp.true_q[:]), speed=sp.speed,
+                yaw_rate=sp.yaw_rate, n_raw=(sp.n_raw_last, sp.n_raw_new), index=index, seed=seed)
+    return ScanPair(sf[: sp.n_surf_flat].copy(), cs[: sp.n_corner_sharp].copy(), sl[: sp.n_surf_last].copy(),
+                    cl[: sp.n_corner_last].copy(), np.array(sp.state[:]), np.array(sp.cov[:]), meta)
+
+
+def synth_batch(n, start=0, seed=SYNTH_SEED):
+    return [synth_pair(start + i, seed) for i in range(n)]
+
+
+def synth_raw_scan(index, k, seed=SYNTH_SEED):
+    a, p = _buf(CLOUD_MAX)
+    n = lib().lins_synth_raw_scan(seed, index, k, p, CLOUD_MAX)
+    if n < 0:
+        raise RuntimeError(f"lins_synth_raw_scan failed: {n}")
+    return a[:n].copy()
+
+
+def frontend_extract(raw, scan_period=0.1):
+    raw = np.ascontiguousarray(raw, dtype=np.float32).reshape(-1, 4)
+    cs, pcs = _buf(192)
+    cls, pcls = _buf(1920)
+    sf, psf = _buf(MAX_QUERY)
+    slf, pslf = _buf(CLOUD_MAX)
+    f = Features()
+    f.corner_sharp, f.corner_less_sharp, f.surf_flat, f.surf_less_flat = pcs, pcls, psf, pslf
+    rc = lib().lins_frontend_extract(raw.ctypes.data_as(C.POINTER(Point)), len(raw), scan_period, C.byref(f))
+    if rc != 0:
+        raise RuntimeError(f"lins_frontend_extract failed: {rc}")
+    return dict(corner_sharp=cs[: f.n_corner_sharp].copy(), corner_less_sharp=cls[: f.n_corner_less_sharp].copy(),
+                surf_flat=sf[: f.n_surf_flat].copy(), surf_less_flat=slf[: f.n_surf_less_flat].copy(),
+                n_segmented=f.n_segmented, n_outlier=f.n_outlier)
+
+
+def transform_to_end(t, q, pts, scan_period=0.1):
+    pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 4)
+    out = np.empty_like(pts)
+    t = (C.c_double * 3)(*t)
+    q = (C.c_double * 4)(*q)
+    lib().lins_transform_to_end(t, q, scan_period, pts.ctypes.data_as(C.POINTER(Point)), len(pts),
+                                out.ctypes.data_as(C.POINTER(Point)))
+    return out
