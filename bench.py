@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py — ESKF iterations/s of the HIP IESKF update path on MI355X.
+
+Workload (BASELINE.json configs[3], the largest single-GPU configuration): a batch
+of 1024 independent seeded synthetic 16x1800 VLP-16 scan pairs per GPU, exactly 10
+IESKF iterations each (fixed_iters throughput mode), inputs resident in HBM before
+the timed region.  One "step" = one pass of the hot path over the batch
+(lins_batch_run) + for N>1 the RCCL all-gather of the fixed-size pose records.
+N GPUs: one process per GPU, each with its own 1024 scans (weak scaling).
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the
+context's stream; `cpu_baseline` times the CPU oracle (kind "port": the reference
+cannot be compiled here) on a bounded sample of the same scans on this box's cores.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = "lins---lidar-inertial-slam_amd"
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="scans per GPU")
+    ap.add_argument("--iters", type=int, default=10, help="IESKF iterations per scan")
+    ap.add_argument("--search", default=os.environ.get("LINS_SEARCH", "binned"))
+    ap.add_argument("--cpu-sample", type=int, default=192, help="scans timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
+
+    import __graft_entry__ as g
+
+    g.build(only_missing=True)
+    pkg = importlib.import_module(PKG)
+    host = importlib.import_module(PKG + ".host")
+    ieskf = importlib.import_module(PKG + ".ieskf")
+    dist_mod = importlib.import_module(PKG + ".dist")
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the HIP path)")
+    torch.cuda.set_device(local_rank)
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    # ---- workload: this rank's contiguous shard of the global batch --------------------
+    lo, hi = dist_mod.shard_range(args.batch * world, rank, world)
+    t0 = time.time()
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        pairs = list(ex.map(host.synth_pair, range(lo, hi)))
+    gen_s = time.time() - t0
+    sizes = np.array([p.sizes() for p in pairs])
+    max_targets = int(sizes[:, 2:].max())
+
+    prm = pkg.default_params(num_iter=args.iters, fixed_iters=1)
+    ctx = ieskf.IeskfContext(prm, device=local_rank, max_batch=len(pairs), max_targets=max(max_targets, 1024),
+                             search=args.search)
+    ctx.upload(pairs)
+    poses = torch.zeros(len(pairs) * 192, dtype=torch.uint8, device="cuda")
+    gathered = torch.zeros(world * len(pairs) * 192, dtype=torch.uint8, device="cuda") if use_dist else None
+
+    def step():
+        ctx.run(poses.data_ptr(), lo)
+        ctx.sync()
+        if use_dist:
+            dist.all_gather_into_tensor(gathered, poses)
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(ctx.last_kernel_ms())
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    iters_local = ctx.total_iters()
+    bytes_iter_local = ctx.bytes_per_iter()  # sum over scans of B_iter
+    stats = torch.tensor([elapsed, float(iters_local)], dtype=torch.float64, device="cuda")
+    if use_dist:
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        isum = stats[1:].clone()
+        dist.all_reduce(isum, op=dist.ReduceOp.SUM)
+        elapsed_max, iters_all = float(tmax.item()), float(isum.item())
+    else:
+        elapsed_max, iters_all = elapsed, float(iters_local)
+
+    if rank == 0:
+        res = ctx.download()
+        n_div = sum(1 for r in res if r.diverged)
+        value = iters_all * args.steps / elapsed_max
+        k_ms = float(np.mean(kernel_ms))
+        # algorithmic bytes per launch = sum_scans B_iter(scan) * iterations(scan); with the
+        # fixed-iteration mode every non-diverged scan runs args.iters iterations
+        alg_bytes = bytes_iter_local / len(pairs) * iters_local
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "ESKF iterations/sec (16x1800 VLP-16, ~2k feat)",
+            "value": value,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64 state / f32 points",
+            "data": "synthetic",
+            "config": {
+                "workload": f"configs[3]: batch of {args.batch} independent scan pairs per GPU, "
+                            f"{args.iters} IESKF iterations each (fixed), 1 workgroup per scan",
+                "scans_per_gpu": len(pairs),
+                "iters_per_scan": args.iters,
+                "search": args.search,
+                "mean_sizes": {"n_sharp": float(sizes[:, 0].mean()), "n_flat": float(sizes[:, 1].mean()),
+                               "n_less_sharp_last": float(sizes[:, 2].mean()),
+                               "n_less_flat_last": float(sizes[:, 3].mean())},
+                "diverged_scans": n_div,
+                "parallelism": f"scan-sharded x{world}" + (", RCCL all-gather of 192 B pose records" if use_dist else ""),
+                "gen_seconds": round(gen_s, 2),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "ieskf_persistent_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "alg_bytes_per_launch": alg_bytes,
+                "kernel_ms": k_ms,
+                "bytes_per_iter_mean": bytes_iter_local / len(pairs),
+            },
+        }
+        if not args.no_cpu and args.cpu_sample > 0:
+            from oracle import oracle
+
+            sample = pairs[: min(args.cpu_sample, len(pairs))]
+            sec1, it1 = oracle.bench(prm, sample, oracle.FORM_DENSE, oracle.NN_KDTREE, threads=1)
+            ncpu = os.cpu_count() or 1
+            secn, itn = oracle.bench(prm, sample, oracle.FORM_DENSE, oracle.NN_KDTREE, threads=ncpu)
+            secr, itr = oracle.bench(prm, sample, oracle.FORM_REDUCED, oracle.NN_KDTREE, threads=1)
+            out["cpu_baseline"] = {
+                "value": it1 / sec1,
+                "unit": "iterations/s",
+                "cores": 1,
+                "kind": "port",
+                "sample": f"first {len(sample)} scan pairs of the same batch x {args.iters} iterations, "
+                          "oracle dense MxM form + kd-tree (the reference's cost model), g++ -O3 no FMA",
+                "all_cores": {"value": itn / secn, "cores": ncpu},
+                "reduced_6x6_form_1core": {"value": itr / secr, "cores": 1},
+            }
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

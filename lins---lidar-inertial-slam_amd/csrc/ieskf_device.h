@@ -1,0 +1,327 @@
+// ieskf_device.h — device-side building blocks of the IESKF update path.
+//
+// Behavioural contract, relative to /root/reference/lins/include/StateEstimator.hpp:
+//   transformToStart                         1066-1080
+//   findCorrespondingSurfFeatures            829-953   (search, walk, plane row)
+//   findCorrespondingCornerFeatures          955-1063  (search, walk, line row)
+//   H row / residual                         507-532
+//   gain / increment / Joseph update         542-549, 594-598 (reduced 6x6 form,
+//                                            SURVEY.md §8a A6 — never inverts P)
+// Arithmetic rules that make the index sets and f32 rows bit-comparable with the
+// reference's CPU path: distances in f32 as ((dx*dx+dy*dy)+dz*dz) with contraction
+// off, geometry in f64 rounded to f32 at the same points, strict '<' first-seen
+// tie rules restated as lexicographic (distance, visit-rank) minima.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/lins_ieskf.h"
+#include "lins_math.h"
+
+namespace lins {
+
+constexpr int kBlock = 256;          // threads per workgroup (4 waves)
+constexpr int kRowsCap = 512;        // LDS row slots per reduction round
+constexpr int kRedGroups = 8;        // partial-sum groups per reduction
+constexpr int kAzSurf = 128;         // azimuth columns per ring, surf targets
+constexpr int kAzCorner = 64;        // azimuth columns per ring, corner targets
+constexpr int kMaxRing = LINS_MAX_RING;
+
+enum { SEARCH_BRUTE = 0, SEARCH_BINNED = 1 };
+
+struct ScanDesc {  // one IESKF problem in the device arena (offsets in points)
+  int off_surf_q, n_surf_q;
+  int off_corner_q, n_corner_q;
+  int off_surf_t, n_surf_t;
+  int off_corner_t, n_corner_t;
+  int surf_sorted, corner_sorted;  // targets ring-sorted (host-validated)?
+  int slot_base;                   // first per-query scratch slot of this scan
+  int pad;
+};
+
+struct DevParams {
+  int num_iter, icp_freq, fixed_iters, search;
+  double r2;          // LIDAR_STD^2
+  double lidar_scale;
+  double inv_period;  // (double)(1.f / SCAN_PERIOD)
+  double nearest;     // NEAREST_FEATURE_SEARCH_SQ_DIST
+  float nearest_f;
+  int pad;
+};
+
+struct IterConst {  // per-iteration constants, hoisted (the reference recomputes per point)
+  double lin[19];   // linState_
+  V3 phi;           // Quat2axis(linState_.qbn_)
+  M3 Rt;            // R(q)^T
+  M3 G;             // Rinvleft(-phi)
+  double d[18];     // filterState (-) linState_
+};
+
+struct QueryOut {
+  int j1, j2, j3, accepted;
+  float c[4];
+  float sel[3];
+};
+
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float sqdist3(float tx, float ty, float tz, float sx, float sy, float sz) {
+  float dx = tx - sx, dy = ty - sy, dz = tz - sz;
+  return dx * dx + dy * dy + dz * dz;  // contraction is off: three roundings, as on the CPU
+}
+
+__device__ __forceinline__ int ring_of(float intensity) { return (int)intensity; }
+
+// transformToStart (SE:1066-1080) with phi hoisted.
+__device__ __forceinline__ void transform_to_start(const DevParams& prm, const V3& phi, const V3& t,
+                                                   const float4& pi, float& ox, float& oy, float& oz) {
+  float frac = pi.w - (float)(int)pi.w;
+  double s = prm.inv_period * (double)frac;
+  Q4 r = axis2quat(s * phi);
+  V3 p1 = qrot(r, V3{(double)pi.x, (double)pi.y, (double)pi.z}) + s * t;
+  ox = (float)p1.x, oy = (float)p1.y, oz = (float)p1.z;
+}
+
+// plane row (SE:917-951)
+__device__ __forceinline__ void surf_row(const DevParams& prm, int iter, float sx, float sy, float sz,
+                                         const float4& t1, const float4& t2, const float4& t3, QueryOut& o) {
+  V3 p0{sx, sy, sz}, p1{t1.x, t1.y, t1.z}, p2{t2.x, t2.y, t2.z}, p3{t3.x, t3.y, t3.z};
+  V3 m = cross(p1 - p2, p1 - p3);
+  double r = dot(p0 - p1, m);
+  double mn = norm(m);
+  float res = (float)(r / mn);
+  V3 jac = m / mn;
+  float s = 1;
+  if (iter >= prm.icp_freq) {
+    float n2 = sx * sx + sy * sy + sz * sz;
+    s = (float)(1 - 1.8 * (double)fabsf(res) / (double)sqrtf(sqrtf(n2)));
+  }
+  if (s > 0.1 && res != 0) {
+    o.accepted = 1;
+    o.c[0] = (float)((double)s * jac.x);
+    o.c[1] = (float)((double)s * jac.y);
+    o.c[2] = (float)((double)s * jac.z);
+    o.c[3] = s * res;
+  }
+}
+
+// line row (SE:1031-1061)
+__device__ __forceinline__ void corner_row(const DevParams& prm, int iter, float sx, float sy, float sz,
+                                           const float4& t1, const float4& t2, QueryOut& o) {
+  V3 p0{sx, sy, sz}, p1{t1.x, t1.y, t1.z}, p2{t2.x, t2.y, t2.z};
+  V3 P = cross(p0 - p1, p0 - p2);
+  float r = (float)norm(P);
+  float d12 = (float)norm(p1 - p2);
+  float res = r / d12;
+  V3 v = p2 - p1;
+  double den = (double)(d12 * r);
+  V3 jac{(P.y * v.z - P.z * v.y) / den, (P.z * v.x - P.x * v.z) / den, (P.x * v.y - P.y * v.x) / den};
+  float s = 1;
+  if (iter >= prm.icp_freq) s = (float)(1 - 1.8 * (double)fabsf(res));
+  if (s > 0.1 && res != 0) {
+    o.accepted = 1;
+    o.c[0] = (float)((double)s * jac.x);
+    o.c[1] = (float)((double)s * jac.y);
+    o.c[2] = (float)((double)s * jac.z);
+    o.c[3] = s * res;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// exact all-pairs search + literal index walk (the reference's own control flow)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void nn_brute(const float4* __restrict__ tg, int nt, float sx, float sy,
+                                         float sz, int& best_j, float& best_d) {
+  best_j = -1;
+  best_d = INFINITY;
+  for (int j = 0; j < nt; ++j) {  // wave-uniform address: one broadcast load per step
+    float4 t = tg[j];
+    float d = sqdist3(t.x, t.y, t.z, sx, sy, sz);
+    if (d < best_d) best_d = d, best_j = j;  // ascending j, strict < : lowest index wins
+  }
+}
+
+__device__ __forceinline__ void walk_surf_literal(const float4* __restrict__ tg, int nt, int nq,
+                                                  float thr, int closest, float sx, float sy, float sz,
+                                                  int& m2, int& m3) {
+  m2 = m3 = -1;
+  int ring = ring_of(tg[closest].w);
+  float d2 = thr, d3 = thr;
+  int fend = nq < nt ? nq : nt;
+  for (int j = closest + 1; j < fend; ++j) {
+    float4 t = tg[j];
+    int rj = ring_of(t.w);
+    if ((double)rj > ring + 2.5) break;
+    float d = sqdist3(t.x, t.y, t.z, sx, sy, sz);
+    if (rj <= ring) {
+      if (d < d2) d2 = d, m2 = j;
+    } else {
+      if (d < d3) d3 = d, m3 = j;
+    }
+  }
+  for (int j = closest - 1; j >= 0; --j) {
+    float4 t = tg[j];
+    int rj = ring_of(t.w);
+    if ((double)rj < ring - 2.5) break;
+    float d = sqdist3(t.x, t.y, t.z, sx, sy, sz);
+    if (rj >= ring) {
+      if (d < d2) d2 = d, m2 = j;
+    } else {
+      if (d < d3) d3 = d, m3 = j;
+    }
+  }
+}
+
+__device__ __forceinline__ void walk_corner_literal(const float4* __restrict__ tg, int nt, int nq,
+                                                    float thr, int closest, float sx, float sy, float sz,
+                                                    int& m2) {
+  m2 = -1;
+  int ring = ring_of(tg[closest].w);
+  float d2 = thr;
+  int fend = nq < nt ? nq : nt;
+  for (int j = closest + 1; j < fend; ++j) {
+    float4 t = tg[j];
+    int rj = ring_of(t.w);
+    if ((double)rj > ring + 2.5) break;
+    float d = sqdist3(t.x, t.y, t.z, sx, sy, sz);
+    if (rj > ring && d < d2) d2 = d, m2 = j;
+  }
+  for (int j = closest - 1; j >= 0; --j) {
+    float4 t = tg[j];
+    int rj = ring_of(t.w);
+    if ((double)rj < ring - 2.5) break;
+    float d = sqdist3(t.x, t.y, t.z, sx, sy, sz);
+    if (rj < ring && d < d2) d2 = d, m2 = j;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// per-iteration constants from the linearisation state (wave-uniform)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void make_iter_const(const double* filt, IterConst& ic) {
+  Q4 q{ic.lin[6], ic.lin[7], ic.lin[8], ic.lin[9]};
+  ic.phi = quat2axis(q);
+  ic.Rt = mtrans(qmat(q));
+  ic.G = rinvleft(V3{-ic.phi.x, -ic.phi.y, -ic.phi.z});
+  // boxMinus(filter, lin), KF:84-94
+  Q4 qf{filt[6], filt[7], filt[8], filt[9]};
+  V3 da = quat2axis(qmul(qinverse(q), qf));
+  for (int k = 0; k < 3; ++k) {
+    ic.d[0 + k] = filt[0 + k] - ic.lin[0 + k];
+    ic.d[3 + k] = filt[3 + k] - ic.lin[3 + k];
+    ic.d[9 + k] = filt[10 + k] - ic.lin[10 + k];
+    ic.d[12 + k] = filt[13 + k] - ic.lin[13 + k];
+    ic.d[15 + k] = filt[16 + k] - ic.lin[16 + k];
+  }
+  ic.d[6] = da.x, ic.d[7] = da.y, ic.d[8] = da.z;
+}
+
+// boxPlus (KF:71-81) applied in place to a 19-vector
+__device__ __forceinline__ void box_plus_inplace(double* s, const double* dx) {
+  for (int k = 0; k < 3; ++k) {
+    s[0 + k] += dx[0 + k];
+    s[3 + k] += dx[3 + k];
+    s[10 + k] += dx[9 + k];
+    s[13 + k] += dx[12 + k];
+    s[16 + k] += dx[15 + k];
+  }
+  Q4 q = qnormalized(qmul(Q4{s[6], s[7], s[8], s[9]}, axis2quat(V3{dx[6], dx[7], dx[8]})));
+  s[6] = q.w, s[7] = q.x, s[8] = q.y, s[9] = q.z;
+}
+
+// ---------------------------------------------------------------------------
+// 6x6 dense helpers, fully unrolled so everything stays in registers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int sidx(int k) { return k < 3 ? k : k + 3; }  // {0,1,2,6,7,8}
+
+// A6 (6x6, pos/att block of H^T H) and g6 from the 28 sums
+__device__ __forceinline__ void sums_to_normal(const double* s, const M3& G, double* A6, double* g6) {
+  M3 App{{s[0], s[1], s[2], s[1], s[3], s[4], s[2], s[4], s[5]}};
+  M3 Apu{{s[6], s[7], s[8], s[9], s[10], s[11], s[12], s[13], s[14]}};
+  M3 Auu{{s[15], s[16], s[17], s[16], s[18], s[19], s[17], s[19], s[20]}};
+  M3 Apa = mmul(Apu, G);
+  M3 Aaa = mmul(mmul(mtrans(G), Auu), G);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      A6[i * 6 + j] = App.m[i * 3 + j];
+      A6[i * 6 + 3 + j] = Apa.m[i * 3 + j];
+      A6[(3 + i) * 6 + j] = Apa.m[j * 3 + i];
+      A6[(3 + i) * 6 + 3 + j] = Aaa.m[i * 3 + j];
+    }
+  g6[0] = s[21], g6[1] = s[22], g6[2] = s[23];
+  V3 ga = rowmul(V3{s[24], s[25], s[26]}, G);
+  g6[3] = ga.x, g6[4] = ga.y, g6[5] = ga.z;
+}
+
+// Gaussian elimination with partial pivoting on [N | B] (6 x (6+NB)), in registers.
+// Row swaps are value selects so no array is dynamically indexed.
+template <int NB>
+__device__ __forceinline__ void lu_solve6(double (&a)[6][6 + NB]) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int p = k;
+    double best = fabs(a[k][k]);
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      double v = fabs(a[i][k]);
+      if (v > best) best = v, p = i;
+    }
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      bool sw = (p == i);
+#pragma unroll
+      for (int j = k; j < 6 + NB; ++j) {
+        double x = a[k][j], y = a[i][j];
+        a[k][j] = sw ? y : x;
+        a[i][j] = sw ? x : y;
+      }
+    }
+    double piv = a[k][k];
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      double f = a[i][k] / piv;
+#pragma unroll
+      for (int j = k + 1; j < 6 + NB; ++j) a[i][j] -= f * a[k][j];
+    }
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      double s = a[i][6 + j];
+#pragma unroll
+      for (int k = i + 1; k < 6; ++k) s -= a[i][k] * a[k][6 + j];
+      a[i][6 + j] = s / a[i][i];
+    }
+  }
+}
+
+// dx = d - P[:,S] (sigma^2 I + A_SS P_SS)^-1 (g + A d)_S      (P: 18x18 row-major)
+__device__ __forceinline__ void update_reduced(double r2, const double* P, const double* A6,
+                                               const double* g6, const double* d, double* dx) {
+  double a[6][7];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double z = g6[i];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) z += A6[i * 6 + k] * d[sidx(k)];
+    a[i][6] = z;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      double t = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) t += A6[i * 6 + k] * P[sidx(k) * 18 + sidx(j)];
+      a[i][j] = t + (i == j ? r2 : 0.0);
+    }
+  }
+  lu_solve6<1>(a);
+  for (int i = 0; i < 18; ++i) {
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s += P[i * 18 + sidx(k)] * a[k][6];
+    dx[i] = d[i] - s;
+  }
+}
+
+}  // namespace lins

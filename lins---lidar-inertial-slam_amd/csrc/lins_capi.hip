@@ -1,0 +1,397 @@
+// lins_capi.hip — implementation of the C ABI in include/lins_ieskf.h.
+//
+// Owns: one HIP stream, the device arena (all four clouds of every uploaded scan
+// pair, 64-byte aligned spans of float4), per-scan descriptors, prior / posterior
+// state + covariance, and pinned host staging.  Caller owns every host buffer it
+// passes in; nothing is retained after a call returns.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ieskf_device.h"
+
+namespace lins {
+void launch_persistent(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const double*,
+                       const double*, double*, double*, void*, int4*, lins_pose_record*, int);
+void launch_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const double*, const double*,
+                 int, int4*, lins_corr*, double*, int*);
+size_t out_rec_size();
+struct OutRecHost {
+  double residual_norm, update_norm;
+  int iters, converged, diverged, m_surf, m_corner, pad[3];
+};
+}  // namespace lins
+
+using namespace lins;
+
+struct lins_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  lins_params prm{};
+  DevParams dprm{};
+  int max_batch = 0, max_targets = 0;
+  size_t arena_cap = 0, slot_cap = 0;  // points / query slots
+  // pinned host staging
+  float4* h_arena = nullptr;
+  ScanDesc* h_desc = nullptr;
+  double* h_state = nullptr;
+  double* h_cov = nullptr;
+  OutRecHost* h_out = nullptr;
+  // device
+  float4* d_arena = nullptr;
+  ScanDesc* d_desc = nullptr;
+  double *d_state_in = nullptr, *d_cov_in = nullptr, *d_state_out = nullptr, *d_cov_out = nullptr;
+  double* d_lin = nullptr;
+  void* d_out = nullptr;
+  int4* d_idx = nullptr;
+  lins_corr* d_dump = nullptr;
+  double* d_sums = nullptr;
+  int* d_counts = nullptr;
+  int n_uploaded = 0;
+  bool ran = false;
+  uint64_t bytes_per_iter = 0;
+  uint64_t total_iters = 0;
+  std::string hip_err;
+};
+
+namespace {
+
+int fail_hip(lins_ctx* ctx, hipError_t e, const char* what) {
+  if (ctx) ctx->hip_err = std::string(what) + ": " + hipGetErrorString(e);
+  return LINS_E_HIP;
+}
+#define HIP_TRY(ctx, expr)                          \
+  do {                                              \
+    hipError_t e__ = (expr);                        \
+    if (e__ != hipSuccess) return fail_hip(ctx, e__, #expr); \
+  } while (0)
+
+inline size_t align4(size_t n) { return (n + 3) & ~size_t(3); }
+
+// input contract: finite xyz, ring id in [0, LINS_MAX_RING); reports ring-sortedness
+int check_cloud(const lins_point* p, int n, bool* sorted) {
+  int prev = -1;
+  bool s = true;
+  for (int i = 0; i < n; ++i) {
+    if (!std::isfinite(p[i].x) || !std::isfinite(p[i].y) || !std::isfinite(p[i].z) || !std::isfinite(p[i].intensity))
+      return LINS_E_INPUT;
+    if (p[i].intensity < 0.f || p[i].intensity >= (float)LINS_MAX_RING) return LINS_E_INPUT;
+    int r = (int)p[i].intensity;
+    if (r < prev) s = false;
+    prev = r;
+  }
+  if (sorted) *sorted = s;
+  return LINS_OK;
+}
+
+void make_dev_params(const lins_params& p, int search, DevParams& d) {
+  d.num_iter = p.num_iter;
+  d.icp_freq = p.icp_freq;
+  d.fixed_iters = p.fixed_iters;
+  d.search = search;
+  d.r2 = p.lidar_std * p.lidar_std;
+  d.lidar_scale = p.lidar_scale;
+  d.inv_period = (double)(1.f / p.scan_period);  // (1.f / SCAN_PERIOD), SE:1067
+  d.nearest = p.nearest_sq_dist;
+  d.nearest_f = (float)p.nearest_sq_dist;
+  d.pad = 0;
+}
+
+int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
+  if (!ctx || !in || n < 0) return LINS_E_ARG;
+  if (n > ctx->max_batch) return LINS_E_CAPACITY;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  size_t off = 0, slots = 0;
+  uint64_t bytes = 0;
+  for (int s = 0; s < n; ++s) {
+    const lins_scan_pair& p = in[s];
+    if (p.n_surf_flat < 0 || p.n_corner_sharp < 0 || p.n_surf_last < 0 || p.n_corner_last < 0) return LINS_E_ARG;
+    if ((p.n_surf_flat && !p.surf_flat) || (p.n_corner_sharp && !p.corner_sharp) ||
+        (p.n_surf_last && !p.surf_less_flat_last) || (p.n_corner_last && !p.corner_less_sharp_last))
+      return LINS_E_ARG;
+    if (p.n_surf_flat > LINS_MAX_QUERY || p.n_corner_sharp > LINS_MAX_QUERY) return LINS_E_CAPACITY;
+    if (p.n_surf_last > ctx->max_targets || p.n_corner_last > ctx->max_targets) return LINS_E_CAPACITY;
+    bool ss = true, cs = true;
+    int rc;
+    if ((rc = check_cloud(p.surf_flat, p.n_surf_flat, nullptr))) return rc;
+    if ((rc = check_cloud(p.corner_sharp, p.n_corner_sharp, nullptr))) return rc;
+    if ((rc = check_cloud(p.surf_less_flat_last, p.n_surf_last, &ss))) return rc;
+    if ((rc = check_cloud(p.corner_less_sharp_last, p.n_corner_last, &cs))) return rc;
+    ScanDesc& d = ctx->h_desc[s];
+    const lins_point* src[4] = {p.surf_flat, p.corner_sharp, p.surf_less_flat_last, p.corner_less_sharp_last};
+    int cnt[4] = {p.n_surf_flat, p.n_corner_sharp, p.n_surf_last, p.n_corner_last};
+    int offs[4];
+    for (int c = 0; c < 4; ++c) {
+      if (off + align4(cnt[c]) > ctx->arena_cap) return LINS_E_CAPACITY;
+      offs[c] = (int)off;
+      if (cnt[c]) std::memcpy(ctx->h_arena + off, src[c], sizeof(lins_point) * cnt[c]);
+      for (size_t k = cnt[c]; k < align4(cnt[c]); ++k) ctx->h_arena[off + k] = make_float4(0, 0, 0, 0);
+      off += align4(cnt[c]);
+    }
+    d.off_surf_q = offs[0], d.n_surf_q = cnt[0];
+    d.off_corner_q = offs[1], d.n_corner_q = cnt[1];
+    d.off_surf_t = offs[2], d.n_surf_t = cnt[2];
+    d.off_corner_t = offs[3], d.n_corner_t = cnt[3];
+    d.surf_sorted = ss, d.corner_sorted = cs;
+    d.slot_base = (int)slots;
+    d.pad = 0;
+    slots += cnt[0] + cnt[1];
+    if (slots > ctx->slot_cap) return LINS_E_CAPACITY;
+    std::memcpy(ctx->h_state + (size_t)s * 19, p.state, sizeof p.state);
+    std::memcpy(ctx->h_cov + (size_t)s * 324, p.cov, sizeof p.cov);
+    bytes += 16ull * (cnt[0] + cnt[1] + cnt[2] + cnt[3]) + 8 * 19 + 8 * 28;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_arena, ctx->h_arena, off * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_desc, ctx->h_desc, (size_t)n * sizeof(ScanDesc), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_state_in, ctx->h_state, (size_t)n * 19 * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_cov_in, ctx->h_cov, (size_t)n * 324 * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->n_uploaded = n;
+  ctx->ran = false;
+  ctx->bytes_per_iter = bytes;
+  return LINS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* lins_strerror(int code) {
+  switch (code) {
+    case LINS_OK: return "ok";
+    case LINS_E_ARG: return "bad argument";
+    case LINS_E_HIP: return "HIP runtime error (see lins_last_hip_error)";
+    case LINS_E_CAPACITY: return "batch or cloud exceeds the context capacity";
+    case LINS_E_INPUT: return "cloud violates the input contract (non-finite value or ring id out of range)";
+    case LINS_E_NODEVICE: return "no usable gfx950 device";
+    case LINS_E_STATE: return "call sequence error";
+    default: return "unknown error";
+  }
+}
+
+const char* lins_last_hip_error(const lins_ctx* ctx) { return ctx ? ctx->hip_err.c_str() : ""; }
+
+int lins_create(const lins_params* params, int device, int max_batch, int max_targets, lins_ctx** out) {
+  if (!params || !out || max_batch < 1 || max_targets < 1) return LINS_E_ARG;
+  if (params->num_iter < 1 || params->icp_freq < 1 || !(params->scan_period > 0)) return LINS_E_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0) return LINS_E_NODEVICE;
+  lins_ctx* ctx = new (std::nothrow) lins_ctx();
+  if (!ctx) return LINS_E_ARG;
+  ctx->device = device;
+  ctx->prm = *params;
+  make_dev_params(*params, SEARCH_BRUTE, ctx->dprm);
+  ctx->max_batch = max_batch;
+  ctx->max_targets = max_targets;
+  ctx->arena_cap = (size_t)max_batch * (2 * align4(max_targets) + 2 * LINS_MAX_QUERY);
+  ctx->slot_cap = (size_t)max_batch * LINS_MAX_QUERY;
+#define CREATE_TRY(expr)                             \
+  do {                                               \
+    hipError_t e__ = (expr);                         \
+    if (e__ != hipSuccess) {                         \
+      fprintf(stderr, "lins_create: %s: %s\n", #expr, hipGetErrorString(e__)); \
+      lins_destroy(ctx);                             \
+      return LINS_E_HIP;                             \
+    }                                                \
+  } while (0)
+  CREATE_TRY(hipSetDevice(device));
+  CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  CREATE_TRY(hipEventCreate(&ctx->ev0));
+  CREATE_TRY(hipEventCreate(&ctx->ev1));
+  const size_t nb = (size_t)max_batch;
+  CREATE_TRY(hipHostMalloc((void**)&ctx->h_arena, ctx->arena_cap * sizeof(float4)));
+  CREATE_TRY(hipHostMalloc((void**)&ctx->h_desc, nb * sizeof(ScanDesc)));
+  CREATE_TRY(hipHostMalloc((void**)&ctx->h_state, nb * 19 * 8));
+  CREATE_TRY(hipHostMalloc((void**)&ctx->h_cov, nb * 324 * 8));
+  CREATE_TRY(hipHostMalloc((void**)&ctx->h_out, nb * sizeof(OutRecHost)));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_arena, ctx->arena_cap * sizeof(float4)));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_desc, nb * sizeof(ScanDesc)));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_state_in, nb * 19 * 8));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_cov_in, nb * 324 * 8));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_state_out, nb * 19 * 8));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_cov_out, nb * 324 * 8));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_lin, nb * 19 * 8));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_out, nb * out_rec_size()));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_idx, ctx->slot_cap * sizeof(int4)));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_dump, 2 * LINS_MAX_QUERY * sizeof(lins_corr)));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_sums, nb * 28 * 8));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_counts, nb * 2 * sizeof(int)));
+#undef CREATE_TRY
+  static_assert(sizeof(OutRecHost) == 48, "OutRec layout");
+  *out = ctx;
+  return LINS_OK;
+}
+
+void lins_destroy(lins_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  (void)hipHostFree(ctx->h_arena);
+  (void)hipHostFree(ctx->h_desc);
+  (void)hipHostFree(ctx->h_state);
+  (void)hipHostFree(ctx->h_cov);
+  (void)hipHostFree(ctx->h_out);
+  (void)hipFree(ctx->d_arena);
+  (void)hipFree(ctx->d_desc);
+  (void)hipFree(ctx->d_state_in);
+  (void)hipFree(ctx->d_cov_in);
+  (void)hipFree(ctx->d_state_out);
+  (void)hipFree(ctx->d_cov_out);
+  (void)hipFree(ctx->d_lin);
+  (void)hipFree(ctx->d_out);
+  (void)hipFree(ctx->d_idx);
+  (void)hipFree(ctx->d_dump);
+  (void)hipFree(ctx->d_sums);
+  (void)hipFree(ctx->d_counts);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int lins_set_search(lins_ctx* ctx, const char* mode) {
+  if (!ctx || !mode) return LINS_E_ARG;
+  if (!std::strcmp(mode, "brute"))
+    ctx->dprm.search = SEARCH_BRUTE;
+  else if (!std::strcmp(mode, "binned"))
+    ctx->dprm.search = SEARCH_BINNED;
+  else
+    return LINS_E_ARG;
+  return LINS_OK;
+}
+
+int lins_batch_upload(lins_ctx* ctx, int n, const lins_scan_pair* in) { return upload(ctx, n, in); }
+
+int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
+  if (!ctx) return LINS_E_ARG;
+  if (ctx->n_uploaded <= 0) return LINS_E_STATE;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  launch_persistent(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_state_in,
+                    ctx->d_cov_in, ctx->d_state_out, ctx->d_cov_out, ctx->d_out, ctx->d_idx,
+                    (lins_pose_record*)d_poses, scan_id_base);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  ctx->ran = true;
+  return LINS_OK;
+}
+
+int lins_sync(lins_ctx* ctx) {
+  if (!ctx) return LINS_E_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LINS_OK;
+}
+
+int lins_batch_download(lins_ctx* ctx, int n, lins_result* out) {
+  if (!ctx || !out || n < 0) return LINS_E_ARG;
+  if (!ctx->ran || n > ctx->n_uploaded) return LINS_E_STATE;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state_out, (size_t)n * 19 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cov, ctx->d_cov_out, (size_t)n * 324 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)n * sizeof(OutRecHost), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t tot = 0;
+  for (int s = 0; s < n; ++s) {
+    lins_result& r = out[s];
+    std::memset(&r, 0, sizeof r);
+    std::memcpy(r.state, ctx->h_state + (size_t)s * 19, sizeof r.state);
+    std::memcpy(r.cov, ctx->h_cov + (size_t)s * 324, sizeof r.cov);
+    const OutRecHost& o = ctx->h_out[s];
+    r.residual_norm = o.residual_norm, r.update_norm = o.update_norm;
+    r.iters = o.iters, r.converged = o.converged, r.diverged = o.diverged;
+    r.m_surf = o.m_surf, r.m_corner = o.m_corner;
+    tot += (uint64_t)o.iters;
+  }
+  if (n == ctx->n_uploaded) ctx->total_iters = tot;
+  return LINS_OK;
+}
+
+int lins_last_kernel_ms(lins_ctx* ctx, float* ms) {
+  if (!ctx || !ms) return LINS_E_ARG;
+  if (!ctx->ran) return LINS_E_STATE;
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+  HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+  return LINS_OK;
+}
+
+int lins_batch_bytes_per_iter(lins_ctx* ctx, uint64_t* bytes) {
+  if (!ctx || !bytes) return LINS_E_ARG;
+  *bytes = ctx->bytes_per_iter;
+  return LINS_OK;
+}
+
+int lins_batch_total_iters(lins_ctx* ctx, uint64_t* iters) {
+  if (!ctx || !iters) return LINS_E_ARG;
+  if (!ctx->ran) return LINS_E_STATE;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int n = ctx->n_uploaded;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)n * sizeof(OutRecHost), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t tot = 0;
+  for (int s = 0; s < n; ++s) tot += (uint64_t)ctx->h_out[s].iters;
+  *iters = ctx->total_iters = tot;
+  return LINS_OK;
+}
+
+int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins_result* out) {
+  int rc = upload(ctx, n, in);
+  if (rc) return rc;
+  if (n == 0) return LINS_OK;
+  if ((rc = lins_batch_run(ctx, nullptr, 0))) return rc;
+  return lins_batch_download(ctx, n, out);
+}
+
+int lins_ieskf_update(lins_ctx* ctx, const lins_scan_pair* in, lins_result* out) {
+  return lins_ieskf_update_batch(ctx, 1, in, out);
+}
+
+static int run_pass(lins_ctx* ctx, const lins_scan_pair* in, const double* lin_state, int iter, bool dump,
+                    bool sums) {
+  int rc = upload(ctx, 1, in);
+  if (rc) return rc;
+  ctx->n_uploaded = 0;  // the single-pass calls do not leave a runnable batch behind
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_lin, lin_state, 19 * 8, hipMemcpyHostToDevice, ctx->stream));
+  launch_pass(ctx->stream, 1, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_lin, ctx->d_state_in, iter, ctx->d_idx,
+              dump ? ctx->d_dump : nullptr, sums ? ctx->d_sums : nullptr, sums ? ctx->d_counts : nullptr);
+  HIP_TRY(ctx, hipGetLastError());
+  return LINS_OK;
+}
+
+int lins_correspondences(lins_ctx* ctx, const lins_scan_pair* in, const double* lin_state, int iter,
+                         lins_corr* surf, lins_corr* corner) {
+  if (!ctx || !in || !lin_state) return LINS_E_ARG;
+  int rc = run_pass(ctx, in, lin_state, iter, true, false);
+  if (rc) return rc;
+  if (surf && in->n_surf_flat)
+    HIP_TRY(ctx, hipMemcpyAsync(surf, ctx->d_dump, sizeof(lins_corr) * in->n_surf_flat, hipMemcpyDeviceToHost, ctx->stream));
+  if (corner && in->n_corner_sharp)
+    HIP_TRY(ctx, hipMemcpyAsync(corner, ctx->d_dump + in->n_surf_flat, sizeof(lins_corr) * in->n_corner_sharp,
+                                hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LINS_OK;
+}
+
+int lins_reduce_pass(lins_ctx* ctx, const lins_scan_pair* in, const double* lin_state, int iter, double* sums28,
+                     int32_t* m_surf, int32_t* m_corner) {
+  if (!ctx || !in || !lin_state || !sums28) return LINS_E_ARG;
+  int rc = run_pass(ctx, in, lin_state, iter, false, true);
+  if (rc) return rc;
+  int counts[2];
+  HIP_TRY(ctx, hipMemcpyAsync(sums28, ctx->d_sums, 28 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(counts, ctx->d_counts, sizeof counts, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (m_surf) *m_surf = counts[0];
+  if (m_corner) *m_corner = counts[1];
+  return LINS_OK;
+}
+
+}  // extern "C"

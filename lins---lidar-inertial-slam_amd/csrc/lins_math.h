@@ -13,6 +13,7 @@
 #include <math.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define LINS_HD __host__ __device__ __forceinline__
 #else
 #define LINS_HD inline

@@ -1,0 +1,243 @@
+"""Binding of liblins_ieskf.so — the HIP IESKF update path behind the C ABI of
+include/lins_ieskf.h.  Host-side mirror of the reference's call surface for this
+path (StateEstimator::performIESKF and the two correspondence functions).
+
+There is NO CPU fallback here: a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._ctypes_defs import (CORR_DTYPE, POSE_DTYPE, Params, PoseRecordC, Result, ResultC, ScanPairC, default_params,
+                           pairs_to_c)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+EXPORTS = [
+    "lins_create", "lins_destroy", "lins_strerror", "lins_last_hip_error", "lins_set_search",
+    "lins_ieskf_update", "lins_ieskf_update_batch", "lins_batch_upload", "lins_batch_run", "lins_sync",
+    "lins_batch_download", "lins_last_kernel_ms", "lins_batch_bytes_per_iter", "lins_batch_total_iters",
+    "lins_correspondences", "lins_reduce_pass", "lins_host_perform_ieskf",
+]
+
+
+class LinsError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "liblins_ieskf.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise LinsError(f"{p} is missing: the HIP extension was not built (run __graft_entry__.build()); "
+                            "there is no CPU fallback for this path")
+        L = C.CDLL(p)
+        vp, dp = C.c_void_p, C.POINTER(C.c_double)
+        L.lins_create.argtypes = [C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+        L.lins_destroy.argtypes = [vp]
+        L.lins_destroy.restype = None
+        L.lins_strerror.argtypes = [C.c_int]
+        L.lins_strerror.restype = C.c_char_p
+        L.lins_last_hip_error.argtypes = [vp]
+        L.lins_last_hip_error.restype = C.c_char_p
+        L.lins_set_search.argtypes = [vp, C.c_char_p]
+        L.lins_ieskf_update.argtypes = [vp, C.POINTER(ScanPairC), C.POINTER(ResultC)]
+        L.lins_ieskf_update_batch.argtypes = [vp, C.c_int, C.POINTER(ScanPairC), C.POINTER(ResultC)]
+        L.lins_batch_upload.argtypes = [vp, C.c_int, C.POINTER(ScanPairC)]
+        L.lins_batch_run.argtypes = [vp, vp, C.c_int32]
+        L.lins_sync.argtypes = [vp]
+        L.lins_batch_download.argtypes = [vp, C.c_int, C.POINTER(ResultC)]
+        L.lins_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.lins_batch_bytes_per_iter.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.lins_batch_total_iters.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.lins_correspondences.argtypes = [vp, C.POINTER(ScanPairC), dp, C.c_int, vp, vp]
+        L.lins_reduce_pass.argtypes = [vp, C.POINTER(ScanPairC), dp, C.c_int, dp, C.POINTER(C.c_int32),
+                                       C.POINTER(C.c_int32)]
+        L.lins_host_perform_ieskf.argtypes = [vp, C.POINTER(Params), C.POINTER(ScanPairC), C.POINTER(ResultC),
+                                              C.POINTER(C.c_int32)]
+        for name in EXPORTS:
+            if name not in ("lins_destroy", "lins_strerror", "lins_last_hip_error"):
+                getattr(L, name).restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+class IeskfContext:
+    """lins_ctx wrapper: one HIP stream + device arena on one GPU."""
+
+    def __init__(self, params=None, device=0, max_batch=1, max_targets=8192, search="brute"):
+        self.params = params if params is not None else default_params()
+        self._h = C.c_void_p()
+        self._check(lib().lins_create(C.byref(self.params), device, max_batch, max_targets, C.byref(self._h)))
+        self.max_batch = max_batch
+        self.set_search(search)
+        self._n = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = lib().lins_strerror(rc).decode()
+            if rc == -2 and self._h:
+                msg += ": " + lib().lins_last_hip_error(self._h).decode()
+            raise LinsError(f"liblins_ieskf error {rc}: {msg}")
+
+    def close(self):
+        if self._h:
+            lib().lins_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_search(self, mode):
+        self._check(lib().lins_set_search(self._h, mode.encode()))
+        self.search = mode
+
+    # -- StateEstimator::performIESKF ------------------------------------------------
+    def update(self, pair):
+        c = pair.as_c()
+        r = ResultC()
+        self._check(lib().lins_ieskf_update(self._h, C.byref(c), C.byref(r)))
+        return Result(r)
+
+    def update_batch(self, pairs):
+        arr = pairs_to_c(pairs)
+        res = (ResultC * len(pairs))()
+        self._check(lib().lins_ieskf_update_batch(self._h, len(pairs), arr, res))
+        return [Result(r) for r in res]
+
+    def perform_ieskf(self, pair):
+        """performIESKF as the node sees it: GPU loop + ICP fallback on divergence."""
+        c = pair.as_c()
+        r = ResultC()
+        used = C.c_int32(0)
+        self._check(lib().lins_host_perform_ieskf(self._h, C.byref(self.params), C.byref(c), C.byref(r), C.byref(used)))
+        return Result(r), bool(used.value)
+
+    # -- staged batch form -------------------------------------------------------------
+    def upload(self, pairs):
+        arr = pairs_to_c(pairs)
+        self._check(lib().lins_batch_upload(self._h, len(pairs), arr))
+        self._n = len(pairs)
+
+    def run(self, poses_ptr=None, scan_id_base=0):
+        self._check(lib().lins_batch_run(self._h, C.c_void_p(poses_ptr) if poses_ptr else None, scan_id_base))
+
+    def sync(self):
+        self._check(lib().lins_sync(self._h))
+
+    def download(self, n=None):
+        n = self._n if n is None else n
+        res = (ResultC * n)()
+        self._check(lib().lins_batch_download(self._h, n, res))
+        return [Result(r) for r in res]
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        self._check(lib().lins_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def bytes_per_iter(self):
+        b = C.c_uint64(0)
+        self._check(lib().lins_batch_bytes_per_iter(self._h, C.byref(b)))
+        return b.value
+
+    def total_iters(self):
+        b = C.c_uint64(0)
+        self._check(lib().lins_batch_total_iters(self._h, C.byref(b)))
+        return b.value
+
+    # -- findCorrespondingSurfFeatures / findCorrespondingCornerFeatures ---------------
+    def correspondences(self, pair, lin_state, it):
+        c = pair.as_c()
+        lin = np.ascontiguousarray(lin_state, dtype=np.float64)
+        surf = np.zeros(c.n_surf_flat, dtype=CORR_DTYPE)
+        corner = np.zeros(c.n_corner_sharp, dtype=CORR_DTYPE)
+        self._check(lib().lins_correspondences(self._h, C.byref(c), lin.ctypes.data_as(C.POINTER(C.c_double)), it,
+                                               surf.ctypes.data, corner.ctypes.data))
+        return surf, corner
+
+    def reduce_pass(self, pair, lin_state, it):
+        c = pair.as_c()
+        lin = np.ascontiguousarray(lin_state, dtype=np.float64)
+        sums = np.zeros(28)
+        ms, mc = C.c_int32(0), C.c_int32(0)
+        self._check(lib().lins_reduce_pass(self._h, C.byref(c), lin.ctypes.data_as(C.POINTER(C.c_double)), it,
+                                           sums.ctypes.data_as(C.POINTER(C.c_double)), C.byref(ms), C.byref(mc)))
+        return sums, ms.value, mc.value
+
+
+def host_solve_from_sums(params, pair, lin_state, sums):
+    """BASELINE.json configs[1]: device correspondences + reduction, host-side
+    18x18 solve.  Faithful dense algebra on the 18-state system embedded from the
+    28 sums: dx = -W P (g + A d) + d with W = (sigma^2 I + P A)^-1."""
+    lin = np.asarray(lin_state, dtype=np.float64)
+    filt = pair.state
+    P = pair.cov
+
+    def quat2axis(q):
+        v = q[1:4]
+        m = np.linalg.norm(v)
+        if m < 1e-10:
+            return v.copy()
+        a = 2.0 * np.arctan2(m, q[0])
+        a = (a + np.pi) % (2 * np.pi) - np.pi
+        return v / m * a
+
+    def qmul(a, b):
+        return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+                         a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                         a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3],
+                         a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1]])
+
+    def rinvleft(ax):
+        th = np.linalg.norm(ax)
+        if th < 1e-10:
+            return np.eye(3)
+        h = th / 2
+        a = ax / th
+        s = h * np.cos(h) / np.sin(h)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        return s * np.eye(3) + (1 - s) * np.outer(a, a) - h * K
+
+    ql, qf = lin[6:10], filt[6:10]
+    G = rinvleft(-quat2axis(ql))
+    qinv = np.array([ql[0], -ql[1], -ql[2], -ql[3]]) / np.dot(ql, ql)
+    d = np.zeros(18)
+    d[0:3] = filt[0:3] - lin[0:3]
+    d[3:6] = filt[3:6] - lin[3:6]
+    d[6:9] = quat2axis(qmul(qinv, qf))
+    d[9:12] = filt[10:13] - lin[10:13]
+    d[12:15] = filt[13:16] - lin[13:16]
+    d[15:18] = filt[16:19] - lin[16:19]
+    s = sums
+    App = np.array([[s[0], s[1], s[2]], [s[1], s[3], s[4]], [s[2], s[4], s[5]]])
+    Apu = s[6:15].reshape(3, 3)
+    Auu = np.array([[s[15], s[16], s[17]], [s[16], s[18], s[19]], [s[17], s[19], s[20]]])
+    A = np.zeros((18, 18))
+    A[0:3, 0:3] = App
+    A[0:3, 6:9] = Apu @ G
+    A[6:9, 0:3] = (Apu @ G).T
+    A[6:9, 6:9] = G.T @ Auu @ G
+    g = np.zeros(18)
+    g[0:3] = s[21:24]
+    g[6:9] = G.T @ s[24:27]
+    r2 = params.lidar_std ** 2
+    W = np.linalg.inv(r2 * np.eye(18) + P @ A)
+    dx = -W @ P @ (g + A @ d) + d
+    return dx, A, W

@@ -1,0 +1,51 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PKG = "lins---lidar-inertial-slam_amd"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Build the in-tree libraries once (no-op when they are already there)."""
+    import __graft_entry__ as g
+
+    g.build(only_missing=True)
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return importlib.import_module(PKG)
+
+
+@pytest.fixture(scope="session")
+def host():
+    return importlib.import_module(PKG + ".host")
+
+
+@pytest.fixture(scope="session")
+def ieskf():
+    return importlib.import_module(PKG + ".ieskf")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as o
+
+    return o
+
+
+@pytest.fixture(scope="session")
+def pairs(host):
+    """A few seeded synthetic scan pairs, cached for the session."""
+    return host.synth_batch(6)

@@ -1,0 +1,110 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU
+oracle on the same seeded inputs.  Bars (BASELINE.json north_star / SURVEY.md §8d):
+  - correspondence index triplets and accepted sets: bit-exact
+  - f32 rows (coeff) and de-skewed points: bit-exact, allowing <=1 ulp on a
+    vanishing fraction (device libm sin/cos/atan2 differ from glibc in the last
+    f64 ulp before the cast to f32)
+  - state: |dp| <= 1e-6 m, |dq| <= 1e-7 ; covariance: max|dP| <= 1e-9 max|P|
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+POS_TOL, ATT_TOL, COV_REL = 1e-6, 1e-7, 1e-9
+
+
+def ulp_diff(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float32).view(np.int32).astype(np.int64)
+    b = np.ascontiguousarray(b, dtype=np.float32).view(np.int32).astype(np.int64)
+    a = np.where(a < 0, -(a & 0x7FFFFFFF), a)
+    b = np.where(b < 0, -(b & 0x7FFFFFFF), b)
+    return np.abs(a - b)
+
+
+def assert_corr_equal(got, want, what):
+    for f in ("ind1", "ind2", "ind3", "accepted"):
+        assert np.array_equal(got[f], want[f]), f"{what}.{f} differs at {np.nonzero(got[f] != want[f])[0][:8]}"
+    for f in ("coeff", "sel"):
+        u = ulp_diff(got[f], want[f])
+        assert u.max(initial=0) <= 1, f"{what}.{f}: {u.max()} ulp"
+        assert (u > 0).mean() <= 1e-3 if u.size else True, f"{what}.{f}: {(u > 0).mean():.2e} of values off by 1 ulp"
+
+
+def assert_result_close(got, want):
+    assert (got.iters, got.converged, got.diverged) == (want.iters, want.converged, want.diverged), (got, want)
+    assert (got.m_surf, got.m_corner) == (want.m_surf, want.m_corner), (got, want)
+    assert np.abs(got.state[:3] - want.state[:3]).max() <= POS_TOL
+    assert np.abs(got.state[6:10] - want.state[6:10]).max() <= ATT_TOL
+    assert np.abs(got.state - want.state).max() <= 1e-5  # v, biases, gravity
+    assert np.abs(got.cov - want.cov).max() <= COV_REL * np.abs(want.cov).max()
+    assert abs(got.residual_norm - want.residual_norm) <= 1e-9 * max(1.0, want.residual_norm)
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg, ieskf):
+    c = ieskf.IeskfContext(pkg.default_params(num_iter=30), device=0, max_batch=64, max_targets=16384)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("search", ["brute", "binned"])
+def test_correspondences_bit_exact_along_oracle_trajectory(pkg, oracle, ctx, pairs, search):
+    """configs[1]: device A2+A3 at every linearisation state the oracle visits."""
+    ctx.set_search(search)
+    prm = pkg.default_params(num_iter=30)
+    for pair in pairs[:3]:
+        _, tr = oracle.ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_BRUTE, trace=True)
+        res = oracle.ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_BRUTE)
+        for k in range(res.iters):
+            surf, corner = ctx.correspondences(pair, tr["lin_state"][k], k)
+            assert_corr_equal(surf, tr["surf"][k], f"iter{k}.surf")
+            assert_corr_equal(corner, tr["corner"][k], f"iter{k}.corner")
+
+
+@pytest.mark.parametrize("search", ["brute", "binned"])
+def test_reduction_and_host_solve(pkg, ieskf, oracle, ctx, pairs, search):
+    """configs[1]: on-device 28-sum reduction + host-side 18x18 solve == oracle dx."""
+    ctx.set_search(search)
+    prm = pkg.default_params(num_iter=30)
+    pair = pairs[0]
+    _, tr = oracle.ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_BRUTE, trace=True)
+    for k in range(3):
+        sums, ms, mc = ctx.reduce_pass(pair, tr["lin_state"][k], k)
+        want = tr["sums28"][k]
+        assert np.abs(sums - want).max() <= 1e-11 * max(1.0, np.abs(want).max())
+        assert ms == int(tr["surf"][k]["accepted"].sum()) and mc == int(tr["corner"][k]["accepted"].sum())
+        dx, _, _ = ieskf.host_solve_from_sums(prm, pair, tr["lin_state"][k], sums)
+        assert np.abs(dx - tr["dx"][k]).max() <= 1e-8 * max(1.0, np.abs(tr["dx"][k]).max())
+
+
+@pytest.mark.parametrize("search", ["brute", "binned"])
+def test_full_ieskf_matches_oracle(pkg, oracle, ctx, pairs, search):
+    """configs[2]: on-device reduction + solve + full loop, reference stop rule."""
+    ctx.set_search(search)
+    prm = pkg.default_params(num_iter=30)
+    for pair in pairs:
+        got = ctx.update(pair)
+        want = oracle.ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_KDTREE)
+        assert_result_close(got, want)
+
+
+def test_fixed_iteration_mode_and_batch(pkg, ieskf, oracle, pairs):
+    """configs[0]/[3]: exactly 10 iterations per scan, batched launch == per-scan oracle."""
+    prm = pkg.default_params(num_iter=10, fixed_iters=1)
+    with ieskf.IeskfContext(prm, max_batch=len(pairs), max_targets=16384) as c:
+        res = c.update_batch(pairs)
+        for got, pair in zip(res, pairs):
+            want = oracle.ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_KDTREE)
+            assert want.iters == 10 or want.diverged
+            assert_result_close(got, want)
+        # staged API: same results, deterministic across runs (fixed reduction tree)
+        c.upload(pairs)
+        c.run()
+        c.sync()
+        again = c.download()
+        for a, b in zip(res, again):
+            assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov)
+        assert c.total_iters() == sum(r.iters for r in res)
+        assert c.bytes_per_iter() == sum(p.bytes_per_iter() for p in pairs)
+        assert c.last_kernel_ms() > 0
