@@ -43,7 +43,7 @@ extern "C" {
 #define LINS_STATE_DIM 19  /* GlobalState as stored: p,v,q(wxyz),ba,bw,g           */
 #define LINS_ERR_DIM 18    /* GlobalState::DIM_OF_STATE_ (KalmanFilter.hpp:39)     */
 #define LINS_MAX_QUERY 1024  /* per cloud; reference caps: 192 sharp / 144 flat    */
-#define LINS_MAX_RING 64     /* int(intensity) must lie in [0, LINS_MAX_RING)      */
+#define LINS_MAX_RING 64     /* intensity in (-1, LINS_MAX_RING): int() in [0, 63]  */
 
 /* error codes */
 #define LINS_OK 0

@@ -75,14 +75,16 @@ int fail_hip(lins_ctx* ctx, hipError_t e, const char* what) {
 
 inline size_t align4(size_t n) { return (n + 3) & ~size_t(3); }
 
-// input contract: finite xyz, ring id in [0, LINS_MAX_RING); reports ring-sortedness
+// input contract: finite fields, int(intensity) in [0, LINS_MAX_RING) — the relative-time
+// fraction may be slightly negative (SE:631-650 produces -0.025..0.125), and C truncation
+// maps (-1, 0) to ring 0 exactly as the reference's int() does; reports ring-sortedness
 int check_cloud(const lins_point* p, int n, bool* sorted) {
   int prev = -1;
   bool s = true;
   for (int i = 0; i < n; ++i) {
     if (!std::isfinite(p[i].x) || !std::isfinite(p[i].y) || !std::isfinite(p[i].z) || !std::isfinite(p[i].intensity))
       return LINS_E_INPUT;
-    if (p[i].intensity < 0.f || p[i].intensity >= (float)LINS_MAX_RING) return LINS_E_INPUT;
+    if (p[i].intensity <= -1.f || p[i].intensity >= (float)LINS_MAX_RING) return LINS_E_INPUT;
     int r = (int)p[i].intensity;
     if (r < prev) s = false;
     prev = r;
