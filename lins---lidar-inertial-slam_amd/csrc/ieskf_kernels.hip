@@ -19,6 +19,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
+#include "ieskf_binned.h"
 #include "ieskf_device.h"
 
 namespace lins {
@@ -28,8 +31,6 @@ struct OutRec {
   int iters, converged, diverged, m_surf, m_corner, pad[3];
 };
 
-struct BinIndex;  // defined with the binned search below
-
 __constant__ unsigned char kPairA[28] = {0, 0, 0, 1, 1, 2, 0, 0, 0, 1, 1, 1, 2, 2,
                                          2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6};
 __constant__ unsigned char kPairB[28] = {0, 1, 2, 1, 2, 2, 3, 4, 5, 3, 4, 5, 3, 4,
@@ -38,10 +39,18 @@ __constant__ unsigned char kPairB[28] = {0, 1, 2, 1, 2, 2, 3, 4, 5, 3, 4, 5, 3, 
 // ---------------------------------------------------------------------------
 // one query feature -> (indices, accepted, coeff)
 // ---------------------------------------------------------------------------
+struct NoBins {};
+
+// LDS views of the two target grids of the scan this workgroup owns
+struct ScanBins {
+  CloudBins surf, corner;
+};
+
 template <int SEARCH>
 __device__ __forceinline__ void process_surf(const DevParams& prm, const ScanDesc& sd,
-                                             const float4* __restrict__ arena, const V3& phi, const V3& t,
-                                             int iter, bool do_search, int i, const float4& q, QueryOut& o) {
+                                             const float4* __restrict__ arena, const ScanBins* sb, const V3& phi,
+                                             const V3& t, int iter, bool do_search, int i, const float4& q,
+                                             QueryOut& o) {
   const float4* tg = arena + sd.off_surf_t;
   transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2]);
   o.accepted = 0;
@@ -50,10 +59,19 @@ __device__ __forceinline__ void process_surf(const DevParams& prm, const ScanDes
     int j1;
     float d1;
     o.j1 = o.j2 = o.j3 = -1;
-    nn_brute(tg, sd.n_surf_t, o.sel[0], o.sel[1], o.sel[2], j1, d1);
-    if (j1 >= 0 && (double)d1 < prm.nearest) {
-      o.j1 = j1;
-      walk_surf_literal(tg, sd.n_surf_t, sd.n_surf_q, prm.nearest_f, j1, o.sel[0], o.sel[1], o.sel[2], o.j2, o.j3);
+    if (SEARCH == SEARCH_BINNED && sd.surf_sorted) {
+      nn_binned(sb->surf, o.sel[0], o.sel[1], o.sel[2], prm.nearest_f, ring_of(q.w), j1, d1);
+      if (j1 >= 0 && (double)d1 < prm.nearest) {
+        o.j1 = j1;
+        walk_surf_binned(sb->surf, sd.n_surf_q, prm.nearest_f, j1, ring_of(tg[j1].w), o.sel[0], o.sel[1], o.sel[2],
+                         o.j2, o.j3);
+      }
+    } else {
+      nn_brute(tg, sd.n_surf_t, o.sel[0], o.sel[1], o.sel[2], j1, d1);
+      if (j1 >= 0 && (double)d1 < prm.nearest) {
+        o.j1 = j1;
+        walk_surf_literal(tg, sd.n_surf_t, sd.n_surf_q, prm.nearest_f, j1, o.sel[0], o.sel[1], o.sel[2], o.j2, o.j3);
+      }
     }
   }
   if (o.j2 >= 0 && o.j3 >= 0)
@@ -62,8 +80,9 @@ __device__ __forceinline__ void process_surf(const DevParams& prm, const ScanDes
 
 template <int SEARCH>
 __device__ __forceinline__ void process_corner(const DevParams& prm, const ScanDesc& sd,
-                                               const float4* __restrict__ arena, const V3& phi, const V3& t,
-                                               int iter, bool do_search, int i, const float4& q, QueryOut& o) {
+                                               const float4* __restrict__ arena, const ScanBins* sb, const V3& phi,
+                                               const V3& t, int iter, bool do_search, int i, const float4& q,
+                                               QueryOut& o) {
   const float4* tg = arena + sd.off_corner_t;
   transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2]);
   o.accepted = 0;
@@ -73,10 +92,19 @@ __device__ __forceinline__ void process_corner(const DevParams& prm, const ScanD
     float d1;
     o.j1 = o.j2 = -1;
     o.j3 = -1;
-    nn_brute(tg, sd.n_corner_t, o.sel[0], o.sel[1], o.sel[2], j1, d1);
-    if (j1 >= 0 && (double)d1 < prm.nearest) {
-      o.j1 = j1;
-      walk_corner_literal(tg, sd.n_corner_t, sd.n_corner_q, prm.nearest_f, j1, o.sel[0], o.sel[1], o.sel[2], o.j2);
+    if (SEARCH == SEARCH_BINNED && sd.corner_sorted) {
+      nn_binned(sb->corner, o.sel[0], o.sel[1], o.sel[2], prm.nearest_f, ring_of(q.w), j1, d1);
+      if (j1 >= 0 && (double)d1 < prm.nearest) {
+        o.j1 = j1;
+        walk_corner_binned(sb->corner, sd.n_corner_q, prm.nearest_f, j1, ring_of(tg[j1].w), o.sel[0], o.sel[1],
+                           o.sel[2], o.j2);
+      }
+    } else {
+      nn_brute(tg, sd.n_corner_t, o.sel[0], o.sel[1], o.sel[2], j1, d1);
+      if (j1 >= 0 && (double)d1 < prm.nearest) {
+        o.j1 = j1;
+        walk_corner_literal(tg, sd.n_corner_t, sd.n_corner_q, prm.nearest_f, j1, o.sel[0], o.sel[1], o.sel[2], o.j2);
+      }
     }
   }
   if (o.j2 >= 0) corner_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], tg[o.j1], tg[o.j2], o);
@@ -85,9 +113,9 @@ __device__ __forceinline__ void process_corner(const DevParams& prm, const ScanD
 // slot -> query (surf slots first, then corner: the reference's concat order SE:499-504)
 template <int SEARCH>
 __device__ __forceinline__ void process_slot(const DevParams& prm, const ScanDesc& sd,
-                                             const float4* __restrict__ arena, const V3& phi, const V3& t,
-                                             int iter, bool do_search, int slot, int4* __restrict__ idx_store,
-                                             QueryOut& o, float4& q, bool& is_surf) {
+                                             const float4* __restrict__ arena, const ScanBins* sb, const V3& phi,
+                                             const V3& t, int iter, bool do_search, int slot,
+                                             int4* __restrict__ idx_store, QueryOut& o, float4& q, bool& is_surf) {
   is_surf = slot < sd.n_surf_q;
   int i = is_surf ? slot : slot - sd.n_surf_q;
   q = arena[(is_surf ? sd.off_surf_q : sd.off_corner_q) + i];
@@ -96,9 +124,9 @@ __device__ __forceinline__ void process_slot(const DevParams& prm, const ScanDes
     o.j1 = s.x, o.j2 = s.y, o.j3 = s.z;
   }
   if (is_surf)
-    process_surf<SEARCH>(prm, sd, arena, phi, t, iter, do_search, i, q, o);
+    process_surf<SEARCH>(prm, sd, arena, sb, phi, t, iter, do_search, i, q, o);
   else
-    process_corner<SEARCH>(prm, sd, arena, phi, t, iter, do_search, i, q, o);
+    process_corner<SEARCH>(prm, sd, arena, sb, phi, t, iter, do_search, i, q, o);
   if (do_search && prm.icp_freq > 1) idx_store[sd.slot_base + slot] = make_int4(o.j1, o.j2, o.j3, 0);
 }
 
@@ -120,6 +148,27 @@ struct Shared {
   int iter, conv, div, pad;
 };
 
+// Build the (ring x column) grids of this scan's two target clouds (binned search only).
+template <int SEARCH>
+__device__ __forceinline__ void setup_bins(const ScanDesc& sd, const float4* __restrict__ arena,
+                                           float4* __restrict__ binned, BinStorage* bs, ScanBins* sb, int tid) {
+  if (SEARCH != SEARCH_BINNED) return;
+  build_az_edges(bs->az_edge, tid);
+  if (sd.surf_sorted)
+    build_cloud_bins(arena + sd.off_surf_t, sd.n_surf_t, kAzSurf, bs->cell_surf, bs->ring_start[0], bs->el_bits[0],
+                     bs->el[0], binned + sd.off_surf_t, tid, bs->scan_tmp);
+  if (sd.corner_sorted)
+    build_cloud_bins(arena + sd.off_corner_t, sd.n_corner_t, kAzCorner, bs->cell_corner, bs->ring_start[1],
+                     bs->el_bits[1], bs->el[1], binned + sd.off_corner_t, tid, bs->scan_tmp);
+  if (tid == 0) {
+    sb->surf = CloudBins{bs->cell_surf, bs->ring_start[0], &bs->el[0][0][0], bs->az_edge, binned + sd.off_surf_t,
+                         kAzSurf, 1, sd.n_surf_t};
+    sb->corner = CloudBins{bs->cell_corner, bs->ring_start[1], &bs->el[1][0][0], bs->az_edge,
+                           binned + sd.off_corner_t, kAzCorner, kAzSurf / kAzCorner, sd.n_corner_t};
+  }
+  __syncthreads();
+}
+
 // rows -> 28 sums.  Group g folds rows g, g+8, ... in order; then the 8 group
 // partials are folded in order.  Same tree every run => deterministic.
 __device__ __forceinline__ void accumulate_rows(const double* rows, int nrows, int tid, double& acc) {
@@ -132,7 +181,8 @@ __device__ __forceinline__ void accumulate_rows(const double* rows, int nrows, i
 
 template <int SEARCH>
 __device__ __forceinline__ void correspondence_round(const DevParams& prm, const ScanDesc& sd,
-                                                     const float4* __restrict__ arena, const IterConst& ic,
+                                                     const float4* __restrict__ arena, const ScanBins* sb,
+                                                     const IterConst& ic,
                                                      int iter, bool do_search, int base, int total,
                                                      int4* __restrict__ idx_store, double* rows, int tid,
                                                      int& ms, int& mc, lins_corr* __restrict__ dump) {
@@ -147,7 +197,7 @@ __device__ __forceinline__ void correspondence_round(const DevParams& prm, const
       QueryOut o;
       float4 q;
       bool is_surf;
-      process_slot<SEARCH>(prm, sd, arena, phi, t, iter, do_search, slot, idx_store, o, q, is_surf);
+      process_slot<SEARCH>(prm, sd, arena, sb, phi, t, iter, do_search, slot, idx_store, o, q, is_surf);
       if (o.accepted) {
         V3 c{(double)o.c[0], (double)o.c[1], (double)o.c[2]};
         V3 w = mvec(ic.Rt, c);
@@ -183,8 +233,10 @@ __global__ __launch_bounds__(kBlock) void ieskf_persistent_kernel(
     DevParams prm, const ScanDesc* __restrict__ descs, const float4* __restrict__ arena,
     const double* __restrict__ state_in, const double* __restrict__ cov_in, double* __restrict__ state_out,
     double* __restrict__ cov_out, OutRec* __restrict__ out, int4* __restrict__ idx_store,
-    lins_pose_record* __restrict__ poses, int scan_id_base) {
+    lins_pose_record* __restrict__ poses, int scan_id_base, float4* __restrict__ binned) {
   __shared__ Shared sh;
+  __shared__ std::conditional_t<SEARCH == SEARCH_BINNED, BinStorage, NoBins> bstore;
+  __shared__ ScanBins sbins;
   const int tid = threadIdx.x;
   const int scan = blockIdx.x;
   const ScanDesc sd = descs[scan];
@@ -201,6 +253,7 @@ __global__ __launch_bounds__(kBlock) void ieskf_persistent_kernel(
     sh.iter = 0, sh.conv = 0, sh.div = 0, sh.m_surf = 0, sh.m_corner = 0;
   }
   __syncthreads();
+  setup_bins<SEARCH>(sd, arena, binned, (BinStorage*)&bstore, &sbins, tid);
 
   for (;;) {
     const int iter = sh.iter;
@@ -225,8 +278,8 @@ __global__ __launch_bounds__(kBlock) void ieskf_persistent_kernel(
     double acc = 0;
     int ms = 0, mc = 0;
     for (int base = 0; base < total; base += kRowsCap) {
-      correspondence_round<SEARCH>(prm, sd, arena, sh.ic, iter, do_search, base, total, idx_store, sh.rows,
-                                   tid, ms, mc, nullptr);
+      correspondence_round<SEARCH>(prm, sd, arena, &sbins, sh.ic, iter, do_search, base, total, idx_store,
+                                   sh.rows, tid, ms, mc, nullptr);
       __syncthreads();
       int nrows = total - base < kRowsCap ? total - base : kRowsCap;
       accumulate_rows(sh.rows, nrows, tid, acc);
@@ -408,7 +461,9 @@ __global__ __launch_bounds__(kBlock) void ieskf_pass_kernel(
     DevParams prm, const ScanDesc* __restrict__ descs, const float4* __restrict__ arena,
     const double* __restrict__ lin_state, const double* __restrict__ filt_state, int iter,
     int4* __restrict__ idx_store, lins_corr* __restrict__ dump, double* __restrict__ sums_out,
-    int* __restrict__ counts_out) {
+    int* __restrict__ counts_out, float4* __restrict__ binned) {
+  __shared__ std::conditional_t<SEARCH == SEARCH_BINNED, BinStorage, NoBins> bstore;
+  __shared__ ScanBins sbins;
   __shared__ IterConst ic;
   __shared__ double rows[kRowsCap * 7];
   __shared__ double partial[kRedGroups * 28];
@@ -427,11 +482,12 @@ __global__ __launch_bounds__(kBlock) void ieskf_pass_kernel(
     }
   }
   __syncthreads();
+  setup_bins<SEARCH>(sd, arena, binned, (BinStorage*)&bstore, &sbins, tid);
   double acc = 0;
   int ms = 0, mc = 0;
   for (int base = 0; base < total; base += kRowsCap) {
-    correspondence_round<SEARCH>(prm, sd, arena, ic, iter, true, base, total, idx_store, rows, tid, ms, mc,
-                                 dump ? dump + sd.slot_base : nullptr);
+    correspondence_round<SEARCH>(prm, sd, arena, &sbins, ic, iter, true, base, total, idx_store, rows, tid, ms,
+                                 mc, dump ? dump + sd.slot_base : nullptr);
     __syncthreads();
     int nrows = total - base < kRowsCap ? total - base : kRowsCap;
     accumulate_rows(rows, nrows, tid, acc);
@@ -455,24 +511,25 @@ __global__ __launch_bounds__(kBlock) void ieskf_pass_kernel(
 // ---------------------------------------------------------------------------
 void launch_persistent(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs,
                        const float4* arena, const double* state_in, const double* cov_in, double* state_out,
-                       double* cov_out, void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base) {
+                       double* cov_out, void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base,
+                       float4* binned) {
   if (prm.search == SEARCH_BINNED)
     hipLaunchKernelGGL(ieskf_persistent_kernel<SEARCH_BINNED>, dim3(n), dim3(kBlock), 0, stream, prm, descs, arena,
-                       state_in, cov_in, state_out, cov_out, (OutRec*)out, idx_store, poses, scan_id_base);
+                       state_in, cov_in, state_out, cov_out, (OutRec*)out, idx_store, poses, scan_id_base, binned);
   else
     hipLaunchKernelGGL(ieskf_persistent_kernel<SEARCH_BRUTE>, dim3(n), dim3(kBlock), 0, stream, prm, descs, arena,
-                       state_in, cov_in, state_out, cov_out, (OutRec*)out, idx_store, poses, scan_id_base);
+                       state_in, cov_in, state_out, cov_out, (OutRec*)out, idx_store, poses, scan_id_base, binned);
 }
 
 void launch_pass(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
                  const double* lin_state, const double* filt_state, int iter, int4* idx_store, lins_corr* dump,
-                 double* sums_out, int* counts_out) {
+                 double* sums_out, int* counts_out, float4* binned) {
   if (prm.search == SEARCH_BINNED)
     hipLaunchKernelGGL(ieskf_pass_kernel<SEARCH_BINNED>, dim3(n), dim3(kBlock), 0, stream, prm, descs, arena,
-                       lin_state, filt_state, iter, idx_store, dump, sums_out, counts_out);
+                       lin_state, filt_state, iter, idx_store, dump, sums_out, counts_out, binned);
   else
     hipLaunchKernelGGL(ieskf_pass_kernel<SEARCH_BRUTE>, dim3(n), dim3(kBlock), 0, stream, prm, descs, arena,
-                       lin_state, filt_state, iter, idx_store, dump, sums_out, counts_out);
+                       lin_state, filt_state, iter, idx_store, dump, sums_out, counts_out, binned);
 }
 
 size_t out_rec_size() { return sizeof(OutRec); }

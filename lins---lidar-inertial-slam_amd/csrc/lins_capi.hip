@@ -18,9 +18,9 @@
 
 namespace lins {
 void launch_persistent(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const double*,
-                       const double*, double*, double*, void*, int4*, lins_pose_record*, int);
+                       const double*, double*, double*, void*, int4*, lins_pose_record*, int, float4*);
 void launch_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const double*, const double*,
-                 int, int4*, lins_corr*, double*, int*);
+                 int, int4*, lins_corr*, double*, int*, float4*);
 size_t out_rec_size();
 struct OutRecHost {
   double residual_norm, update_norm;
@@ -46,6 +46,7 @@ struct lins_ctx {
   OutRecHost* h_out = nullptr;
   // device
   float4* d_arena = nullptr;
+  float4* d_binned = nullptr;  // (ring x column)-sorted copies of the target clouds
   ScanDesc* d_desc = nullptr;
   double *d_state_in = nullptr, *d_cov_in = nullptr, *d_state_out = nullptr, *d_cov_out = nullptr;
   double* d_lin = nullptr;
@@ -80,13 +81,13 @@ inline size_t align4(size_t n) { return (n + 3) & ~size_t(3); }
 // maps (-1, 0) to ring 0 exactly as the reference's int() does; reports ring-sortedness
 int check_cloud(const lins_point* p, int n, bool* sorted) {
   int prev = -1;
-  bool s = true;
+  bool s = true;  // "grid-able": ring-sorted and every ring id < 16 (binned search precondition)
   for (int i = 0; i < n; ++i) {
     if (!std::isfinite(p[i].x) || !std::isfinite(p[i].y) || !std::isfinite(p[i].z) || !std::isfinite(p[i].intensity))
       return LINS_E_INPUT;
     if (p[i].intensity <= -1.f || p[i].intensity >= (float)LINS_MAX_RING) return LINS_E_INPUT;
     int r = (int)p[i].intensity;
-    if (r < prev) s = false;
+    if (r < prev || r >= 16) s = false;
     prev = r;
   }
   if (sorted) *sorted = s;
@@ -215,6 +216,7 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_cov, nb * 324 * 8));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_out, nb * sizeof(OutRecHost)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_arena, ctx->arena_cap * sizeof(float4)));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_binned, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_desc, nb * sizeof(ScanDesc)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_state_in, nb * 19 * 8));
   CREATE_TRY(hipMalloc((void**)&ctx->d_cov_in, nb * 324 * 8));
@@ -242,6 +244,7 @@ void lins_destroy(lins_ctx* ctx) {
   (void)hipHostFree(ctx->h_cov);
   (void)hipHostFree(ctx->h_out);
   (void)hipFree(ctx->d_arena);
+  (void)hipFree(ctx->d_binned);
   (void)hipFree(ctx->d_desc);
   (void)hipFree(ctx->d_state_in);
   (void)hipFree(ctx->d_cov_in);
@@ -279,7 +282,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   launch_persistent(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_state_in,
                     ctx->d_cov_in, ctx->d_state_out, ctx->d_cov_out, ctx->d_out, ctx->d_idx,
-                    (lins_pose_record*)d_poses, scan_id_base);
+                    (lins_pose_record*)d_poses, scan_id_base, ctx->d_binned);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->ran = true;
@@ -363,7 +366,7 @@ static int run_pass(lins_ctx* ctx, const lins_scan_pair* in, const double* lin_s
   ctx->n_uploaded = 0;  // the single-pass calls do not leave a runnable batch behind
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_lin, lin_state, 19 * 8, hipMemcpyHostToDevice, ctx->stream));
   launch_pass(ctx->stream, 1, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_lin, ctx->d_state_in, iter, ctx->d_idx,
-              dump ? ctx->d_dump : nullptr, sums ? ctx->d_sums : nullptr, sums ? ctx->d_counts : nullptr);
+              dump ? ctx->d_dump : nullptr, sums ? ctx->d_sums : nullptr, sums ? ctx->d_counts : nullptr, ctx->d_binned);
   HIP_TRY(ctx, hipGetLastError());
   return LINS_OK;
 }
