@@ -170,11 +170,12 @@ int lins_batch_total_iters(lins_ctx* ctx, uint64_t* iters);
 int lins_correspondences(lins_ctx* ctx, const lins_scan_pair* in,
                          const double* lin_state, int iter, lins_corr* surf,
                          lins_corr* corner);
-/* Same pass followed by the on-device reduction: 28 f64 sums
- *   [0..5]  A_pp (upper tri, row-major: 00 01 02 11 12 22)
- *   [6..14] A_pu (3x3 row-major)     [15..20] A_uu (upper tri)
- *   [21..23] g_p  [24..26] g_u  [27] sum r^2
- *  and the accepted-row counts.                          */
+/* Same pass followed by the on-device reduction: 28 f64 sums over the accepted
+ * rows h = (c0 c1 c2 a0 a1 a2), a = Rinvleft(-phi)^T (p x R^T c)  (SE:526-531):
+ *   [0..20]  upper triangle of H^T H, row-major (00 01 .. 05 11 12 .. 55)
+ *   [21..26] H^T r        [27] r^T r
+ * i.e. the non-zero 6x6 block (columns pos 0-2, att 6-8) of the 18x18 normal
+ * equations, and the accepted-row counts.                    */
 int lins_reduce_pass(lins_ctx* ctx, const lins_scan_pair* in,
                      const double* lin_state, int iter, double* sums28,
                      int32_t* m_surf, int32_t* m_corner);

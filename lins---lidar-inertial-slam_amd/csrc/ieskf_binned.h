@@ -69,33 +69,69 @@ __device__ __forceinline__ float ring_bound_sq(const float* el, float rho, float
   return 0.f;
 }
 
-// Visit the cells of ring r in order of growing column distance from a0 while the
-// column bound does not exceed `bound()`; `visit(cell)` may tighten the bound.
-template <class Bound, class Visit>
-__device__ __forceinline__ void for_ring_cells(const CloudBins& cb, int r, int a0, float qx, float qy, float qn,
-                                               Bound bound, Visit visit) {
-  const int naz = cb.naz, base = r * naz;
-  visit(base + a0);
-  bool right = true, left = true;
-  for (int k = 1; k <= naz / 2 && (right || left); ++k) {
-    if (right) {
-      int a = a0 + k;  // lower edge of column a0+k
-      float2 u = cb.az_edge[(a <= naz ? a : a - naz) * cb.az_stride];
-      if (ray_bound_sq(qx, qy, qn, u) > bound())
-        right = false;
-      else
-        visit(base + (a >= naz ? a - naz : a));
-    }
-    if (left && k <= naz / 2 - 1) {
-      int a = a0 - k;  // upper edge of column a0-k is edge (a0-k+1)
-      int e = a + 1;
-      float2 u = cb.az_edge[(e >= 0 ? e : e + naz) * cb.az_stride];
-      if (ray_bound_sq(qx, qy, qn, u) > bound())
-        left = false;
-      else
-        visit(base + (a < 0 ? a + naz : a));
-    }
+// All points of binned[s, e): four independent 16-byte loads in flight per step (the
+// gather is latency-bound; a column window is one contiguous span of the cell-major array).
+template <class F>
+__device__ __forceinline__ void for_span_points(const float4* __restrict__ b, unsigned s, unsigned e, F f) {
+  for (unsigned p = s; p < e; p += 4) {
+    const unsigned last = e - 1;
+    float4 t0 = b[p];
+    float4 t1 = b[p + 1 < last ? p + 1 : last];
+    float4 t2 = b[p + 2 < last ? p + 2 : last];
+    float4 t3 = b[p + 3 < last ? p + 3 : last];
+    f(t0);
+    if (p + 1 < e) f(t1);
+    if (p + 2 < e) f(t2);
+    if (p + 3 < e) f(t3);
   }
+}
+
+// columns [lo, hi] of ring-row `base` (lo, hi may run past the wrap on either side)
+template <class F>
+__device__ __forceinline__ void for_columns(const CloudBins& cb, int base, int lo, int hi, F f) {
+  const int naz = cb.naz;
+  if (lo > hi) return;
+  auto span = [&](int a, int b) {  // 0 <= a <= b < naz
+    int c0 = base + a, c1 = base + b;
+    for_span_points(cb.binned, c0 ? cb.cell_end[c0 - 1] : 0u, cb.cell_end[c1], f);
+  };
+  if (lo < 0) {
+    span(lo + naz, naz - 1);
+    if (hi >= 0) span(0, hi);
+  } else if (hi >= naz) {
+    span(lo, naz - 1);
+    span(0, hi - naz);
+  } else {
+    span(lo, hi);
+  }
+}
+
+// Visit ring r: first the seed window a0-1..a0+1, then — with the bound tightened by
+// the seed — the columns to the right and to the left whose edge bound does not exceed
+// `bound()`.  The window is fixed before each span is read (a superset of what a
+// cell-by-cell adaptive walk would touch, never a subset), so a ring costs at most
+// three dependent gather rounds instead of one per cell.
+template <class Bound, class F>
+__device__ __forceinline__ void scan_ring(const CloudBins& cb, int r, int a0, float qx, float qy, float qn,
+                                          Bound bound, F f) {
+  const int naz = cb.naz, base = r * naz, half = naz / 2;
+  for_columns(cb, base, a0 - 1, a0 + 1, f);
+  // column a0+k is needed iff the bound of its lower edge (a0+k) is within reach
+  int kr = 1;
+  while (kr < half) {
+    int e = a0 + kr + 1;
+    if (ray_bound_sq(qx, qy, qn, cb.az_edge[(e <= naz ? e : e - naz) * cb.az_stride]) > bound()) break;
+    ++kr;
+  }
+  // column a0-k is needed iff the bound of its upper edge (a0-k+1) is within reach
+  int kl = 1;
+  while (kl < half - 1) {
+    int e = a0 - kl;
+    if (ray_bound_sq(qx, qy, qn, cb.az_edge[(e >= 0 ? e : e + naz) * cb.az_stride]) > bound()) break;
+    ++kl;
+  }
+  for_columns(cb, base, a0 + 2, a0 + kr, f);
+  for_columns(cb, base, a0 - kl, a0 - 2, f);
 }
 
 // ---- pass 1: exact nearest neighbour (lowest index wins ties) -----------------------
@@ -112,16 +148,12 @@ __device__ __forceinline__ void nn_binned(const CloudBins& cb, float sx, float s
     if (r < 0 || r >= kRingsBinned) continue;
     if (cb.ring_start[r + 1] == cb.ring_start[r]) continue;
     if (ring_bound_sq(cb.el + 4 * r, rho, sz, qn3) > best_d) continue;
-    for_ring_cells(
+    scan_ring(
         cb, r, a0, sx, sy, rho, [&]() { return best_d; },
-        [&](int cell) {
-          unsigned e = cb.cell_end[cell], s = cell ? cb.cell_end[cell - 1] : 0u;
-          for (unsigned p = s; p < e; ++p) {
-            float4 t = cb.binned[p];
-            int j = __float_as_int(t.w);
-            float d = sqdist3(t.x, t.y, t.z, sx, sy, sz);
-            if (d < best_d || (d == best_d && j < best_j)) best_d = d, best_j = j;
-          }
+        [&](const float4& t) {
+          int j = __float_as_int(t.w);
+          float d = sqdist3(t.x, t.y, t.z, sx, sy, sz);
+          if (d < best_d || (d == best_d && j < best_j)) best_d = d, best_j = j;
         });
   }
 }
@@ -144,29 +176,27 @@ __device__ __forceinline__ void walk_surf_binned(const CloudBins& cb, int nq, fl
   const float rho_q = sqrtf(sx * sx + sy * sy);
   const float qn3 = sqrtf(rho_q * rho_q + sz * sz);
   const int a0 = az_bin(sx, sy, cb.naz);
-  for (int r = r_lo; r < r_hi; ++r) {
+  for (int i = 0; i < 5; ++i) {  // rho, rho-1, rho+1, rho-2, rho+2: near rings tighten the bounds first
+    const int r = rho + ((i & 1) ? -((i + 1) / 2) : i / 2);
+    if (r < r_lo || r >= r_hi) continue;
     const int rs = cb.ring_start[r], re = cb.ring_start[r + 1];
     const bool fwd = (j1 + 1 > rs ? j1 + 1 : rs) < (f_hi < re ? f_hi : re);
     const bool bwd = (b_lo > rs ? b_lo : rs) < (j1 < re ? j1 : re);
     if (!fwd && !bwd) continue;
     const bool c2 = (r == rho);
     if (ring_bound_sq(cb.el + 4 * r, rho_q, sz, qn3) > (c2 ? d2 : d3)) continue;
-    for_ring_cells(
+    scan_ring(
         cb, r, a0, sx, sy, rho_q, [&]() { return c2 ? d2 : d3; },
-        [&](int cell) {
-          unsigned e = cb.cell_end[cell], s = cell ? cb.cell_end[cell - 1] : 0u;
-          for (unsigned p = s; p < e; ++p) {
-            float4 t = cb.binned[p];
-            int j = __float_as_int(t.w);
-            bool ok = (j > j1 && j < f_hi) || (j < j1 && j >= b_lo);
-            if (!ok) continue;
-            int rank = j > j1 ? j - j1 : kBackRank + (j1 - j);
-            float d = sqdist3(t.x, t.y, t.z, sx, sy, sz);
-            if (c2) {
-              if (d < d2 || (d == d2 && m2 >= 0 && rank < k2)) d2 = d, m2 = j, k2 = rank;
-            } else {
-              if (d < d3 || (d == d3 && m3 >= 0 && rank < k3)) d3 = d, m3 = j, k3 = rank;
-            }
+        [&](const float4& t) {
+          int j = __float_as_int(t.w);
+          bool ok = (j > j1 && j < f_hi) || (j < j1 && j >= b_lo);
+          if (!ok) return;
+          int rank = j > j1 ? j - j1 : kBackRank + (j1 - j);
+          float d = sqdist3(t.x, t.y, t.z, sx, sy, sz);
+          if (c2) {
+            if (d < d2 || (d == d2 && m2 >= 0 && rank < k2)) d2 = d, m2 = j, k2 = rank;
+          } else {
+            if (d < d3 || (d == d3 && m3 >= 0 && rank < k3)) d3 = d, m3 = j, k3 = rank;
           }
         });
   }
@@ -186,26 +216,23 @@ __device__ __forceinline__ void walk_corner_binned(const CloudBins& cb, int nq, 
   const float rho_q = sqrtf(sx * sx + sy * sy);
   const float qn3 = sqrtf(rho_q * rho_q + sz * sz);
   const int a0 = az_bin(sx, sy, cb.naz);
-  for (int r = r_lo; r < r_hi; ++r) {
-    if (r == rho) continue;
+  for (int i = 1; i < 5; ++i) {  // rho-1, rho+1, rho-2, rho+2
+    const int r = rho + ((i & 1) ? -((i + 1) / 2) : i / 2);
+    if (r < r_lo || r >= r_hi) continue;
     const int rs = cb.ring_start[r], re = cb.ring_start[r + 1];
     const bool any = r > rho ? ((j1 + 1 > rs ? j1 + 1 : rs) < (f_hi < re ? f_hi : re))
                              : ((b_lo > rs ? b_lo : rs) < (j1 < re ? j1 : re));
     if (!any) continue;
     if (ring_bound_sq(cb.el + 4 * r, rho_q, sz, qn3) > d2) continue;
-    for_ring_cells(
+    scan_ring(
         cb, r, a0, sx, sy, rho_q, [&]() { return d2; },
-        [&](int cell) {
-          unsigned e = cb.cell_end[cell], s = cell ? cb.cell_end[cell - 1] : 0u;
-          for (unsigned p = s; p < e; ++p) {
-            float4 t = cb.binned[p];
-            int j = __float_as_int(t.w);
-            bool ok = (j > j1 && j < f_hi) || (j < j1 && j >= b_lo);
-            if (!ok) continue;
-            int rank = j > j1 ? j - j1 : kBackRank + (j1 - j);
-            float d = sqdist3(t.x, t.y, t.z, sx, sy, sz);
-            if (d < d2 || (d == d2 && m2 >= 0 && rank < k2)) d2 = d, m2 = j, k2 = rank;
-          }
+        [&](const float4& t) {
+          int j = __float_as_int(t.w);
+          bool ok = (j > j1 && j < f_hi) || (j < j1 && j >= b_lo);
+          if (!ok) return;
+          int rank = j > j1 ? j - j1 : kBackRank + (j1 - j);
+          float d = sqdist3(t.x, t.y, t.z, sx, sy, sz);
+          if (d < d2 || (d == d2 && m2 >= 0 && rank < k2)) d2 = d, m2 = j, k2 = rank;
         });
   }
 }
@@ -258,14 +285,16 @@ __device__ __forceinline__ void build_cloud_bins(const float4* __restrict__ tg, 
   }
   __syncthreads();
   // exclusive scan over the cells: thread t owns cells [t*per, (t+1)*per)
-  const int per = ncell / kBlock;
+  const int per = (ncell + kBlock - 1) / kBlock;
+  const int c_lo = tid * per < ncell ? tid * per : ncell;
+  const int c_hi = c_lo + per < ncell ? c_lo + per : ncell;
   int local = 0;
-  for (int k = 0; k < per; ++k) local += (int)cell[tid * per + k];
+  for (int c = c_lo; c < c_hi; ++c) local += (int)cell[c];
   int run = block_exclusive_scan(local, tid, tmp);
-  for (int k = 0; k < per; ++k) {
-    int c = (int)cell[tid * per + k];
-    cell[tid * per + k] = (unsigned)run;  // start offset, used as the scatter cursor
-    run += c;
+  for (int c = c_lo; c < c_hi; ++c) {
+    int cnt = (int)cell[c];
+    cell[c] = (unsigned)run;  // start offset, used as the scatter cursor
+    run += cnt;
   }
   __syncthreads();
   for (int j = tid; j < n; j += kBlock) {

@@ -20,9 +20,10 @@
 
 namespace lins {
 
-constexpr int kBlock = 256;          // threads per workgroup (4 waves)
-constexpr int kRowsCap = 512;        // LDS row slots per reduction round
-constexpr int kRedGroups = 8;        // partial-sum groups per reduction
+constexpr int kBlock = 320;          // threads per workgroup (5 waves): one round covers a typical
+                                     // VLP-16 scan's ~260 query features (caps: 192 + 144)
+constexpr int kRowsCap = kBlock;     // LDS row slots per reduction round
+constexpr int kRedGroups = kBlock / 32;  // partial-sum groups per reduction
 constexpr int kAzSurf = 128;         // azimuth columns per ring, surf targets
 constexpr int kAzCorner = 64;        // azimuth columns per ring, corner targets
 constexpr int kMaxRing = LINS_MAX_RING;
@@ -53,7 +54,7 @@ struct IterConst {  // per-iteration constants, hoisted (the reference recompute
   double lin[19];   // linState_
   V3 phi;           // Quat2axis(linState_.qbn_)
   M3 Rt;            // R(q)^T
-  M3 G;             // Rinvleft(-phi)
+  M3 Gt;            // Rinvleft(-phi)^T
   double d[18];     // filterState (-) linState_
 };
 
@@ -201,7 +202,7 @@ __device__ __forceinline__ void make_iter_const(const double* filt, IterConst& i
   Q4 q{ic.lin[6], ic.lin[7], ic.lin[8], ic.lin[9]};
   ic.phi = quat2axis(q);
   ic.Rt = mtrans(qmat(q));
-  ic.G = rinvleft(V3{-ic.phi.x, -ic.phi.y, -ic.phi.z});
+  ic.Gt = mtrans(rinvleft(V3{-ic.phi.x, -ic.phi.y, -ic.phi.z}));
   // boxMinus(filter, lin), KF:84-94
   Q4 qf{filt[6], filt[7], filt[8], filt[9]};
   V3 da = quat2axis(qmul(qinverse(q), qf));
@@ -228,100 +229,11 @@ __device__ __forceinline__ void box_plus_inplace(double* s, const double* dx) {
   s[6] = q.w, s[7] = q.x, s[8] = q.y, s[9] = q.z;
 }
 
-// ---------------------------------------------------------------------------
-// 6x6 dense helpers, fully unrolled so everything stays in registers
-// ---------------------------------------------------------------------------
 __device__ __forceinline__ int sidx(int k) { return k < 3 ? k : k + 3; }  // {0,1,2,6,7,8}
-
-// A6 (6x6, pos/att block of H^T H) and g6 from the 28 sums
-__device__ __forceinline__ void sums_to_normal(const double* s, const M3& G, double* A6, double* g6) {
-  M3 App{{s[0], s[1], s[2], s[1], s[3], s[4], s[2], s[4], s[5]}};
-  M3 Apu{{s[6], s[7], s[8], s[9], s[10], s[11], s[12], s[13], s[14]}};
-  M3 Auu{{s[15], s[16], s[17], s[16], s[18], s[19], s[17], s[19], s[20]}};
-  M3 Apa = mmul(Apu, G);
-  M3 Aaa = mmul(mmul(mtrans(G), Auu), G);
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      A6[i * 6 + j] = App.m[i * 3 + j];
-      A6[i * 6 + 3 + j] = Apa.m[i * 3 + j];
-      A6[(3 + i) * 6 + j] = Apa.m[j * 3 + i];
-      A6[(3 + i) * 6 + 3 + j] = Aaa.m[i * 3 + j];
-    }
-  g6[0] = s[21], g6[1] = s[22], g6[2] = s[23];
-  V3 ga = rowmul(V3{s[24], s[25], s[26]}, G);
-  g6[3] = ga.x, g6[4] = ga.y, g6[5] = ga.z;
-}
-
-// Gaussian elimination with partial pivoting on [N | B] (6 x (6+NB)), in registers.
-// Row swaps are value selects so no array is dynamically indexed.
-template <int NB>
-__device__ __forceinline__ void lu_solve6(double (&a)[6][6 + NB]) {
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    int p = k;
-    double best = fabs(a[k][k]);
-#pragma unroll
-    for (int i = k + 1; i < 6; ++i) {
-      double v = fabs(a[i][k]);
-      if (v > best) best = v, p = i;
-    }
-#pragma unroll
-    for (int i = k + 1; i < 6; ++i) {
-      bool sw = (p == i);
-#pragma unroll
-      for (int j = k; j < 6 + NB; ++j) {
-        double x = a[k][j], y = a[i][j];
-        a[k][j] = sw ? y : x;
-        a[i][j] = sw ? x : y;
-      }
-    }
-    double piv = a[k][k];
-#pragma unroll
-    for (int i = k + 1; i < 6; ++i) {
-      double f = a[i][k] / piv;
-#pragma unroll
-      for (int j = k + 1; j < 6 + NB; ++j) a[i][j] -= f * a[k][j];
-    }
-  }
-#pragma unroll
-  for (int i = 5; i >= 0; --i) {
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      double s = a[i][6 + j];
-#pragma unroll
-      for (int k = i + 1; k < 6; ++k) s -= a[i][k] * a[k][6 + j];
-      a[i][6 + j] = s / a[i][i];
-    }
-  }
-}
-
-// dx = d - P[:,S] (sigma^2 I + A_SS P_SS)^-1 (g + A d)_S      (P: 18x18 row-major)
-__device__ __forceinline__ void update_reduced(double r2, const double* P, const double* A6,
-                                               const double* g6, const double* d, double* dx) {
-  double a[6][7];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    double z = g6[i];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) z += A6[i * 6 + k] * d[sidx(k)];
-    a[i][6] = z;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      double t = 0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) t += A6[i * 6 + k] * P[sidx(k) * 18 + sidx(j)];
-      a[i][j] = t + (i == j ? r2 : 0.0);
-    }
-  }
-  lu_solve6<1>(a);
-  for (int i = 0; i < 18; ++i) {
-    double s = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) s += P[i * 18 + sidx(k)] * a[k][6];
-    dx[i] = d[i] - s;
-  }
+// position of (i, j), i <= j, in the row-major upper triangle of a 6x6
+__device__ __forceinline__ int tri6(int i, int j) { return 6 * i - (i * (i - 1)) / 2 + (j - i); }
+__device__ __forceinline__ double sym6(const double* tri, int i, int j) {
+  return i <= j ? tri[tri6(i, j)] : tri[tri6(j, i)];
 }
 
 }  // namespace lins

@@ -1,21 +1,27 @@
 // ieskf_kernels.hip — CDNA4 (gfx950) kernels of the IESKF update path.
 //
-// One workgroup (4 wave64) owns one scan pair for the WHOLE iterated update
-// (persistent over <= NUM_ITER iterations, no host round trips, SE:475-583):
+// ieskf_persistent_kernel: one workgroup (5 wave64) owns one scan pair for the
+// WHOLE iterated update (<= NUM_ITER iterations, no host round trips, SE:475-583):
 //
-//   wave 0        per-iteration constants  (phi, R^T, Rinvleft(-phi), x_f (-) x_lin)
-//   all lanes     one query feature each: de-skew (f64) -> exact NN + index walk
-//                 (f32) -> plane/line residual + Jacobian (f64 -> f32) -> row
-//                 (c, u = p x R^T c, r) into an LDS slot   [A2, A3, A4, A5]
-//   224 lanes     28 f64 sums of the 7x7 outer products, fixed-shape two-stage
-//                 tree (8 strided groups -> ordered fold) => bit-reproducible
-//   wave 0        6x6 pivoted solve of (sigma^2 I + A_SS P_SS), dx, NaN /
-//                 divergence / convergence tests, boxPlus                   [A6, A7]
-//   all lanes     after the loop: Joseph covariance update, 18x18 in LDS.
+//   once          counting-sort both target clouds into (ring x azimuth-column)
+//                 grids — a coarse range image of the previous scan (ieskf_binned.h)
+//   per iteration
+//     all lanes   one query feature each: de-skew (f64) -> exact NN + index walk
+//                 (f32, grid-pruned) -> plane/line residual + Jacobian (f64 -> f32)
+//                 -> H row (c, a = G^T (p x R^T c), r) into an LDS slot [A2-A5]
+//     280 lanes   28 f64 sums (upper triangle of the 6x6 H^T H, H^T r, r^T r):
+//                 fixed-shape two-stage tree (10 strided groups -> ordered fold),
+//                 bit-reproducible from run to run
+//     <=42 lanes  (sigma^2 I + A P_SS) w = (g + A d) by pivoted elimination in LDS,
+//                 dx = d - P[:,S] w                                        [A6]
+//     wave 0      NaN / divergence / convergence tests, boxPlus, next constants [A7]
+// ieskf_joseph_kernel: once per scan after the loop, the Joseph covariance update
+//   with the last iteration's A (SE:594-598) — split off so that its 18x18 algebra
+//   does not dictate the register budget (occupancy) of the search loop.
 //
-// No dense contraction anywhere => MFMA unused; the path is HBM/VALU work.
-// Inputs are read from HBM once per scan (targets stay L2-resident across
-// iterations); the only per-iteration global traffic is the target gather.
+// No dense contraction anywhere => MFMA unused; the path is gather/VALU work over
+// HBM-resident clouds that are read from HBM once per update and re-gathered from
+// L2 on every iteration.
 
 #include <hip/hip_runtime.h>
 
@@ -31,14 +37,13 @@ struct OutRec {
   int iters, converged, diverged, m_surf, m_corner, pad[3];
 };
 
-__constant__ unsigned char kPairA[28] = {0, 0, 0, 1, 1, 2, 0, 0, 0, 1, 1, 1, 2, 2,
+// row vector v = (c0 c1 c2 a0 a1 a2 r); sum k accumulates v[A[k]] * v[B[k]]:
+// [0..20] upper triangle of H^T H (row-major), [21..26] H^T r, [27] r^T r
+__constant__ unsigned char kPairA[28] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2,
                                          2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6};
-__constant__ unsigned char kPairB[28] = {0, 1, 2, 1, 2, 2, 3, 4, 5, 3, 4, 5, 3, 4,
+__constant__ unsigned char kPairB[28] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4,
                                          5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6};
 
-// ---------------------------------------------------------------------------
-// one query feature -> (indices, accepted, coeff)
-// ---------------------------------------------------------------------------
 struct NoBins {};
 
 // LDS views of the two target grids of the scan this workgroup owns
@@ -46,11 +51,13 @@ struct ScanBins {
   CloudBins surf, corner;
 };
 
+// ---------------------------------------------------------------------------
+// one query feature -> (indices, accepted, coeff)
+// ---------------------------------------------------------------------------
 template <int SEARCH>
 __device__ __forceinline__ void process_surf(const DevParams& prm, const ScanDesc& sd,
                                              const float4* __restrict__ arena, const ScanBins* sb, const V3& phi,
-                                             const V3& t, int iter, bool do_search, int i, const float4& q,
-                                             QueryOut& o) {
+                                             const V3& t, int iter, bool do_search, const float4& q, QueryOut& o) {
   const float4* tg = arena + sd.off_surf_t;
   transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2]);
   o.accepted = 0;
@@ -59,9 +66,11 @@ __device__ __forceinline__ void process_surf(const DevParams& prm, const ScanDes
     int j1;
     float d1;
     o.j1 = o.j2 = o.j3 = -1;
-    if (SEARCH == SEARCH_BINNED && sd.surf_sorted) {
+    if (prm.pad & 2) {
+      j1 = -1, d1 = 0;
+    } else if (SEARCH == SEARCH_BINNED && sd.surf_sorted) {
       nn_binned(sb->surf, o.sel[0], o.sel[1], o.sel[2], prm.nearest_f, ring_of(q.w), j1, d1);
-      if (j1 >= 0 && (double)d1 < prm.nearest) {
+      if (j1 >= 0 && (double)d1 < prm.nearest && !(prm.pad & 1)) {
         o.j1 = j1;
         walk_surf_binned(sb->surf, sd.n_surf_q, prm.nearest_f, j1, ring_of(tg[j1].w), o.sel[0], o.sel[1], o.sel[2],
                          o.j2, o.j3);
@@ -81,8 +90,7 @@ __device__ __forceinline__ void process_surf(const DevParams& prm, const ScanDes
 template <int SEARCH>
 __device__ __forceinline__ void process_corner(const DevParams& prm, const ScanDesc& sd,
                                                const float4* __restrict__ arena, const ScanBins* sb, const V3& phi,
-                                               const V3& t, int iter, bool do_search, int i, const float4& q,
-                                               QueryOut& o) {
+                                               const V3& t, int iter, bool do_search, const float4& q, QueryOut& o) {
   const float4* tg = arena + sd.off_corner_t;
   transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2]);
   o.accepted = 0;
@@ -92,9 +100,11 @@ __device__ __forceinline__ void process_corner(const DevParams& prm, const ScanD
     float d1;
     o.j1 = o.j2 = -1;
     o.j3 = -1;
-    if (SEARCH == SEARCH_BINNED && sd.corner_sorted) {
+    if (prm.pad & 2) {
+      j1 = -1, d1 = 0;
+    } else if (SEARCH == SEARCH_BINNED && sd.corner_sorted) {
       nn_binned(sb->corner, o.sel[0], o.sel[1], o.sel[2], prm.nearest_f, ring_of(q.w), j1, d1);
-      if (j1 >= 0 && (double)d1 < prm.nearest) {
+      if (j1 >= 0 && (double)d1 < prm.nearest && !(prm.pad & 1)) {
         o.j1 = j1;
         walk_corner_binned(sb->corner, sd.n_corner_q, prm.nearest_f, j1, ring_of(tg[j1].w), o.sel[0], o.sel[1],
                            o.sel[2], o.j2);
@@ -124,29 +134,62 @@ __device__ __forceinline__ void process_slot(const DevParams& prm, const ScanDes
     o.j1 = s.x, o.j2 = s.y, o.j3 = s.z;
   }
   if (is_surf)
-    process_surf<SEARCH>(prm, sd, arena, sb, phi, t, iter, do_search, i, q, o);
+    process_surf<SEARCH>(prm, sd, arena, sb, phi, t, iter, do_search, q, o);
   else
-    process_corner<SEARCH>(prm, sd, arena, sb, phi, t, iter, do_search, i, q, o);
+    process_corner<SEARCH>(prm, sd, arena, sb, phi, t, iter, do_search, q, o);
   if (do_search && prm.icp_freq > 1) idx_store[sd.slot_base + slot] = make_int4(o.j1, o.j2, o.j3, 0);
 }
 
-// ---------------------------------------------------------------------------
-// LDS layout of the persistent kernel
-// ---------------------------------------------------------------------------
-struct Shared {
-  IterConst ic;
-  double filt[19];
-  double P[324];
-  double rows[kRowsCap * 7];  // later reused for the Joseph update (IKH, T)
-  double partial[kRedGroups * 28];
-  double sums[28];
-  double A6[36];
-  double Y[36], Zt[36];
-  double dx[18];
-  double res_prev, res_last, upd_norm;
-  int m_surf, m_corner;
-  int iter, conv, div, pad;
-};
+// One round of <= kRowsCap query slots: each lane turns its query into an H row in LDS.
+template <int SEARCH>
+__device__ __forceinline__ void correspondence_round(const DevParams& prm, const ScanDesc& sd,
+                                                     const float4* __restrict__ arena, const ScanBins* sb,
+                                                     const IterConst& ic, int iter, bool do_search, int base,
+                                                     int total, int4* __restrict__ idx_store, double* rows, int tid,
+                                                     int& ms, int& mc, lins_corr* __restrict__ dump) {
+  const int slot = base + tid;
+  double row[7] = {0, 0, 0, 0, 0, 0, 0};
+  if (slot < total) {
+    V3 phi = ic.phi;
+    V3 t{ic.lin[0], ic.lin[1], ic.lin[2]};
+    QueryOut o;
+    float4 q;
+    bool is_surf;
+    process_slot<SEARCH>(prm, sd, arena, sb, phi, t, iter, do_search, slot, idx_store, o, q, is_surf);
+    if (o.accepted) {
+      // H row (SE:526-531): pos block c^T, att block c^T (-R [p]x) Rinvleft(-phi) = (G^T (p x R^T c))^T
+      V3 c{(double)o.c[0], (double)o.c[1], (double)o.c[2]};
+      V3 u = cross(V3{(double)q.x, (double)q.y, (double)q.z}, mvec(ic.Rt, c));
+      V3 a = mvec(ic.Gt, u);
+      row[0] = c.x, row[1] = c.y, row[2] = c.z;
+      row[3] = a.x, row[4] = a.y, row[5] = a.z;
+      row[6] = prm.lidar_scale * (double)o.c[3];
+      if (is_surf)
+        ++ms;
+      else
+        ++mc;
+    }
+    if (dump) {
+      lins_corr r;
+      r.ind1 = o.j1, r.ind2 = o.j2, r.ind3 = is_surf ? o.j3 : -1, r.accepted = o.accepted;
+      for (int k = 0; k < 4; ++k) r.coeff[k] = o.c[k];
+      r.sel[0] = o.sel[0], r.sel[1] = o.sel[1], r.sel[2] = o.sel[2], r.sel[3] = q.w;
+      dump[slot] = r;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) rows[tid * 7 + k] = row[k];
+}
+
+// rows -> 28 sums.  Group g folds rows g, g+G, ... in order; then the G group partials
+// are folded in order.  Same tree every run => deterministic.
+__device__ __forceinline__ void accumulate_rows(const double* rows, int nrows, int tid, double& acc) {
+  int g = tid >> 5, k = tid & 31;
+  if (k < 28) {
+    int a = kPairA[k], b = kPairB[k];
+    for (int r = g; r < nrows; r += kRedGroups) acc += rows[r * 7 + a] * rows[r * 7 + b];
+  }
+}
 
 // Build the (ring x column) grids of this scan's two target clouds (binned search only).
 template <int SEARCH>
@@ -169,71 +212,83 @@ __device__ __forceinline__ void setup_bins(const ScanDesc& sd, const float4* __r
   __syncthreads();
 }
 
-// rows -> 28 sums.  Group g folds rows g, g+8, ... in order; then the 8 group
-// partials are folded in order.  Same tree every run => deterministic.
-__device__ __forceinline__ void accumulate_rows(const double* rows, int nrows, int tid, double& acc) {
-  int g = tid >> 5, k = tid & 31;
-  if (k < 28) {
-    int a = kPairA[k], b = kPairB[k];
-    for (int r = g; r < nrows; r += kRedGroups) acc += rows[r * 7 + a] * rows[r * 7 + b];
-  }
-}
-
-template <int SEARCH>
-__device__ __forceinline__ void correspondence_round(const DevParams& prm, const ScanDesc& sd,
-                                                     const float4* __restrict__ arena, const ScanBins* sb,
-                                                     const IterConst& ic,
-                                                     int iter, bool do_search, int base, int total,
-                                                     int4* __restrict__ idx_store, double* rows, int tid,
-                                                     int& ms, int& mc, lins_corr* __restrict__ dump) {
-  V3 phi = ic.phi;
-  V3 t{ic.lin[0], ic.lin[1], ic.lin[2]};
-#pragma unroll 1
-  for (int h = 0; h < kRowsCap / kBlock; ++h) {
-    int local = h * kBlock + tid;
-    int slot = base + local;
-    double row[7] = {0, 0, 0, 0, 0, 0, 0};
-    if (slot < total) {
-      QueryOut o;
-      float4 q;
-      bool is_surf;
-      process_slot<SEARCH>(prm, sd, arena, sb, phi, t, iter, do_search, slot, idx_store, o, q, is_surf);
-      if (o.accepted) {
-        V3 c{(double)o.c[0], (double)o.c[1], (double)o.c[2]};
-        V3 w = mvec(ic.Rt, c);
-        V3 u = cross(V3{(double)q.x, (double)q.y, (double)q.z}, w);
-        row[0] = c.x, row[1] = c.y, row[2] = c.z;
-        row[3] = u.x, row[4] = u.y, row[5] = u.z;
-        row[6] = prm.lidar_scale * (double)o.c[3];
-        if (is_surf)
-          ++ms;
-        else
-          ++mc;
-      }
-      if (dump) {
-        lins_corr r;
-        r.ind1 = o.j1, r.ind2 = o.j2, r.ind3 = is_surf ? o.j3 : -1, r.accepted = o.accepted;
-        for (int k = 0; k < 4; ++k) r.coeff[k] = o.c[k];
-        r.sel[0] = o.sel[0], r.sel[1] = o.sel[1], r.sel[2] = o.sel[2], r.sel[3] = q.w;
-        dump[slot] = r;
-      }
+// ---------------------------------------------------------------------------
+// 6 x 6 pivoted elimination in LDS, cooperative over the block.
+// aug = [N | B] row-major 6 x nc; sol (nrhs = nc - 6 columns, row-major 6 x nrhs) = N^-1 B.
+// Pivot rows are chosen per column among the not-yet-used rows (implicit row
+// exchange).  Every thread of the block must call this (it contains barriers).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void block_solve6(double* aug, int nc, double* sol, int* piv, int* used, int tid) {
+  if (tid < 6) used[tid] = 0;
+  __syncthreads();
+  for (int k = 0; k < 6; ++k) {
+    if (tid == 0) {
+      int p = -1;
+      double best = -1.0;
+      for (int i = 0; i < 6; ++i)
+        if (!used[i]) {
+          double v = fabs(aug[i * nc + k]);
+          if (p < 0 || v > best) best = v, p = i;
+        }
+      piv[k] = p;
+      used[p] = 1;
     }
-    if (rows) {
+    __syncthreads();
+    const int p = piv[k];
+    const int i = tid / nc, j = tid - i * nc;
+    if (i < 6 && !used[i] && j > k) {
+      double f = aug[i * nc + k] / aug[p * nc + k];
+      aug[i * nc + j] -= f * aug[p * nc + j];
+    }
+    __syncthreads();
+  }
+  const int nrhs = nc - 6;
+  if (tid < nrhs) {
+    const int col = 6 + tid;
+    double x[6];
 #pragma unroll
-      for (int k = 0; k < 7; ++k) rows[local * 7 + k] = row[k];
+    for (int k = 5; k >= 0; --k) {
+      const int p = piv[k];
+      double s = aug[p * nc + col];
+#pragma unroll
+      for (int j = k + 1; j < 6; ++j) s -= aug[p * nc + j] * x[j];
+      x[k] = s / aug[p * nc + k];
     }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sol[k * nrhs + tid] = x[k];
   }
+  __syncthreads();
 }
 
 // ---------------------------------------------------------------------------
-// persistent IESKF kernel: grid = scans, block = 256
+// LDS layout of the persistent kernel
+// ---------------------------------------------------------------------------
+struct Shared {
+  IterConst ic;
+  double filt[19];
+  double P[324];
+  double rows[kRowsCap * 7];
+  double partial[kRedGroups * 28];
+  double sums[28];
+  double aug[6 * 7];
+  double w[6];
+  double dx[18];
+  double res_prev, res_last, upd_norm;
+  int piv[6], used[6];
+  int m_surf, m_corner;
+  int iter, conv, div, pad;
+};
+
+// ---------------------------------------------------------------------------
+// persistent IESKF kernel: grid = scans, block = kBlock
 // ---------------------------------------------------------------------------
 template <int SEARCH>
-__global__ __launch_bounds__(kBlock) void ieskf_persistent_kernel(
+__global__ __launch_bounds__(kBlock, 4) void ieskf_persistent_kernel(
     DevParams prm, const ScanDesc* __restrict__ descs, const float4* __restrict__ arena,
     const double* __restrict__ state_in, const double* __restrict__ cov_in, double* __restrict__ state_out,
-    double* __restrict__ cov_out, OutRec* __restrict__ out, int4* __restrict__ idx_store,
-    lins_pose_record* __restrict__ poses, int scan_id_base, float4* __restrict__ binned) {
+    double* __restrict__ a6_out, OutRec* __restrict__ out, int4* __restrict__ idx_store,
+    lins_pose_record* __restrict__ poses, int scan_id_base, float4* __restrict__ binned,
+    long long* __restrict__ prof) {
   __shared__ Shared sh;
   __shared__ std::conditional_t<SEARCH == SEARCH_BINNED, BinStorage, NoBins> bstore;
   __shared__ ScanBins sbins;
@@ -241,6 +296,11 @@ __global__ __launch_bounds__(kBlock) void ieskf_persistent_kernel(
   const int scan = blockIdx.x;
   const ScanDesc sd = descs[scan];
   const int total = sd.n_surf_q + sd.n_corner_q;
+  // optional phase profile (prof != nullptr): shader-clock ticks per phase, per workgroup:
+  // [0] setup+grid build [1] correspondence (critical path) [2] reduction [3] solve
+  // [4] state update [5] total [6..10] per-wave correspondence time
+  long long pt[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const long long t_begin = prof ? clock64() : 0;
 
   for (int k = tid; k < 324; k += kBlock) sh.P[k] = cov_in[(size_t)scan * 324 + k];
   if (tid < 19) {
@@ -248,39 +308,42 @@ __global__ __launch_bounds__(kBlock) void ieskf_persistent_kernel(
     sh.filt[tid] = v;
     sh.ic.lin[tid] = v;
   }
+  if (tid < 28) sh.sums[tid] = 0;
   if (tid == 0) {
     sh.res_prev = 1e6, sh.res_last = 0, sh.upd_norm = 0;
     sh.iter = 0, sh.conv = 0, sh.div = 0, sh.m_surf = 0, sh.m_corner = 0;
   }
   __syncthreads();
-  setup_bins<SEARCH>(sd, arena, binned, (BinStorage*)&bstore, &sbins, tid);
+  if (tid < 64) {  // wave 0, lane-redundant: constants of iteration 0
+    IterConst ic;
+    double filt[19];
+    for (int k = 0; k < 19; ++k) ic.lin[k] = filt[k] = sh.filt[k];
+    make_iter_const(filt, ic);
+    if (tid == 0) {
+      sh.ic.phi = ic.phi, sh.ic.Rt = ic.Rt, sh.ic.Gt = ic.Gt;
+      for (int k = 0; k < 18; ++k) sh.ic.d[k] = ic.d[k];
+    }
+  }
+  setup_bins<SEARCH>(sd, arena, binned, (BinStorage*)&bstore, &sbins, tid);  // ends with a barrier
+  __syncthreads();
+  if (prof) pt[0] = clock64() - t_begin;
 
   for (;;) {
     const int iter = sh.iter;
     if (iter >= prm.num_iter || sh.conv || sh.div) break;
-    if (tid < 64) {  // wave 0, lane-redundant scalar work
-      IterConst ic;
-      for (int k = 0; k < 19; ++k) ic.lin[k] = sh.ic.lin[k];
-      double filt[19];
-      for (int k = 0; k < 19; ++k) filt[k] = sh.filt[k];
-      make_iter_const(filt, ic);
-      if (tid == 0) {
-        sh.ic.phi = ic.phi;
-        sh.ic.Rt = ic.Rt;
-        sh.ic.G = ic.G;
-        for (int k = 0; k < 18; ++k) sh.ic.d[k] = ic.d[k];
-        sh.m_surf = 0, sh.m_corner = 0;
-      }
-    }
-    __syncthreads();
+    __syncthreads();  // everyone has read the loop state before it is rewritten
+    if (tid == 0) sh.m_surf = 0, sh.m_corner = 0;
 
     const bool do_search = (iter % prm.icp_freq) == 0;
     double acc = 0;
     int ms = 0, mc = 0;
+    long long t0 = prof ? clock64() : 0, t1 = t0, t2 = t0, t3 = t0;
     for (int base = 0; base < total; base += kRowsCap) {
       correspondence_round<SEARCH>(prm, sd, arena, &sbins, sh.ic, iter, do_search, base, total, idx_store,
                                    sh.rows, tid, ms, mc, nullptr);
+      if (prof) pt[6] += clock64() - t0;  // this wave's own search time (kept per lane, lane 0 of each wave reports)
       __syncthreads();
+      if (prof) t1 = clock64();
       int nrows = total - base < kRowsCap ? total - base : kRowsCap;
       accumulate_rows(sh.rows, nrows, tid, acc);
       __syncthreads();
@@ -296,140 +359,87 @@ __global__ __launch_bounds__(kBlock) void ieskf_persistent_kernel(
       sh.sums[tid] = s;
     }
     __syncthreads();
+    if (prof) t2 = clock64();
 
-    if (tid < 64) {  // wave 0: solve + state update (SE:542-580), lane-redundant
-      double sums[28];
-      for (int k = 0; k < 28; ++k) sums[k] = sh.sums[k];
-      double A6[36], g6[6], d[18], dx[18];
-      M3 G = sh.ic.G;
-      for (int k = 0; k < 18; ++k) d[k] = sh.ic.d[k];
-      sums_to_normal(sums, G, A6, g6);
-      update_reduced(prm.r2, sh.P, A6, g6, d, dx);
-      double rn = sqrt(sums[27]);
+    // (sigma^2 I + A P_SS) w = g + A d_S     (push-through form of SE:542-549)
+    if (tid < 36) {
+      int i = tid / 6, j = tid - i * 6;
+      double t = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) t += sym6(sh.sums, i, k) * sh.P[sidx(k) * 18 + sidx(j)];
+      sh.aug[i * 7 + j] = t + (i == j ? prm.r2 : 0.0);
+    } else if (tid < 42) {
+      int i = tid - 36;
+      double z = sh.sums[21 + i];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) z += sym6(sh.sums, i, k) * sh.ic.d[sidx(k)];
+      sh.aug[i * 7 + 6] = z;
+    }
+    __syncthreads();
+    block_solve6(sh.aug, 7, sh.w, sh.piv, sh.used, tid);
+    if (tid < 18) {  // dx = d - P[:,S] w
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s += sh.P[tid * 18 + sidx(k)] * sh.w[k];
+      sh.dx[tid] = sh.ic.d[tid] - s;
+    }
+    __syncthreads();
+    if (prof) t3 = clock64();
+
+    if (tid < 64) {  // wave 0, lane-redundant: SE:552-580 + constants of the next iteration
+      double dx[18];
+      for (int k = 0; k < 18; ++k) dx[k] = sh.dx[k];
+      double rn = sqrt(sh.sums[27]);
       bool has_nan = false;
       for (int k = 0; k < 18; ++k)
         if (isnan(dx[k])) has_nan = true;
       int div = 0, conv = 0;
-      double lin[19];
-      for (int k = 0; k < 19; ++k) lin[k] = sh.ic.lin[k];
+      IterConst ic;
+      for (int k = 0; k < 19; ++k) ic.lin[k] = sh.ic.lin[k];
       double un = sh.upd_norm, res_prev = sh.res_prev;
       if (has_nan) {
         div = 2;
       } else if (rn > res_prev * 10) {
         div = 1;
       } else {
-        box_plus_inplace(lin, dx);
+        box_plus_inplace(ic.lin, dx);
         un = 0;
         for (int k = 0; k < 18; ++k) un += dx[k] * dx[k];
         un = sqrt(un);
         if (un <= 1e-2 && !prm.fixed_iters) conv = 1;
         res_prev = rn;
+        double filt[19];
+        for (int k = 0; k < 19; ++k) filt[k] = sh.filt[k];
+        make_iter_const(filt, ic);
       }
       if (tid == 0) {
-        for (int k = 0; k < 36; ++k) sh.A6[k] = A6[k];
-        for (int k = 0; k < 19; ++k) sh.ic.lin[k] = lin[k];
-        sh.res_last = rn;
-        sh.res_prev = res_prev;
-        sh.upd_norm = un;
+        if (!div) {
+          for (int k = 0; k < 19; ++k) sh.ic.lin[k] = ic.lin[k];
+          sh.ic.phi = ic.phi, sh.ic.Rt = ic.Rt, sh.ic.Gt = ic.Gt;
+          for (int k = 0; k < 18; ++k) sh.ic.d[k] = ic.d[k];
+        }
+        sh.res_last = rn, sh.res_prev = res_prev, sh.upd_norm = un;
         sh.conv = conv, sh.div = div;
         sh.iter = iter + 1;
       }
     }
     __syncthreads();
+    if (prof) {
+      long long t4 = clock64();
+      pt[1] += t1 - t0, pt[2] += t2 - t1, pt[3] += t3 - t2, pt[4] += t4 - t3;
+    }
+  }
+  if (prof) {
+    pt[5] = clock64() - t_begin;
+    if (tid == 0)
+      for (int k = 0; k < 6; ++k) prof[(size_t)scan * 16 + k] = pt[k];
+    if ((tid & 63) == 0) prof[(size_t)scan * 16 + 6 + (tid >> 6)] = pt[6];
   }
 
-  // ---- after the loop (SE:585-598) ----------------------------------------
+  // ---- hand-off to the Joseph kernel / the caller (SE:585-598) ---------------
   const int div = sh.div;
-  if (div) {
-    // the caller runs the ICP fallback; hand back the un-updated filter state / Pk_
-    for (int k = tid; k < 324; k += kBlock) cov_out[(size_t)scan * 324 + k] = sh.P[k];
-    if (tid < 19) state_out[(size_t)scan * 19 + tid] = sh.filt[tid];
-  } else {
-    // Joseph update with the LAST executed iteration's A (SE:594-598), reduced form:
-    //   KH = P[:,S] Y E_S^T,  Y = N^-1 A ;  K R K^T = sigma^2 P[:,S] (Y N^-T) P[:,S]^T
-    if (tid < 64) {
-      double n[6][12];
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          double t = 0;
-#pragma unroll
-          for (int k = 0; k < 6; ++k) t += sh.A6[i * 6 + k] * sh.P[sidx(k) * 18 + sidx(j)];
-          n[i][j] = t + (i == j ? prm.r2 : 0.0);
-          n[i][6 + j] = sh.A6[i * 6 + j];
-        }
-      double nn[6][6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) nn[i][j] = n[i][j];
-      lu_solve6<6>(n);  // Y = N^-1 A
-      double z[6][12];
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          z[i][j] = nn[i][j];
-          z[i][6 + j] = n[j][6 + i];  // Y^T
-        }
-      lu_solve6<6>(z);  // Zt = N^-1 Y^T  (Z = Y N^-T)
-      if (tid == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-          for (int j = 0; j < 6; ++j) sh.Y[i * 6 + j] = n[i][6 + j], sh.Zt[i * 6 + j] = z[i][6 + j];
-      }
-    }
-    __syncthreads();
-    double* IKH = sh.rows;         // 324
-    double* T = sh.rows + 324;     // 324
-    double* PSZ = sh.rows + 648;   // 18 x 6
-    for (int e = tid; e < 324; e += kBlock) {
-      int i = e / 18, j = e % 18;
-      double v = (i == j) ? 1.0 : 0.0;
-      // column j of KH is non-zero only for j in S
-      int kj = (j < 3) ? j : ((j >= 6 && j < 9) ? j - 3 : -1);
-      if (kj >= 0) {
-        double s = 0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) s += sh.P[i * 18 + sidx(k)] * sh.Y[k * 6 + kj];
-        v -= s;
-      }
-      IKH[e] = v;
-    }
-    for (int e = tid; e < 108; e += kBlock) {
-      int i = e / 6, j = e % 6;
-      double s = 0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) s += sh.P[i * 18 + sidx(k)] * sh.Zt[j * 6 + k];
-      PSZ[e] = s;
-    }
-    __syncthreads();
-    for (int e = tid; e < 324; e += kBlock) {
-      int i = e / 18, j = e % 18;
-      double s = 0;
-      for (int k = 0; k < 18; ++k) s += IKH[i * 18 + k] * sh.P[k * 18 + j];
-      T[e] = s;
-    }
-    __syncthreads();
-    double* O = sh.rows + 756;  // 324
-    for (int e = tid; e < 324; e += kBlock) {
-      int i = e / 18, j = e % 18;
-      double s = 0;
-      for (int k = 0; k < 18; ++k) s += T[i * 18 + k] * IKH[j * 18 + k];
-      double kk = 0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) kk += PSZ[i * 6 + k] * sh.P[j * 18 + sidx(k)];
-      O[e] = s + prm.r2 * kk;
-    }
-    __syncthreads();
-    for (int e = tid; e < 324; e += kBlock) {
-      int i = e / 18, j = e % 18;
-      cov_out[(size_t)scan * 324 + e] = 0.5 * (O[i * 18 + j] + O[j * 18 + i]);
-    }
-    if (tid < 19) state_out[(size_t)scan * 19 + tid] = sh.ic.lin[tid];
-  }
+  if (tid < 19) state_out[(size_t)scan * 19 + tid] = div ? sh.filt[tid] : sh.ic.lin[tid];
+  if (tid < 21) a6_out[(size_t)scan * 21 + tid] = sh.sums[tid];  // A of the LAST executed iteration
   if (tid == 0) {
     OutRec r;
     r.residual_norm = sh.res_last, r.update_norm = sh.upd_norm;
@@ -452,10 +462,99 @@ __global__ __launch_bounds__(kBlock) void ieskf_persistent_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// single pass kernels (BASELINE.json configs[1]: device correspondences, host solve)
+// Joseph covariance update (SE:594-598) in the reduced form, one workgroup per scan:
+//   N = sigma^2 I + A P_SS,  Y = N^-1 A,  Z = Y N^-T
+//   KH = P[:,S] Y E_S^T,  K R K^T = sigma^2 P[:,S] Z P[:,S]^T
+//   P+ = (I - KH) P (I - KH)^T + K R K^T, symmetrised (enforceSymmetry).
+// Diverged scans get the un-updated Pk_ back (SE:592).
 // ---------------------------------------------------------------------------
-// One correspondence + residual/Jacobian pass for a caller-supplied linearisation
-// state; optionally dumps per-query records and/or the 28 reduced sums.
+constexpr int kJosephBlock = 128;
+
+__global__ __launch_bounds__(kJosephBlock) void ieskf_joseph_kernel(DevParams prm, const double* __restrict__ cov_in,
+                                                                    const double* __restrict__ a6_in,
+                                                                    const OutRec* __restrict__ out,
+                                                                    double* __restrict__ cov_out) {
+  __shared__ double P[324], IKH[324], T[324], O[324];
+  __shared__ double A[21], aug[72], Y[36], Zt[36], PSZ[108];
+  __shared__ int piv[6], used[6];
+  const int tid = threadIdx.x, scan = blockIdx.x;
+  for (int k = tid; k < 324; k += kJosephBlock) P[k] = cov_in[(size_t)scan * 324 + k];
+  if (out[scan].diverged) {
+    __syncthreads();
+    for (int k = tid; k < 324; k += kJosephBlock) cov_out[(size_t)scan * 324 + k] = P[k];
+    return;
+  }
+  if (tid < 21) A[tid] = a6_in[(size_t)scan * 21 + tid];
+  __syncthreads();
+  if (tid < 36) {
+    int i = tid / 6, j = tid - i * 6;
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t += sym6(A, i, k) * P[sidx(k) * 18 + sidx(j)];
+    aug[i * 12 + j] = t + (i == j ? prm.r2 : 0.0);
+    aug[i * 12 + 6 + j] = sym6(A, i, j);
+  }
+  __syncthreads();
+  block_solve6(aug, 12, Y, piv, used, tid);  // Y = N^-1 A
+  if (tid < 36) {
+    int i = tid / 6, j = tid - i * 6;
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t += sym6(A, i, k) * P[sidx(k) * 18 + sidx(j)];
+    aug[i * 12 + j] = t + (i == j ? prm.r2 : 0.0);
+    aug[i * 12 + 6 + j] = Y[j * 6 + i];  // Y^T
+  }
+  __syncthreads();
+  block_solve6(aug, 12, Zt, piv, used, tid);  // Zt = N^-1 Y^T  => Z = Y N^-T
+  for (int e = tid; e < 324; e += kJosephBlock) {
+    int i = e / 18, j = e - i * 18;
+    double v = (i == j) ? 1.0 : 0.0;
+    int kj = (j < 3) ? j : ((j >= 6 && j < 9) ? j - 3 : -1);  // KH has non-zero columns only in S
+    if (kj >= 0) {
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s += P[i * 18 + sidx(k)] * Y[k * 6 + kj];
+      v -= s;
+    }
+    IKH[e] = v;
+  }
+  for (int e = tid; e < 108; e += kJosephBlock) {
+    int i = e / 6, j = e - i * 6;
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s += P[i * 18 + sidx(k)] * Zt[j * 6 + k];  // Z[k][j] = Zt[j][k]
+    PSZ[e] = s;
+  }
+  __syncthreads();
+  for (int e = tid; e < 324; e += kJosephBlock) {
+    int i = e / 18, j = e - i * 18;
+    double s = 0;
+    for (int k = 0; k < 18; ++k) s += IKH[i * 18 + k] * P[k * 18 + j];
+    T[e] = s;
+  }
+  __syncthreads();
+  for (int e = tid; e < 324; e += kJosephBlock) {
+    int i = e / 18, j = e - i * 18;
+    double s = 0;
+    for (int k = 0; k < 18; ++k) s += T[i * 18 + k] * IKH[j * 18 + k];
+    double kk = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) kk += PSZ[i * 6 + k] * P[j * 18 + sidx(k)];
+    O[e] = s + prm.r2 * kk;
+  }
+  __syncthreads();
+  for (int e = tid; e < 324; e += kJosephBlock) {
+    int i = e / 18, j = e - i * 18;
+    cov_out[(size_t)scan * 324 + e] = 0.5 * (O[i * 18 + j] + O[j * 18 + i]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// single pass kernel (BASELINE.json configs[1]: device correspondences + reduction,
+// host-side 18x18 solve).  One correspondence + residual/Jacobian pass for a
+// caller-supplied linearisation state; optionally dumps per-query records and/or the
+// 28 sums.
+// ---------------------------------------------------------------------------
 template <int SEARCH>
 __global__ __launch_bounds__(kBlock) void ieskf_pass_kernel(
     DevParams prm, const ScanDesc* __restrict__ descs, const float4* __restrict__ arena,
@@ -511,14 +610,16 @@ __global__ __launch_bounds__(kBlock) void ieskf_pass_kernel(
 // ---------------------------------------------------------------------------
 void launch_persistent(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs,
                        const float4* arena, const double* state_in, const double* cov_in, double* state_out,
-                       double* cov_out, void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base,
-                       float4* binned) {
+                       double* cov_out, double* a6, void* out, int4* idx_store, lins_pose_record* poses,
+                       int scan_id_base, float4* binned, long long* prof) {
   if (prm.search == SEARCH_BINNED)
     hipLaunchKernelGGL(ieskf_persistent_kernel<SEARCH_BINNED>, dim3(n), dim3(kBlock), 0, stream, prm, descs, arena,
-                       state_in, cov_in, state_out, cov_out, (OutRec*)out, idx_store, poses, scan_id_base, binned);
+                       state_in, cov_in, state_out, a6, (OutRec*)out, idx_store, poses, scan_id_base, binned, prof);
   else
     hipLaunchKernelGGL(ieskf_persistent_kernel<SEARCH_BRUTE>, dim3(n), dim3(kBlock), 0, stream, prm, descs, arena,
-                       state_in, cov_in, state_out, cov_out, (OutRec*)out, idx_store, poses, scan_id_base, binned);
+                       state_in, cov_in, state_out, a6, (OutRec*)out, idx_store, poses, scan_id_base, binned, prof);
+  hipLaunchKernelGGL(ieskf_joseph_kernel, dim3(n), dim3(kJosephBlock), 0, stream, prm, cov_in, a6, (const OutRec*)out,
+                     cov_out);
 }
 
 void launch_pass(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,

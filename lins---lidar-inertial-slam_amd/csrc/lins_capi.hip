@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -18,7 +19,7 @@
 
 namespace lins {
 void launch_persistent(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const double*,
-                       const double*, double*, double*, void*, int4*, lins_pose_record*, int, float4*);
+                       const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, float4*, long long*);
 void launch_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const double*, const double*,
                  int, int4*, lins_corr*, double*, int*, float4*);
 size_t out_rec_size();
@@ -50,6 +51,8 @@ struct lins_ctx {
   ScanDesc* d_desc = nullptr;
   double *d_state_in = nullptr, *d_cov_in = nullptr, *d_state_out = nullptr, *d_cov_out = nullptr;
   double* d_lin = nullptr;
+  long long* d_prof = nullptr;  // optional per-workgroup phase profile (lins_debug_phase_profile)
+  double* d_a6 = nullptr;  // upper triangle of the last iteration's H^T H, per scan
   void* d_out = nullptr;
   int4* d_idx = nullptr;
   lins_corr* d_dump = nullptr;
@@ -105,6 +108,7 @@ void make_dev_params(const lins_params& p, int search, DevParams& d) {
   d.nearest = p.nearest_sq_dist;
   d.nearest_f = (float)p.nearest_sq_dist;
   d.pad = 0;
+  if (const char* e = std::getenv("LINS_DEBUG_SKIP")) d.pad = std::atoi(e);  // profiling aid: 1 = skip walks, 2 = skip search
 }
 
 int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
@@ -223,6 +227,7 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   CREATE_TRY(hipMalloc((void**)&ctx->d_state_out, nb * 19 * 8));
   CREATE_TRY(hipMalloc((void**)&ctx->d_cov_out, nb * 324 * 8));
   CREATE_TRY(hipMalloc((void**)&ctx->d_lin, nb * 19 * 8));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_a6, nb * 21 * 8));
   CREATE_TRY(hipMalloc((void**)&ctx->d_out, nb * out_rec_size()));
   CREATE_TRY(hipMalloc((void**)&ctx->d_idx, ctx->slot_cap * sizeof(int4)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_dump, 2 * LINS_MAX_QUERY * sizeof(lins_corr)));
@@ -251,6 +256,8 @@ void lins_destroy(lins_ctx* ctx) {
   (void)hipFree(ctx->d_state_out);
   (void)hipFree(ctx->d_cov_out);
   (void)hipFree(ctx->d_lin);
+  (void)hipFree(ctx->d_a6);
+  (void)hipFree(ctx->d_prof);
   (void)hipFree(ctx->d_out);
   (void)hipFree(ctx->d_idx);
   (void)hipFree(ctx->d_dump);
@@ -281,11 +288,33 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   launch_persistent(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_state_in,
-                    ctx->d_cov_in, ctx->d_state_out, ctx->d_cov_out, ctx->d_out, ctx->d_idx,
-                    (lins_pose_record*)d_poses, scan_id_base, ctx->d_binned);
+                    ctx->d_cov_in, ctx->d_state_out, ctx->d_cov_out, ctx->d_a6, ctx->d_out, ctx->d_idx,
+                    (lins_pose_record*)d_poses, scan_id_base, ctx->d_binned, ctx->d_prof);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->ran = true;
+  return LINS_OK;
+}
+
+/* Debug aid (not part of the drop-in surface): enable / read the per-workgroup phase
+ * profile of the persistent kernel: 16 int64 shader-clock ticks per scan
+ * ([0] setup [1] correspondence [2] reduction [3] solve [4] update [5] total [6..10] per wave). */
+int lins_debug_phase_profile(lins_ctx* ctx, int enable, long long* out, int n_scans) {
+  if (!ctx) return LINS_E_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (enable && !ctx->d_prof) {
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_prof, (size_t)ctx->max_batch * 16 * sizeof(long long)));
+    HIP_TRY(ctx, hipMemset(ctx->d_prof, 0, (size_t)ctx->max_batch * 16 * sizeof(long long)));
+  }
+  if (out && ctx->d_prof) {
+    if (n_scans > ctx->max_batch) return LINS_E_CAPACITY;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->d_prof, (size_t)n_scans * 16 * sizeof(long long), hipMemcpyDeviceToHost));
+  }
+  if (!enable && ctx->d_prof) {
+    (void)hipFree(ctx->d_prof);
+    ctx->d_prof = nullptr;
+  }
   return LINS_OK;
 }
 

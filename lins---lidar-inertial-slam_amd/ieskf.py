@@ -205,18 +205,7 @@ def host_solve_from_sums(params, pair, lin_state, sums):
                          a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3],
                          a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1]])
 
-    def rinvleft(ax):
-        th = np.linalg.norm(ax)
-        if th < 1e-10:
-            return np.eye(3)
-        h = th / 2
-        a = ax / th
-        s = h * np.cos(h) / np.sin(h)
-        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
-        return s * np.eye(3) + (1 - s) * np.outer(a, a) - h * K
-
     ql, qf = lin[6:10], filt[6:10]
-    G = rinvleft(-quat2axis(ql))
     qinv = np.array([ql[0], -ql[1], -ql[2], -ql[3]]) / np.dot(ql, ql)
     d = np.zeros(18)
     d[0:3] = filt[0:3] - lin[0:3]
@@ -225,18 +214,14 @@ def host_solve_from_sums(params, pair, lin_state, sums):
     d[9:12] = filt[10:13] - lin[10:13]
     d[12:15] = filt[13:16] - lin[13:16]
     d[15:18] = filt[16:19] - lin[16:19]
-    s = sums
-    App = np.array([[s[0], s[1], s[2]], [s[1], s[3], s[4]], [s[2], s[4], s[5]]])
-    Apu = s[6:15].reshape(3, 3)
-    Auu = np.array([[s[15], s[16], s[17]], [s[16], s[18], s[19]], [s[17], s[19], s[20]]])
+    S = [0, 1, 2, 6, 7, 8]
+    A6 = np.zeros((6, 6))
+    A6[np.triu_indices(6)] = sums[:21]
+    A6 = A6 + np.triu(A6, 1).T
     A = np.zeros((18, 18))
-    A[0:3, 0:3] = App
-    A[0:3, 6:9] = Apu @ G
-    A[6:9, 0:3] = (Apu @ G).T
-    A[6:9, 6:9] = G.T @ Auu @ G
+    A[np.ix_(S, S)] = A6
     g = np.zeros(18)
-    g[0:3] = s[21:24]
-    g[6:9] = G.T @ s[24:27]
+    g[S] = sums[21:27]
     r2 = params.lidar_std ** 2
     W = np.linalg.inv(r2 * np.eye(18) + P @ A)
     dx = -W @ P @ (g + A @ d) + d

@@ -540,7 +540,6 @@ void assemble(const lins_params& prm, const State& lin, const lins_point* qs, co
   M3 negR;
   for (int k = 0; k < 9; ++k) negR.m[k] = -R.m[k];
   M3 G = rinvleft({-axis.x, -axis.y, -axis.z});
-  M3 Rt{{R.m[0], R.m[3], R.m[6], R.m[1], R.m[4], R.m[7], R.m[2], R.m[5], R.m[8]}};
   auto push = [&](const lins_point& kp, const lins_corr& c) {
     V3 p{kp.x, kp.y, kp.z};
     V3 cf{c.coeff[0], c.coeff[1], c.coeff[2]};
@@ -550,21 +549,12 @@ void assemble(const lins_params& prm, const State& lin, const lins_point* qs, co
     rows.h.insert(rows.h.end(), row, row + 6);
     rows.r.push_back(res);
     rows.m++;
-    // reduced-form sums use u = p x (R^T c)
-    V3 w{Rt.m[0] * cf.x + Rt.m[1] * cf.y + Rt.m[2] * cf.z, Rt.m[3] * cf.x + Rt.m[4] * cf.y + Rt.m[5] * cf.z,
-         Rt.m[6] * cf.x + Rt.m[7] * cf.y + Rt.m[8] * cf.z};
-    V3 u = cross(p, w);
-    double cv[3] = {cf.x, cf.y, cf.z}, uv[3] = {u.x, u.y, u.z};
+    // 28 sums over the H rows: upper triangle of H^T H, H^T r, r^T r
     double* s = rows.sums;
     int k = 0;
-    for (int a = 0; a < 3; ++a)
-      for (int b = a; b < 3; ++b) s[k++] += cv[a] * cv[b];
-    for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b) s[k++] += cv[a] * uv[b];
-    for (int a = 0; a < 3; ++a)
-      for (int b = a; b < 3; ++b) s[k++] += uv[a] * uv[b];
-    for (int a = 0; a < 3; ++a) s[k++] += cv[a] * res;
-    for (int a = 0; a < 3; ++a) s[k++] += uv[a] * res;
+    for (int a = 0; a < 6; ++a)
+      for (int b = a; b < 6; ++b) s[k++] += row[a] * row[b];
+    for (int a = 0; a < 6; ++a) s[k++] += row[a] * res;
     s[k] += res * res;
   };
   for (int i = 0; i < ns; ++i)  // surf rows first, then corner rows (SE:499-504)
@@ -656,31 +646,12 @@ void joseph_dense(const lins_params& prm, const double* P, const Rows& rows, con
     for (int j = 0; j < 18; ++j) Pout[i * 18 + j] = 0.5 * (O[i * 18 + j] + O[j * 18 + i]);
 }
 
-// 6x6 block of A = H^T H and g = H^T r from the 28 sums (Appendix C):
-// A_pa = A_pu G, A_aa = G^T A_uu G, g_a = G^T g_u.
-void sums_to_normal(const double* s, const M3& G, double* A6, double* g6) {
-  double App[9], Apu[9], Auu[9];
-  App[0] = s[0], App[1] = App[3] = s[1], App[2] = App[6] = s[2], App[4] = s[3], App[5] = App[7] = s[4],
-  App[8] = s[5];
-  for (int k = 0; k < 9; ++k) Apu[k] = s[6 + k];
-  Auu[0] = s[15], Auu[1] = Auu[3] = s[16], Auu[2] = Auu[6] = s[17], Auu[4] = s[18],
-  Auu[5] = Auu[7] = s[19], Auu[8] = s[20];
-  M3 mpu, muu;
-  std::memcpy(mpu.m, Apu, sizeof Apu);
-  std::memcpy(muu.m, Auu, sizeof Auu);
-  M3 Apa = mmul(mpu, G);
-  M3 Gt{{G.m[0], G.m[3], G.m[6], G.m[1], G.m[4], G.m[7], G.m[2], G.m[5], G.m[8]}};
-  M3 Aaa = mmul(mmul(Gt, muu), G);
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) {
-      A6[i * 6 + j] = App[i * 3 + j];
-      A6[i * 6 + 3 + j] = Apa.m[i * 3 + j];
-      A6[(3 + i) * 6 + j] = Apa.m[j * 3 + i];
-      A6[(3 + i) * 6 + 3 + j] = Aaa.m[i * 3 + j];
-    }
-  g6[0] = s[21], g6[1] = s[22], g6[2] = s[23];
-  V3 ga = rowmul({s[24], s[25], s[26]}, G);  // G^T g_u
-  g6[3] = ga.x, g6[4] = ga.y, g6[5] = ga.z;
+// 6x6 block of A = H^T H and g = H^T r from the 28 sums.
+void sums_to_normal(const double* s, double* A6, double* g6) {
+  int k = 0;
+  for (int a = 0; a < 6; ++a)
+    for (int b = a; b < 6; ++b) A6[a * 6 + b] = A6[b * 6 + a] = s[k++];
+  for (int a = 0; a < 6; ++a) g6[a] = s[k++];
 }
 
 // Reduced (push-through) form: dx = d - P[:,S] (sigma^2 I + A_SS P_SS)^-1 (g + A d)_S.
@@ -812,8 +783,7 @@ int ieskf(const lins_params& prm, const lins_scan_pair& in, int form, int nn_mod
     if (form == ORACLE_FORM_DENSE) {
       update_dense(prm, P, rows, d, dx, gain);
     } else {
-      V3 axis = quat2axis(lin.q);
-      sums_to_normal(rows.sums, rinvleft({-axis.x, -axis.y, -axis.z}), A6, g6);
+      sums_to_normal(rows.sums, A6, g6);
       update_reduced(prm, P, A6, g6, d, dx);
     }
     if (tr && iter < tr->max_iters && tr->dx) std::memcpy(tr->dx + 18 * iter, dx, sizeof dx);

@@ -31,7 +31,7 @@ typedef struct oracle_trace {
   lins_corr* corner;   /* [max_iters][n_corner_sharp]                           */
   double* lin_state;   /* [max_iters][19] linearisation state entering iter k   */
   double* dx;          /* [max_iters][18] updateVec_ of iter k                  */
-  double* sums28;      /* [max_iters][28] reduced-form sums (Appendix C)        */
+  double* sums28;      /* [max_iters][28] H^T H upper triangle (21), H^T r (6), r^T r */
 } oracle_trace;
 
 /* findCorrespondingSurfFeatures / findCorrespondingCornerFeatures for one

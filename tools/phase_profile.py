@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""Per-phase shader-clock profile of the persistent IESKF kernel (debug aid).
+usage: tools/phase_profile.py [batch] [search]"""
+import ctypes as C
+import importlib
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "lins---lidar-inertial-slam_amd"
+pkg = importlib.import_module(PKG)
+host = importlib.import_module(PKG + ".host")
+ieskf = importlib.import_module(PKG + ".ieskf")
+
+batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+search = sys.argv[2] if len(sys.argv) > 2 else "binned"
+with ThreadPoolExecutor(16) as ex:
+    pairs = list(ex.map(host.synth_pair, range(batch)))
+prm = pkg.default_params(num_iter=10, fixed_iters=1)
+ctx = ieskf.IeskfContext(prm, max_batch=batch, max_targets=16384, search=search)
+L = ieskf.lib()
+L.lins_debug_phase_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+ctx.upload(pairs)
+for _ in range(2):
+    ctx.run()
+    ctx.sync()
+L.lins_debug_phase_profile(ctx._h, 1, None, 0)
+ctx.run()
+ctx.sync()
+prof = np.zeros((batch, 16), dtype=np.int64)
+L.lins_debug_phase_profile(ctx._h, 1, prof.ctypes.data, batch)
+print(f"batch {batch} search {search}: kernel ms", ctx.last_kernel_ms())
+names = ["setup", "corr", "reduce", "solve", "update", "total", "w0", "w1", "w2", "w3", "w4"]
+m = prof[:, :11].astype(float)
+for i, n in enumerate(names):
+    print(f"{n:7s} mean {m[:, i].mean():12.0f}  min {m[:, i].min():12.0f}  max {m[:, i].max():12.0f} ticks")
