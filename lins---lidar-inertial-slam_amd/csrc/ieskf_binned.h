@@ -95,14 +95,20 @@ __device__ __forceinline__ void for_columns(const CloudBins& cb, int base, int l
     int c0 = base + a, c1 = base + b;
     for_span_points(cb.binned, c0 ? cb.cell_end[c0 - 1] : 0u, cb.cell_end[c1], f);
   };
-  if (lo < 0) {
-    span(lo + naz, naz - 1);
-    if (hi >= 0) span(0, hi);
-  } else if (hi >= naz) {
+  // normalise: lo into [0, naz), at most naz columns, at most two contiguous pieces
+  int len = hi - lo;
+  if (len >= naz - 1) {
+    span(0, naz - 1);
+    return;
+  }
+  lo %= naz;
+  if (lo < 0) lo += naz;
+  hi = lo + len;
+  if (hi < naz) {
+    span(lo, hi);
+  } else {
     span(lo, naz - 1);
     span(0, hi - naz);
-  } else {
-    span(lo, hi);
   }
 }
 

@@ -622,6 +622,12 @@ void launch_persistent(hipStream_t stream, int n, const DevParams& prm, const Sc
                      cov_out);
 }
 
+void launch_joseph(hipStream_t stream, int n, const DevParams& prm, const double* cov_in, const double* a6,
+                   const void* out, double* cov_out) {
+  hipLaunchKernelGGL(ieskf_joseph_kernel, dim3(n), dim3(kJosephBlock), 0, stream, prm, cov_in, a6, (const OutRec*)out,
+                     cov_out);
+}
+
 void launch_pass(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
                  const double* lin_state, const double* filt_state, int iter, int4* idx_store, lins_corr* dump,
                  double* sums_out, int* counts_out, float4* binned) {

@@ -1,0 +1,686 @@
+// ieskf_lds.hip — the LDS-resident IESKF kernel: the fast path for VLP-16 sized scans.
+//
+// One 1024-thread workgroup (16 wave64, one per CU: it declares ~159 KB of the CU's
+// 160 KB LDS) owns one scan pair for the whole iterated update.  Both target clouds of
+// the scan are counting-sorted ONCE into (ring x azimuth-column) grids that live in
+// LDS as SoA (x[], y[], z[] f32 + u16 original index): after that single coalesced
+// pass over the scan's ~125 KB in HBM, every iteration's correspondence search is LDS
+// traffic only — the candidate windows are staged in LDS, not re-gathered from L2.
+//
+//   per iteration
+//     3 lanes / query   de-skew (f64, redundantly per lane) -> exact NN + index walk on
+//                       the LDS grid, the ring windows of one query split over its
+//                       three lanes and merged with wave shuffles on (distance, key)
+//     1 lane / query    plane / line residual + Jacobian (f64 -> f32) -> H row in LDS
+//     224 lanes         28 f64 sums, fixed-shape tree (8 strided groups -> ordered fold)
+//     <=42 lanes        6x6 pivoted elimination in LDS, dx
+//     wave 0            NaN / divergence / convergence, boxPlus, next constants
+//   16 waves x 21 queries = 336 queries per round = the VLP-16 caps (144 flat + 192 sharp).
+//
+// Scans that do not fit (more than kNpCap target points, ring ids >= 16, unsorted
+// rings) take the global-memory kernel in ieskf_kernels.hip — same results.
+
+#include <hip/hip_runtime.h>
+
+#include "ieskf_binned.h"
+#include "ieskf_device.h"
+
+namespace lins {
+
+struct OutRec {
+  double residual_norm, update_norm;
+  int iters, converged, diverged, m_surf, m_corner, pad[3];
+};
+
+constexpr int kLBlock = 1024;
+constexpr int kLWaves = kLBlock / 64;
+constexpr int kNpCap = 9216;          // target points (surf + corner) resident in LDS
+constexpr int kQPerWave = 21;         // 3 lanes per query, lane 63 idle
+constexpr int kQPerRound = kLWaves * kQPerWave;  // 336
+constexpr int kSlotCap = 352;         // >= kQPerRound, row slots of 7 doubles
+constexpr int kLRedGroups = 8;
+constexpr int kCellsSurf = kRingsBinned * kAzSurf, kCellsCorner = kRingsBinned * kAzCorner;
+
+__constant__ unsigned char kLPairA[28] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2,
+                                          2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6};
+__constant__ unsigned char kLPairB[28] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4,
+                                          5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6};
+
+struct LdsStore {
+  float px[kNpCap], py[kNpCap], pz[kNpCap];  // grid-sorted targets: surf cells, then corner cells
+  unsigned short pidx[kNpCap];               // original index inside its cloud
+  double slots[kSlotCap * 7];                // H rows; also the histogram scratch of the build
+  unsigned short cell_end[kCellsSurf + kCellsCorner];  // exclusive end (absolute position) per cell
+  double P[324];
+  IterConst ic;
+  double filt[19];
+  double sums[28];
+  double partial[kLRedGroups * 28];
+  double aug[42];
+  double w[6];
+  double dx[18];
+  double res_prev, res_last, upd_norm;
+  float2 az_edge[kAzSurf + 1];
+  float el[2][kRingsBinned][4];
+  int el_bits[2][kRingsBinned][2];
+  int ring_start[2][kRingsBinned + 1];  // per cloud, in (original) index space
+  int piv[6], used[6];
+  int scan_tmp[kLWaves + 4];
+  int m_surf, m_corner, iter, conv, div, pad;
+};
+static_assert(sizeof(LdsStore) <= 163840, "LDS budget of one CU");
+
+struct LCloud {  // one target cloud's grid (all pointers into LDS)
+  const unsigned short* cell_end;  // this cloud's cells (absolute positions)
+  const int* ring_start;
+  const float* el;
+  int naz, stride, base, n;
+};
+
+// Running best of a search: (distance, tie key) packed so that ONE unsigned 64-bit compare
+// is the reference's "strict < , first seen wins" rule: distances are non-negative floats
+// (their bit patterns order like the values, NaN above everything), the tie key is the
+// original index (pass 1: lowest index wins) or the visit rank (pass 2).  Initialised to
+// (threshold, 0): a candidate must be strictly closer than the threshold (SE:851, 856).
+struct Best {
+  unsigned long long k;
+  int pos, ring;
+  __device__ __forceinline__ float d() const { return __uint_as_float((unsigned)(k >> 32)); }
+  __device__ __forceinline__ int key() const { return (int)(unsigned)k; }
+};
+__device__ __forceinline__ Best best_init(float thr) {
+  return Best{(unsigned long long)__float_as_uint(thr) << 32, -1, -1};
+}
+__device__ __forceinline__ void consider(Best& b, float d, int key, int pos, int ring) {
+  unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)key;
+  if (k < b.k) b = Best{k, pos, ring};
+}
+__device__ __forceinline__ void merge_from_lane(Best& b, int src_lane) {
+  unsigned lo = __shfl((unsigned)b.k, src_lane), hi = __shfl((unsigned)(b.k >> 32), src_lane);
+  int pos = __shfl(b.pos, src_lane), ring = __shfl(b.ring, src_lane);
+  unsigned long long k = ((unsigned long long)hi << 32) | lo;
+  if (k < b.k) b = Best{k, pos, ring};
+}
+
+// ---- columns / windows on the LDS grid ----------------------------------------------------
+// All lanes of a wave run the SAME code on different (ring, column-range) data: every
+// scan goes through scan_cols(), whose point loop exists once per call site, so splitting
+// a query's ring windows over three lanes is real parallelism, not serialised branches.
+template <class F>
+__device__ __forceinline__ void scan_cols(const LdsStore& L, const LCloud& c, int r, int lo, int hi, F f) {
+  int s0 = 0, e0 = 0, s1 = 0, e1 = 0;
+  if (lo <= hi) {
+    const int naz = c.naz, row = r * naz;
+    int len = hi - lo;
+    if (len >= naz - 1) lo = 0, len = naz - 1;  // at most naz columns
+    lo %= naz;
+    if (lo < 0) lo += naz;
+    hi = lo + len;
+    const int c0 = row + lo, c1 = row + (hi < naz ? hi : naz - 1);
+    s0 = c0 ? (int)c.cell_end[c0 - 1] : c.base;
+    e0 = (int)c.cell_end[c1];
+    if (hi >= naz) {  // wrapped tail: columns 0 .. hi-naz
+      s1 = row ? (int)c.cell_end[row - 1] : c.base;
+      e1 = (int)c.cell_end[row + hi - naz];
+    }
+  }
+#pragma unroll 1
+  for (int k = 0; k < 2; ++k) {
+    const int s = k ? s1 : s0, e = k ? e1 : e0;
+#pragma unroll 2
+    for (int p = s; p < e; ++p) f(L.px[p], L.py[p], L.pz[p], (int)L.pidx[p], p);
+  }
+}
+
+// How many columns either side of a0 can hold a point within sqrt(bound) of the query:
+// a point at azimuth difference D from the query is at least rho*sin(D) away (rho for
+// D >= 90 deg), so D <= asin(sqrt(bound)/rho); the query sits anywhere inside its own
+// column, hence the +2 (one for its offset, one for rounding) — a superset, never less.
+__device__ __forceinline__ int reach(const LCloud& c, float rho, float bound) {
+  const int half = c.naz / 2;
+  float s = (sqrtf(bound) * (1.f + 1e-6f) + kSlack * rho + 1e-6f) / rho;  // rho == 0 -> inf/nan -> all columns
+  if (!(s < 1.f)) return half;
+  int k = (int)(asinf(s) * ((float)c.naz * (0.5f / kPiF))) + 2;
+  return k < half ? k : half;
+}
+
+__device__ __forceinline__ bool ring_nonempty(const LCloud& c, int r) {
+  return r >= 0 && r < kRingsBinned && c.ring_start[r + 1] > c.ring_start[r];
+}
+
+// ---- pass 1: exact NN, ring windows split over the query's 3 lanes ---------------------
+__device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float sx, float sy, float sz, float thr,
+                                       int rq, int role, int lane_base) {
+  Best b = best_init(thr);
+  const float rho = sqrtf(sx * sx + sy * sy);
+  const float qn3 = sqrtf(rho * rho + sz * sz);
+  const int a0 = az_bin(sx, sy, c.naz);
+  rq = rq < 0 ? 0 : (rq >= kRingsBinned ? kRingsBinned - 1 : rq);
+  int rcur = rq;
+  auto f = [&](float x, float y, float z, int j, int p) { consider(b, sqdist3(x, y, z, sx, sy, sz), j, p, rcur); };
+  const bool own = ring_nonempty(c, rq);
+  scan_cols(L, c, rq, own ? a0 - 1 : 1, own ? a0 + 1 : 0, f);  // seed: all three lanes
+  const float B = b.d();  // fixed bound for everything below (conservative: >= the final best)
+  const int K = reach(c, rho, B);
+  // This lane's tasks as a bit mask (bit i <-> task t = role + 3 i): task 0 = own ring right of
+  // the seed, 1 = own ring left of it, 2.. = the other rings rq+1, rq-1, rq+2, ...  The ring
+  // tests are independent LDS reads, issued together; only surviving tasks enter the scan loop.
+  unsigned todo = 0;
+#pragma unroll
+  for (int i = 0; i < 11; ++i) {
+    const int t = role + 3 * i;
+    const int k = t - 2, off = (k >> 1) + 1;
+    const int r = t < 2 ? rq : rq + ((k & 1) ? -off : off);
+    bool go = t < 2 + 2 * (kRingsBinned - 1) && ring_nonempty(c, r);
+    if (t < 2)
+      go = go && K >= 2;
+    else if (go)
+      go = !(ring_bound_sq(c.el + 4 * r, rho, sz, qn3) > B);
+    todo |= go ? (1u << i) : 0u;
+  }
+#pragma unroll 1
+  while (todo) {
+    const int i = __ffs(todo) - 1;
+    todo &= todo - 1;
+    const int t = role + 3 * i;
+    const int k = t - 2, off = (k >> 1) + 1;
+    const int r = t < 2 ? rq : rq + ((k & 1) ? -off : off);
+    rcur = r;
+    scan_cols(L, c, r, t == 0 ? a0 + 2 : a0 - K, t == 1 ? a0 - 2 : a0 + K, f);
+  }
+  merge_from_lane(b, lane_base + (role + 1) % 3);
+  merge_from_lane(b, lane_base + (role + 2) % 3);
+  return b;
+}
+
+constexpr int kBackRankL = 0x40000000;
+
+struct WalkCtx {
+  int j1, f_hi, b_lo;
+};
+__device__ __forceinline__ bool walk_ring_has_candidates(const LCloud& c, const WalkCtx& w, int r) {
+  if (r < 0 || r >= kRingsBinned) return false;
+  const int rs = c.ring_start[r], re = c.ring_start[r + 1];
+  const bool fwd = (w.j1 + 1 > rs ? w.j1 + 1 : rs) < (w.f_hi < re ? w.f_hi : re);
+  const bool bwd = (w.b_lo > rs ? w.b_lo : rs) < (w.j1 < re ? w.j1 : re);
+  return fwd || bwd;
+}
+
+// candidate filter + visit rank of the index walk: forward part (j1, f_hi) in ascending
+// order first, then the backward part [b_lo, j1) in descending order
+__device__ __forceinline__ bool walk_rank(const WalkCtx& w, int j, int& rank) {
+  const bool fwd = (unsigned)(j - w.j1 - 1) < (unsigned)(w.f_hi > w.j1 + 1 ? w.f_hi - w.j1 - 1 : 0);
+  const bool bwd = (unsigned)(j - w.b_lo) < (unsigned)(w.j1 - w.b_lo);  // b_lo <= j1 always
+  rank = fwd ? j - w.j1 : kBackRankL + (w.j1 - j);
+  return fwd || bwd;
+}
+
+// One walk task: candidates of ring r for the running best `cur` (rank-keyed).  full:
+// seed window + both extensions with the tightened bound; !full: extensions only (the
+// seed of that ring was scanned by all lanes before).  Same code for every lane.
+__device__ __forceinline__ void walk_task(const LdsStore& L, const LCloud& c, const WalkCtx& w, int r, bool full,
+                                          int a0, float sx, float sy, float sz, float rho_q, float qn3, Best& cur) {
+  bool go = walk_ring_has_candidates(c, w, r);
+  if (go) go = !(ring_bound_sq(c.el + 4 * r, rho_q, sz, qn3) > cur.d());
+  auto f = [&](float x, float y, float z, int j, int p) {
+    int rank;
+    if (walk_rank(w, j, rank)) consider(cur, sqdist3(x, y, z, sx, sy, sz), rank, p, 0);
+  };
+  const bool seed = go && full;
+  scan_cols(L, c, r, seed ? a0 - 1 : 1, seed ? a0 + 1 : 0, f);
+  const int K = reach(c, rho_q, cur.d());
+  go = go && K >= 2;
+  scan_cols(L, c, r, go ? a0 + 2 : 1, go ? a0 + K : 0, f);
+  scan_cols(L, c, r, go ? a0 - K : 1, go ? a0 - 2 : 0, f);
+}
+
+// ---- pass 2 (SE:859-910 surf, SE:983-1024 corner) ----------------------------------------
+// surf:   class 2 = ring rho (second point), class 3 = rings rho+-1, rho+-2 (third point)
+// corner: class 2 = rings rho+-1, rho+-2 (second point on a different ring), no class 3
+__device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, bool is_surf, int nq, float thr, int j1,
+                                         int rho, float sx, float sy, float sz, int role, int lane_base, Best& c2,
+                                         Best& c3) {
+  const int fend = nq < c.n ? nq : c.n;
+  const int r_hi = rho + 3 < kRingsBinned ? rho + 3 : kRingsBinned;
+  const int r_lo = rho - 2 > 0 ? rho - 2 : 0;
+  const WalkCtx w{j1, fend < c.ring_start[r_hi] ? fend : c.ring_start[r_hi], c.ring_start[r_lo]};
+  c2 = best_init(thr);
+  c3 = best_init(thr);
+  const float rho_q = sqrtf(sx * sx + sy * sy);
+  const float qn3 = sqrtf(rho_q * rho_q + sz * sz);
+  const int a0 = az_bin(sx, sy, c.naz);
+  if (is_surf) {  // class-2 seed on ring rho: all three lanes (wave-uniform branch except one wave)
+    bool go = walk_ring_has_candidates(c, w, rho);
+    auto f = [&](float x, float y, float z, int j, int p) {
+      int rank;
+      if (walk_rank(w, j, rank)) consider(c2, sqdist3(x, y, z, sx, sy, sz), rank, p, 0);
+    };
+    scan_cols(L, c, rho, go ? a0 - 1 : 1, go ? a0 + 1 : 0, f);
+  }
+  // two tasks per lane, chosen by role (data, not code):
+  //   surf    role 0: rho (class 2, extensions)   rho+2 (class 3)
+  //           role 1: rho-1 (class 3)             rho+1 (class 3)
+  //           role 2: rho-2 (class 3)             -
+  //   corner  role 0: rho-1                       -
+  //           role 1: rho+1                       rho+2
+  //           role 2: rho-2                       -
+#pragma unroll 1
+  for (int i = 0; i < 2; ++i) {
+    int r;
+    bool use2, full = true;
+    if (is_surf) {
+      const int dr = role == 0 ? (i ? 2 : 0) : (role == 1 ? (i ? 1 : -1) : (i ? 99 : -2));
+      r = rho + dr;
+      use2 = dr == 0;
+      full = dr != 0;
+    } else {
+      const int dr = role == 0 ? (i ? 99 : -1) : (role == 1 ? (i ? 2 : 1) : (i ? 99 : -2));
+      r = rho + dr;
+      use2 = true;
+    }
+    Best cur = use2 ? c2 : c3;
+    walk_task(L, c, w, r, full, a0, sx, sy, sz, rho_q, qn3, cur);
+    if (use2)
+      c2 = cur;
+    else
+      c3 = cur;
+  }
+  merge_from_lane(c2, lane_base + (role + 1) % 3);
+  merge_from_lane(c2, lane_base + (role + 2) % 3);
+  merge_from_lane(c3, lane_base + (role + 1) % 3);
+  merge_from_lane(c3, lane_base + (role + 2) % 3);
+}
+
+// ---- grid build: both clouds of the scan, once -----------------------------------------------
+__device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, const float4* __restrict__ arena,
+                                               int tid) {
+  unsigned* cnt = reinterpret_cast<unsigned*>(L.slots);  // kCellsSurf + kCellsCorner counters
+  constexpr int ncell = kCellsSurf + kCellsCorner;
+  for (int c = tid; c < ncell; c += kLBlock) cnt[c] = 0;
+  for (int a = tid; a <= kAzSurf; a += kLBlock) {
+    float th = -kPiF + (float)a * (2.f * kPiF / (float)kAzSurf);
+    L.az_edge[a] = make_float2(cosf(th), sinf(th));
+  }
+  if (tid < 2 * kRingsBinned) {
+    L.el_bits[tid / kRingsBinned][tid % kRingsBinned][0] = 0x7FFFFFFF;
+    L.el_bits[tid / kRingsBinned][tid % kRingsBinned][1] = (int)0x80000000;
+  }
+  __syncthreads();
+  const float4* ts = arena + sd.off_surf_t;
+  const float4* tc = arena + sd.off_corner_t;
+  for (int j = tid; j < sd.n_surf_t + sd.n_corner_t; j += kLBlock) {
+    const bool is_s = j < sd.n_surf_t;
+    float4 p = is_s ? ts[j] : tc[j - sd.n_surf_t];
+    int r = ring_of(p.w);
+    int cell = is_s ? r * kAzSurf + az_bin(p.x, p.y, kAzSurf) : kCellsSurf + r * kAzCorner + az_bin(p.x, p.y, kAzCorner);
+    atomicAdd(&cnt[cell], 1u);
+    int eb = ordered_int(atan2f(p.z, sqrtf(p.x * p.x + p.y * p.y)));
+    atomicMin(&L.el_bits[is_s ? 0 : 1][r][0], eb);
+    atomicMax(&L.el_bits[is_s ? 0 : 1][r][1], eb);
+  }
+  __syncthreads();
+  // exclusive scan over all cells: surf cells first, so corner positions start at n_surf_t
+  constexpr int per = (ncell + kLBlock - 1) / kLBlock;
+  const int c_lo = tid * per < ncell ? tid * per : ncell;
+  const int c_hi = c_lo + per < ncell ? c_lo + per : ncell;
+  int local = 0;
+  for (int c = c_lo; c < c_hi; ++c) local += (int)cnt[c];
+  int run = block_exclusive_scan(local, tid, L.scan_tmp);
+  for (int c = c_lo; c < c_hi; ++c) {
+    int n = (int)cnt[c];
+    cnt[c] = (unsigned)run;
+    run += n;
+  }
+  __syncthreads();
+  for (int j = tid; j < sd.n_surf_t + sd.n_corner_t; j += kLBlock) {
+    const bool is_s = j < sd.n_surf_t;
+    const int jj = is_s ? j : j - sd.n_surf_t;
+    float4 p = is_s ? ts[jj] : tc[jj];
+    int r = ring_of(p.w);
+    int cell = is_s ? r * kAzSurf + az_bin(p.x, p.y, kAzSurf) : kCellsSurf + r * kAzCorner + az_bin(p.x, p.y, kAzCorner);
+    unsigned pos = atomicAdd(&cnt[cell], 1u);  // order inside a cell is irrelevant (keyed ties)
+    L.px[pos] = p.x, L.py[pos] = p.y, L.pz[pos] = p.z;
+    L.pidx[pos] = (unsigned short)jj;
+  }
+  __syncthreads();  // cnt[c] is now the exclusive END of cell c
+  for (int c = tid; c < ncell; c += kLBlock) L.cell_end[c] = (unsigned short)cnt[c];
+  if (tid <= kRingsBinned) {
+    L.ring_start[0][tid] = tid == 0 ? 0 : (int)cnt[tid * kAzSurf - 1];
+    L.ring_start[1][tid] = (tid == 0 ? (int)cnt[kCellsSurf - 1] : (int)cnt[kCellsSurf + tid * kAzCorner - 1]) - sd.n_surf_t;
+  }
+  if (tid < 2 * kRingsBinned) {
+    int cl = tid / kRingsBinned, r = tid % kRingsBinned;
+    float lo = ordered_float(L.el_bits[cl][r][0]) - kSlack, hi = ordered_float(L.el_bits[cl][r][1]) + kSlack;
+    L.el[cl][r][0] = cosf(lo), L.el[cl][r][1] = sinf(lo), L.el[cl][r][2] = cosf(hi), L.el[cl][r][3] = sinf(hi);
+  }
+  __syncthreads();
+}
+
+// 6 x 6 pivoted elimination in LDS, cooperative over the block (see ieskf_kernels.hip)
+__device__ __forceinline__ void l_block_solve6(double* aug, int nc, double* sol, int* piv, int* used, int tid) {
+  if (tid < 6) used[tid] = 0;
+  __syncthreads();
+  for (int k = 0; k < 6; ++k) {
+    if (tid == 0) {
+      int p = -1;
+      double best = -1.0;
+      for (int i = 0; i < 6; ++i)
+        if (!used[i]) {
+          double v = fabs(aug[i * nc + k]);
+          if (p < 0 || v > best) best = v, p = i;
+        }
+      piv[k] = p;
+      used[p] = 1;
+    }
+    __syncthreads();
+    const int p = piv[k];
+    const int i = tid / nc, j = tid - i * nc;
+    if (i < 6 && !used[i] && j > k) {
+      double f = aug[i * nc + k] / aug[p * nc + k];
+      aug[i * nc + j] -= f * aug[p * nc + j];
+    }
+    __syncthreads();
+  }
+  const int nrhs = nc - 6;
+  if (tid < nrhs) {
+    const int col = 6 + tid;
+    double x[6];
+#pragma unroll
+    for (int k = 5; k >= 0; --k) {
+      const int p = piv[k];
+      double s = aug[p * nc + col];
+#pragma unroll
+      for (int j = k + 1; j < 6; ++j) s -= aug[p * nc + j] * x[j];
+      x[k] = s / aug[p * nc + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) sol[k * nrhs + tid] = x[k];
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// the kernel.  PASS_ONLY: one correspondence pass at a caller-supplied linearisation
+// state (lins_correspondences / lins_reduce_pass), dumping records / sums.
+// ---------------------------------------------------------------------------
+template <bool PASS_ONLY>
+__global__ __launch_bounds__(kLBlock) void ieskf_lds_kernel(
+    DevParams prm, const ScanDesc* __restrict__ descs, const float4* __restrict__ arena,
+    const double* __restrict__ state_in, const double* __restrict__ cov_in, const double* __restrict__ lin_in,
+    int iter_arg, double* __restrict__ state_out, double* __restrict__ a6_out, OutRec* __restrict__ out,
+    int4* __restrict__ idx_store, lins_pose_record* __restrict__ poses, int scan_id_base,
+    lins_corr* __restrict__ dump, double* __restrict__ sums_out, int* __restrict__ counts_out,
+    long long* __restrict__ prof) {
+  __shared__ LdsStore L;
+  // optional phase profile: [0] setup+grid build [1] correspondence [2] reduction [3] solve [4] update [5] total
+  long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [6..9] wave 0: de-skew, NN, walk, geometry
+  const long long t_begin = prof ? clock64() : 0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int scan = blockIdx.x;
+  const ScanDesc sd = descs[scan];
+  const int total = sd.n_surf_q + sd.n_corner_q;
+  const float4* tg_unused = arena;
+  (void)tg_unused;
+
+  for (int k = tid; k < 324; k += kLBlock) L.P[k] = PASS_ONLY ? 0.0 : cov_in[(size_t)scan * 324 + k];
+  if (tid < 19) {
+    double v = state_in[(size_t)scan * 19 + tid];
+    L.filt[tid] = v;
+    L.ic.lin[tid] = PASS_ONLY ? lin_in[(size_t)scan * 19 + tid] : v;
+  }
+  if (tid < 28) L.sums[tid] = 0;
+  if (tid == 0) {
+    L.res_prev = 1e6, L.res_last = 0, L.upd_norm = 0;
+    L.iter = PASS_ONLY ? iter_arg : 0, L.conv = 0, L.div = 0, L.m_surf = 0, L.m_corner = 0;
+  }
+  __syncthreads();
+  if (tid < 64) {  // wave 0, lane-redundant: constants of the first iteration
+    IterConst ic;
+    double filt[19];
+    for (int k = 0; k < 19; ++k) ic.lin[k] = L.ic.lin[k], filt[k] = L.filt[k];
+    make_iter_const(filt, ic);
+    if (tid == 0) {
+      L.ic.phi = ic.phi, L.ic.Rt = ic.Rt, L.ic.Gt = ic.Gt;
+      for (int k = 0; k < 18; ++k) L.ic.d[k] = ic.d[k];
+    }
+  }
+  build_lds_grid(L, sd, arena, tid);  // ends with a barrier
+  if (prof) pt[0] = clock64() - t_begin;
+
+  const LCloud cs{L.cell_end, L.ring_start[0], &L.el[0][0][0], kAzSurf, 1, 0, sd.n_surf_t};
+  const LCloud cc{L.cell_end + kCellsSurf, L.ring_start[1], &L.el[1][0][0], kAzCorner, kAzSurf / kAzCorner,
+                  sd.n_surf_t, sd.n_corner_t};
+  const int role = lane % 3, lane_base = lane - role, q_in_wave = lane / 3;
+
+  for (;;) {
+    const int iter = L.iter;
+    if (!PASS_ONLY && (iter >= prm.num_iter || L.conv || L.div)) break;
+    __syncthreads();  // everyone has read the loop state before it is rewritten
+    if (tid == 0) L.m_surf = 0, L.m_corner = 0;
+
+    const bool do_search = PASS_ONLY || (iter % prm.icp_freq) == 0;
+    double acc = 0;
+    int ms = 0, mc = 0;
+    long long t0 = prof ? clock64() : 0, t1 = t0, t2 = t0, t3 = t0;
+    for (int base = 0; base < total; base += kQPerRound) {
+      const int slot = base + wave * kQPerWave + q_in_wave;
+      const bool active = lane < 63 && slot < total;
+      double row[7] = {0, 0, 0, 0, 0, 0, 0};
+      if (active) {
+        const bool is_surf = slot < sd.n_surf_q;
+        const int qi = is_surf ? slot : slot - sd.n_surf_q;
+        const float4 q = arena[(is_surf ? sd.off_surf_q : sd.off_corner_q) + qi];
+        const LCloud& c = is_surf ? cs : cc;
+        V3 phi = L.ic.phi;
+        V3 t{L.ic.lin[0], L.ic.lin[1], L.ic.lin[2]};
+        QueryOut o;
+        long long s0 = prof ? clock64() : 0, s1 = s0, s2 = s0;
+        transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2]);
+        if (prof) s1 = clock64(), pt[6] += s1 - s0;
+        o.accepted = 0;
+        o.c[0] = o.c[1] = o.c[2] = o.c[3] = 0.f;
+        int p1 = -1, p2 = -1, p3 = -1;  // grid positions of the three target points
+        if (do_search) {
+          Best b1 = nn_lds(L, c, o.sel[0], o.sel[1], o.sel[2], prm.nearest_f, ring_of(q.w), role, lane_base);
+          if (prof) s2 = clock64(), pt[7] += s2 - s1;
+          if (b1.pos >= 0 && (double)b1.d() < prm.nearest) {
+            p1 = b1.pos;
+            Best c2, c3;
+            walk_lds(L, c, is_surf, is_surf ? sd.n_surf_q : sd.n_corner_q, prm.nearest_f, b1.key(), b1.ring, o.sel[0],
+                     o.sel[1], o.sel[2], role, lane_base, c2, c3);
+            p2 = c2.pos, p3 = c3.pos;
+          }
+          if (prof) pt[8] += clock64() - s2;
+          if (prm.icp_freq > 1 && role == 0) idx_store[sd.slot_base + slot] = make_int4(p1, p2, p3, 0);
+        } else {
+          int4 s = idx_store[sd.slot_base + slot];
+          p1 = s.x, p2 = s.y, p3 = s.z;
+        }
+        long long s3 = prof ? clock64() : 0;
+        if (role == 0) {
+          if (is_surf) {
+            if (p2 >= 0 && p3 >= 0)
+              surf_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], make_float4(L.px[p1], L.py[p1], L.pz[p1], 0.f),
+                       make_float4(L.px[p2], L.py[p2], L.pz[p2], 0.f), make_float4(L.px[p3], L.py[p3], L.pz[p3], 0.f),
+                       o);
+          } else if (p2 >= 0) {
+            corner_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], make_float4(L.px[p1], L.py[p1], L.pz[p1], 0.f),
+                       make_float4(L.px[p2], L.py[p2], L.pz[p2], 0.f), o);
+          }
+          if (o.accepted) {
+            V3 cv{(double)o.c[0], (double)o.c[1], (double)o.c[2]};
+            V3 u = cross(V3{(double)q.x, (double)q.y, (double)q.z}, mvec(L.ic.Rt, cv));
+            V3 a = mvec(L.ic.Gt, u);
+            row[0] = cv.x, row[1] = cv.y, row[2] = cv.z, row[3] = a.x, row[4] = a.y, row[5] = a.z;
+            row[6] = prm.lidar_scale * (double)o.c[3];
+            if (is_surf)
+              ++ms;
+            else
+              ++mc;
+          }
+          if (PASS_ONLY && dump) {
+            lins_corr r;
+            r.ind1 = p1 >= 0 ? (int)L.pidx[p1] : -1;
+            r.ind2 = p2 >= 0 ? (int)L.pidx[p2] : -1;
+            r.ind3 = (is_surf && p3 >= 0) ? (int)L.pidx[p3] : -1;
+            r.accepted = o.accepted;
+            for (int k = 0; k < 4; ++k) r.coeff[k] = o.c[k];
+            r.sel[0] = o.sel[0], r.sel[1] = o.sel[1], r.sel[2] = o.sel[2], r.sel[3] = q.w;
+            dump[sd.slot_base + slot] = r;
+          }
+        }
+        if (prof) pt[9] += clock64() - s3;
+      }
+      if (lane < 63 && role == 0) {
+        const int local = wave * kQPerWave + q_in_wave;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) L.slots[local * 7 + k] = row[k];
+      }
+      __syncthreads();
+      if (prof) t1 = clock64();
+      const int nrows = total - base < kQPerRound ? total - base : kQPerRound;
+      if (tid < kLRedGroups * 32) {
+        int g = tid >> 5, k = tid & 31;
+        if (k < 28) {
+          int a = kLPairA[k], b = kLPairB[k];
+          for (int r = g; r < nrows; r += kLRedGroups) acc += L.slots[r * 7 + a] * L.slots[r * 7 + b];
+        }
+      }
+      __syncthreads();
+    }
+    if (tid < kLRedGroups * 32 && (tid & 31) < 28) L.partial[(tid >> 5) * 28 + (tid & 31)] = acc;
+    if (ms) atomicAdd(&L.m_surf, ms);
+    if (mc) atomicAdd(&L.m_corner, mc);
+    __syncthreads();
+    if (tid < 28) {
+      double s = 0;
+#pragma unroll
+      for (int g = 0; g < kLRedGroups; ++g) s += L.partial[g * 28 + tid];
+      L.sums[tid] = s;
+    }
+    __syncthreads();
+    if (prof) t2 = clock64();
+    if (PASS_ONLY) {
+      if (sums_out && tid < 28) sums_out[(size_t)scan * 28 + tid] = L.sums[tid];
+      if (counts_out && tid == 0) counts_out[scan * 2] = L.m_surf, counts_out[scan * 2 + 1] = L.m_corner;
+      return;
+    }
+
+    // (sigma^2 I + A P_SS) w = g + A d_S     (push-through form of SE:542-549)
+    if (tid < 36) {
+      int i = tid / 6, j = tid - i * 6;
+      double t = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) t += sym6(L.sums, i, k) * L.P[sidx(k) * 18 + sidx(j)];
+      L.aug[i * 7 + j] = t + (i == j ? prm.r2 : 0.0);
+    } else if (tid < 42) {
+      int i = tid - 36;
+      double z = L.sums[21 + i];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) z += sym6(L.sums, i, k) * L.ic.d[sidx(k)];
+      L.aug[i * 7 + 6] = z;
+    }
+    __syncthreads();
+    l_block_solve6(L.aug, 7, L.w, L.piv, L.used, tid);
+    if (tid < 18) {
+      double s = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s += L.P[tid * 18 + sidx(k)] * L.w[k];
+      L.dx[tid] = L.ic.d[tid] - s;
+    }
+    __syncthreads();
+    if (prof) t3 = clock64();
+
+    if (tid < 64) {  // wave 0, lane-redundant: SE:552-580 + constants of the next iteration
+      double dx[18];
+      for (int k = 0; k < 18; ++k) dx[k] = L.dx[k];
+      double rn = sqrt(L.sums[27]);
+      bool has_nan = false;
+      for (int k = 0; k < 18; ++k)
+        if (isnan(dx[k])) has_nan = true;
+      int div = 0, conv = 0;
+      IterConst ic;
+      for (int k = 0; k < 19; ++k) ic.lin[k] = L.ic.lin[k];
+      double un = L.upd_norm, res_prev = L.res_prev;
+      if (has_nan) {
+        div = 2;
+      } else if (rn > res_prev * 10) {
+        div = 1;
+      } else {
+        box_plus_inplace(ic.lin, dx);
+        un = 0;
+        for (int k = 0; k < 18; ++k) un += dx[k] * dx[k];
+        un = sqrt(un);
+        if (un <= 1e-2 && !prm.fixed_iters) conv = 1;
+        res_prev = rn;
+        double filt[19];
+        for (int k = 0; k < 19; ++k) filt[k] = L.filt[k];
+        make_iter_const(filt, ic);
+      }
+      if (tid == 0) {
+        if (!div) {
+          for (int k = 0; k < 19; ++k) L.ic.lin[k] = ic.lin[k];
+          L.ic.phi = ic.phi, L.ic.Rt = ic.Rt, L.ic.Gt = ic.Gt;
+          for (int k = 0; k < 18; ++k) L.ic.d[k] = ic.d[k];
+        }
+        L.res_last = rn, L.res_prev = res_prev, L.upd_norm = un;
+        L.conv = conv, L.div = div;
+        L.iter = iter + 1;
+      }
+    }
+    __syncthreads();
+    if (prof) {
+      long long t4 = clock64();
+      pt[1] += t1 - t0, pt[2] += t2 - t1, pt[3] += t3 - t2, pt[4] += t4 - t3;
+    }
+  }
+  if (prof && tid == 0) {
+    pt[5] = clock64() - t_begin;
+    for (int k = 0; k < 10; ++k) prof[(size_t)scan * 16 + k] = pt[k];
+  }
+
+  // ---- hand-off to the Joseph kernel / the caller (SE:585-598) ---------------
+  const int div = L.div;
+  if (tid < 19) state_out[(size_t)scan * 19 + tid] = div ? L.filt[tid] : L.ic.lin[tid];
+  if (tid < 21) a6_out[(size_t)scan * 21 + tid] = L.sums[tid];
+  if (tid == 0) {
+    OutRec r;
+    r.residual_norm = L.res_last, r.update_norm = L.upd_norm;
+    r.iters = L.iter, r.converged = L.conv, r.diverged = div;
+    r.m_surf = L.m_surf, r.m_corner = L.m_corner;
+    r.pad[0] = r.pad[1] = r.pad[2] = 0;
+    out[scan] = r;
+  }
+  if (poses && tid < 32) {
+    lins_pose_record* pr = poses + scan;
+    const double* st = div ? L.filt : L.ic.lin;
+    if (tid < 19) pr->state[tid] = st[tid];
+    if (tid == 19) pr->residual_norm = L.res_last;
+    if (tid == 20) {
+      pr->iters = L.iter, pr->converged = L.conv, pr->diverged = div;
+      pr->m_surf = L.m_surf, pr->m_corner = L.m_corner, pr->scan_id = scan_id_base + scan;
+      pr->pad[0] = pr->pad[1] = 0;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+int lds_np_cap() { return kNpCap; }
+
+void launch_lds(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
+                const double* state_in, const double* cov_in, double* state_out, double* a6, void* out,
+                int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof) {
+  hipLaunchKernelGGL(ieskf_lds_kernel<false>, dim3(n), dim3(kLBlock), 0, stream, prm, descs, arena, state_in, cov_in,
+                     (const double*)nullptr, 0, state_out, a6, (OutRec*)out, idx_store, poses, scan_id_base,
+                     (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof);
+}
+
+void launch_lds_pass(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
+                     const double* lin_state, const double* filt_state, int iter, int4* idx_store, lins_corr* dump,
+                     double* sums_out, int* counts_out) {
+  hipLaunchKernelGGL(ieskf_lds_kernel<true>, dim3(n), dim3(kLBlock), 0, stream, prm, descs, arena, filt_state,
+                     (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr, (OutRec*)nullptr,
+                     idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out, (long long*)nullptr);
+}
+
+}  // namespace lins

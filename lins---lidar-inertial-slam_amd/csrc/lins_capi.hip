@@ -22,6 +22,12 @@ void launch_persistent(hipStream_t, int, const DevParams&, const ScanDesc*, cons
                        const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, float4*, long long*);
 void launch_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const double*, const double*,
                  int, int4*, lins_corr*, double*, int*, float4*);
+void launch_joseph(hipStream_t, int, const DevParams&, const double*, const double*, const void*, double*);
+void launch_lds(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const double*, const double*,
+                double*, double*, void*, int4*, lins_pose_record*, int, long long*);
+void launch_lds_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const double*, const double*,
+                     int, int4*, lins_corr*, double*, int*);
+int lds_np_cap();
 size_t out_rec_size();
 struct OutRecHost {
   double residual_norm, update_norm;
@@ -59,6 +65,7 @@ struct lins_ctx {
   double* d_sums = nullptr;
   int* d_counts = nullptr;
   int n_uploaded = 0;
+  bool lds_ok = false;  // every uploaded scan fits the LDS-resident kernel
   bool ran = false;
   uint64_t bytes_per_iter = 0;
   uint64_t total_iters = 0;
@@ -117,6 +124,7 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   size_t off = 0, slots = 0;
   uint64_t bytes = 0;
+  bool lds_ok = true;
   for (int s = 0; s < n; ++s) {
     const lins_scan_pair& p = in[s];
     if (p.n_surf_flat < 0 || p.n_corner_sharp < 0 || p.n_surf_last < 0 || p.n_corner_last < 0) return LINS_E_ARG;
@@ -147,6 +155,7 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
     d.off_surf_t = offs[2], d.n_surf_t = cnt[2];
     d.off_corner_t = offs[3], d.n_corner_t = cnt[3];
     d.surf_sorted = ss, d.corner_sorted = cs;
+    if (!ss || !cs || cnt[2] + cnt[3] > lds_np_cap()) lds_ok = false;
     d.slot_base = (int)slots;
     d.pad = 0;
     slots += cnt[0] + cnt[1];
@@ -161,6 +170,7 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_cov_in, ctx->h_cov, (size_t)n * 324 * 8, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->n_uploaded = n;
+  ctx->lds_ok = lds_ok;
   ctx->ran = false;
   ctx->bytes_per_iter = bytes;
   return LINS_OK;
@@ -275,6 +285,8 @@ int lins_set_search(lins_ctx* ctx, const char* mode) {
     ctx->dprm.search = SEARCH_BRUTE;
   else if (!std::strcmp(mode, "binned"))
     ctx->dprm.search = SEARCH_BINNED;
+  else if (!std::strcmp(mode, "lds"))
+    ctx->dprm.search = SEARCH_LDS;
   else
     return LINS_E_ARG;
   return LINS_OK;
@@ -287,9 +299,17 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   if (ctx->n_uploaded <= 0) return LINS_E_STATE;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  launch_persistent(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_state_in,
-                    ctx->d_cov_in, ctx->d_state_out, ctx->d_cov_out, ctx->d_a6, ctx->d_out, ctx->d_idx,
-                    (lins_pose_record*)d_poses, scan_id_base, ctx->d_binned, ctx->d_prof);
+  if (ctx->dprm.search == SEARCH_LDS && ctx->lds_ok) {
+    launch_lds(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_state_in, ctx->d_cov_in,
+               ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx, (lins_pose_record*)d_poses, scan_id_base, ctx->d_prof);
+    launch_joseph(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_cov_in, ctx->d_a6, ctx->d_out, ctx->d_cov_out);
+  } else {
+    DevParams dp = ctx->dprm;
+    if (dp.search == SEARCH_LDS) dp.search = SEARCH_BINNED;  // a scan does not fit LDS: global-memory grid
+    launch_persistent(ctx->stream, ctx->n_uploaded, dp, ctx->d_desc, ctx->d_arena, ctx->d_state_in, ctx->d_cov_in,
+                      ctx->d_state_out, ctx->d_cov_out, ctx->d_a6, ctx->d_out, ctx->d_idx,
+                      (lins_pose_record*)d_poses, scan_id_base, ctx->d_binned, ctx->d_prof);
+  }
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   ctx->ran = true;
@@ -394,8 +414,17 @@ static int run_pass(lins_ctx* ctx, const lins_scan_pair* in, const double* lin_s
   if (rc) return rc;
   ctx->n_uploaded = 0;  // the single-pass calls do not leave a runnable batch behind
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_lin, lin_state, 19 * 8, hipMemcpyHostToDevice, ctx->stream));
-  launch_pass(ctx->stream, 1, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_lin, ctx->d_state_in, iter, ctx->d_idx,
-              dump ? ctx->d_dump : nullptr, sums ? ctx->d_sums : nullptr, sums ? ctx->d_counts : nullptr, ctx->d_binned);
+  if (ctx->dprm.search == SEARCH_LDS && ctx->lds_ok) {
+    launch_lds_pass(ctx->stream, 1, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_lin, ctx->d_state_in, iter,
+                    ctx->d_idx, dump ? ctx->d_dump : nullptr, sums ? ctx->d_sums : nullptr,
+                    sums ? ctx->d_counts : nullptr);
+  } else {
+    DevParams dp = ctx->dprm;
+    if (dp.search == SEARCH_LDS) dp.search = SEARCH_BINNED;
+    launch_pass(ctx->stream, 1, dp, ctx->d_desc, ctx->d_arena, ctx->d_lin, ctx->d_state_in, iter, ctx->d_idx,
+                dump ? ctx->d_dump : nullptr, sums ? ctx->d_sums : nullptr, sums ? ctx->d_counts : nullptr,
+                ctx->d_binned);
+  }
   HIP_TRY(ctx, hipGetLastError());
   return LINS_OK;
 }

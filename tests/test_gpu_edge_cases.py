@@ -62,7 +62,7 @@ def ctx(pkg, ieskf):
     c.close()
 
 
-@pytest.mark.parametrize("search", ["brute", "binned"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds"])
 @pytest.mark.parametrize("kind", ["lattice", "dup", "axis", "offgrid"])
 def test_adversarial_clouds_exact_indices(pkg, oracle, ctx, search, kind):
     ctx.set_search(search)
@@ -79,7 +79,7 @@ def test_adversarial_clouds_exact_indices(pkg, oracle, ctx, search, kind):
             assert_same_corr(corner, wc, f"{kind}/{trial}/it{it}/corner")
 
 
-@pytest.mark.parametrize("search", ["brute", "binned"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds"])
 def test_forward_walk_is_bounded_by_query_count(pkg, oracle, ctx, search):
     """SE:859/983: the forward walk stops at j < N_query.  Few queries => forward part empty;
     many queries (> targets) => our min(N_query, N_target) guard."""
@@ -97,7 +97,7 @@ def test_forward_walk_is_bounded_by_query_count(pkg, oracle, ctx, search):
             assert not fwd[ws["ind1"] >= 3].any()
 
 
-@pytest.mark.parametrize("search", ["brute", "binned"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds"])
 def test_unsorted_rings_and_high_ring_ids_fall_back_exactly(pkg, oracle, ctx, search):
     ctx.set_search(search)
     prm = pkg.default_params()
@@ -110,7 +110,7 @@ def test_unsorted_rings_and_high_ring_ids_fall_back_exactly(pkg, oracle, ctx, se
         assert_same_corr(corner, wc, "corner")
 
 
-@pytest.mark.parametrize("search", ["brute", "binned"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds"])
 def test_empty_and_ragged_inputs(pkg, oracle, ctx, search):
     ctx.set_search(search)
     prm = pkg.default_params(num_iter=5)
@@ -129,7 +129,7 @@ def test_empty_and_ragged_inputs(pkg, oracle, ctx, search):
     del prm
 
 
-@pytest.mark.parametrize("search", ["brute", "binned"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds"])
 def test_maximum_sizes(pkg, oracle, ctx, search):
     """1024 queries per cloud (LINS_MAX_QUERY; > one 512-slot reduction round) and a
     full 16x1800 target cloud."""
@@ -147,7 +147,7 @@ def test_maximum_sizes(pkg, oracle, ctx, search):
 
 def test_icp_freq_reuses_indices(pkg, ieskf, oracle, pairs):
     prm = pkg.default_params(num_iter=12, icp_freq=3)
-    with ieskf.IeskfContext(prm, max_batch=2, max_targets=16384, search="binned") as c:
+    with ieskf.IeskfContext(prm, max_batch=2, max_targets=16384, search="lds") as c:
         for pair in pairs[:2]:
             got = c.update(pair)
             want = oracle.ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_BRUTE)
@@ -162,7 +162,7 @@ def test_divergence_reports_and_icp_fallback(pkg, ieskf, oracle, pairs):
     runs the ICP fallback (SE:585-592) with GPU correspondences."""
     prm = pkg.default_params(num_iter=30)
     found = 0
-    with ieskf.IeskfContext(prm, max_batch=1, max_targets=16384, search="binned") as c:
+    with ieskf.IeskfContext(prm, max_batch=1, max_targets=16384, search="lds") as c:
         for k, base in enumerate(pairs):
             st = base.state.copy()
             st[0:3] += [1.5, -1.0, 0.3]
@@ -191,7 +191,7 @@ def test_icp_matches_oracle(pkg, ieskf, oracle, pairs):
 
     prm = pkg.default_params(num_iter=30)
     defs = ieskf  # noqa: F841
-    with ieskf.IeskfContext(prm, max_batch=1, max_targets=16384, search="binned") as c:
+    with ieskf.IeskfContext(prm, max_batch=1, max_targets=16384, search="lds") as c:
         pair = pairs[1]
         # force the fallback: NaN covariance => NaN update => diverged = 2 (SE:552-563)
         bad = pkg.ScanPair(pair.surf_flat, pair.corner_sharp, pair.surf_last, pair.corner_last, pair.state,
