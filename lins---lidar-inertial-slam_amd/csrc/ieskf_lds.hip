@@ -56,7 +56,7 @@ struct LdsStore {
   double filt[19];
   double sums[28];
   double partial[kLRedGroups * 28];
-  double aug[42];
+  double aug[3][42];  // one staging copy of [N | z] per solving wave
   double w[6];
   double dx[18];
   double res_prev, res_last, upd_norm;
@@ -400,6 +400,76 @@ __device__ __forceinline__ void l_block_solve6(double* aug, int nc, double* sol,
 }
 
 // ---------------------------------------------------------------------------
+// 6x6 pivoted elimination, every lane of the wave redundantly in registers (the wave is
+// one instruction stream anyway): no shuffles, no LDS traffic, no barriers.  Fully
+// unrolled; row exchanges are value selects so nothing is dynamically indexed.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void reg_solve6(double (&a)[6][7], double (&x)[6]) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int p = k;
+    double best = fabs(a[k][k]);
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      double v = fabs(a[i][k]);
+      if (v > best) best = v, p = i;
+    }
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      const bool sw = (p == i);
+#pragma unroll
+      for (int j = k; j < 7; ++j) {
+        double u = a[k][j], w = a[i][j];
+        a[k][j] = sw ? w : u;
+        a[i][j] = sw ? u : w;
+      }
+    }
+    const double inv = 1.0 / a[k][k];
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      const double f = a[i][k] * inv;
+#pragma unroll
+      for (int j = k + 1; j < 7; ++j) a[i][j] -= f * a[k][j];
+    }
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double sacc = a[i][6];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) sacc -= a[i][k] * x[k];
+    x[i] = sacc / a[i][i];
+  }
+}
+
+// Rinvleft(-phi)^T and phi from a unit quaternion without libm sin/cos: with
+// h = |phi|/2 the half angle, cos h = |w| / |q| and sin h = |v| / |q| exactly, so
+// s = h cot h needs only the atan2 that Quat2axis performs anyway (math_utils.h:75-88,
+// 304-321; differs from the sin/cos route in the last ulp only).
+__device__ __forceinline__ void phi_and_Gt(const Q4& q, V3& phi, M3& Gt) {
+  const double mag = sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
+  phi = V3{q.x, q.y, q.z};
+  Gt = M3{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+  if (!(mag >= 1e-10)) return;  // Quat2axis leaves v unscaled; |phi| < 1e-10 => Rinvleft = I
+  const double ang = wrap_pi(2.0 * atan2(mag, q.w));
+  const V3 u = V3{q.x, q.y, q.z} / mag;
+  phi = ang * u;
+  const double theta = norm(phi);
+  if (theta < 1e-10) return;
+  const double h = theta / 2.0;
+  const double n = sqrt(q.w * q.w + mag * mag);
+  const double s = h * ((fabs(q.w) / n) / (mag / n));
+  const V3 a = V3{-phi.x, -phi.y, -phi.z} / theta;  // axis of -phi
+  const M3 k = skew(a);
+  const double av[3] = {a.x, a.y, a.z};
+  // Rinvleft(-phi) = s I + (1 - s) a a^T - h [a]x ; store the transpose
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj)
+      Gt.m[jj * 3 + i] = (s * (i == jj ? 1.0 : 0.0) + (1.0 - s) * av[i] * av[jj]) - h * k.m[i * 3 + jj];
+}
+
+// ---------------------------------------------------------------------------
 // the kernel.  PASS_ONLY: one correspondence pass at a caller-supplied linearisation
 // state (lins_correspondences / lins_reduce_pass), dumping records / sums.
 // ---------------------------------------------------------------------------
@@ -566,67 +636,102 @@ __global__ __launch_bounds__(kLBlock) void ieskf_lds_kernel(
       return;
     }
 
-    // (sigma^2 I + A P_SS) w = g + A d_S     (push-through form of SE:542-549)
-    if (tid < 36) {
-      int i = tid / 6, j = tid - i * 6;
-      double t = 0;
+    // ---- solve + state update: waves 0-2, each redundantly, in registers ----------------------
+    // (sigma^2 I + A P_SS) w = g + A d_S  (push-through form of SE:542-549), dx = d - P[:,S] w,
+    // NaN / divergence / convergence tests and boxPlus (SE:552-580); after one barrier the three
+    // waves split the constants of the next iteration: wave 0 -> linState_, flags, R^T;
+    // wave 1 -> phi, Rinvleft(-phi)^T;  wave 2 -> x_filter (-) x_lin.
+    double lin[19];
+    double rn = 0, un = 0, res_prev = 0;
+    int div = 0, conv = 0;
+    if (wave < 3) {
+      if (lane < 42) {
+        const int i = lane / 7, j = lane % 7;
+        double v;
+        if (j < 6) {
+          v = (i == j ? prm.r2 : 0.0);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) t += sym6(L.sums, i, k) * L.P[sidx(k) * 18 + sidx(j)];
-      L.aug[i * 7 + j] = t + (i == j ? prm.r2 : 0.0);
-    } else if (tid < 42) {
-      int i = tid - 36;
-      double z = L.sums[21 + i];
+          for (int k = 0; k < 6; ++k) v += sym6(L.sums, i, k) * L.P[sidx(k) * 18 + sidx(j)];
+        } else {
+          v = L.sums[21 + i];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) z += sym6(L.sums, i, k) * L.ic.d[sidx(k)];
-      L.aug[i * 7 + 6] = z;
-    }
-    __syncthreads();
-    l_block_solve6(L.aug, 7, L.w, L.piv, L.used, tid);
-    if (tid < 18) {
-      double s = 0;
+          for (int k = 0; k < 6; ++k) v += sym6(L.sums, i, k) * L.ic.d[sidx(k)];
+        }
+        L.aug[wave][lane] = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double a[6][7], wsol[6];
 #pragma unroll
-      for (int k = 0; k < 6; ++k) s += L.P[tid * 18 + sidx(k)] * L.w[k];
-      L.dx[tid] = L.ic.d[tid] - s;
-    }
-    __syncthreads();
-    if (prof) t3 = clock64();
-
-    if (tid < 64) {  // wave 0, lane-redundant: SE:552-580 + constants of the next iteration
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 7; ++j) a[i][j] = L.aug[wave][i * 7 + j];
+      reg_solve6(a, wsol);
+      double dxi = 0;
+      if (lane < 18) {
+        double sacc = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sacc += L.P[lane * 18 + sidx(k)] * wsol[k];
+        dxi = L.ic.d[lane] - sacc;
+      }
       double dx[18];
-      for (int k = 0; k < 18; ++k) dx[k] = L.dx[k];
-      double rn = sqrt(L.sums[27]);
+#pragma unroll
+      for (int k = 0; k < 18; ++k) dx[k] = __shfl(dxi, k);
+      if (prof) t3 = clock64();
+      rn = sqrt(L.sums[27]);
       bool has_nan = false;
+#pragma unroll
       for (int k = 0; k < 18; ++k)
         if (isnan(dx[k])) has_nan = true;
-      int div = 0, conv = 0;
-      IterConst ic;
-      for (int k = 0; k < 19; ++k) ic.lin[k] = L.ic.lin[k];
-      double un = L.upd_norm, res_prev = L.res_prev;
+#pragma unroll
+      for (int k = 0; k < 19; ++k) lin[k] = L.ic.lin[k];
+      un = L.upd_norm, res_prev = L.res_prev;
       if (has_nan) {
         div = 2;
       } else if (rn > res_prev * 10) {
         div = 1;
       } else {
-        box_plus_inplace(ic.lin, dx);
+        box_plus_inplace(lin, dx);
         un = 0;
+#pragma unroll
         for (int k = 0; k < 18; ++k) un += dx[k] * dx[k];
         un = sqrt(un);
         if (un <= 1e-2 && !prm.fixed_iters) conv = 1;
         res_prev = rn;
-        double filt[19];
-        for (int k = 0; k < 19; ++k) filt[k] = L.filt[k];
-        make_iter_const(filt, ic);
       }
-      if (tid == 0) {
-        if (!div) {
-          for (int k = 0; k < 19; ++k) L.ic.lin[k] = ic.lin[k];
-          L.ic.phi = ic.phi, L.ic.Rt = ic.Rt, L.ic.Gt = ic.Gt;
-          for (int k = 0; k < 18; ++k) L.ic.d[k] = ic.d[k];
+    }
+    __syncthreads();  // every reader of the old linearisation state is done
+    if (wave < 3 && !div) {
+      const Q4 q{lin[6], lin[7], lin[8], lin[9]};
+      if (wave == 0) {
+        const M3 Rt = mtrans(qmat(q));
+        if (lane < 19) L.ic.lin[lane] = lin[lane];
+        if (lane < 9) L.ic.Rt.m[lane] = Rt.m[lane];
+      } else if (wave == 1) {
+        V3 phi;
+        M3 Gt;
+        phi_and_Gt(q, phi, Gt);
+        if (lane == 0) L.ic.phi = phi;
+        if (lane < 9) L.ic.Gt.m[lane] = Gt.m[lane];
+      } else {
+        // boxMinus(filter, lin), KF:84-94
+        const Q4 qf{L.filt[6], L.filt[7], L.filt[8], L.filt[9]};
+        const V3 da = quat2axis(qmul(qinverse(q), qf));
+        if (lane < 3) {
+          L.ic.d[0 + lane] = L.filt[0 + lane] - lin[0 + lane];
+          L.ic.d[3 + lane] = L.filt[3 + lane] - lin[3 + lane];
+          L.ic.d[9 + lane] = L.filt[10 + lane] - lin[10 + lane];
+          L.ic.d[12 + lane] = L.filt[13 + lane] - lin[13 + lane];
+          L.ic.d[15 + lane] = L.filt[16 + lane] - lin[16 + lane];
+          L.ic.d[6 + lane] = lane == 0 ? da.x : (lane == 1 ? da.y : da.z);
         }
-        L.res_last = rn, L.res_prev = res_prev, L.upd_norm = un;
-        L.conv = conv, L.div = div;
-        L.iter = iter + 1;
       }
+    }
+    if (tid == 0) {
+      L.res_last = rn, L.res_prev = res_prev, L.upd_norm = un;
+      L.conv = conv, L.div = div;
+      L.iter = iter + 1;
     }
     __syncthreads();
     if (prof) {
