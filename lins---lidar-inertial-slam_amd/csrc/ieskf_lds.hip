@@ -32,12 +32,9 @@ struct OutRec {
   int iters, converged, diverged, m_surf, m_corner, pad[3];
 };
 
-constexpr int kLBlock = 1024;
-constexpr int kLWaves = kLBlock / 64;
-constexpr int kNpCap = 9216;          // target points (surf + corner) resident in LDS
-constexpr int kQPerWave = 21;         // 3 lanes per query, lane 63 idle
-constexpr int kQPerRound = kLWaves * kQPerWave;  // 336
-constexpr int kSlotCap = 352;         // >= kQPerRound, row slots of 7 doubles
+constexpr int kMaxLWaves = 16;
+constexpr int kNpCap = 9088;          // target points (surf + corner) resident in LDS
+constexpr int kSlotCap = 384;         // >= queries per round, row slots of 7 doubles
 constexpr int kLRedGroups = 8;
 constexpr int kCellsSurf = kRingsBinned * kAzSurf, kCellsCorner = kRingsBinned * kAzCorner;
 
@@ -61,11 +58,11 @@ struct LdsStore {
   double dx[18];
   double res_prev, res_last, upd_norm;
   float2 az_edge[kAzSurf + 1];
-  float el[2][kRingsBinned][4];
+  float el_ang[2][kRingsBinned][2];  // the same wedge as angles (lo - slack, hi + slack)
   int el_bits[2][kRingsBinned][2];
   int ring_start[2][kRingsBinned + 1];  // per cloud, in (original) index space
   int piv[6], used[6];
-  int scan_tmp[kLWaves + 4];
+  int scan_tmp[kMaxLWaves + 4];
   int m_surf, m_corner, iter, conv, div, pad;
 };
 static_assert(sizeof(LdsStore) <= 163840, "LDS budget of one CU");
@@ -73,7 +70,7 @@ static_assert(sizeof(LdsStore) <= 163840, "LDS budget of one CU");
 struct LCloud {  // one target cloud's grid (all pointers into LDS)
   const unsigned short* cell_end;  // this cloud's cells (absolute positions)
   const int* ring_start;
-  const float* el;
+  const float* el_ang;
   int naz, stride, base, n;
 };
 
@@ -148,48 +145,65 @@ __device__ __forceinline__ bool ring_nonempty(const LCloud& c, int r) {
   return r >= 0 && r < kRingsBinned && c.ring_start[r + 1] > c.ring_start[r];
 }
 
-// ---- pass 1: exact NN, ring windows split over the query's 3 lanes ---------------------
+// ring r can hold a point within sqrt(bound) of the query only if the query's elevation
+// is within delta = asin(sqrt(bound)/|q|) of the ring's elevation wedge (a point at
+// elevation difference g < 90 deg is at least |q| sin g away, |q| beyond that)
+__device__ __forceinline__ float reach_elev(float qn3, float bound) {
+  float s = (sqrtf(bound) * (1.f + 1e-6f) + kSlack * qn3 + 1e-6f) / qn3;
+  return s < 1.f ? asinf(s) + kSlack : 4.f;  // 4 rad > any elevation difference
+}
+__device__ __forceinline__ bool ring_in_reach(const LCloud& c, int r, float el_q, float delta) {
+  return el_q >= c.el_ang[2 * r] - delta && el_q <= c.el_ang[2 * r + 1] + delta;
+}
+
+// ---- pass 1: exact NN; with LANES = 3 the ring windows of a query are split over its lanes
+template <int LANES>
 __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float sx, float sy, float sz, float thr,
                                        int rq, int role, int lane_base) {
   Best b = best_init(thr);
   const float rho = sqrtf(sx * sx + sy * sy);
   const float qn3 = sqrtf(rho * rho + sz * sz);
+  const float el_q = atan2f(sz, rho);
   const int a0 = az_bin(sx, sy, c.naz);
   rq = rq < 0 ? 0 : (rq >= kRingsBinned ? kRingsBinned - 1 : rq);
   int rcur = rq;
   auto f = [&](float x, float y, float z, int j, int p) { consider(b, sqdist3(x, y, z, sx, sy, sz), j, p, rcur); };
   const bool own = ring_nonempty(c, rq);
-  scan_cols(L, c, rq, own ? a0 - 1 : 1, own ? a0 + 1 : 0, f);  // seed: all three lanes
+  scan_cols(L, c, rq, own ? a0 - 1 : 1, own ? a0 + 1 : 0, f);  // seed: all lanes of the query
   const float B = b.d();  // fixed bound for everything below (conservative: >= the final best)
   const int K = reach(c, rho, B);
-  // This lane's tasks as a bit mask (bit i <-> task t = role + 3 i): task 0 = own ring right of
-  // the seed, 1 = own ring left of it, 2.. = the other rings rq+1, rq-1, rq+2, ...  The ring
+  const float delta = reach_elev(qn3, B);
+  // This lane's tasks as a bit mask (bit i <-> task t = role + LANES i): task 0 = own ring right
+  // of the seed, 1 = own ring left of it, 2.. = the other rings rq+1, rq-1, rq+2, ...  The ring
   // tests are independent LDS reads, issued together; only surviving tasks enter the scan loop.
+  constexpr int kTasks = 2 + 2 * (kRingsBinned - 1), kPerLane = (kTasks + LANES - 1) / LANES;
   unsigned todo = 0;
 #pragma unroll
-  for (int i = 0; i < 11; ++i) {
-    const int t = role + 3 * i;
+  for (int i = 0; i < kPerLane; ++i) {
+    const int t = role + LANES * i;
     const int k = t - 2, off = (k >> 1) + 1;
     const int r = t < 2 ? rq : rq + ((k & 1) ? -off : off);
-    bool go = t < 2 + 2 * (kRingsBinned - 1) && ring_nonempty(c, r);
+    bool go = t < kTasks && ring_nonempty(c, r);
     if (t < 2)
       go = go && K >= 2;
     else if (go)
-      go = !(ring_bound_sq(c.el + 4 * r, rho, sz, qn3) > B);
+      go = ring_in_reach(c, r, el_q, delta);
     todo |= go ? (1u << i) : 0u;
   }
 #pragma unroll 1
   while (todo) {
     const int i = __ffs(todo) - 1;
     todo &= todo - 1;
-    const int t = role + 3 * i;
+    const int t = role + LANES * i;
     const int k = t - 2, off = (k >> 1) + 1;
     const int r = t < 2 ? rq : rq + ((k & 1) ? -off : off);
     rcur = r;
     scan_cols(L, c, r, t == 0 ? a0 + 2 : a0 - K, t == 1 ? a0 - 2 : a0 + K, f);
   }
-  merge_from_lane(b, lane_base + (role + 1) % 3);
-  merge_from_lane(b, lane_base + (role + 2) % 3);
+  if (LANES == 3) {
+    merge_from_lane(b, lane_base + (role + 1) % 3);
+    merge_from_lane(b, lane_base + (role + 2) % 3);
+  }
   return b;
 }
 
@@ -219,9 +233,10 @@ __device__ __forceinline__ bool walk_rank(const WalkCtx& w, int j, int& rank) {
 // seed window + both extensions with the tightened bound; !full: extensions only (the
 // seed of that ring was scanned by all lanes before).  Same code for every lane.
 __device__ __forceinline__ void walk_task(const LdsStore& L, const LCloud& c, const WalkCtx& w, int r, bool full,
-                                          int a0, float sx, float sy, float sz, float rho_q, float qn3, Best& cur) {
+                                          int a0, float sx, float sy, float sz, float rho_q, float qn3, float el_q,
+                                          Best& cur) {
   bool go = walk_ring_has_candidates(c, w, r);
-  if (go) go = !(ring_bound_sq(c.el + 4 * r, rho_q, sz, qn3) > cur.d());
+  if (go) go = ring_in_reach(c, r, el_q, reach_elev(qn3, cur.d()));
   auto f = [&](float x, float y, float z, int j, int p) {
     int rank;
     if (walk_rank(w, j, rank)) consider(cur, sqdist3(x, y, z, sx, sy, sz), rank, p, 0);
@@ -237,6 +252,7 @@ __device__ __forceinline__ void walk_task(const LdsStore& L, const LCloud& c, co
 // ---- pass 2 (SE:859-910 surf, SE:983-1024 corner) ----------------------------------------
 // surf:   class 2 = ring rho (second point), class 3 = rings rho+-1, rho+-2 (third point)
 // corner: class 2 = rings rho+-1, rho+-2 (second point on a different ring), no class 3
+template <int LANES>
 __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, bool is_surf, int nq, float thr, int j1,
                                          int rho, float sx, float sy, float sz, int role, int lane_base, Best& c2,
                                          Best& c3) {
@@ -248,8 +264,9 @@ __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, boo
   c3 = best_init(thr);
   const float rho_q = sqrtf(sx * sx + sy * sy);
   const float qn3 = sqrtf(rho_q * rho_q + sz * sz);
+  const float el_q = atan2f(sz, rho_q);
   const int a0 = az_bin(sx, sy, c.naz);
-  if (is_surf) {  // class-2 seed on ring rho: all three lanes (wave-uniform branch except one wave)
+  if (is_surf) {  // class-2 seed on ring rho: all lanes of the query (wave-uniform branch except one wave)
     bool go = walk_ring_has_candidates(c, w, rho);
     auto f = [&](float x, float y, float z, int j, int p) {
       int rank;
@@ -257,43 +274,40 @@ __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, boo
     };
     scan_cols(L, c, rho, go ? a0 - 1 : 1, go ? a0 + 1 : 0, f);
   }
-  // two tasks per lane, chosen by role (data, not code):
-  //   surf    role 0: rho (class 2, extensions)   rho+2 (class 3)
-  //           role 1: rho-1 (class 3)             rho+1 (class 3)
-  //           role 2: rho-2 (class 3)             -
-  //   corner  role 0: rho-1                       -
-  //           role 1: rho+1                       rho+2
-  //           role 2: rho-2                       -
+  // tasks (data, not code), dealt round-robin to the query's lanes:
+  //   surf    t0: rho (class 2, extensions)  t1: rho-1  t2: rho-2  t3: rho+1  t4: rho+2  (class 3)
+  //   corner  t0: rho-1  t1: rho+1  t2: rho-2  t3: rho+2
+  constexpr int kPerLane = (5 + LANES - 1) / LANES;
 #pragma unroll 1
-  for (int i = 0; i < 2; ++i) {
-    int r;
-    bool use2, full = true;
-    if (is_surf) {
-      const int dr = role == 0 ? (i ? 2 : 0) : (role == 1 ? (i ? 1 : -1) : (i ? 99 : -2));
-      r = rho + dr;
-      use2 = dr == 0;
-      full = dr != 0;
-    } else {
-      const int dr = role == 0 ? (i ? 99 : -1) : (role == 1 ? (i ? 2 : 1) : (i ? 99 : -2));
-      r = rho + dr;
-      use2 = true;
-    }
+  for (int i = 0; i < kPerLane; ++i) {
+    const int t = role + LANES * i;
+    int dr;
+    if (is_surf)
+      dr = t == 0 ? 0 : (t == 1 ? -1 : (t == 2 ? -2 : (t == 3 ? 1 : (t == 4 ? 2 : 99))));
+    else
+      dr = t == 0 ? -1 : (t == 1 ? 1 : (t == 2 ? -2 : (t == 3 ? 2 : 99)));
+    const bool use2 = !is_surf || dr == 0;
+    const bool full = !is_surf || dr != 0;
     Best cur = use2 ? c2 : c3;
-    walk_task(L, c, w, r, full, a0, sx, sy, sz, rho_q, qn3, cur);
+    walk_task(L, c, w, rho + dr, full, a0, sx, sy, sz, rho_q, qn3, el_q, cur);
     if (use2)
       c2 = cur;
     else
       c3 = cur;
   }
-  merge_from_lane(c2, lane_base + (role + 1) % 3);
-  merge_from_lane(c2, lane_base + (role + 2) % 3);
-  merge_from_lane(c3, lane_base + (role + 1) % 3);
-  merge_from_lane(c3, lane_base + (role + 2) % 3);
+  if (LANES == 3) {
+    merge_from_lane(c2, lane_base + (role + 1) % 3);
+    merge_from_lane(c2, lane_base + (role + 2) % 3);
+    merge_from_lane(c3, lane_base + (role + 1) % 3);
+    merge_from_lane(c3, lane_base + (role + 2) % 3);
+  }
 }
 
 // ---- grid build: both clouds of the scan, once -----------------------------------------------
+template <int BLOCK>
 __device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, const float4* __restrict__ arena,
                                                int tid) {
+  constexpr int kLBlock = BLOCK;
   unsigned* cnt = reinterpret_cast<unsigned*>(L.slots);  // kCellsSurf + kCellsCorner counters
   constexpr int ncell = kCellsSurf + kCellsCorner;
   for (int c = tid; c < ncell; c += kLBlock) cnt[c] = 0;
@@ -351,7 +365,7 @@ __device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, 
   if (tid < 2 * kRingsBinned) {
     int cl = tid / kRingsBinned, r = tid % kRingsBinned;
     float lo = ordered_float(L.el_bits[cl][r][0]) - kSlack, hi = ordered_float(L.el_bits[cl][r][1]) + kSlack;
-    L.el[cl][r][0] = cosf(lo), L.el[cl][r][1] = sinf(lo), L.el[cl][r][2] = cosf(hi), L.el[cl][r][3] = sinf(hi);
+    L.el_ang[cl][r][0] = lo, L.el_ang[cl][r][1] = hi;
   }
   __syncthreads();
 }
@@ -473,14 +487,16 @@ __device__ __forceinline__ void phi_and_Gt(const Q4& q, V3& phi, M3& Gt) {
 // the kernel.  PASS_ONLY: one correspondence pass at a caller-supplied linearisation
 // state (lins_correspondences / lins_reduce_pass), dumping records / sums.
 // ---------------------------------------------------------------------------
-template <bool PASS_ONLY>
-__global__ __launch_bounds__(kLBlock) void ieskf_lds_kernel(
+template <int BLOCK, int LANES, bool PASS_ONLY>
+__global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     DevParams prm, const ScanDesc* __restrict__ descs, const float4* __restrict__ arena,
     const double* __restrict__ state_in, const double* __restrict__ cov_in, const double* __restrict__ lin_in,
     int iter_arg, double* __restrict__ state_out, double* __restrict__ a6_out, OutRec* __restrict__ out,
     int4* __restrict__ idx_store, lins_pose_record* __restrict__ poses, int scan_id_base,
     lins_corr* __restrict__ dump, double* __restrict__ sums_out, int* __restrict__ counts_out,
     long long* __restrict__ prof) {
+  constexpr int kLBlock = BLOCK, kQPerWave = 64 / LANES, kQPerRound = (BLOCK / 64) * kQPerWave;
+  static_assert(kQPerRound <= kSlotCap && BLOCK >= 256 && BLOCK / 64 <= kMaxLWaves, "block shape");
   __shared__ LdsStore L;
   // optional phase profile: [0] setup+grid build [1] correspondence [2] reduction [3] solve [4] update [5] total
   long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [6..9] wave 0: de-skew, NN, walk, geometry
@@ -514,13 +530,14 @@ __global__ __launch_bounds__(kLBlock) void ieskf_lds_kernel(
       for (int k = 0; k < 18; ++k) L.ic.d[k] = ic.d[k];
     }
   }
-  build_lds_grid(L, sd, arena, tid);  // ends with a barrier
+  build_lds_grid<BLOCK>(L, sd, arena, tid);  // ends with a barrier
   if (prof) pt[0] = clock64() - t_begin;
 
-  const LCloud cs{L.cell_end, L.ring_start[0], &L.el[0][0][0], kAzSurf, 1, 0, sd.n_surf_t};
-  const LCloud cc{L.cell_end + kCellsSurf, L.ring_start[1], &L.el[1][0][0], kAzCorner, kAzSurf / kAzCorner,
-                  sd.n_surf_t, sd.n_corner_t};
-  const int role = lane % 3, lane_base = lane - role, q_in_wave = lane / 3;
+  const LCloud cs{L.cell_end, L.ring_start[0], &L.el_ang[0][0][0], kAzSurf, 1, 0, sd.n_surf_t};
+  const LCloud cc{L.cell_end + kCellsSurf, L.ring_start[1], &L.el_ang[1][0][0], kAzCorner,
+                  kAzSurf / kAzCorner, sd.n_surf_t, sd.n_corner_t};
+  const int role = lane % LANES, lane_base = lane - role, q_in_wave = lane / LANES;
+  const bool lane_used = lane < kQPerWave * LANES;
 
   for (;;) {
     const int iter = L.iter;
@@ -534,7 +551,7 @@ __global__ __launch_bounds__(kLBlock) void ieskf_lds_kernel(
     long long t0 = prof ? clock64() : 0, t1 = t0, t2 = t0, t3 = t0;
     for (int base = 0; base < total; base += kQPerRound) {
       const int slot = base + wave * kQPerWave + q_in_wave;
-      const bool active = lane < 63 && slot < total;
+      const bool active = lane_used && slot < total;
       double row[7] = {0, 0, 0, 0, 0, 0, 0};
       if (active) {
         const bool is_surf = slot < sd.n_surf_q;
@@ -551,12 +568,12 @@ __global__ __launch_bounds__(kLBlock) void ieskf_lds_kernel(
         o.c[0] = o.c[1] = o.c[2] = o.c[3] = 0.f;
         int p1 = -1, p2 = -1, p3 = -1;  // grid positions of the three target points
         if (do_search) {
-          Best b1 = nn_lds(L, c, o.sel[0], o.sel[1], o.sel[2], prm.nearest_f, ring_of(q.w), role, lane_base);
+          Best b1 = nn_lds<LANES>(L, c, o.sel[0], o.sel[1], o.sel[2], prm.nearest_f, ring_of(q.w), role, lane_base);
           if (prof) s2 = clock64(), pt[7] += s2 - s1;
           if (b1.pos >= 0 && (double)b1.d() < prm.nearest) {
             p1 = b1.pos;
             Best c2, c3;
-            walk_lds(L, c, is_surf, is_surf ? sd.n_surf_q : sd.n_corner_q, prm.nearest_f, b1.key(), b1.ring, o.sel[0],
+            walk_lds<LANES>(L, c, is_surf, is_surf ? sd.n_surf_q : sd.n_corner_q, prm.nearest_f, b1.key(), b1.ring, o.sel[0],
                      o.sel[1], o.sel[2], role, lane_base, c2, c3);
             p2 = c2.pos, p3 = c3.pos;
           }
@@ -601,7 +618,7 @@ __global__ __launch_bounds__(kLBlock) void ieskf_lds_kernel(
         }
         if (prof) pt[9] += clock64() - s3;
       }
-      if (lane < 63 && role == 0) {
+      if (lane_used && role == 0) {
         const int local = wave * kQPerWave + q_in_wave;
 #pragma unroll
         for (int k = 0; k < 7; ++k) L.slots[local * 7 + k] = row[k];
@@ -772,20 +789,33 @@ __global__ __launch_bounds__(kLBlock) void ieskf_lds_kernel(
 // ---------------------------------------------------------------------------
 int lds_np_cap() { return kNpCap; }
 
-void launch_lds(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
-                const double* state_in, const double* cov_in, double* state_out, double* a6, void* out,
-                int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof) {
-  hipLaunchKernelGGL(ieskf_lds_kernel<false>, dim3(n), dim3(kLBlock), 0, stream, prm, descs, arena, state_in, cov_in,
-                     (const double*)nullptr, 0, state_out, a6, (OutRec*)out, idx_store, poses, scan_id_base,
-                     (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof);
+// Two shapes of the same kernel:
+//   lanes = 1: 384 threads, one lane per query  (fewest instructions issued per update)
+//   lanes = 3: 1024 threads, three lanes per query (shortest critical path per iteration)
+void launch_lds(hipStream_t stream, int n, const DevParams& prm, int lanes, const ScanDesc* descs,
+                const float4* arena, const double* state_in, const double* cov_in, double* state_out, double* a6,
+                void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof) {
+  if (lanes == 3)
+    hipLaunchKernelGGL((ieskf_lds_kernel<1024, 3, false>), dim3(n), dim3(1024), 0, stream, prm, descs, arena, state_in,
+                       cov_in, (const double*)nullptr, 0, state_out, a6, (OutRec*)out, idx_store, poses, scan_id_base,
+                       (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof);
+  else
+    hipLaunchKernelGGL((ieskf_lds_kernel<384, 1, false>), dim3(n), dim3(384), 0, stream, prm, descs, arena, state_in,
+                       cov_in, (const double*)nullptr, 0, state_out, a6, (OutRec*)out, idx_store, poses, scan_id_base,
+                       (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof);
 }
 
-void launch_lds_pass(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
-                     const double* lin_state, const double* filt_state, int iter, int4* idx_store, lins_corr* dump,
-                     double* sums_out, int* counts_out) {
-  hipLaunchKernelGGL(ieskf_lds_kernel<true>, dim3(n), dim3(kLBlock), 0, stream, prm, descs, arena, filt_state,
-                     (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr, (OutRec*)nullptr,
-                     idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out, (long long*)nullptr);
+void launch_lds_pass(hipStream_t stream, int n, const DevParams& prm, int lanes, const ScanDesc* descs,
+                     const float4* arena, const double* lin_state, const double* filt_state, int iter,
+                     int4* idx_store, lins_corr* dump, double* sums_out, int* counts_out) {
+  if (lanes == 3)
+    hipLaunchKernelGGL((ieskf_lds_kernel<1024, 3, true>), dim3(n), dim3(1024), 0, stream, prm, descs, arena, filt_state,
+                       (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr, (OutRec*)nullptr,
+                       idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out, (long long*)nullptr);
+  else
+    hipLaunchKernelGGL((ieskf_lds_kernel<384, 1, true>), dim3(n), dim3(384), 0, stream, prm, descs, arena, filt_state,
+                       (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr, (OutRec*)nullptr,
+                       idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out, (long long*)nullptr);
 }
 
 }  // namespace lins

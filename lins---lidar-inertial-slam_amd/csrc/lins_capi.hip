@@ -23,10 +23,10 @@ void launch_persistent(hipStream_t, int, const DevParams&, const ScanDesc*, cons
 void launch_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const double*, const double*,
                  int, int4*, lins_corr*, double*, int*, float4*);
 void launch_joseph(hipStream_t, int, const DevParams&, const double*, const double*, const void*, double*);
-void launch_lds(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const double*, const double*,
+void launch_lds(hipStream_t, int, const DevParams&, int, const ScanDesc*, const float4*, const double*, const double*,
                 double*, double*, void*, int4*, lins_pose_record*, int, long long*);
-void launch_lds_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const double*, const double*,
-                     int, int4*, lins_corr*, double*, int*);
+void launch_lds_pass(hipStream_t, int, const DevParams&, int, const ScanDesc*, const float4*, const double*,
+                     const double*, int, int4*, lins_corr*, double*, int*);
 int lds_np_cap();
 size_t out_rec_size();
 struct OutRecHost {
@@ -287,6 +287,8 @@ int lins_set_search(lins_ctx* ctx, const char* mode) {
     ctx->dprm.search = SEARCH_BINNED;
   else if (!std::strcmp(mode, "lds"))
     ctx->dprm.search = SEARCH_LDS;
+  else if (!std::strcmp(mode, "lds3"))
+    ctx->dprm.search = SEARCH_LDS3;
   else
     return LINS_E_ARG;
   return LINS_OK;
@@ -299,13 +301,14 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   if (ctx->n_uploaded <= 0) return LINS_E_STATE;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  if (ctx->dprm.search == SEARCH_LDS && ctx->lds_ok) {
-    launch_lds(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_state_in, ctx->d_cov_in,
+  const bool want_lds = ctx->dprm.search == SEARCH_LDS || ctx->dprm.search == SEARCH_LDS3;
+  if (want_lds && ctx->lds_ok) {
+    launch_lds(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->dprm.search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc, ctx->d_arena, ctx->d_state_in, ctx->d_cov_in,
                ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx, (lins_pose_record*)d_poses, scan_id_base, ctx->d_prof);
     launch_joseph(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_cov_in, ctx->d_a6, ctx->d_out, ctx->d_cov_out);
   } else {
     DevParams dp = ctx->dprm;
-    if (dp.search == SEARCH_LDS) dp.search = SEARCH_BINNED;  // a scan does not fit LDS: global-memory grid
+    if (want_lds) dp.search = SEARCH_BINNED;  // a scan does not fit LDS: global-memory grid
     launch_persistent(ctx->stream, ctx->n_uploaded, dp, ctx->d_desc, ctx->d_arena, ctx->d_state_in, ctx->d_cov_in,
                       ctx->d_state_out, ctx->d_cov_out, ctx->d_a6, ctx->d_out, ctx->d_idx,
                       (lins_pose_record*)d_poses, scan_id_base, ctx->d_binned, ctx->d_prof);
@@ -414,13 +417,14 @@ static int run_pass(lins_ctx* ctx, const lins_scan_pair* in, const double* lin_s
   if (rc) return rc;
   ctx->n_uploaded = 0;  // the single-pass calls do not leave a runnable batch behind
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_lin, lin_state, 19 * 8, hipMemcpyHostToDevice, ctx->stream));
-  if (ctx->dprm.search == SEARCH_LDS && ctx->lds_ok) {
-    launch_lds_pass(ctx->stream, 1, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_lin, ctx->d_state_in, iter,
+  const bool want_lds = ctx->dprm.search == SEARCH_LDS || ctx->dprm.search == SEARCH_LDS3;
+  if (want_lds && ctx->lds_ok) {
+    launch_lds_pass(ctx->stream, 1, ctx->dprm, ctx->dprm.search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc, ctx->d_arena, ctx->d_lin, ctx->d_state_in, iter,
                     ctx->d_idx, dump ? ctx->d_dump : nullptr, sums ? ctx->d_sums : nullptr,
                     sums ? ctx->d_counts : nullptr);
   } else {
     DevParams dp = ctx->dprm;
-    if (dp.search == SEARCH_LDS) dp.search = SEARCH_BINNED;
+    if (want_lds) dp.search = SEARCH_BINNED;
     launch_pass(ctx->stream, 1, dp, ctx->d_desc, ctx->d_arena, ctx->d_lin, ctx->d_state_in, iter, ctx->d_idx,
                 dump ? ctx->d_dump : nullptr, sums ? ctx->d_sums : nullptr, sums ? ctx->d_counts : nullptr,
                 ctx->d_binned);
