@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="scans per GPU")
     ap.add_argument("--iters", type=int, default=10, help="IESKF iterations per scan")
-    ap.add_argument("--search", default=os.environ.get("LINS_SEARCH", "binned"))
+    ap.add_argument("--search", default=os.environ.get("LINS_SEARCH", "lds"))
     ap.add_argument("--cpu-sample", type=int, default=192, help="scans timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -153,7 +153,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ieskf_persistent_kernel",
+                "kernel": "ieskf_lds_kernel" if args.search.startswith("lds") else "ieskf_persistent_kernel",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

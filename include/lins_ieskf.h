@@ -135,7 +135,13 @@ int lins_create(const lins_params* params, int device, int max_batch,
 void lins_destroy(lins_ctx* ctx);
 const char* lins_strerror(int code);
 const char* lins_last_hip_error(const lins_ctx* ctx);
-/* "brute" (exact all-pairs search) or "binned" (exact pruned search).         */
+/* Search strategy — every mode returns the same (exact) correspondences:
+ *   "lds"    (ring x azimuth-column) grid of the targets resident in LDS, one 1024-thread
+ *            workgroup per scan, 3 lanes per query — the fast path for VLP-16 sized scans
+ *   "lds1"   same grid in LDS, 384 threads, 1 lane per query
+ *   "binned" the grid in global memory (any cloud size; automatic fallback of "lds*")
+ *   "brute"  all-pairs search + the literal index walk (any input; the fallback for
+ *            clouds that are not ring-sorted or carry ring ids >= 16)                   */
 int lins_set_search(lins_ctx* ctx, const char* mode);
 
 /* --- replaces StateEstimator::performIESKF() (SE:465-600) ----------------- */

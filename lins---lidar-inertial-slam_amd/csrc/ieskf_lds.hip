@@ -549,9 +549,21 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     double acc = 0;
     int ms = 0, mc = 0;
     long long t0 = prof ? clock64() : 0, t1 = t0, t2 = t0, t3 = t0;
-    for (int base = 0; base < total; base += kQPerRound) {
-      const int slot = base + wave * kQPerWave + q_in_wave;
-      const bool active = lane_used && slot < total;
+    // Query -> lane layout.  When both kinds fit one round with the corner queries starting on
+    // a wave boundary, do that: no wave then mixes plane and line code paths.
+    const int surf_waves = (sd.n_surf_q + kQPerWave - 1) / kQPerWave;
+    const bool aligned = surf_waves * kQPerWave + sd.n_corner_q <= kQPerRound;
+    const int span = aligned ? surf_waves * kQPerWave + sd.n_corner_q : total;  // row slots in use
+    for (int base = 0; base < span; base += kQPerRound) {
+      const int vslot = base + wave * kQPerWave + q_in_wave;  // position in the (padded) layout
+      int slot = vslot;                                        // query index: surf first, then corner
+      bool active = lane_used && vslot < span;
+      if (aligned) {
+        if (wave < surf_waves)
+          active = active && vslot < sd.n_surf_q;
+        else
+          slot = vslot - surf_waves * kQPerWave + sd.n_surf_q;
+      }
       double row[7] = {0, 0, 0, 0, 0, 0, 0};
       if (active) {
         const bool is_surf = slot < sd.n_surf_q;
@@ -625,7 +637,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       }
       __syncthreads();
       if (prof) t1 = clock64();
-      const int nrows = total - base < kQPerRound ? total - base : kQPerRound;
+      const int nrows = span - base < kQPerRound ? span - base : kQPerRound;
       if (tid < kLRedGroups * 32) {
         int g = tid >> 5, k = tid & 31;
         if (k < 28) {
@@ -692,28 +704,35 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         for (int k = 0; k < 6; ++k) sacc += L.P[lane * 18 + sidx(k)] * wsol[k];
         dxi = L.ic.d[lane] - sacc;
       }
-      double dx[18];
-#pragma unroll
-      for (int k = 0; k < 18; ++k) dx[k] = __shfl(dxi, k);
       if (prof) t3 = clock64();
-      rn = sqrt(L.sums[27]);
-      bool has_nan = false;
-#pragma unroll
-      for (int k = 0; k < 18; ++k)
-        if (isnan(dx[k])) has_nan = true;
+      // broadcast dx lane by lane and fold it straight into the state (no dx[18] array: this
+      // section runs under the search loop's 128-VGPR budget): additive blocks now, the
+      // attitude increment through the quaternion below (boxPlus, KF:71-81)
 #pragma unroll
       for (int k = 0; k < 19; ++k) lin[k] = L.ic.lin[k];
-      un = L.upd_norm, res_prev = L.res_prev;
-      if (has_nan) {
-        div = 2;
-      } else if (rn > res_prev * 10) {
-        div = 1;
-      } else {
-        box_plus_inplace(lin, dx);
-        un = 0;
+      double dth[3] = {0, 0, 0};
+      bool has_nan = false;
+      un = 0;
 #pragma unroll
-        for (int k = 0; k < 18; ++k) un += dx[k] * dx[k];
-        un = sqrt(un);
+      for (int k = 0; k < 18; ++k) {
+        const double vk = __shfl(dxi, k);
+        has_nan = has_nan || isnan(vk);
+        un += vk * vk;
+        if (k >= 6 && k < 9)
+          dth[k - 6] = vk;
+        else
+          lin[k < 6 ? k : k + 1] += vk;  // p,v at 0..5; ba,bw,g at 10..18 (q occupies 6..9)
+      }
+      un = sqrt(un);
+      rn = sqrt(L.sums[27]);
+      res_prev = L.res_prev;
+      if (has_nan) {
+        div = 2, un = L.upd_norm;
+      } else if (rn > res_prev * 10) {
+        div = 1, un = L.upd_norm;
+      } else {
+        const Q4 qn = qnormalized(qmul(Q4{lin[6], lin[7], lin[8], lin[9]}, axis2quat(V3{dth[0], dth[1], dth[2]})));
+        lin[6] = qn.w, lin[7] = qn.x, lin[8] = qn.y, lin[9] = qn.z;
         if (un <= 1e-2 && !prm.fixed_iters) conv = 1;
         res_prev = rn;
       }
@@ -721,27 +740,33 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     __syncthreads();  // every reader of the old linearisation state is done
     if (wave < 3 && !div) {
       const Q4 q{lin[6], lin[7], lin[8], lin[9]};
+      // (static indices only: a lane-indexed register array would be spilled to scratch)
       if (wave == 0) {
         const M3 Rt = mtrans(qmat(q));
-        if (lane < 19) L.ic.lin[lane] = lin[lane];
-        if (lane < 9) L.ic.Rt.m[lane] = Rt.m[lane];
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 19; ++k) L.ic.lin[k] = lin[k];
+          L.ic.Rt = Rt;
+        }
       } else if (wave == 1) {
         V3 phi;
         M3 Gt;
         phi_and_Gt(q, phi, Gt);
-        if (lane == 0) L.ic.phi = phi;
-        if (lane < 9) L.ic.Gt.m[lane] = Gt.m[lane];
+        if (lane == 0) L.ic.phi = phi, L.ic.Gt = Gt;
       } else {
         // boxMinus(filter, lin), KF:84-94
         const Q4 qf{L.filt[6], L.filt[7], L.filt[8], L.filt[9]};
         const V3 da = quat2axis(qmul(qinverse(q), qf));
-        if (lane < 3) {
-          L.ic.d[0 + lane] = L.filt[0 + lane] - lin[0 + lane];
-          L.ic.d[3 + lane] = L.filt[3 + lane] - lin[3 + lane];
-          L.ic.d[9 + lane] = L.filt[10 + lane] - lin[10 + lane];
-          L.ic.d[12 + lane] = L.filt[13 + lane] - lin[13 + lane];
-          L.ic.d[15 + lane] = L.filt[16 + lane] - lin[16 + lane];
-          L.ic.d[6 + lane] = lane == 0 ? da.x : (lane == 1 ? da.y : da.z);
+        if (lane == 0) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            L.ic.d[0 + k] = L.filt[0 + k] - lin[0 + k];
+            L.ic.d[3 + k] = L.filt[3 + k] - lin[3 + k];
+            L.ic.d[9 + k] = L.filt[10 + k] - lin[10 + k];
+            L.ic.d[12 + k] = L.filt[13 + k] - lin[13 + k];
+            L.ic.d[15 + k] = L.filt[16 + k] - lin[16 + k];
+          }
+          L.ic.d[6] = da.x, L.ic.d[7] = da.y, L.ic.d[8] = da.z;
         }
       }
     }

@@ -285,10 +285,10 @@ int lins_set_search(lins_ctx* ctx, const char* mode) {
     ctx->dprm.search = SEARCH_BRUTE;
   else if (!std::strcmp(mode, "binned"))
     ctx->dprm.search = SEARCH_BINNED;
-  else if (!std::strcmp(mode, "lds"))
-    ctx->dprm.search = SEARCH_LDS;
-  else if (!std::strcmp(mode, "lds3"))
+  else if (!std::strcmp(mode, "lds"))  // LDS-resident grid, 1024 threads, 3 lanes per query
     ctx->dprm.search = SEARCH_LDS3;
+  else if (!std::strcmp(mode, "lds1"))  // LDS-resident grid, 384 threads, 1 lane per query
+    ctx->dprm.search = SEARCH_LDS;
   else
     return LINS_E_ARG;
   return LINS_OK;

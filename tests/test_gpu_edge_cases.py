@@ -62,7 +62,7 @@ def ctx(pkg, ieskf):
     c.close()
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds3"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
 @pytest.mark.parametrize("kind", ["lattice", "dup", "axis", "offgrid"])
 def test_adversarial_clouds_exact_indices(pkg, oracle, ctx, search, kind):
     ctx.set_search(search)
@@ -79,7 +79,7 @@ def test_adversarial_clouds_exact_indices(pkg, oracle, ctx, search, kind):
             assert_same_corr(corner, wc, f"{kind}/{trial}/it{it}/corner")
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds3"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
 def test_forward_walk_is_bounded_by_query_count(pkg, oracle, ctx, search):
     """SE:859/983: the forward walk stops at j < N_query.  Few queries => forward part empty;
     many queries (> targets) => our min(N_query, N_target) guard."""
@@ -97,7 +97,7 @@ def test_forward_walk_is_bounded_by_query_count(pkg, oracle, ctx, search):
             assert not fwd[ws["ind1"] >= 3].any()
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds3"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
 def test_unsorted_rings_and_high_ring_ids_fall_back_exactly(pkg, oracle, ctx, search):
     ctx.set_search(search)
     prm = pkg.default_params()
@@ -110,7 +110,7 @@ def test_unsorted_rings_and_high_ring_ids_fall_back_exactly(pkg, oracle, ctx, se
         assert_same_corr(corner, wc, "corner")
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds3"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
 def test_empty_and_ragged_inputs(pkg, oracle, ctx, search):
     ctx.set_search(search)
     prm = pkg.default_params(num_iter=5)
@@ -129,7 +129,7 @@ def test_empty_and_ragged_inputs(pkg, oracle, ctx, search):
     del prm
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds3"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
 def test_maximum_sizes(pkg, oracle, ctx, search):
     """1024 queries per cloud (LINS_MAX_QUERY; > one 512-slot reduction round) and a
     full 16x1800 target cloud."""

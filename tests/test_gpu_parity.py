@@ -48,7 +48,7 @@ def ctx(pkg, ieskf):
     c.close()
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds3"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
 def test_correspondences_bit_exact_along_oracle_trajectory(pkg, oracle, ctx, pairs, search):
     """configs[1]: device A2+A3 at every linearisation state the oracle visits."""
     ctx.set_search(search)
@@ -62,7 +62,7 @@ def test_correspondences_bit_exact_along_oracle_trajectory(pkg, oracle, ctx, pai
             assert_corr_equal(corner, tr["corner"][k], f"iter{k}.corner")
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds3"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
 def test_reduction_and_host_solve(pkg, ieskf, oracle, ctx, pairs, search):
     """configs[1]: on-device 28-sum reduction + host-side 18x18 solve == oracle dx."""
     ctx.set_search(search)
@@ -78,7 +78,7 @@ def test_reduction_and_host_solve(pkg, ieskf, oracle, ctx, pairs, search):
         assert np.abs(dx - tr["dx"][k]).max() <= 1e-8 * max(1.0, np.abs(tr["dx"][k]).max())
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds3"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
 def test_full_ieskf_matches_oracle(pkg, oracle, ctx, pairs, search):
     """configs[2]: on-device reduction + solve + full loop, reference stop rule."""
     ctx.set_search(search)
