@@ -158,7 +158,9 @@ int lins_batch_upload(lins_ctx* ctx, int n, const lins_scan_pair* in);
 int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base);
 int lins_sync(lins_ctx* ctx);
 int lins_batch_download(lins_ctx* ctx, int n, lins_result* out);
-/* HIP-event time (ms) of the IESKF kernel(s) of the last lins_batch_run().    */
+/* HIP-event time (ms), on the context's stream, of the dominant kernel of the last
+ * lins_batch_run(): the persistent IESKF kernel ("lds*" modes: without the small Joseph
+ * covariance kernel that follows it; "binned"/"brute": both).                       */
 int lins_last_kernel_ms(lins_ctx* ctx, float* ms);
 /* Algorithmic bytes of one iteration summed over the uploaded batch
  * (16*(Nsharp+Nflat+Nls+Nlf) + 8*19 + 8*28 per scan).          */

@@ -40,7 +40,7 @@ using namespace lins;
 struct lins_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;  // IESKF kernel start / end, Joseph kernel end
   lins_params prm{};
   DevParams dprm{};
   int max_batch = 0, max_targets = 0;
@@ -223,6 +223,7 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   CREATE_TRY(hipEventCreate(&ctx->ev0));
   CREATE_TRY(hipEventCreate(&ctx->ev1));
+  CREATE_TRY(hipEventCreate(&ctx->ev2));
   const size_t nb = (size_t)max_batch;
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_arena, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_desc, nb * sizeof(ScanDesc)));
@@ -275,6 +276,7 @@ void lins_destroy(lins_ctx* ctx) {
   (void)hipFree(ctx->d_counts);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -305,6 +307,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   if (want_lds && ctx->lds_ok) {
     launch_lds(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->dprm.search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc, ctx->d_arena, ctx->d_state_in, ctx->d_cov_in,
                ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx, (lins_pose_record*)d_poses, scan_id_base, ctx->d_prof);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     launch_joseph(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_cov_in, ctx->d_a6, ctx->d_out, ctx->d_cov_out);
   } else {
     DevParams dp = ctx->dprm;
@@ -314,7 +317,8 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
                       (lins_pose_record*)d_poses, scan_id_base, ctx->d_binned, ctx->d_prof);
   }
   HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  if (!(want_lds && ctx->lds_ok)) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
   ctx->ran = true;
   return LINS_OK;
 }

@@ -1,0 +1,72 @@
+"""The C ABI boundary without a GPU: both shared libraries load, export every symbol that
+include/*.h declares, and the ctypes mirrors have the C structs' sizes."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DECL = re.compile(r"^\s*(?:const\s+)?(?:int|void|char\s*\*|const char\s*\*)\s*\*?\s*(lins_\w+)\s*\(", re.M)
+
+
+def declared(header):
+    return sorted(set(DECL.findall(open(os.path.join(ROOT, "include", header)).read())))
+
+
+def test_headers_declare_the_expected_surface():
+    names = declared("lins_ieskf.h")
+    for must in ("lins_create", "lins_destroy", "lins_ieskf_update", "lins_ieskf_update_batch", "lins_batch_upload",
+                 "lins_batch_run", "lins_batch_download", "lins_correspondences", "lins_reduce_pass", "lins_strerror"):
+        assert must in names
+    assert "lins_host_perform_ieskf" in declared("lins_host.h")
+
+
+def test_ieskf_library_exports_every_declared_symbol(ieskf):
+    L = ieskf.lib()  # loads liblins_ieskf.so (cross-compiled for gfx950; loading needs no GPU)
+    for name in declared("lins_ieskf.h") + ["lins_host_perform_ieskf"]:
+        assert hasattr(L, name), f"liblins_ieskf.so does not export {name}"
+    assert L.lins_strerror(0) == b"ok" and b"capacity" in L.lins_strerror(-3)
+
+
+def test_host_library_exports_every_declared_symbol(host):
+    L = host.lib()
+    for name in declared("lins_host.h"):
+        if name == "lins_host_perform_ieskf":
+            continue  # lives in liblins_ieskf.so (it drives the GPU path)
+        assert hasattr(L, name), f"liblins_host.so does not export {name}"
+
+
+def test_no_compute_without_a_device(pkg, ieskf):
+    """Creating a context without a GPU fails loudly (there is no CPU fallback)."""
+    import pytest
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(ieskf.LinsError, match="-5|-2"):
+        ieskf.IeskfContext(pkg.default_params())
+
+
+def test_ctypes_mirrors_match_the_c_structs(pkg, host):
+    defs = __import__("importlib").import_module("lins---lidar-inertial-slam_amd._ctypes_defs")
+    src = r"""
+#include <stdio.h>
+#include "lins_host.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(lins_point), sizeof(lins_params), sizeof(lins_scan_pair),
+         sizeof(lins_result), sizeof(lins_pose_record), sizeof(lins_corr), sizeof(lins_filter), sizeof(lins_features),
+         sizeof(lins_synth_pair));
+  return 0;
+}
+"""
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    want = [C.sizeof(defs.Point), C.sizeof(defs.Params), C.sizeof(defs.ScanPairC), C.sizeof(defs.ResultC),
+            C.sizeof(defs.PoseRecordC), defs.CORR_DTYPE.itemsize, C.sizeof(host.Filter), C.sizeof(host.Features),
+            C.sizeof(host.SynthPairC)]
+    assert sizes == want
