@@ -67,6 +67,10 @@ struct LdsStore {
 };
 static_assert(sizeof(LdsStore) <= 163840, "LDS budget of one CU");
 
+// The one LDS block of the workgroup.  File scope so that out-of-line device functions address
+// it as LDS (ds_* instructions) instead of through a generic pointer.
+__shared__ LdsStore g_lds;
+
 struct LCloud {  // one target cloud's grid (all pointers into LDS)
   const unsigned short* cell_end;  // this cloud's cells (absolute positions)
   const int* ring_start;
@@ -484,20 +488,142 @@ __device__ __forceinline__ void phi_and_Gt(const Q4& q, V3& phi, M3& Gt) {
 }
 
 // ---------------------------------------------------------------------------
+// The serial tail of one iteration, kept out of line: its register needs (a 6x7 system in
+// registers, the 19-state) are allocated on their own instead of inflating — and spilling —
+// the search loop it would otherwise be fused with.  Called by every thread (barriers inside).
+// ---------------------------------------------------------------------------
+__device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int iter, bool prof, long long& t3) {
+  LdsStore& L = g_lds;
+  const int lane = tid & 63, wave = tid >> 6;
+  // ---- solve + state update: waves 0-2, each redundantly, in registers ----------------------
+  // (sigma^2 I + A P_SS) w = g + A d_S  (push-through form of SE:542-549), dx = d - P[:,S] w,
+  // NaN / divergence / convergence tests and boxPlus (SE:552-580); after one barrier the three
+  // waves split the constants of the next iteration: wave 0 -> linState_, flags, R^T;
+  // wave 1 -> phi, Rinvleft(-phi)^T;  wave 2 -> x_filter (-) x_lin.
+  double lin[19];
+  double rn = 0, un = 0, res_prev = 0;
+  int div = 0, conv = 0;
+  if (wave < 3) {
+    if (lane < 42) {
+      const int i = lane / 7, j = lane % 7;
+      double v;
+      if (j < 6) {
+        v = (i == j ? prm.r2 : 0.0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v += sym6(L.sums, i, k) * L.P[sidx(k) * 18 + sidx(j)];
+      } else {
+        v = L.sums[21 + i];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v += sym6(L.sums, i, k) * L.ic.d[sidx(k)];
+      }
+      L.aug[wave][lane] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double a[6][7], wsol[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 7; ++j) a[i][j] = L.aug[wave][i * 7 + j];
+    reg_solve6(a, wsol);
+    double dxi = 0;
+    if (lane < 18) {
+      double sacc = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sacc += L.P[lane * 18 + sidx(k)] * wsol[k];
+      dxi = L.ic.d[lane] - sacc;
+    }
+    if (prof) t3 = clock64();
+    // broadcast dx lane by lane and fold it straight into the state (no dx[18] array: this
+    // section runs under the search loop's 128-VGPR budget): additive blocks now, the
+    // attitude increment through the quaternion below (boxPlus, KF:71-81)
+#pragma unroll
+    for (int k = 0; k < 19; ++k) lin[k] = L.ic.lin[k];
+    double dth[3] = {0, 0, 0};
+    bool has_nan = false;
+    un = 0;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) {
+      const double vk = __shfl(dxi, k);
+      has_nan = has_nan || isnan(vk);
+      un += vk * vk;
+      if (k >= 6 && k < 9)
+        dth[k - 6] = vk;
+      else
+        lin[k < 6 ? k : k + 1] += vk;  // p,v at 0..5; ba,bw,g at 10..18 (q occupies 6..9)
+    }
+    un = sqrt(un);
+    rn = sqrt(L.sums[27]);
+    res_prev = L.res_prev;
+    if (has_nan) {
+      div = 2, un = L.upd_norm;
+    } else if (rn > res_prev * 10) {
+      div = 1, un = L.upd_norm;
+    } else {
+      const Q4 qn = qnormalized(qmul(Q4{lin[6], lin[7], lin[8], lin[9]}, axis2quat(V3{dth[0], dth[1], dth[2]})));
+      lin[6] = qn.w, lin[7] = qn.x, lin[8] = qn.y, lin[9] = qn.z;
+      if (un <= 1e-2 && !prm.fixed_iters) conv = 1;
+      res_prev = rn;
+    }
+  }
+  __syncthreads();  // every reader of the old linearisation state is done
+  if (wave < 3 && !div) {
+    const Q4 q{lin[6], lin[7], lin[8], lin[9]};
+    // (static indices only: a lane-indexed register array would be spilled to scratch)
+    if (wave == 0) {
+      const M3 Rt = mtrans(qmat(q));
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 19; ++k) L.ic.lin[k] = lin[k];
+        L.ic.Rt = Rt;
+      }
+    } else if (wave == 1) {
+      V3 phi;
+      M3 Gt;
+      phi_and_Gt(q, phi, Gt);
+      if (lane == 0) L.ic.phi = phi, L.ic.Gt = Gt;
+    } else {
+      // boxMinus(filter, lin), KF:84-94
+      const Q4 qf{L.filt[6], L.filt[7], L.filt[8], L.filt[9]};
+      const V3 da = quat2axis(qmul(qinverse(q), qf));
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          L.ic.d[0 + k] = L.filt[0 + k] - lin[0 + k];
+          L.ic.d[3 + k] = L.filt[3 + k] - lin[3 + k];
+          L.ic.d[9 + k] = L.filt[10 + k] - lin[10 + k];
+          L.ic.d[12 + k] = L.filt[13 + k] - lin[13 + k];
+          L.ic.d[15 + k] = L.filt[16 + k] - lin[16 + k];
+        }
+        L.ic.d[6] = da.x, L.ic.d[7] = da.y, L.ic.d[8] = da.z;
+      }
+    }
+  }
+  if (tid == 0) {
+    L.res_last = rn, L.res_prev = res_prev, L.upd_norm = un;
+    L.conv = conv, L.div = div;
+    L.iter = iter + 1;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
 // the kernel.  PASS_ONLY: one correspondence pass at a caller-supplied linearisation
 // state (lins_correspondences / lins_reduce_pass), dumping records / sums.
 // ---------------------------------------------------------------------------
-template <int BLOCK, int LANES, bool PASS_ONLY>
+template <int BLOCK, int LANES, bool PASS_ONLY, bool PROF>
 __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     DevParams prm, const ScanDesc* __restrict__ descs, const float4* __restrict__ arena,
     const double* __restrict__ state_in, const double* __restrict__ cov_in, const double* __restrict__ lin_in,
     int iter_arg, double* __restrict__ state_out, double* __restrict__ a6_out, OutRec* __restrict__ out,
     int4* __restrict__ idx_store, lins_pose_record* __restrict__ poses, int scan_id_base,
     lins_corr* __restrict__ dump, double* __restrict__ sums_out, int* __restrict__ counts_out,
-    long long* __restrict__ prof) {
+    long long* __restrict__ prof_buf) {
+  constexpr bool prof = PROF;  // phase profile compiled in only for the debug variant
   constexpr int kLBlock = BLOCK, kQPerWave = 64 / LANES, kQPerRound = (BLOCK / 64) * kQPerWave;
   static_assert(kQPerRound <= kSlotCap && BLOCK >= 256 && BLOCK / 64 <= kMaxLWaves, "block shape");
-  __shared__ LdsStore L;
+  LdsStore& L = g_lds;
   // optional phase profile: [0] setup+grid build [1] correspondence [2] reduction [3] solve [4] update [5] total
   long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [6..9] wave 0: de-skew, NN, walk, geometry
   const long long t_begin = prof ? clock64() : 0;
@@ -665,125 +791,16 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       return;
     }
 
-    // ---- solve + state update: waves 0-2, each redundantly, in registers ----------------------
-    // (sigma^2 I + A P_SS) w = g + A d_S  (push-through form of SE:542-549), dx = d - P[:,S] w,
-    // NaN / divergence / convergence tests and boxPlus (SE:552-580); after one barrier the three
-    // waves split the constants of the next iteration: wave 0 -> linState_, flags, R^T;
-    // wave 1 -> phi, Rinvleft(-phi)^T;  wave 2 -> x_filter (-) x_lin.
-    double lin[19];
-    double rn = 0, un = 0, res_prev = 0;
-    int div = 0, conv = 0;
-    if (wave < 3) {
-      if (lane < 42) {
-        const int i = lane / 7, j = lane % 7;
-        double v;
-        if (j < 6) {
-          v = (i == j ? prm.r2 : 0.0);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) v += sym6(L.sums, i, k) * L.P[sidx(k) * 18 + sidx(j)];
-        } else {
-          v = L.sums[21 + i];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) v += sym6(L.sums, i, k) * L.ic.d[sidx(k)];
-        }
-        L.aug[wave][lane] = v;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      double a[6][7], wsol[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 7; ++j) a[i][j] = L.aug[wave][i * 7 + j];
-      reg_solve6(a, wsol);
-      double dxi = 0;
-      if (lane < 18) {
-        double sacc = 0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) sacc += L.P[lane * 18 + sidx(k)] * wsol[k];
-        dxi = L.ic.d[lane] - sacc;
-      }
-      if (prof) t3 = clock64();
-      // broadcast dx lane by lane and fold it straight into the state (no dx[18] array: this
-      // section runs under the search loop's 128-VGPR budget): additive blocks now, the
-      // attitude increment through the quaternion below (boxPlus, KF:71-81)
-#pragma unroll
-      for (int k = 0; k < 19; ++k) lin[k] = L.ic.lin[k];
-      double dth[3] = {0, 0, 0};
-      bool has_nan = false;
-      un = 0;
-#pragma unroll
-      for (int k = 0; k < 18; ++k) {
-        const double vk = __shfl(dxi, k);
-        has_nan = has_nan || isnan(vk);
-        un += vk * vk;
-        if (k >= 6 && k < 9)
-          dth[k - 6] = vk;
-        else
-          lin[k < 6 ? k : k + 1] += vk;  // p,v at 0..5; ba,bw,g at 10..18 (q occupies 6..9)
-      }
-      un = sqrt(un);
-      rn = sqrt(L.sums[27]);
-      res_prev = L.res_prev;
-      if (has_nan) {
-        div = 2, un = L.upd_norm;
-      } else if (rn > res_prev * 10) {
-        div = 1, un = L.upd_norm;
-      } else {
-        const Q4 qn = qnormalized(qmul(Q4{lin[6], lin[7], lin[8], lin[9]}, axis2quat(V3{dth[0], dth[1], dth[2]})));
-        lin[6] = qn.w, lin[7] = qn.x, lin[8] = qn.y, lin[9] = qn.z;
-        if (un <= 1e-2 && !prm.fixed_iters) conv = 1;
-        res_prev = rn;
-      }
-    }
-    __syncthreads();  // every reader of the old linearisation state is done
-    if (wave < 3 && !div) {
-      const Q4 q{lin[6], lin[7], lin[8], lin[9]};
-      // (static indices only: a lane-indexed register array would be spilled to scratch)
-      if (wave == 0) {
-        const M3 Rt = mtrans(qmat(q));
-        if (lane == 0) {
-#pragma unroll
-          for (int k = 0; k < 19; ++k) L.ic.lin[k] = lin[k];
-          L.ic.Rt = Rt;
-        }
-      } else if (wave == 1) {
-        V3 phi;
-        M3 Gt;
-        phi_and_Gt(q, phi, Gt);
-        if (lane == 0) L.ic.phi = phi, L.ic.Gt = Gt;
-      } else {
-        // boxMinus(filter, lin), KF:84-94
-        const Q4 qf{L.filt[6], L.filt[7], L.filt[8], L.filt[9]};
-        const V3 da = quat2axis(qmul(qinverse(q), qf));
-        if (lane == 0) {
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            L.ic.d[0 + k] = L.filt[0 + k] - lin[0 + k];
-            L.ic.d[3 + k] = L.filt[3 + k] - lin[3 + k];
-            L.ic.d[9 + k] = L.filt[10 + k] - lin[10 + k];
-            L.ic.d[12 + k] = L.filt[13 + k] - lin[13 + k];
-            L.ic.d[15 + k] = L.filt[16 + k] - lin[16 + k];
-          }
-          L.ic.d[6] = da.x, L.ic.d[7] = da.y, L.ic.d[8] = da.z;
-        }
-      }
-    }
-    if (tid == 0) {
-      L.res_last = rn, L.res_prev = res_prev, L.upd_norm = un;
-      L.conv = conv, L.div = div;
-      L.iter = iter + 1;
-    }
-    __syncthreads();
+    solve_and_update(prm, tid, iter, prof, t3);
     if (prof) {
       long long t4 = clock64();
       pt[1] += t1 - t0, pt[2] += t2 - t1, pt[3] += t3 - t2, pt[4] += t4 - t3;
     }
   }
   if (prof && tid == 0) {
+    long long* prof_out = prof_buf;
     pt[5] = clock64() - t_begin;
-    for (int k = 0; k < 10; ++k) prof[(size_t)scan * 16 + k] = pt[k];
+    for (int k = 0; k < 10; ++k) prof_out[(size_t)scan * 16 + k] = pt[k];
   }
 
   // ---- hand-off to the Joseph kernel / the caller (SE:585-598) ---------------
@@ -820,25 +837,33 @@ int lds_np_cap() { return kNpCap; }
 void launch_lds(hipStream_t stream, int n, const DevParams& prm, int lanes, const ScanDesc* descs,
                 const float4* arena, const double* state_in, const double* cov_in, double* state_out, double* a6,
                 void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof) {
-  if (lanes == 3)
-    hipLaunchKernelGGL((ieskf_lds_kernel<1024, 3, false>), dim3(n), dim3(1024), 0, stream, prm, descs, arena, state_in,
-                       cov_in, (const double*)nullptr, 0, state_out, a6, (OutRec*)out, idx_store, poses, scan_id_base,
-                       (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof);
-  else
-    hipLaunchKernelGGL((ieskf_lds_kernel<384, 1, false>), dim3(n), dim3(384), 0, stream, prm, descs, arena, state_in,
-                       cov_in, (const double*)nullptr, 0, state_out, a6, (OutRec*)out, idx_store, poses, scan_id_base,
-                       (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof);
+#define LINS_LAUNCH_LDS(B, LN, PR)                                                                              \
+  hipLaunchKernelGGL((ieskf_lds_kernel<B, LN, false, PR>), dim3(n), dim3(B), 0, stream, prm, descs, arena, state_in, \
+                     cov_in, (const double*)nullptr, 0, state_out, a6, (OutRec*)out, idx_store, poses, scan_id_base, \
+                     (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof)
+  if (lanes == 3) {
+    if (prof)
+      LINS_LAUNCH_LDS(1024, 3, true);
+    else
+      LINS_LAUNCH_LDS(1024, 3, false);
+  } else {
+    if (prof)
+      LINS_LAUNCH_LDS(384, 1, true);
+    else
+      LINS_LAUNCH_LDS(384, 1, false);
+  }
+#undef LINS_LAUNCH_LDS
 }
 
 void launch_lds_pass(hipStream_t stream, int n, const DevParams& prm, int lanes, const ScanDesc* descs,
                      const float4* arena, const double* lin_state, const double* filt_state, int iter,
                      int4* idx_store, lins_corr* dump, double* sums_out, int* counts_out) {
   if (lanes == 3)
-    hipLaunchKernelGGL((ieskf_lds_kernel<1024, 3, true>), dim3(n), dim3(1024), 0, stream, prm, descs, arena, filt_state,
+    hipLaunchKernelGGL((ieskf_lds_kernel<1024, 3, true, false>), dim3(n), dim3(1024), 0, stream, prm, descs, arena, filt_state,
                        (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr, (OutRec*)nullptr,
                        idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out, (long long*)nullptr);
   else
-    hipLaunchKernelGGL((ieskf_lds_kernel<384, 1, true>), dim3(n), dim3(384), 0, stream, prm, descs, arena, filt_state,
+    hipLaunchKernelGGL((ieskf_lds_kernel<384, 1, true, false>), dim3(n), dim3(384), 0, stream, prm, descs, arena, filt_state,
                        (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr, (OutRec*)nullptr,
                        idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out, (long long*)nullptr);
 }
