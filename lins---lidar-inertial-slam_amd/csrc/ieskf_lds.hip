@@ -33,9 +33,8 @@ struct OutRec {
 };
 
 constexpr int kMaxLWaves = 16;
-constexpr int kNpCap = 9088;          // target points (surf + corner) resident in LDS
+constexpr int kNpCap = 8960;          // target points (surf + corner) resident in LDS
 constexpr int kSlotCap = 384;         // >= queries per round, row slots of 7 doubles
-constexpr int kLRedGroups = 8;
 constexpr int kCellsSurf = kRingsBinned * kAzSurf, kCellsCorner = kRingsBinned * kAzCorner;
 
 __constant__ unsigned char kLPairA[28] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2,
@@ -52,7 +51,7 @@ struct LdsStore {
   IterConst ic;
   double filt[19];
   double sums[28];
-  double partial[kLRedGroups * 28];
+  double partial[kMaxLWaves * 28];  // one partial 28-vector per wave
   double aug[3][42];  // one staging copy of [N | z] per solving wave
   double w[6];
   double dx[18];
@@ -763,25 +762,29 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       }
       __syncthreads();
       if (prof) t1 = clock64();
+      // rows -> 28 sums, every wave takes part: half-wave h of wave w folds rows 2w+h, 2w+h+G, ...
+      // (G = 2 * waves) in order, the two halves are added, then the wave partials are folded in
+      // wave order.  The tree is fixed, so the sums are bit-reproducible from run to run.
       const int nrows = span - base < kQPerRound ? span - base : kQPerRound;
-      if (tid < kLRedGroups * 32) {
-        int g = tid >> 5, k = tid & 31;
-        if (k < 28) {
-          int a = kLPairA[k], b = kLPairB[k];
-          for (int r = g; r < nrows; r += kLRedGroups) acc += L.slots[r * 7 + a] * L.slots[r * 7 + b];
-        }
+      {
+        constexpr int G = 2 * (BLOCK / 64);
+        const int k = lane & 31;
+        const int a = kLPairA[k < 28 ? k : 0], b = kLPairB[k < 28 ? k : 0];
+#pragma unroll 2
+        for (int r = 2 * wave + (lane >> 5); r < nrows; r += G) acc += L.slots[r * 7 + a] * L.slots[r * 7 + b];
       }
       __syncthreads();
     }
-    if (tid < kLRedGroups * 32 && (tid & 31) < 28) L.partial[(tid >> 5) * 28 + (tid & 31)] = acc;
+    acc += __shfl_down(acc, 32);
+    if (lane < 28) L.partial[wave * 28 + lane] = acc;
     if (ms) atomicAdd(&L.m_surf, ms);
     if (mc) atomicAdd(&L.m_corner, mc);
     __syncthreads();
     if (tid < 28) {
-      double s = 0;
+      double sacc = 0;
 #pragma unroll
-      for (int g = 0; g < kLRedGroups; ++g) s += L.partial[g * 28 + tid];
-      L.sums[tid] = s;
+      for (int g = 0; g < BLOCK / 64; ++g) sacc += L.partial[g * 28 + tid];
+      L.sums[tid] = sacc;
     }
     __syncthreads();
     if (prof) t2 = clock64();
