@@ -60,7 +60,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the HIP path)")
     torch.cuda.set_device(local_rank)
-    use_dist = world > 1
+    use_dist = world > 1 or os.environ.get("LINS_FORCE_DIST") == "1"  # (force: exercise the RCCL path on 1 GPU)
     if use_dist:
         import torch.distributed as dist
 
@@ -115,6 +115,12 @@ def main():
         elapsed_max, iters_all = float(tmax.item()), float(isum.item())
     else:
         elapsed_max, iters_all = elapsed, float(iters_local)
+
+    if use_dist:  # the gathered pose records must be complete and in scan order (outside the timed region)
+        defs = importlib.import_module(PKG + "._ctypes_defs")
+        rec = np.frombuffer(gathered.cpu().numpy().tobytes(), dtype=defs.POSE_DTYPE)
+        assert np.array_equal(rec["scan_id"], np.arange(world * len(pairs))), "pose gather out of order"
+        assert int(rec["iters"].sum()) == int(iters_all), "pose gather incomplete"
 
     if rank == 0:
         res = ctx.download()

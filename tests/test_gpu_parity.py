@@ -108,3 +108,19 @@ def test_fixed_iteration_mode_and_batch(pkg, ieskf, oracle, pairs):
         assert c.total_iters() == sum(r.iters for r in res)
         assert c.bytes_per_iter() == sum(p.bytes_per_iter() for p in pairs)
         assert c.last_kernel_ms() > 0
+
+
+@pytest.mark.parametrize("search", ["lds", "lds1"])
+def test_warm_started_search_returns_the_same_triplets(pkg, ieskf, oracle, pairs, search, monkeypatch):
+    """Iterations >= 1 start the search from the previous iteration's triplet (bounds only).
+    Debug flag 4 makes the single-pass kernel run the pass twice, the second time warm: the
+    dumped records must still be the oracle's, bit for bit."""
+    monkeypatch.setenv("LINS_DEBUG_SKIP", "4")
+    prm = pkg.default_params(num_iter=30)
+    with ieskf.IeskfContext(prm, max_batch=1, max_targets=16384, search=search) as c:
+        for pair in pairs[:3]:
+            _, tr = oracle.ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_BRUTE, trace=True)
+            for k in (0, 1, 3):
+                surf, corner = c.correspondences(pair, tr["lin_state"][k], k)
+                assert_corr_equal(surf, tr["surf"][k], f"warm.iter{k}.surf")
+                assert_corr_equal(corner, tr["corner"][k], f"warm.iter{k}.corner")
