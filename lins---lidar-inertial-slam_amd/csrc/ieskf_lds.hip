@@ -217,6 +217,8 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
   if (LANES == 3) {
     merge_from_lane(b, lane_base + (role + 1) % 3);
     merge_from_lane(b, lane_base + (role + 2) % 3);
+  } else if (LANES == 2) {
+    merge_from_lane(b, lane_base + (role ^ 1));
   }
   return b;
 }
@@ -329,6 +331,9 @@ __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, boo
     merge_from_lane(c2, lane_base + (role + 2) % 3);
     merge_from_lane(c3, lane_base + (role + 1) % 3);
     merge_from_lane(c3, lane_base + (role + 2) % 3);
+  } else if (LANES == 2) {
+    merge_from_lane(c2, lane_base + (role ^ 1));
+    merge_from_lane(c3, lane_base + (role ^ 1));
   }
 }
 

@@ -303,7 +303,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   if (ctx->n_uploaded <= 0) return LINS_E_STATE;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  const bool want_lds = ctx->dprm.search == SEARCH_LDS || ctx->dprm.search == SEARCH_LDS3;
+  const bool want_lds = ctx->dprm.search >= SEARCH_LDS;
   if (want_lds && ctx->lds_ok) {
     launch_lds(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->dprm.search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc, ctx->d_arena, ctx->d_state_in, ctx->d_cov_in,
                ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx, (lins_pose_record*)d_poses, scan_id_base, ctx->d_prof);
@@ -421,7 +421,7 @@ static int run_pass(lins_ctx* ctx, const lins_scan_pair* in, const double* lin_s
   if (rc) return rc;
   ctx->n_uploaded = 0;  // the single-pass calls do not leave a runnable batch behind
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_lin, lin_state, 19 * 8, hipMemcpyHostToDevice, ctx->stream));
-  const bool want_lds = ctx->dprm.search == SEARCH_LDS || ctx->dprm.search == SEARCH_LDS3;
+  const bool want_lds = ctx->dprm.search >= SEARCH_LDS;
   if (want_lds && ctx->lds_ok) {
     launch_lds_pass(ctx->stream, 1, ctx->dprm, ctx->dprm.search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc, ctx->d_arena, ctx->d_lin, ctx->d_state_in, iter,
                     ctx->d_idx, dump ? ctx->d_dump : nullptr, sums ? ctx->d_sums : nullptr,
