@@ -95,6 +95,32 @@ def test_forward_walk_is_bounded_by_query_count(pkg, oracle, ctx, search):
         if n_q == 3:
             fwd = (ws["ind2"] > ws["ind1"]) & (ws["ind2"] >= 0)
             assert not fwd[ws["ind1"] >= 3].any()
+        if n_q == 900:  # 1800 queries: several 336-slot rounds in the LDS kernel, reduced across rounds
+            one = pkg.default_params(num_iter=1)
+            _, tr = oracle.ieskf(one, pair, oracle.FORM_DENSE, oracle.NN_BRUTE, trace=True)
+            sums, ms, mc = ctx.reduce_pass(pair, pair.state, 0)
+            assert ms == int(tr["surf"][0]["accepted"].sum()) and mc == int(tr["corner"][0]["accepted"].sum())
+            assert np.abs(sums - tr["sums28"][0]).max() <= 1e-10 * max(1.0, np.abs(tr["sums28"][0]).max())
+            got = ctx.update(pair)
+            want = oracle.ieskf(pkg.default_params(num_iter=30), pair, oracle.FORM_DENSE, oracle.NN_BRUTE)
+            assert (got.iters, got.converged, got.diverged) == (want.iters, want.converged, want.diverged)
+            if not want.diverged:
+                assert np.abs(got.state - want.state).max() <= 1e-6 * max(1.0, np.abs(want.state).max())
+
+
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
+def test_mixed_batch_with_one_oversized_scan(pkg, oracle, ctx, search):
+    """One scan too large for LDS sends the whole batch down the global-memory grid path."""
+    ctx.set_search(search)
+    rng = np.random.default_rng(21)
+    pairs = [make_pair(pkg, rng, 40, 50, 600, 200, "offgrid"), make_pair(pkg, rng, 40, 50, 12000, 900, "offgrid"),
+             make_pair(pkg, rng, 30, 30, 500, 100, "offgrid")]
+    for got, pair in zip(ctx.update_batch(pairs), pairs):
+        want = oracle.ieskf(pkg.default_params(num_iter=30), pair, oracle.FORM_DENSE, oracle.NN_BRUTE)
+        assert (got.iters, got.converged, got.diverged, got.m_surf, got.m_corner) == (
+            want.iters, want.converged, want.diverged, want.m_surf, want.m_corner)
+        if not want.diverged:
+            assert np.abs(got.state - want.state).max() <= 1e-6 * max(1.0, np.abs(want.state).max())
 
 
 @pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
