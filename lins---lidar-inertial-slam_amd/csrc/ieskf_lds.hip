@@ -551,12 +551,24 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double a[6][7], wsol[6];
+    // one lane per wave eliminates (registers, unrolled); a single active lane keeps whatever the
+    // register allocator spills for the 6x7 system to 1/64 of the scratch traffic
+    if (lane == 0) {
+      double a[6][7], x6[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+      for (int i = 0; i < 6; ++i)
 #pragma unroll
-      for (int j = 0; j < 7; ++j) a[i][j] = L.aug[wave][i * 7 + j];
-    reg_solve6(a, wsol);
+        for (int j = 0; j < 7; ++j) a[i][j] = L.aug[wave][i * 7 + j];
+      reg_solve6(a, x6);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) L.aug[wave][k] = x6[k];  // the system is consumed: reuse its first row
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double wsol[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) wsol[k] = L.aug[wave][k];
     double dxi = 0;
     if (lane < 18) {
       double sacc = 0;
