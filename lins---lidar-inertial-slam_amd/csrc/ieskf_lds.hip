@@ -82,6 +82,12 @@ struct LCloud {  // one target cloud's grid (all pointers into LDS)
 // (their bit patterns order like the values, NaN above everything), the tie key is the
 // original index (pass 1: lowest index wins) or the visit rank (pass 2).  Initialised to
 // (threshold, 0): a candidate must be strictly closer than the threshold (SE:851, 856).
+// polar view of a de-skewed query, computed once and shared by both search passes
+struct QueryPolar {
+  float rho, qn3, el, inv_unused;
+  int a0_surf_or_corner;
+};
+
 struct Best {
   unsigned long long k;
   int pos, ring;
@@ -136,11 +142,16 @@ __device__ __forceinline__ void scan_cols(const LdsStore& L, const LCloud& c, in
 // a point at azimuth difference D from the query is at least rho*sin(D) away (rho for
 // D >= 90 deg), so D <= asin(sqrt(bound)/rho); the query sits anywhere inside its own
 // column, hence the +2 (one for its offset, one for rounding) — a superset, never less.
-__device__ __forceinline__ int reach(const LCloud& c, float rho, float bound) {
+// asin(s) <= s + (pi/2 - 1) s^3 on [0, 1] (every term of asin's series beyond s is <= its
+// coefficient times s^3, and the coefficients sum to pi/2 - 1): a cheap upper bound is all the
+// pruning needs — a slightly wider window never changes the result.
+__device__ __forceinline__ float asin_ub(float s) { return s + 0.5707964f * s * s * s; }
+
+__device__ __forceinline__ int reach(const LCloud& c, float rho, float sqrt_bound) {
   const int half = c.naz / 2;
-  float s = (sqrtf(bound) * (1.f + 1e-6f) + kSlack * rho + 1e-6f) / rho;  // rho == 0 -> inf/nan -> all columns
+  float s = (sqrt_bound * (1.f + 1e-6f) + kSlack * rho + 1e-6f) / rho;  // rho == 0 -> inf/nan -> all columns
   if (!(s < 1.f)) return half;
-  int k = (int)(asinf(s) * ((float)c.naz * (0.5f / kPiF))) + 2;
+  int k = (int)(asin_ub(s) * (1.f + 1e-6f) * ((float)c.naz * (0.5f / kPiF))) + 2;
   return k < half ? k : half;
 }
 
@@ -151,9 +162,9 @@ __device__ __forceinline__ bool ring_nonempty(const LCloud& c, int r) {
 // ring r can hold a point within sqrt(bound) of the query only if the query's elevation
 // is within delta = asin(sqrt(bound)/|q|) of the ring's elevation wedge (a point at
 // elevation difference g < 90 deg is at least |q| sin g away, |q| beyond that)
-__device__ __forceinline__ float reach_elev(float qn3, float bound) {
-  float s = (sqrtf(bound) * (1.f + 1e-6f) + kSlack * qn3 + 1e-6f) / qn3;
-  return s < 1.f ? asinf(s) + kSlack : 4.f;  // 4 rad > any elevation difference
+__device__ __forceinline__ float reach_elev(float qn3, float sqrt_bound) {
+  float s = (sqrt_bound * (1.f + 1e-6f) + kSlack * qn3 + 1e-6f) / qn3;
+  return s < 1.f ? asin_ub(s) * (1.f + 1e-6f) + kSlack : 4.f;  // 4 rad > any elevation difference
 }
 __device__ __forceinline__ bool ring_in_reach(const LCloud& c, int r, float el_q, float delta) {
   return el_q >= c.el_ang[2 * r] - delta && el_q <= c.el_ang[2 * r + 1] + delta;
@@ -161,8 +172,9 @@ __device__ __forceinline__ bool ring_in_reach(const LCloud& c, int r, float el_q
 
 // ---- pass 1: exact NN; with LANES = 3 the ring windows of a query are split over its lanes
 template <int LANES>
-__device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float sx, float sy, float sz, float thr,
-                                       int rq, int role, int lane_base, int warm_pos, int warm_ring) {
+__device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float sx, float sy, float sz,
+                                       const QueryPolar& qp, float thr, int rq, int role, int lane_base, int warm_pos,
+                                       int warm_ring) {
   Best b = best_init(thr);
   // Warm start (iterations >= 1): last iteration's nearest neighbour is still a candidate, and its
   // distance to the re-de-skewed query bounds the search from the start — the seed scan is skipped
@@ -172,10 +184,8 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
   if (warm)
     consider(b, sqdist3(L.px[warm_pos], L.py[warm_pos], L.pz[warm_pos], sx, sy, sz), (int)L.pidx[warm_pos], warm_pos,
              warm_ring);
-  const float rho = sqrtf(sx * sx + sy * sy);
-  const float qn3 = sqrtf(rho * rho + sz * sz);
-  const float el_q = atan2f(sz, rho);
-  const int a0 = az_bin(sx, sy, c.naz);
+  const float rho = qp.rho, qn3 = qp.qn3, el_q = qp.el;
+  const int a0 = qp.a0_surf_or_corner;
   rq = rq < 0 ? 0 : (rq >= kRingsBinned ? kRingsBinned - 1 : rq);
   int rcur = rq;
   auto f = [&](float x, float y, float z, int j, int p) { consider(b, sqdist3(x, y, z, sx, sy, sz), j, p, rcur); };
@@ -184,8 +194,9 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
   scan_cols(L, c, rq, seed ? a0 - 1 : 1, seed ? a0 + 1 : 0, f);  // seed: all lanes of the query
   const int cin = warm ? 0 : 2;  // first column either side that the seed has not covered
   const float B = b.d();  // fixed bound for everything below (conservative: >= the final best)
-  const int K = reach(c, rho, B);
-  const float delta = reach_elev(qn3, B);
+  const float sqrtB = sqrtf(B);
+  const int K = reach(c, rho, sqrtB);
+  const float delta = reach_elev(qn3, sqrtB);
   // This lane's tasks as a bit mask (bit i <-> task t = role + LANES i): task 0 = own ring right
   // of the seed, 1 = own ring left of it, 2.. = the other rings rq+1, rq-1, rq+2, ...  The ring
   // tests are independent LDS reads, issued together; only surviving tasks enter the scan loop.
@@ -254,14 +265,14 @@ __device__ __forceinline__ void walk_task(const LdsStore& L, const LCloud& c, co
                                           bool centre_done, int a0, float sx, float sy, float sz, float rho_q,
                                           float qn3, float el_q, Best& cur) {
   bool go = walk_ring_has_candidates(c, w, r);
-  if (go) go = ring_in_reach(c, r, el_q, reach_elev(qn3, cur.d()));
+  if (go) go = ring_in_reach(c, r, el_q, reach_elev(qn3, sqrtf(cur.d())));
   auto f = [&](float x, float y, float z, int j, int p) {
     int rank;
     if (walk_rank(w, j, rank)) consider(cur, sqdist3(x, y, z, sx, sy, sz), rank, p, 0);
   };
   const bool seed = go && seed_first;
   scan_cols(L, c, r, seed ? a0 - 1 : 1, seed ? a0 + 1 : 0, f);
-  const int K = reach(c, rho_q, cur.d());
+  const int K = reach(c, rho_q, sqrtf(cur.d()));
   const bool done = seed_first || centre_done;
   go = go && K >= (done ? 2 : 0);
   scan_cols(L, c, r, go ? a0 + (done ? 2 : 0) : 1, go ? a0 + K : 0, f);
@@ -273,18 +284,16 @@ __device__ __forceinline__ void walk_task(const LdsStore& L, const LCloud& c, co
 // corner: class 2 = rings rho+-1, rho+-2 (second point on a different ring), no class 3
 template <int LANES>
 __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, bool is_surf, int nq, float thr, int j1,
-                                         int rho, float sx, float sy, float sz, int role, int lane_base, int warm2,
-                                         int warm3, Best& c2, Best& c3) {
+                                         int rho, float sx, float sy, float sz, const QueryPolar& qp, int role,
+                                         int lane_base, int warm2, int warm3, Best& c2, Best& c3) {
   const int fend = nq < c.n ? nq : c.n;
   const int r_hi = rho + 3 < kRingsBinned ? rho + 3 : kRingsBinned;
   const int r_lo = rho - 2 > 0 ? rho - 2 : 0;
   const WalkCtx w{j1, fend < c.ring_start[r_hi] ? fend : c.ring_start[r_hi], c.ring_start[r_lo]};
   c2 = best_init(thr);
   c3 = best_init(thr);
-  const float rho_q = sqrtf(sx * sx + sy * sy);
-  const float qn3 = sqrtf(rho_q * rho_q + sz * sz);
-  const float el_q = atan2f(sz, rho_q);
-  const int a0 = az_bin(sx, sy, c.naz);
+  const float rho_q = qp.rho, qn3 = qp.qn3, el_q = qp.el;
+  const int a0 = qp.a0_surf_or_corner;
   // warm start: last iteration's second / third point (same nearest neighbour => same index
   // intervals and classes) are candidates whose distances bound the walk from the start
   auto warm_cand = [&](Best& b, int pos) {
@@ -753,15 +762,24 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         if (do_search) {
           const bool single_round = span <= kQPerRound;
           if (!single_round) wp1 = wp2 = wp3 = -1;
-          Best b1 = nn_lds<LANES>(L, c, o.sel[0], o.sel[1], o.sel[2], prm.nearest_f, ring_of(q.w), role, lane_base,
-                                  wp1, wr1);
+          QueryPolar qp;
+          qp.rho = sqrtf(o.sel[0] * o.sel[0] + o.sel[1] * o.sel[1]);
+          qp.qn3 = sqrtf(qp.rho * qp.rho + o.sel[2] * o.sel[2]);
+          qp.el = atan2f(o.sel[2], qp.rho);
+          qp.inv_unused = 0.f;
+          qp.a0_surf_or_corner = az_bin(o.sel[0], o.sel[1], c.naz);
+          Best b1 = best_init(prm.nearest_f);
+          if (!(prm.pad & 2))  // (profiling aid: LINS_DEBUG_SKIP=2 skips the search, 1 skips the walk)
+            b1 = nn_lds<LANES>(L, c, o.sel[0], o.sel[1], o.sel[2], qp, prm.nearest_f, ring_of(q.w), role, lane_base,
+                               wp1, wr1);
           if (prof) s2 = clock64(), pt[7] += s2 - s1;
           if (b1.pos >= 0 && (double)b1.d() < prm.nearest) {
             p1 = b1.pos;
-            Best c2, c3;
+            Best c2 = best_init(prm.nearest_f), c3 = c2;
             const bool same_nn = b1.pos == wp1;
+            if (!(prm.pad & 1))
             walk_lds<LANES>(L, c, is_surf, is_surf ? sd.n_surf_q : sd.n_corner_q, prm.nearest_f, b1.key(), b1.ring, o.sel[0],
-                            o.sel[1], o.sel[2], role, lane_base, same_nn ? wp2 : -1, same_nn ? wp3 : -1, c2, c3);
+                            o.sel[1], o.sel[2], qp, role, lane_base, same_nn ? wp2 : -1, same_nn ? wp3 : -1, c2, c3);
             p2 = c2.pos, p3 = c3.pos;
           }
           wp1 = p1, wp2 = p2, wp3 = p3, wr1 = b1.ring;
