@@ -47,7 +47,9 @@ struct DevParams {
   double inv_period;  // (double)(1.f / SCAN_PERIOD)
   double nearest;     // NEAREST_FEATURE_SEARCH_SQ_DIST
   float nearest_f;
-  int pad;
+  int pad;            // debug / profiling flags (LINS_DEBUG_SKIP)
+  float margin_cold;  // certificate margins of the LDS search [m] (ieskf_lds.hip)
+  float margin_warm;
 };
 
 struct IterConst {  // per-iteration constants, hoisted (the reference recomputes per point)

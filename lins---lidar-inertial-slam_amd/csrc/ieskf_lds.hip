@@ -63,6 +63,7 @@ struct LdsStore {
   int piv[6], used[6];
   int scan_tmp[kMaxLWaves + 4];
   int m_surf, m_corner, iter, conv, div, pad;
+  int dbg[4];  // [0] certificate disagreements (verify mode) [1] NN searches skipped [2] walks skipped
 };
 static_assert(sizeof(LdsStore) <= 163840, "LDS budget of one CU");
 
@@ -77,35 +78,66 @@ struct LCloud {  // one target cloud's grid (all pointers into LDS)
   int naz, stride, base, n;
 };
 
-// Running best of a search: (distance, tie key) packed so that ONE unsigned 64-bit compare
-// is the reference's "strict < , first seen wins" rule: distances are non-negative floats
-// (their bit patterns order like the values, NaN above everything), the tie key is the
-// original index (pass 1: lowest index wins) or the visit rank (pass 2).  Initialised to
-// (threshold, 0): a candidate must be strictly closer than the threshold (SE:851, 856).
 // polar view of a de-skewed query, computed once and shared by both search passes
 struct QueryPolar {
   float rho, qn3, el, inv_unused;
   int a0_surf_or_corner;
 };
 
+// Running best of a search: (distance, tie key) packed so that ONE unsigned 64-bit compare
+// is the reference's "strict < , first seen wins" rule: distances are non-negative floats
+// (their bit patterns order like the values, NaN above everything), the tie key is the
+// original index (pass 1: lowest index wins) or the visit rank (pass 2).  Initialised to
+// (threshold, 0): a candidate must be strictly closer than the threshold (SE:851, 856).
 struct Best {
   unsigned long long k;
   int pos, ring;
+  float omin;  // smallest squared distance of any OTHER candidate seen (for the certificates below)
   __device__ __forceinline__ float d() const { return __uint_as_float((unsigned)(k >> 32)); }
   __device__ __forceinline__ int key() const { return (int)(unsigned)k; }
 };
 __device__ __forceinline__ Best best_init(float thr) {
-  return Best{(unsigned long long)__float_as_uint(thr) << 32, -1, -1};
+  return Best{(unsigned long long)__float_as_uint(thr) << 32, -1, -1, INFINITY};
 }
 __device__ __forceinline__ void consider(Best& b, float d, int key, int pos, int ring) {
   unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)key;
-  if (k < b.k) b = Best{k, pos, ring};
+  if (k < b.k) {
+    if (b.pos >= 0) b.omin = fminf(b.omin, b.d());  // the dethroned best becomes an "other"
+    b.k = k, b.pos = pos, b.ring = ring;
+  } else if (k > b.k) {  // (equal key = the same point seen again: not its own runner-up)
+    b.omin = fminf(b.omin, d);
+  }
 }
 __device__ __forceinline__ void merge_from_lane(Best& b, int src_lane) {
   unsigned lo = __shfl((unsigned)b.k, src_lane), hi = __shfl((unsigned)(b.k >> 32), src_lane);
   int pos = __shfl(b.pos, src_lane), ring = __shfl(b.ring, src_lane);
+  float om = __shfl(b.omin, src_lane);
   unsigned long long k = ((unsigned long long)hi << 32) | lo;
-  if (k < b.k) b = Best{k, pos, ring};
+  b.omin = fminf(b.omin, om);
+  if (pos >= 0) {
+    if (k < b.k) {
+      if (b.pos >= 0) b.omin = fminf(b.omin, b.d());
+      b.k = k, b.pos = pos, b.ring = ring;
+    } else if (k > b.k) {
+      b.omin = fminf(b.omin, __uint_as_float(hi));
+    }
+  }
+}
+
+// ---- certificates: skipping a search that provably returns the same answer -----------------
+// After a search run with its pruning bound inflated by `margin` metres, every candidate other
+// than the winner is at least  lb = min(sqrt(omin), sqrt(d_best) + margin)  away from the query
+// (scanned ones: measured; pruned ones: beyond the inflated bound).  If the de-skewed query has
+// since moved by `drift`, any other candidate is still at least lb - drift away, so while
+//     dist(query, winner)  <  lb - drift        (with slack for the f32 roundings)
+// the winner is the unique strict minimum of the reference's comparison and the search can be
+// skipped.  With no winner (nothing inside the search radius) the same test against the radius
+// certifies that there is still none.
+__device__ __forceinline__ float cert_lb(const Best& b, float thr, float margin) {
+  return fminf(sqrtf(b.omin), sqrtf(b.pos >= 0 ? b.d() : thr) + margin);
+}
+__device__ __forceinline__ bool certified(float d_now, float lb, float drift) {
+  return sqrtf(d_now) * (1.f + 4e-6f) + 2e-6f < (lb - drift * (1.f + 4e-6f)) * (1.f - 4e-6f);
 }
 
 // ---- columns / windows on the LDS grid ----------------------------------------------------
@@ -173,8 +205,8 @@ __device__ __forceinline__ bool ring_in_reach(const LCloud& c, int r, float el_q
 // ---- pass 1: exact NN; with LANES = 3 the ring windows of a query are split over its lanes
 template <int LANES>
 __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float sx, float sy, float sz,
-                                       const QueryPolar& qp, float thr, int rq, int role, int lane_base, int warm_pos,
-                                       int warm_ring) {
+                                       const QueryPolar& qp, float thr, float margin, int rq, int role, int lane_base,
+                                       int warm_pos, int warm_ring) {
   Best b = best_init(thr);
   // Warm start (iterations >= 1): last iteration's nearest neighbour is still a candidate, and its
   // distance to the re-de-skewed query bounds the search from the start — the seed scan is skipped
@@ -194,7 +226,7 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
   scan_cols(L, c, rq, seed ? a0 - 1 : 1, seed ? a0 + 1 : 0, f);  // seed: all lanes of the query
   const int cin = warm ? 0 : 2;  // first column either side that the seed has not covered
   const float B = b.d();  // fixed bound for everything below (conservative: >= the final best)
-  const float sqrtB = sqrtf(B);
+  const float sqrtB = sqrtf(B) + margin;  // pruning bound inflated by the certificate margin
   const int K = reach(c, rho, sqrtB);
   const float delta = reach_elev(qn3, sqrtB);
   // This lane's tasks as a bit mask (bit i <-> task t = role + LANES i): task 0 = own ring right
@@ -263,16 +295,16 @@ __device__ __forceinline__ bool walk_rank(const WalkCtx& w, int j, int& rank) {
 // were already scanned (by the all-lane class-2 seed) — otherwise the extensions include them.
 __device__ __forceinline__ void walk_task(const LdsStore& L, const LCloud& c, const WalkCtx& w, int r, bool seed_first,
                                           bool centre_done, int a0, float sx, float sy, float sz, float rho_q,
-                                          float qn3, float el_q, Best& cur) {
+                                          float qn3, float el_q, float margin, Best& cur) {
   bool go = walk_ring_has_candidates(c, w, r);
-  if (go) go = ring_in_reach(c, r, el_q, reach_elev(qn3, sqrtf(cur.d())));
+  if (go) go = ring_in_reach(c, r, el_q, reach_elev(qn3, sqrtf(cur.d()) + margin));
   auto f = [&](float x, float y, float z, int j, int p) {
     int rank;
     if (walk_rank(w, j, rank)) consider(cur, sqdist3(x, y, z, sx, sy, sz), rank, p, 0);
   };
   const bool seed = go && seed_first;
   scan_cols(L, c, r, seed ? a0 - 1 : 1, seed ? a0 + 1 : 0, f);
-  const int K = reach(c, rho_q, sqrtf(cur.d()));
+  const int K = reach(c, rho_q, sqrtf(cur.d()) + margin);
   const bool done = seed_first || centre_done;
   go = go && K >= (done ? 2 : 0);
   scan_cols(L, c, r, go ? a0 + (done ? 2 : 0) : 1, go ? a0 + K : 0, f);
@@ -284,8 +316,8 @@ __device__ __forceinline__ void walk_task(const LdsStore& L, const LCloud& c, co
 // corner: class 2 = rings rho+-1, rho+-2 (second point on a different ring), no class 3
 template <int LANES>
 __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, bool is_surf, int nq, float thr, int j1,
-                                         int rho, float sx, float sy, float sz, const QueryPolar& qp, int role,
-                                         int lane_base, int warm2, int warm3, Best& c2, Best& c3) {
+                                         int rho, float sx, float sy, float sz, const QueryPolar& qp, float margin,
+                                         int role, int lane_base, int warm2, int warm3, Best& c2, Best& c3) {
   const int fend = nq < c.n ? nq : c.n;
   const int r_hi = rho + 3 < kRingsBinned ? rho + 3 : kRingsBinned;
   const int r_lo = rho - 2 > 0 ? rho - 2 : 0;
@@ -329,7 +361,7 @@ __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, boo
     const bool seed_first = !have_bound && (!is_surf || dr != 0);
     const bool centre_done = is_surf && dr == 0 && !w2;
     Best cur = use2 ? c2 : c3;
-    walk_task(L, c, w, rho + dr, seed_first, centre_done, a0, sx, sy, sz, rho_q, qn3, el_q, cur);
+    walk_task(L, c, w, rho + dr, seed_first, centre_done, a0, sx, sy, sz, rho_q, qn3, el_q, margin, cur);
     if (use2)
       c2 = cur;
     else
@@ -695,6 +727,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   if (tid == 0) {
     L.res_prev = 1e6, L.res_last = 0, L.upd_norm = 0;
     L.iter = PASS_ONLY ? iter_arg : 0, L.conv = 0, L.div = 0, L.m_surf = 0, L.m_corner = 0;
+    L.dbg[0] = L.dbg[1] = L.dbg[2] = L.dbg[3] = 0;
   }
   __syncthreads();
   if (tid < 64) {  // wave 0, lane-redundant: constants of the first iteration
@@ -718,6 +751,10 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   // last iteration's triplet of this lane's query (grid positions) for the warm start; only
   // meaningful when the scan needs a single round (the lane <-> query mapping is then fixed)
   int wp1 = -1, wp2 = -1, wp3 = -1, wr1 = -1;
+  // certificates of those three selections (see cert_lb / certified): lower bounds of every other
+  // candidate's distance and the query positions they were established at
+  float lb1 = 0.f, lb2 = 0.f, lb3 = 0.f, certA[3] = {0.f, 0.f, 0.f}, certB[3] = {0.f, 0.f, 0.f};
+  bool have_cert = false;
 
   for (;;) {
     const int iter = L.iter;
@@ -761,28 +798,72 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         int p1 = -1, p2 = -1, p3 = -1;  // grid positions of the three target points
         if (do_search) {
           const bool single_round = span <= kQPerRound;
-          if (!single_round) wp1 = wp2 = wp3 = -1;
+          if (!single_round) wp1 = wp2 = wp3 = -1, have_cert = false;
           QueryPolar qp;
           qp.rho = sqrtf(o.sel[0] * o.sel[0] + o.sel[1] * o.sel[1]);
           qp.qn3 = sqrtf(qp.rho * qp.rho + o.sel[2] * o.sel[2]);
           qp.el = atan2f(o.sel[2], qp.rho);
           qp.inv_unused = 0.f;
           qp.a0_surf_or_corner = az_bin(o.sel[0], o.sel[1], c.naz);
-          Best b1 = best_init(prm.nearest_f);
-          if (!(prm.pad & 2))  // (profiling aid: LINS_DEBUG_SKIP=2 skips the search, 1 skips the walk)
-            b1 = nn_lds<LANES>(L, c, o.sel[0], o.sel[1], o.sel[2], qp, prm.nearest_f, ring_of(q.w), role, lane_base,
-                               wp1, wr1);
-          if (prof) s2 = clock64(), pt[7] += s2 - s1;
-          if (b1.pos >= 0 && (double)b1.d() < prm.nearest) {
-            p1 = b1.pos;
-            Best c2 = best_init(prm.nearest_f), c3 = c2;
-            const bool same_nn = b1.pos == wp1;
-            if (!(prm.pad & 1))
-            walk_lds<LANES>(L, c, is_surf, is_surf ? sd.n_surf_q : sd.n_corner_q, prm.nearest_f, b1.key(), b1.ring, o.sel[0],
-                            o.sel[1], o.sel[2], qp, role, lane_base, same_nn ? wp2 : -1, same_nn ? wp3 : -1, c2, c3);
-            p2 = c2.pos, p3 = c3.pos;
+          const float thr = prm.nearest_f;
+          const float margin = have_cert ? prm.margin_warm : prm.margin_cold;
+          auto dist_to = [&](int pos) { return sqdist3(L.px[pos], L.py[pos], L.pz[pos], o.sel[0], o.sel[1], o.sel[2]); };
+          auto drift_from = [&](const float* cp) {
+            float ex = o.sel[0] - cp[0], ey = o.sel[1] - cp[1], ez = o.sel[2] - cp[2];
+            return sqrtf(ex * ex + ey * ey + ez * ez);
+          };
+          // --- nearest neighbour: keep the certified one, or search (warm, inflated bound) ----------
+          const float d1_now = wp1 >= 0 ? dist_to(wp1) : thr;
+          bool ok1 = have_cert && !(prm.pad & 16) && (wp1 < 0 || d1_now < thr) && certified(d1_now, lb1, drift_from(certA));
+          const bool verify = (prm.pad & 8) != 0;  // test aid: search anyway and count disagreements
+          const bool said1 = ok1;
+          if (verify) ok1 = false;
+          int j1 = -1, rho1 = wr1;
+          bool need_walk = !have_cert;  // (or a changed nearest neighbour, below)
+          if (!ok1) {
+            Best b1 = best_init(thr);
+            if (!(prm.pad & 2))  // (profiling aid: LINS_DEBUG_SKIP=2 skips the search, 1 skips the walk)
+              b1 = nn_lds<LANES>(L, c, o.sel[0], o.sel[1], o.sel[2], qp, thr, margin, ring_of(q.w), role, lane_base, wp1,
+                                 wr1);
+            const int np1 = (b1.pos >= 0 && (double)b1.d() < prm.nearest) ? b1.pos : -1;
+            if (said1 && np1 != wp1 && role == 0) atomicAdd(&L.dbg[0], 1);
+            if (np1 != wp1) wp2 = wp3 = -1, need_walk = true;  // new nearest neighbour: new candidate sets
+            p1 = np1, rho1 = b1.ring, j1 = b1.key();
+            lb1 = cert_lb(b1, thr, margin);
+            certA[0] = o.sel[0], certA[1] = o.sel[1], certA[2] = o.sel[2];
+          } else {
+            p1 = wp1;
+            if (p1 >= 0) j1 = (int)L.pidx[p1];
+            if (role == 0) atomicAdd(&L.dbg[1], 1);
           }
-          wp1 = p1, wp2 = p2, wp3 = p3, wr1 = b1.ring;
+          if (prof) s2 = clock64(), pt[7] += s2 - s1;
+          // --- second / third point ------------------------------------------------------------------
+          if (p1 >= 0) {
+            bool said23 = false;
+            if (!need_walk) {
+              const float dB = drift_from(certB);
+              const float d2_now = wp2 >= 0 ? dist_to(wp2) : thr, d3_now = wp3 >= 0 ? dist_to(wp3) : thr;
+              bool ok23 = (wp2 < 0 || d2_now < thr) && certified(d2_now, lb2, dB);
+              if (is_surf) ok23 = ok23 && (wp3 < 0 || d3_now < thr) && certified(d3_now, lb3, dB);
+              said23 = ok23;
+              need_walk = !ok23 || verify;
+            }
+            if (need_walk) {
+              Best c2 = best_init(thr), c3 = c2;
+              if (!(prm.pad & 1))
+                walk_lds<LANES>(L, c, is_surf, is_surf ? sd.n_surf_q : sd.n_corner_q, thr, j1, rho1, o.sel[0], o.sel[1],
+                                o.sel[2], qp, margin, role, lane_base, wp2, wp3, c2, c3);
+              if (said23 && (c2.pos != wp2 || c3.pos != wp3) && role == 0) atomicAdd(&L.dbg[0], 1);
+              p2 = c2.pos, p3 = c3.pos;
+              lb2 = cert_lb(c2, thr, margin), lb3 = cert_lb(c3, thr, margin);
+              certB[0] = o.sel[0], certB[1] = o.sel[1], certB[2] = o.sel[2];
+            } else {
+              p2 = wp2, p3 = wp3;
+              if (role == 0) atomicAdd(&L.dbg[2], 1);
+            }
+          }
+          wp1 = p1, wp2 = p2, wp3 = p3, wr1 = rho1;
+          have_cert = single_round;
           if (prof) pt[8] += clock64() - s2;
           if (prm.icp_freq > 1 && role == 0) idx_store[sd.slot_base + slot] = make_int4(p1, p2, p3, 0);
         } else {
@@ -891,7 +972,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     r.residual_norm = L.res_last, r.update_norm = L.upd_norm;
     r.iters = L.iter, r.converged = L.conv, r.diverged = div;
     r.m_surf = L.m_surf, r.m_corner = L.m_corner;
-    r.pad[0] = r.pad[1] = r.pad[2] = 0;
+    r.pad[0] = L.dbg[0], r.pad[1] = L.dbg[1], r.pad[2] = L.dbg[2];
     out[scan] = r;
   }
   if (poses && tid < 32) {

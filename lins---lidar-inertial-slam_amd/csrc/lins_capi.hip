@@ -115,6 +115,10 @@ void make_dev_params(const lins_params& p, int search, DevParams& d) {
   d.nearest = p.nearest_sq_dist;
   d.nearest_f = (float)p.nearest_sq_dist;
   d.pad = 0;
+  d.margin_cold = 0.10f;
+  d.margin_warm = 0.04f;
+  if (const char* e = std::getenv("LINS_MARGIN_COLD")) d.margin_cold = (float)std::atof(e);
+  if (const char* e = std::getenv("LINS_MARGIN_WARM")) d.margin_warm = (float)std::atof(e);
   if (const char* e = std::getenv("LINS_DEBUG_SKIP")) d.pad = std::atoi(e);  // profiling aid: 1 = skip walks, 2 = skip search
 }
 
@@ -370,6 +374,7 @@ int lins_batch_download(lins_ctx* ctx, int n, lins_result* out) {
     r.residual_norm = o.residual_norm, r.update_norm = o.update_norm;
     r.iters = o.iters, r.converged = o.converged, r.diverged = o.diverged;
     r.m_surf = o.m_surf, r.m_corner = o.m_corner;
+    r.reserved[0] = o.pad[0], r.reserved[1] = o.pad[1], r.reserved[2] = o.pad[2];
     tot += (uint64_t)o.iters;
   }
   if (n == ctx->n_uploaded) ctx->total_iters = tot;

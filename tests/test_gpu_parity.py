@@ -124,3 +124,38 @@ def test_warm_started_search_returns_the_same_triplets(pkg, ieskf, oracle, pairs
                 surf, corner = c.correspondences(pair, tr["lin_state"][k], k)
                 assert_corr_equal(surf, tr["surf"][k], f"warm.iter{k}.surf")
                 assert_corr_equal(corner, tr["corner"][k], f"warm.iter{k}.corner")
+
+
+@pytest.mark.parametrize("search", ["lds", "lds1"])
+def test_search_certificates_never_disagree_with_a_real_search(pkg, ieskf, oracle, host, search, monkeypatch):
+    """From iteration 1 on a query keeps its previous triplet when a certificate proves a search
+    would return it again.  Debug flag 8 searches anyway and counts disagreements on device."""
+    prm = pkg.default_params(num_iter=10, fixed_iters=1)
+    batch = host.synth_batch(24, start=100)
+    want = [oracle.ieskf(prm, p, oracle.FORM_DENSE, oracle.NN_KDTREE) for p in batch]
+    monkeypatch.setenv("LINS_DEBUG_SKIP", "8")
+    lib = ieskf.lib()
+    import ctypes as C
+    defs = __import__("importlib").import_module("lins---lidar-inertial-slam_amd._ctypes_defs")
+    with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384, search=search) as c:
+        arr = defs.pairs_to_c(batch)
+        res = (defs.ResultC * len(batch))()
+        assert lib.lins_ieskf_update_batch(c._h, len(batch), arr, res) == 0
+        said = 0
+        for r, w in zip(res, want):
+            assert r.reserved[0] == 0, f"{r.reserved[0]} certificate disagreements"
+            said += r.reserved[1] + r.reserved[2]
+            assert (r.iters, r.diverged, r.m_surf, r.m_corner) == (w.iters, w.diverged, w.m_surf, w.m_corner)
+    monkeypatch.delenv("LINS_DEBUG_SKIP")
+    with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384, search=search) as c:
+        arr = defs.pairs_to_c(batch)
+        res = (defs.ResultC * len(batch))()
+        assert lib.lins_ieskf_update_batch(c._h, len(batch), arr, res) == 0
+        skipped = sum(r.reserved[1] + r.reserved[2] for r in res)
+        assert skipped > 0  # the certificates do fire in normal operation
+        for r, w in zip(res, want):
+            got = defs.Result(r)
+            assert (got.iters, got.diverged, got.m_surf, got.m_corner) == (w.iters, w.diverged, w.m_surf, w.m_corner)
+            assert np.abs(got.state[:3] - w.state[:3]).max() <= POS_TOL
+            assert np.abs(got.cov - w.cov).max() <= COV_REL * np.abs(w.cov).max()
+    del C
