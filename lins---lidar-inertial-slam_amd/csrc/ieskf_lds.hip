@@ -90,38 +90,47 @@ struct QueryPolar {
 // original index (pass 1: lowest index wins) or the visit rank (pass 2).  Initialised to
 // (threshold, 0): a candidate must be strictly closer than the threshold (SE:851, 856).
 struct Best {
-  unsigned long long k;
+  unsigned long long k;   // winner: (distance bits, tie key); pos < 0: none yet (k = threshold sentinel)
   int pos, ring;
-  float omin;  // smallest squared distance of any OTHER candidate seen (for the certificates below)
+  unsigned long long k2;  // runner-up, kept with its identity so that a near-tie can be re-decided
+  int pos2, ring2;        //   later from two distance evaluations instead of a search
+  float omin;             // smallest squared distance of every OTHER candidate seen
   __device__ __forceinline__ float d() const { return __uint_as_float((unsigned)(k >> 32)); }
   __device__ __forceinline__ int key() const { return (int)(unsigned)k; }
 };
 __device__ __forceinline__ Best best_init(float thr) {
-  return Best{(unsigned long long)__float_as_uint(thr) << 32, -1, -1, INFINITY};
+  return Best{(unsigned long long)__float_as_uint(thr) << 32, -1, -1, ~0ull, -1, -1, INFINITY};
+}
+__device__ __forceinline__ unsigned long long pack_key(float d, int key) {
+  return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)key;
+}
+// insert candidate (k, pos, ring) into the top-2 list; equal keys are the same point seen again
+__device__ __forceinline__ void insert_key(Best& b, unsigned long long k, int pos, int ring) {
+  if (k < b.k) {
+    if (b.pos2 >= 0) b.omin = fminf(b.omin, __uint_as_float((unsigned)(b.k2 >> 32)));
+    b.k2 = b.k, b.pos2 = b.pos, b.ring2 = b.ring;  // (a dethroned sentinel stays a sentinel: pos2 < 0)
+    b.k = k, b.pos = pos, b.ring = ring;
+  } else if (k > b.k) {
+    if (k < b.k2) {
+      if (b.pos2 >= 0) b.omin = fminf(b.omin, __uint_as_float((unsigned)(b.k2 >> 32)));
+      b.k2 = k, b.pos2 = pos, b.ring2 = ring;
+    } else if (k > b.k2) {
+      b.omin = fminf(b.omin, __uint_as_float((unsigned)(k >> 32)));
+    }
+  }
 }
 __device__ __forceinline__ void consider(Best& b, float d, int key, int pos, int ring) {
-  unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)key;
-  if (k < b.k) {
-    if (b.pos >= 0) b.omin = fminf(b.omin, b.d());  // the dethroned best becomes an "other"
-    b.k = k, b.pos = pos, b.ring = ring;
-  } else if (k > b.k) {  // (equal key = the same point seen again: not its own runner-up)
-    b.omin = fminf(b.omin, d);
-  }
+  insert_key(b, pack_key(d, key), pos, ring);
 }
 __device__ __forceinline__ void merge_from_lane(Best& b, int src_lane) {
   unsigned lo = __shfl((unsigned)b.k, src_lane), hi = __shfl((unsigned)(b.k >> 32), src_lane);
+  unsigned lo2 = __shfl((unsigned)b.k2, src_lane), hi2 = __shfl((unsigned)(b.k2 >> 32), src_lane);
   int pos = __shfl(b.pos, src_lane), ring = __shfl(b.ring, src_lane);
+  int pos2 = __shfl(b.pos2, src_lane), ring2 = __shfl(b.ring2, src_lane);
   float om = __shfl(b.omin, src_lane);
-  unsigned long long k = ((unsigned long long)hi << 32) | lo;
   b.omin = fminf(b.omin, om);
-  if (pos >= 0) {
-    if (k < b.k) {
-      if (b.pos >= 0) b.omin = fminf(b.omin, b.d());
-      b.k = k, b.pos = pos, b.ring = ring;
-    } else if (k > b.k) {
-      b.omin = fminf(b.omin, __uint_as_float(hi));
-    }
-  }
+  if (pos >= 0) insert_key(b, ((unsigned long long)hi << 32) | lo, pos, ring);
+  if (pos2 >= 0) insert_key(b, ((unsigned long long)hi2 << 32) | lo2, pos2, ring2);
 }
 
 // ---- certificates: skipping a search that provably returns the same answer -----------------
@@ -288,6 +297,15 @@ __device__ __forceinline__ bool walk_rank(const WalkCtx& w, int j, int& rank) {
   return fwd || bwd;
 }
 
+// index intervals of the walk around nearest neighbour j1 on ring rho (sorted cloud):
+// forward (j1, min(N_query, N_target, start[rho+3])), backward [start[rho-2], j1)
+__device__ __forceinline__ WalkCtx make_walk_ctx(const LCloud& c, int nq, int j1, int rho) {
+  const int fend = nq < c.n ? nq : c.n;
+  const int r_hi = rho + 3 < kRingsBinned ? rho + 3 : kRingsBinned;
+  const int r_lo = rho - 2 > 0 ? rho - 2 : 0;
+  return WalkCtx{j1, fend < c.ring_start[r_hi] ? fend : c.ring_start[r_hi], c.ring_start[r_lo]};
+}
+
 // One walk task: candidates of ring r for the running best `cur` (rank-keyed).  full:
 // seed window + both extensions with the tightened bound; !full: extensions only (the
 // seed of that ring was scanned by all lanes before).  Same code for every lane.
@@ -318,10 +336,7 @@ template <int LANES>
 __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, bool is_surf, int nq, float thr, int j1,
                                          int rho, float sx, float sy, float sz, const QueryPolar& qp, float margin,
                                          int role, int lane_base, int warm2, int warm3, Best& c2, Best& c3) {
-  const int fend = nq < c.n ? nq : c.n;
-  const int r_hi = rho + 3 < kRingsBinned ? rho + 3 : kRingsBinned;
-  const int r_lo = rho - 2 > 0 ? rho - 2 : 0;
-  const WalkCtx w{j1, fend < c.ring_start[r_hi] ? fend : c.ring_start[r_hi], c.ring_start[r_lo]};
+  const WalkCtx w = make_walk_ctx(c, nq, j1, rho);
   c2 = best_init(thr);
   c3 = best_init(thr);
   const float rho_q = qp.rho, qn3 = qp.qn3, el_q = qp.el;
@@ -750,7 +765,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   const bool lane_used = lane < kQPerWave * LANES;
   // last iteration's triplet of this lane's query (grid positions) for the warm start; only
   // meaningful when the scan needs a single round (the lane <-> query mapping is then fixed)
-  int wp1 = -1, wp2 = -1, wp3 = -1, wr1 = -1;
+  int a1 = -1, b1c = -1, ra1 = -1, rb1 = -1;  // nearest neighbour: tracked winner / runner-up (+ their rings)
+  int a2 = -1, b2c = -1, a3 = -1, b3c = -1;    // second and third point: tracked winner / runner-up
+  int sel1 = -1;                               // last iteration's nearest neighbour
   // certificates of those three selections (see cert_lb / certified): lower bounds of every other
   // candidate's distance and the query positions they were established at
   float lb1 = 0.f, lb2 = 0.f, lb3 = 0.f, certA[3] = {0.f, 0.f, 0.f}, certB[3] = {0.f, 0.f, 0.f};
@@ -798,7 +815,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         int p1 = -1, p2 = -1, p3 = -1;  // grid positions of the three target points
         if (do_search) {
           const bool single_round = span <= kQPerRound;
-          if (!single_round) wp1 = wp2 = wp3 = -1, have_cert = false;
+          if (!single_round) a1 = b1c = a2 = b2c = a3 = b3c = sel1 = -1, have_cert = false;
           QueryPolar qp;
           qp.rho = sqrtf(o.sel[0] * o.sel[0] + o.sel[1] * o.sel[1]);
           qp.qn3 = sqrtf(qp.rho * qp.rho + o.sel[2] * o.sel[2]);
@@ -812,57 +829,96 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
             float ex = o.sel[0] - cp[0], ey = o.sel[1] - cp[1], ez = o.sel[2] - cp[2];
             return sqrtf(ex * ex + ey * ey + ez * ez);
           };
-          // --- nearest neighbour: keep the certified one, or search (warm, inflated bound) ----------
-          const float d1_now = wp1 >= 0 ? dist_to(wp1) : thr;
-          bool ok1 = have_cert && !(prm.pad & 16) && (wp1 < 0 || d1_now < thr) && certified(d1_now, lb1, drift_from(certA));
+          // Per selection the last search left two tracked candidates — the winner A and the
+          // runner-up B (grid positions, -1 = absent) — and a lower bound lb for the distance of every
+          // other candidate.  While everybody else is certified to stay farther than the closer of
+          // A and B, the selection is re-decided between those two from their distances alone
+          // (same strict (distance, key) order as the search); otherwise the search runs again,
+          // warm-started from A.
+          const unsigned long long kNone = ~0ull;
           const bool verify = (prm.pad & 8) != 0;  // test aid: search anyway and count disagreements
-          const bool said1 = ok1;
-          if (verify) ok1 = false;
-          int j1 = -1, rho1 = wr1;
-          bool need_walk = !have_cert;  // (or a changed nearest neighbour, below)
-          if (!ok1) {
-            Best b1 = best_init(thr);
-            if (!(prm.pad & 2))  // (profiling aid: LINS_DEBUG_SKIP=2 skips the search, 1 skips the walk)
-              b1 = nn_lds<LANES>(L, c, o.sel[0], o.sel[1], o.sel[2], qp, thr, margin, ring_of(q.w), role, lane_base, wp1,
-                                 wr1);
-            const int np1 = (b1.pos >= 0 && (double)b1.d() < prm.nearest) ? b1.pos : -1;
-            if (said1 && np1 != wp1 && role == 0) atomicAdd(&L.dbg[0], 1);
-            if (np1 != wp1) wp2 = wp3 = -1, need_walk = true;  // new nearest neighbour: new candidate sets
-            p1 = np1, rho1 = b1.ring, j1 = b1.key();
-            lb1 = cert_lb(b1, thr, margin);
-            certA[0] = o.sel[0], certA[1] = o.sel[1], certA[2] = o.sel[2];
-          } else {
-            p1 = wp1;
-            if (p1 >= 0) j1 = (int)L.pidx[p1];
-            if (role == 0) atomicAdd(&L.dbg[1], 1);
+          // --- nearest neighbour -----------------------------------------------------------------------
+          {
+            const float da = a1 >= 0 ? dist_to(a1) : INFINITY, db = b1c >= 0 ? dist_to(b1c) : INFINITY;
+            bool ok = have_cert && !(prm.pad & 16) && certified(fminf(fminf(da, db), thr), lb1, drift_from(certA));
+            const unsigned long long ka = da < thr ? pack_key(da, (int)L.pidx[a1]) : kNone;
+            const unsigned long long kb = db < thr ? pack_key(db, (int)L.pidx[b1c]) : kNone;
+            const bool flip = kb < ka;
+            const int pred = (flip ? kb : ka) == kNone ? -1 : (flip ? b1c : a1);
+            const bool said = ok;
+            if (verify) ok = false;
+            if (!ok) {
+              if ((prm.pad & 32) && __ffsll(__ballot(1)) - 1 == lane) atomicAdd(&L.dbg[3], 1 + (iter >= 3 ? 1000 : 0));
+              Best bb = best_init(thr);
+              if (!(prm.pad & 2))  // (profiling aid: LINS_DEBUG_SKIP=2 skips the search, 1 skips the walk)
+                bb = nn_lds<LANES>(L, c, o.sel[0], o.sel[1], o.sel[2], qp, thr, margin, ring_of(q.w), role, lane_base, a1,
+                                   ra1);
+              p1 = bb.pos;  // (a winner beat the threshold sentinel, so its distance is < thr, SE:851)
+              if (said && p1 != pred && role == 0) atomicAdd(&L.dbg[0], 1);
+              a1 = bb.pos, ra1 = bb.ring, b1c = bb.pos2, rb1 = bb.ring2;
+              lb1 = cert_lb(bb, thr, margin);
+              certA[0] = o.sel[0], certA[1] = o.sel[1], certA[2] = o.sel[2];
+            } else {
+              p1 = pred;
+              if (flip) {  // the runner-up took over: swap the two tracked candidates
+                const int tp = a1, tr = ra1;
+                a1 = b1c, ra1 = rb1, b1c = tp, rb1 = tr;
+              }
+              if (role == 0) atomicAdd(&L.dbg[1], 1);
+            }
           }
+          const bool nn_changed = p1 != sel1;
+          sel1 = p1;
           if (prof) s2 = clock64(), pt[7] += s2 - s1;
           // --- second / third point ------------------------------------------------------------------
           if (p1 >= 0) {
-            bool said23 = false;
+            const int j1 = (int)L.pidx[p1], rho1 = ra1;  // (p1 >= 0 => p1 is candidate A)
+            bool need_walk = nn_changed || !have_cert;
+            int pred2 = -1, pred3 = -1;
+            bool flip2 = false, flip3 = false, said23 = false;
             if (!need_walk) {
+              const WalkCtx w = make_walk_ctx(c, is_surf ? sd.n_surf_q : sd.n_corner_q, j1, rho1);
               const float dB = drift_from(certB);
-              const float d2_now = wp2 >= 0 ? dist_to(wp2) : thr, d3_now = wp3 >= 0 ? dist_to(wp3) : thr;
-              bool ok23 = (wp2 < 0 || d2_now < thr) && certified(d2_now, lb2, dB);
-              if (is_surf) ok23 = ok23 && (wp3 < 0 || d3_now < thr) && certified(d3_now, lb3, dB);
+              auto judge = [&](int pa, int pb, float lb, int& pred, bool& flip) {
+                const float da = pa >= 0 ? dist_to(pa) : INFINITY, db = pb >= 0 ? dist_to(pb) : INFINITY;
+                int rka = 0, rkb = 0;
+                if (pa >= 0) walk_rank(w, (int)L.pidx[pa], rka);
+                if (pb >= 0) walk_rank(w, (int)L.pidx[pb], rkb);
+                const unsigned long long ka = da < thr ? pack_key(da, rka) : kNone;
+                const unsigned long long kb = db < thr ? pack_key(db, rkb) : kNone;
+                flip = kb < ka;
+                pred = (flip ? kb : ka) == kNone ? -1 : (flip ? pb : pa);
+                return certified(fminf(fminf(da, db), thr), lb, dB);
+              };
+              bool ok23 = judge(a2, b2c, lb2, pred2, flip2);
+              if (is_surf) ok23 = judge(a3, b3c, lb3, pred3, flip3) && ok23;
               said23 = ok23;
               need_walk = !ok23 || verify;
             }
             if (need_walk) {
+              if ((prm.pad & 32) && __ffsll(__ballot(1)) - 1 == lane) atomicAdd(&L.dbg[0], 1 + (iter >= 3 ? 1000 : 0));
               Best c2 = best_init(thr), c3 = c2;
               if (!(prm.pad & 1))
                 walk_lds<LANES>(L, c, is_surf, is_surf ? sd.n_surf_q : sd.n_corner_q, thr, j1, rho1, o.sel[0], o.sel[1],
-                                o.sel[2], qp, margin, role, lane_base, wp2, wp3, c2, c3);
-              if (said23 && (c2.pos != wp2 || c3.pos != wp3) && role == 0) atomicAdd(&L.dbg[0], 1);
+                                o.sel[2], qp, margin, role, lane_base, nn_changed ? -1 : a2, nn_changed ? -1 : a3, c2, c3);
+              if (said23 && (c2.pos != pred2 || (is_surf && c3.pos != pred3)) && role == 0) atomicAdd(&L.dbg[0], 1);
               p2 = c2.pos, p3 = c3.pos;
+              a2 = c2.pos, b2c = c2.pos2, a3 = c3.pos, b3c = c3.pos2;
               lb2 = cert_lb(c2, thr, margin), lb3 = cert_lb(c3, thr, margin);
               certB[0] = o.sel[0], certB[1] = o.sel[1], certB[2] = o.sel[2];
             } else {
-              p2 = wp2, p3 = wp3;
+              p2 = pred2, p3 = pred3;
+              if (flip2) {
+                const int tp = a2;
+                a2 = b2c, b2c = tp;
+              }
+              if (flip3) {
+                const int tp = a3;
+                a3 = b3c, b3c = tp;
+              }
               if (role == 0) atomicAdd(&L.dbg[2], 1);
             }
           }
-          wp1 = p1, wp2 = p2, wp3 = p3, wr1 = rho1;
           have_cert = single_round;
           if (prof) pt[8] += clock64() - s2;
           if (prm.icp_freq > 1 && role == 0) idx_store[sd.slot_base + slot] = make_int4(p1, p2, p3, 0);
@@ -972,7 +1028,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     r.residual_norm = L.res_last, r.update_norm = L.upd_norm;
     r.iters = L.iter, r.converged = L.conv, r.diverged = div;
     r.m_surf = L.m_surf, r.m_corner = L.m_corner;
-    r.pad[0] = L.dbg[0], r.pad[1] = L.dbg[1], r.pad[2] = L.dbg[2];
+    r.pad[0] = L.dbg[0], r.pad[1] = (prm.pad & 32) ? L.dbg[3] : L.dbg[1], r.pad[2] = L.dbg[2];
     out[scan] = r;
   }
   if (poses && tid < 32) {
