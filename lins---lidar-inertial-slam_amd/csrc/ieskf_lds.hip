@@ -412,15 +412,26 @@ __device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, 
   __syncthreads();
   const float4* ts = arena + sd.off_surf_t;
   const float4* tc = arena + sd.off_corner_t;
-  for (int j = tid; j < sd.n_surf_t + sd.n_corner_t; j += kLBlock) {
-    const bool is_s = j < sd.n_surf_t;
-    float4 p = is_s ? ts[j] : tc[j - sd.n_surf_t];
-    int r = ring_of(p.w);
-    int cell = is_s ? r * kAzSurf + az_bin(p.x, p.y, kAzSurf) : kCellsSurf + r * kAzCorner + az_bin(p.x, p.y, kAzCorner);
-    atomicAdd(&cnt[cell], 1u);
-    int eb = ordered_int(atan2f(p.z, sqrtf(p.x * p.x + p.y * p.y)));
-    atomicMin(&L.el_bits[is_s ? 0 : 1][r][0], eb);
-    atomicMax(&L.el_bits[is_s ? 0 : 1][r][1], eb);
+  const int n_all = sd.n_surf_t + sd.n_corner_t;
+  // each thread owns the points tid, tid + BLOCK, ...; the cell of each is kept in a register
+  // between the histogram pass and the scatter pass (no second atan2f, no second classification)
+  constexpr int kPerThread = (kNpCap + BLOCK - 1) / BLOCK;
+  int cell_of[kPerThread];
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    const int j = tid + k * kLBlock;
+    cell_of[k] = -1;
+    if (j < n_all) {
+      const bool is_s = j < sd.n_surf_t;
+      float4 p = is_s ? ts[j] : tc[j - sd.n_surf_t];
+      int r = ring_of(p.w);
+      int cell = is_s ? r * kAzSurf + az_bin(p.x, p.y, kAzSurf) : kCellsSurf + r * kAzCorner + az_bin(p.x, p.y, kAzCorner);
+      cell_of[k] = cell;
+      atomicAdd(&cnt[cell], 1u);
+      int eb = ordered_int(atan2f(p.z, sqrtf(p.x * p.x + p.y * p.y)));
+      atomicMin(&L.el_bits[is_s ? 0 : 1][r][0], eb);
+      atomicMax(&L.el_bits[is_s ? 0 : 1][r][1], eb);
+    }
   }
   __syncthreads();
   // exclusive scan over all cells: surf cells first, so corner positions start at n_surf_t
@@ -436,15 +447,17 @@ __device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, 
     run += n;
   }
   __syncthreads();
-  for (int j = tid; j < sd.n_surf_t + sd.n_corner_t; j += kLBlock) {
-    const bool is_s = j < sd.n_surf_t;
-    const int jj = is_s ? j : j - sd.n_surf_t;
-    float4 p = is_s ? ts[jj] : tc[jj];
-    int r = ring_of(p.w);
-    int cell = is_s ? r * kAzSurf + az_bin(p.x, p.y, kAzSurf) : kCellsSurf + r * kAzCorner + az_bin(p.x, p.y, kAzCorner);
-    unsigned pos = atomicAdd(&cnt[cell], 1u);  // order inside a cell is irrelevant (keyed ties)
-    L.px[pos] = p.x, L.py[pos] = p.y, L.pz[pos] = p.z;
-    L.pidx[pos] = (unsigned short)jj;
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    const int j = tid + k * kLBlock;
+    if (cell_of[k] >= 0) {
+      const bool is_s = j < sd.n_surf_t;
+      const int jj = is_s ? j : j - sd.n_surf_t;
+      float4 p = is_s ? ts[jj] : tc[jj];  // (L2 hit: read a moment ago)
+      unsigned pos = atomicAdd(&cnt[cell_of[k]], 1u);  // order inside a cell is irrelevant (keyed ties)
+      L.px[pos] = p.x, L.py[pos] = p.y, L.pz[pos] = p.z;
+      L.pidx[pos] = (unsigned short)jj;
+    }
   }
   __syncthreads();  // cnt[c] is now the exclusive END of cell c
   for (int c = tid; c < ncell; c += kLBlock) L.cell_end[c] = (unsigned short)cnt[c];
