@@ -28,6 +28,24 @@ PKG = "lins---lidar-inertial-slam_amd"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def traffic_from_profiles(search):
+    """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE x2 on gfx950 +
+    WRITE_SIZE, MI355X_MICROARCH.md).  PMC collection needs rocprofv3 around the process, so it is
+    measured in a separate run of this same command (tools/pmc_run.sh) and read back from the latest
+    profiles/rNN_pmc_traffic.json; null when there is no such file for this search mode."""
+    import glob
+
+    if search != "lds":
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        return float(json.load(open(files[-1]))["traffic_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,7 +182,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic_from_profiles(args.search),
                 "alg_bytes_per_launch": alg_bytes,
                 "kernel_ms": k_ms,
                 "bytes_per_iter_mean": bytes_iter_local / len(pairs),
