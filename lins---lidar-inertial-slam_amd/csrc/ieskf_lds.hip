@@ -63,6 +63,7 @@ struct LdsStore {
   int piv[6], used[6];
   int scan_tmp[kMaxLWaves + 4];
   int m_surf, m_corner, iter, conv, div, pad;
+  long long prof_acc[16];  // phase profile accumulators of the PROF variant (written by thread 0)
   int dbg[4];  // [0] certificate disagreements (verify mode) [1] NN searches skipped [2] walks skipped
 };
 static_assert(sizeof(LdsStore) <= 163840, "LDS budget of one CU");
@@ -736,7 +737,10 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   static_assert(kQPerRound <= kSlotCap && BLOCK >= 256 && BLOCK / 64 <= kMaxLWaves, "block shape");
   LdsStore& L = g_lds;
   // optional phase profile: [0] setup+grid build [1] correspondence [2] reduction [3] solve [4] update [5] total
-  long long pt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [6..9] wave 0: de-skew, NN, walk, geometry
+  // accumulators live in LDS (thread 0 only) so that the profiled variant keeps the register
+  // allocation of the production one: [0] setup [1] corr [2] reduce [3] solve [4] update [5] total
+  // [6..9] thread 0's own de-skew / NN / walk / geometry  [10..15] per-iteration time of iterations 0..5
+  if (prof && threadIdx.x < 16) g_lds.prof_acc[threadIdx.x] = 0;
   const long long t_begin = prof ? clock64() : 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int scan = blockIdx.x;
@@ -769,7 +773,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     }
   }
   build_lds_grid<BLOCK>(L, sd, arena, tid);  // ends with a barrier
-  if (prof) pt[0] = clock64() - t_begin;
+  if (prof && tid == 0) L.prof_acc[0] = clock64() - t_begin;
 
   const LCloud cs{L.cell_end, L.ring_start[0], &L.el_ang[0][0][0], kAzSurf, 1, 0, sd.n_surf_t};
   const LCloud cc{L.cell_end + kCellsSurf, L.ring_start[1], &L.el_ang[1][0][0], kAzCorner,
@@ -822,7 +826,10 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         QueryOut o;
         long long s0 = prof ? clock64() : 0, s1 = s0, s2 = s0;
         transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2]);
-        if (prof) s1 = clock64(), pt[6] += s1 - s0;
+        if (prof) {
+          s1 = clock64();
+          if (tid == 0) L.prof_acc[6] += s1 - s0;
+        }
         o.accepted = 0;
         o.c[0] = o.c[1] = o.c[2] = o.c[3] = 0.f;
         int p1 = -1, p2 = -1, p3 = -1;  // grid positions of the three target points
@@ -882,7 +889,10 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           }
           const bool nn_changed = p1 != sel1;
           sel1 = p1;
-          if (prof) s2 = clock64(), pt[7] += s2 - s1;
+          if (prof) {
+            s2 = clock64();
+            if (tid == 0) L.prof_acc[7] += s2 - s1;
+          }
           // --- second / third point ------------------------------------------------------------------
           if (p1 >= 0) {
             const int j1 = (int)L.pidx[p1], rho1 = ra1;  // (p1 >= 0 => p1 is candidate A)
@@ -933,7 +943,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
             }
           }
           have_cert = single_round;
-          if (prof) pt[8] += clock64() - s2;
+          if (prof && tid == 0) L.prof_acc[8] += clock64() - s2;
           if (prm.icp_freq > 1 && role == 0) idx_store[sd.slot_base + slot] = make_int4(p1, p2, p3, 0);
         } else {
           int4 s = idx_store[sd.slot_base + slot];
@@ -972,7 +982,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
             dump[sd.slot_base + slot] = r;
           }
         }
-        if (prof) pt[9] += clock64() - s3;
+        if (prof && tid == 0) L.prof_acc[9] += clock64() - s3;
       }
       if (lane_used && role == 0) {
         const int local = wave * kQPerWave + q_in_wave;
@@ -1023,13 +1033,16 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     solve_and_update(prm, tid, iter, prof, t3);
     if (prof) {
       long long t4 = clock64();
-      pt[1] += t1 - t0, pt[2] += t2 - t1, pt[3] += t3 - t2, pt[4] += t4 - t3;
+      if (tid == 0) {
+        L.prof_acc[1] += t1 - t0, L.prof_acc[2] += t2 - t1, L.prof_acc[3] += t3 - t2, L.prof_acc[4] += t4 - t3;
+        if (iter < 6) L.prof_acc[10 + iter] = t4 - t0;
+      }
     }
   }
   if (prof && tid == 0) {
     long long* prof_out = prof_buf;
-    pt[5] = clock64() - t_begin;
-    for (int k = 0; k < 10; ++k) prof_out[(size_t)scan * 16 + k] = pt[k];
+    L.prof_acc[5] = clock64() - t_begin;
+    for (int k = 0; k < 16; ++k) prof_out[(size_t)scan * 16 + k] = L.prof_acc[k];
   }
 
   // ---- hand-off to the Joseph kernel / the caller (SE:585-598) ---------------

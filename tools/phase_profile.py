@@ -34,7 +34,7 @@ ctx.sync()
 prof = np.zeros((batch, 16), dtype=np.int64)
 L.lins_debug_phase_profile(ctx._h, 1, prof.ctypes.data, batch)
 print(f"batch {batch} search {search}: kernel ms", ctx.last_kernel_ms())
-names = ["setup", "corr", "reduce", "solve", "update", "total", "w0/deskew", "w1/nn", "w2/walk", "w3/geom", "w4"]
-m = prof[:, :11].astype(float)
+names = ["setup", "corr", "reduce", "solve", "update", "total", "t0/deskew", "t0/nn", "t0/walk", "t0/geom", "iter0", "iter1", "iter2", "iter3", "iter4", "iter5"]
+m = prof[:, :16].astype(float)
 for i, n in enumerate(names):
     print(f"{n:7s} mean {m[:, i].mean():12.0f}  min {m[:, i].min():12.0f}  max {m[:, i].max():12.0f} ticks")
