@@ -232,8 +232,31 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
   int rcur = rq;
   auto f = [&](float x, float y, float z, int j, int p) { consider(b, sqdist3(x, y, z, sx, sy, sz), j, p, rcur); };
   const bool own = ring_nonempty(c, rq);
-  const bool seed = own && !warm;
-  scan_cols(L, c, rq, seed ? a0 - 1 : 1, seed ? a0 + 1 : 0, f);  // seed: all lanes of the query
+  // cold seed: columns a0-1..a0+1 of the query's own ring and of its two neighbours, one ring per
+  // lane, merged before the bound is fixed — a query that sits between rings (or whose own ring is
+  // empty there) still starts from a real neighbour instead of sweeping the whole search radius
+  {
+    const int rs = LANES == 1 ? rq : rq + (role == 0 ? 0 : (role == 1 ? 1 : -1));
+    const bool seed = !warm && ring_nonempty(c, rs);
+    rcur = rs;
+    scan_cols(L, c, rs, seed ? a0 - 1 : 1, seed ? a0 + 1 : 0, f);
+    if (LANES == 1) {
+#pragma unroll 1
+      for (int dr = -1; dr <= 1; dr += 2) {
+        const bool sd2 = !warm && ring_nonempty(c, rq + dr);
+        rcur = rq + dr;
+        scan_cols(L, c, rq + dr, sd2 ? a0 - 1 : 1, sd2 ? a0 + 1 : 0, f);
+      }
+    } else if (!warm) {  // (wave-uniform from iteration to iteration: cold only in iteration 0)
+      if (LANES == 3) {
+        merge_from_lane(b, lane_base + (role + 1) % 3);
+        merge_from_lane(b, lane_base + (role + 2) % 3);
+      } else {
+        merge_from_lane(b, lane_base + (role ^ 1));
+      }
+    }
+    rcur = rq;
+  }
   const int cin = warm ? 0 : 2;  // first column either side that the seed has not covered
   const float B = b.d();  // fixed bound for everything below (conservative: >= the final best)
   const float sqrtB = sqrtf(B) + margin;  // pruning bound inflated by the certificate margin
@@ -323,11 +346,22 @@ __device__ __forceinline__ void walk_task(const LdsStore& L, const LCloud& c, co
   };
   const bool seed = go && seed_first;
   scan_cols(L, c, r, seed ? a0 - 1 : 1, seed ? a0 + 1 : 0, f);
-  const int K = reach(c, rho_q, sqrtf(cur.d()) + margin);
   const bool done = seed_first || centre_done;
-  go = go && K >= (done ? 2 : 0);
-  scan_cols(L, c, r, go ? a0 + (done ? 2 : 0) : 1, go ? a0 + K : 0, f);
-  scan_cols(L, c, r, go ? a0 - K : 1, go ? a0 - (done ? 2 : 1) : 0, f);
+  // Widen progressively: the window needed for the current bound, but at most 4x the width already
+  // covered per round — when the seed window was empty the bound tightens as soon as the first real
+  // candidate shows up, instead of one sweep over the whole search radius.
+  int kk = done ? 1 : -1;  // columns a0-kk..a0+kk are covered (-1: nothing yet)
+  const int half = c.naz / 2;
+#pragma unroll 1
+  for (int round = 0; round < 8 && go; ++round) {
+    const int K = reach(c, rho_q, sqrtf(cur.d()) + margin);
+    if (K <= kk) break;
+    const int nk = kk < 1 ? K : (K < 4 * kk ? K : 4 * kk);  // (a bound from a warm candidate: one shot)
+    scan_cols(L, c, r, a0 + kk + 1, a0 + nk, f);
+    scan_cols(L, c, r, a0 - nk, a0 - (kk < 0 ? 1 : kk + 1), f);
+    kk = nk;
+    if (kk >= half) break;
+  }
 }
 
 // ---- pass 2 (SE:859-910 surf, SE:983-1024 corner) ----------------------------------------
