@@ -57,7 +57,8 @@ struct LdsStore {
   double dx[18];
   double res_prev, res_last, upd_norm;
   float2 az_edge[kAzSurf + 1];
-  float el_ang[2][kRingsBinned][2];  // the same wedge as angles (lo - slack, hi + slack)
+  float2 el_ang[2][kRingsBinned];    // elevation wedge of each ring as angles (lo - slack, hi + slack);
+                                     // an empty ring gets (+inf, -inf): never within reach
   int el_bits[2][kRingsBinned][2];
   int ring_start[2][kRingsBinned + 1];  // per cloud, in (original) index space
   int piv[6], used[6];
@@ -75,7 +76,7 @@ __shared__ LdsStore g_lds;
 struct LCloud {  // one target cloud's grid (all pointers into LDS)
   const unsigned short* cell_end;  // this cloud's cells (absolute positions)
   const int* ring_start;
-  const float* el_ang;
+  const float2* el_ang;
   int naz, stride, base, n;
 };
 
@@ -209,7 +210,8 @@ __device__ __forceinline__ float reach_elev(float qn3, float sqrt_bound) {
   return s < 1.f ? asin_ub(s) * (1.f + 1e-6f) + kSlack : 4.f;  // 4 rad > any elevation difference
 }
 __device__ __forceinline__ bool ring_in_reach(const LCloud& c, int r, float el_q, float delta) {
-  return el_q >= c.el_ang[2 * r] - delta && el_q <= c.el_ang[2 * r + 1] + delta;
+  const float2 w = c.el_ang[r];  // one 8-byte LDS read; empty rings fail both tests
+  return el_q >= w.x - delta && el_q <= w.y + delta;
 }
 
 // ---- pass 1: exact NN; with LANES = 3 the ring windows of a query are split over its lanes
@@ -272,11 +274,11 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
     const int t = role + LANES * i;
     const int k = t - 2, off = (k >> 1) + 1;
     const int r = t < 2 ? rq : rq + ((k & 1) ? -off : off);
-    bool go = t < kTasks && ring_nonempty(c, r);
+    bool go;
     if (t < 2)
-      go = go && K >= cin;
-    else if (go)
-      go = ring_in_reach(c, r, el_q, delta);
+      go = own && K >= cin;
+    else
+      go = t < kTasks && r >= 0 && r < kRingsBinned && ring_in_reach(c, r < 0 ? 0 : (r >= kRingsBinned ? kRingsBinned - 1 : r), el_q, delta);
     todo |= go ? (1u << i) : 0u;
   }
 #pragma unroll 1
@@ -503,7 +505,8 @@ __device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, 
   if (tid < 2 * kRingsBinned) {
     int cl = tid / kRingsBinned, r = tid % kRingsBinned;
     float lo = ordered_float(L.el_bits[cl][r][0]) - kSlack, hi = ordered_float(L.el_bits[cl][r][1]) + kSlack;
-    L.el_ang[cl][r][0] = lo, L.el_ang[cl][r][1] = hi;
+    const bool empty = L.el_bits[cl][r][0] == 0x7FFFFFFF;  // no point touched the ring's min/max
+    L.el_ang[cl][r] = empty ? make_float2(INFINITY, -INFINITY) : make_float2(lo, hi);
   }
   __syncthreads();
 }
@@ -809,8 +812,8 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   build_lds_grid<BLOCK>(L, sd, arena, tid);  // ends with a barrier
   if (prof && tid == 0) L.prof_acc[0] = clock64() - t_begin;
 
-  const LCloud cs{L.cell_end, L.ring_start[0], &L.el_ang[0][0][0], kAzSurf, 1, 0, sd.n_surf_t};
-  const LCloud cc{L.cell_end + kCellsSurf, L.ring_start[1], &L.el_ang[1][0][0], kAzCorner,
+  const LCloud cs{L.cell_end, L.ring_start[0], &L.el_ang[0][0], kAzSurf, 1, 0, sd.n_surf_t};
+  const LCloud cc{L.cell_end + kCellsSurf, L.ring_start[1], &L.el_ang[1][0], kAzCorner,
                   kAzSurf / kAzCorner, sd.n_surf_t, sd.n_corner_t};
   const int role = lane % LANES, lane_base = lane - role, q_in_wave = lane / LANES;
   const bool lane_used = lane < kQPerWave * LANES;
