@@ -188,6 +188,27 @@ int lins_reduce_pass(lins_ctx* ctx, const lins_scan_pair* in,
                      const double* lin_state, int iter, double* sums28,
                      int32_t* m_surf, int32_t* m_corner);
 
+/* --- next row after the update: updatePointCloud's re-projection --------- */
+/* transformToEnd (SE:1083-1101) of whole clouds with the scan's final relative pose
+ * (t = linState_.rn_, q = linState_.qbn_ as w,x,y,z): what turns the new scan's less-sharp /
+ * less-flat clouds into the NEXT update's targets (SE:1122-1139), plus, optionally, the
+ * YZX axis-swapped copy published to the mapping node (point.x = y, .y = z, .z = x,
+ * SE:1125-1129).  Host buffers in and out; in == out_xyz is allowed (the reference
+ * transforms in place).                                                                    */
+typedef struct lins_reproject_job {
+  const lins_point* in;
+  lins_point* out_xyz;   /* re-projected cloud, XYZ axes                                   */
+  lins_point* out_yzx;   /* NULL or the axis-swapped copy                                   */
+  int32_t n;
+  int32_t reserved;
+  double t[3];
+  double q[4];
+} lins_reproject_job;
+int lins_transform_to_end_batch(lins_ctx* ctx, int n_jobs, const lins_reproject_job* jobs);
+/* HIP-event time (ms) of the re-projection kernel of the last call, and the bytes it moved
+ * (16 B read + 16 or 32 B written per point).                                              */
+int lins_last_reproject_stats(lins_ctx* ctx, float* kernel_ms, uint64_t* bytes);
+
 #ifdef __cplusplus
 }
 #endif

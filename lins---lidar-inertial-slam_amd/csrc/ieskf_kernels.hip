@@ -639,6 +639,49 @@ void launch_pass(hipStream_t stream, int n, const DevParams& prm, const ScanDesc
                        lin_state, filt_state, iter, idx_store, dump, sums_out, counts_out, binned);
 }
 
+// ---------------------------------------------------------------------------
+// updatePointCloud's re-projection (SE:1116-1139): transformToEnd (SE:1083-1101) per point.
+// One thread per point, blockIdx.y = cloud; pure streaming (16 B in, 16 or 32 B out per point)
+// with ~300 f64 flops of de-skew per point in between.
+// ---------------------------------------------------------------------------
+struct ReprojectJob {
+  long long off;  // first point of the cloud in the in / out arenas
+  int n, has_yzx;
+  double t[3], q[4];
+  double inv_period;
+};
+
+__global__ __launch_bounds__(256) void transform_to_end_kernel(const ReprojectJob* __restrict__ jobs,
+                                                               const float4* __restrict__ in,
+                                                               float4* __restrict__ out_xyz,
+                                                               float4* __restrict__ out_yzx) {
+  const ReprojectJob jb = jobs[blockIdx.y];
+  const V3 t{jb.t[0], jb.t[1], jb.t[2]};
+  const Q4 q{jb.q[0], jb.q[1], jb.q[2], jb.q[3]};
+  const V3 phi = quat2axis(q);
+  const Q4 qinv = qinverse(q);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += gridDim.x * blockDim.x) {
+    const float4 pi = in[jb.off + i];
+    const float frac = pi.w - (float)(int)pi.w;
+    const double s = jb.inv_period * (double)frac;
+    const V3 p1 = qrot(axis2quat(s * phi), V3{(double)pi.x, (double)pi.y, (double)pi.z}) + s * t;
+    const V3 p2 = qrot(qinv, p1 - t);
+    const float x = (float)p2.x, y = (float)p2.y, z = (float)p2.z;
+    out_xyz[jb.off + i] = make_float4(x, y, z, pi.w);
+    if (jb.has_yzx) out_yzx[jb.off + i] = make_float4(y, z, x, pi.w);
+  }
+}
+
+void launch_transform_to_end(hipStream_t stream, int n_jobs, int max_n, const void* jobs, const float4* in,
+                             float4* out_xyz, float4* out_yzx) {
+  int gx = (max_n + 255) / 256;
+  if (gx < 1) gx = 1;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(transform_to_end_kernel, dim3(gx, n_jobs), dim3(256), 0, stream, (const ReprojectJob*)jobs, in,
+                     out_xyz, out_yzx);
+}
+size_t reproject_job_size() { return sizeof(ReprojectJob); }
+
 size_t out_rec_size() { return sizeof(OutRec); }
 
 }  // namespace lins

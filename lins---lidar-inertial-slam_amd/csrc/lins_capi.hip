@@ -28,6 +28,14 @@ void launch_lds(hipStream_t, int, const DevParams&, int, const ScanDesc*, const 
 void launch_lds_pass(hipStream_t, int, const DevParams&, int, const ScanDesc*, const float4*, const double*,
                      const double*, int, int4*, lins_corr*, double*, int*);
 int lds_np_cap();
+void launch_transform_to_end(hipStream_t, int, int, const void*, const float4*, float4*, float4*);
+size_t reproject_job_size();
+struct ReprojectJobHost {
+  long long off;
+  int n, has_yzx;
+  double t[3], q[4];
+  double inv_period;
+};
 size_t out_rec_size();
 struct OutRecHost {
   double residual_norm, update_norm;
@@ -57,6 +65,10 @@ struct lins_ctx {
   ScanDesc* d_desc = nullptr;
   double *d_state_in = nullptr, *d_cov_in = nullptr, *d_state_out = nullptr, *d_cov_out = nullptr;
   double* d_lin = nullptr;
+  float4* d_aux = nullptr;     // third point arena (YZX copies of the re-projection), lazily allocated
+  void* d_jobs = nullptr;
+  float reproject_ms = 0.f;
+  uint64_t reproject_bytes = 0;
   long long* d_prof = nullptr;  // optional per-workgroup phase profile (lins_debug_phase_profile)
   double* d_a6 = nullptr;  // upper triangle of the last iteration's H^T H, per scan
   void* d_out = nullptr;
@@ -273,6 +285,8 @@ void lins_destroy(lins_ctx* ctx) {
   (void)hipFree(ctx->d_lin);
   (void)hipFree(ctx->d_a6);
   (void)hipFree(ctx->d_prof);
+  (void)hipFree(ctx->d_aux);
+  (void)hipFree(ctx->d_jobs);
   (void)hipFree(ctx->d_out);
   (void)hipFree(ctx->d_idx);
   (void)hipFree(ctx->d_dump);
@@ -344,8 +358,72 @@ int lins_debug_phase_profile(lins_ctx* ctx, int enable, long long* out, int n_sc
   }
   if (!enable && ctx->d_prof) {
     (void)hipFree(ctx->d_prof);
+  (void)hipFree(ctx->d_aux);
+  (void)hipFree(ctx->d_jobs);
     ctx->d_prof = nullptr;
   }
+  return LINS_OK;
+}
+
+int lins_transform_to_end_batch(lins_ctx* ctx, int n_jobs, const lins_reproject_job* jobs) {
+  if (!ctx || n_jobs < 0 || (n_jobs && !jobs)) return LINS_E_ARG;
+  if (n_jobs == 0) return LINS_OK;
+  static_assert(sizeof(ReprojectJobHost) == 80, "ReprojectJob layout");
+  if (reproject_job_size() != sizeof(ReprojectJobHost)) return LINS_E_STATE;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  std::vector<ReprojectJobHost> hj(n_jobs);
+  size_t off = 0;
+  int max_n = 0;
+  bool any_yzx = false;
+  for (int k = 0; k < n_jobs; ++k) {
+    const lins_reproject_job& j = jobs[k];
+    if (j.n < 0 || (j.n && (!j.in || !j.out_xyz))) return LINS_E_ARG;
+    if (off + align4(j.n) > ctx->arena_cap) return LINS_E_CAPACITY;
+    for (int i = 0; i < j.n; ++i)
+      if (!std::isfinite(j.in[i].x) || !std::isfinite(j.in[i].y) || !std::isfinite(j.in[i].z) ||
+          !std::isfinite(j.in[i].intensity))
+        return LINS_E_INPUT;
+    if (j.n) std::memcpy(ctx->h_arena + off, j.in, sizeof(lins_point) * j.n);
+    hj[k].off = (long long)off, hj[k].n = j.n, hj[k].has_yzx = j.out_yzx != nullptr;
+    std::memcpy(hj[k].t, j.t, sizeof j.t);
+    std::memcpy(hj[k].q, j.q, sizeof j.q);
+    hj[k].inv_period = (double)(1.f / ctx->prm.scan_period);
+    any_yzx = any_yzx || j.out_yzx;
+    max_n = j.n > max_n ? j.n : max_n;
+    off += align4(j.n);
+  }
+  if (any_yzx && !ctx->d_aux) HIP_TRY(ctx, hipMalloc((void**)&ctx->d_aux, ctx->arena_cap * sizeof(float4)));
+  (void)hipFree(ctx->d_jobs);
+  ctx->d_jobs = nullptr;
+  HIP_TRY(ctx, hipMalloc(&ctx->d_jobs, (size_t)n_jobs * sizeof(ReprojectJobHost)));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_jobs, hj.data(), (size_t)n_jobs * sizeof(ReprojectJobHost), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_arena, ctx->h_arena, off * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  launch_transform_to_end(ctx->stream, n_jobs, max_n, ctx->d_jobs, ctx->d_arena, ctx->d_binned, ctx->d_aux);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
+  ctx->n_uploaded = 0;  // the arenas no longer hold an IESKF batch
+  ctx->ran = false;
+  uint64_t bytes = 0;
+  for (int k = 0; k < n_jobs; ++k) bytes += (uint64_t)jobs[k].n * (jobs[k].out_yzx ? 48 : 32);
+  for (int pass = 0; pass < (any_yzx ? 2 : 1); ++pass) {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_arena, pass == 0 ? ctx->d_binned : ctx->d_aux, off * sizeof(float4),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < n_jobs; ++k) {
+      lins_point* dst = pass == 0 ? jobs[k].out_xyz : jobs[k].out_yzx;
+      if (dst && jobs[k].n) std::memcpy(dst, ctx->h_arena + hj[k].off, sizeof(lins_point) * jobs[k].n);
+    }
+  }
+  HIP_TRY(ctx, hipEventElapsedTime(&ctx->reproject_ms, ctx->ev0, ctx->ev2));
+  ctx->reproject_bytes = bytes;
+  return LINS_OK;
+}
+
+int lins_last_reproject_stats(lins_ctx* ctx, float* kernel_ms, uint64_t* bytes) {
+  if (!ctx) return LINS_E_ARG;
+  if (kernel_ms) *kernel_ms = ctx->reproject_ms;
+  if (bytes) *bytes = ctx->reproject_bytes;
   return LINS_OK;
 }
 

@@ -19,12 +19,18 @@ EXPORTS = [
     "lins_create", "lins_destroy", "lins_strerror", "lins_last_hip_error", "lins_set_search",
     "lins_ieskf_update", "lins_ieskf_update_batch", "lins_batch_upload", "lins_batch_run", "lins_sync",
     "lins_batch_download", "lins_last_kernel_ms", "lins_batch_bytes_per_iter", "lins_batch_total_iters",
-    "lins_correspondences", "lins_reduce_pass", "lins_host_perform_ieskf",
+    "lins_correspondences", "lins_reduce_pass", "lins_host_perform_ieskf", "lins_transform_to_end_batch",
+    "lins_last_reproject_stats",
 ]
 
 
 class LinsError(RuntimeError):
     pass
+
+
+class ReprojectJob(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("out_xyz", C.c_void_p), ("out_yzx", C.c_void_p), ("n", C.c_int32),
+                ("reserved", C.c_int32), ("t", C.c_double * 3), ("q", C.c_double * 4)]
 
 
 def lib_path():
@@ -62,6 +68,8 @@ def lib():
                                        C.POINTER(C.c_int32)]
         L.lins_host_perform_ieskf.argtypes = [vp, C.POINTER(Params), C.POINTER(ScanPairC), C.POINTER(ResultC),
                                               C.POINTER(C.c_int32)]
+        L.lins_transform_to_end_batch.argtypes = [vp, C.c_int, C.POINTER(ReprojectJob)]
+        L.lins_last_reproject_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
         for name in EXPORTS:
             if name not in ("lins_destroy", "lins_strerror", "lins_last_hip_error"):
                 getattr(L, name).restype = C.c_int
@@ -161,6 +169,30 @@ class IeskfContext:
         b = C.c_uint64(0)
         self._check(lib().lins_batch_total_iters(self._h, C.byref(b)))
         return b.value
+
+    # -- StateEstimator::updatePointCloud's re-projection (transformToEnd) -----------------
+    def transform_to_end(self, clouds, poses, yzx=True):
+        """clouds: list of (n,4) f32 arrays; poses: list of (t[3], q[4]).  Returns (xyz, yzx) lists."""
+        jobs = (ReprojectJob * len(clouds))()
+        keep = []
+        for k, (cl, (t, q)) in enumerate(zip(clouds, poses)):
+            cl = np.ascontiguousarray(cl, dtype=np.float32).reshape(-1, 4)
+            o1 = np.empty_like(cl)
+            o2 = np.empty_like(cl) if yzx else None
+            keep.append((cl, o1, o2))
+            jobs[k].inp, jobs[k].out_xyz = cl.ctypes.data, o1.ctypes.data
+            jobs[k].out_yzx = o2.ctypes.data if yzx else None
+            jobs[k].n = len(cl)
+            jobs[k].t[:] = list(t)
+            jobs[k].q[:] = list(q)
+        self._check(lib().lins_transform_to_end_batch(self._h, len(clouds), jobs))
+        self._n = 0
+        return [k[1] for k in keep], [k[2] for k in keep]
+
+    def reproject_stats(self):
+        ms, b = C.c_float(0), C.c_uint64(0)
+        self._check(lib().lins_last_reproject_stats(self._h, C.byref(ms), C.byref(b)))
+        return ms.value, b.value
 
     # -- findCorrespondingSurfFeatures / findCorrespondingCornerFeatures ---------------
     def correspondences(self, pair, lin_state, it):

@@ -254,3 +254,30 @@ def test_abi_error_behaviour(pkg, ieskf):
         ieskf.IeskfContext(pkg.default_params(num_iter=0))
     with pytest.raises(ieskf.LinsError, match="-5"):
         ieskf.IeskfContext(prm, device=99)
+
+
+def test_update_point_cloud_reprojection_matches_host(pkg, ieskf, host, pairs):
+    """transformToEnd of whole clouds on device == the host restatement
+    (SE:1083-1101), XYZ and the YZX copy (SE:1125-1129); empty and in-place clouds included."""
+    rng = np.random.default_rng(9)
+    clouds, poses = [], []
+    for p in pairs[:3]:
+        for cl in (p.surf_last, p.corner_last):
+            clouds.append(cl)
+            poses.append((rng.normal(0, 0.3, 3), (lambda v: v / np.linalg.norm(v))(np.array([1.0, *rng.normal(0, 0.02, 3)]))))
+    clouds.append(np.zeros((0, 4), np.float32))
+    poses.append((np.zeros(3), np.array([1.0, 0, 0, 0])))
+    with ieskf.IeskfContext(pkg.default_params(), max_batch=4, max_targets=16384) as c:
+        xyz, yzx = c.transform_to_end(clouds, poses, yzx=True)
+        ms, nbytes = c.reproject_stats()
+        assert ms > 0 and nbytes == 48 * sum(len(cl) for cl in clouds)
+        for cl, (t, q), a, b in zip(clouds, poses, xyz, yzx):
+            want = host.transform_to_end(t, q, cl)
+            ulp = np.abs(a.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+            assert ulp.max(initial=0) <= 1 and (ulp > 0).mean() <= 1e-3 if ulp.size else True
+            assert np.array_equal(b[:, 0], a[:, 1]) and np.array_equal(b[:, 1], a[:, 2]) and np.array_equal(b[:, 2], a[:, 0])
+            assert np.array_equal(b[:, 3], cl[:, 3]) and np.array_equal(a[:, 3], cl[:, 3])
+        xyz2, none = c.transform_to_end(clouds[:2], poses[:2], yzx=False)
+        assert none == [None, None] and np.array_equal(xyz2[0], xyz[0])
+        # a context that has just re-projected can go straight back to IESKF updates
+        assert c.update(pairs[0]).iters >= 1
