@@ -35,7 +35,7 @@ def traffic_from_profiles(search):
     profiles/rNN_pmc_traffic.json; null when there is no such file for this search mode."""
     import glob
 
-    if search != "lds":
+    if search not in ("auto", "mr"):
         return None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="scans per GPU")
     ap.add_argument("--iters", type=int, default=10, help="IESKF iterations per scan")
-    ap.add_argument("--search", default=os.environ.get("LINS_SEARCH", "lds"))
+    ap.add_argument("--search", default=os.environ.get("LINS_SEARCH", "auto"))
     ap.add_argument("--cpu-sample", type=int, default=192, help="scans timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -164,7 +164,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"configs[3]: batch of {args.batch} independent scan pairs per GPU, "
-                            f"{args.iters} IESKF iterations each (fixed), 1 workgroup per scan",
+                            f"{args.iters} IESKF iterations each (fixed), 1 workgroup per scan, 2 scans resident per CU",
                 "scans_per_gpu": len(pairs),
                 "iters_per_scan": args.iters,
                 "search": args.search,
@@ -177,7 +177,9 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ieskf_lds_kernel" if args.search.startswith("lds") else "ieskf_persistent_kernel",
+                "kernel": {"auto": "lds_mr::ieskf_lds_kernel<512,1>" if len(pairs) > 256 else "lds_full::ieskf_lds_kernel<1024,3>",
+                           "mr": "lds_mr::ieskf_lds_kernel<512,1>", "lds": "lds_full::ieskf_lds_kernel<1024,3>",
+                           "lds1": "lds_full::ieskf_lds_kernel<384,1>"}.get(args.search, "ieskf_persistent_kernel"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -136,10 +136,14 @@ void lins_destroy(lins_ctx* ctx);
 const char* lins_strerror(int code);
 const char* lins_last_hip_error(const lins_ctx* ctx);
 /* Search strategy — every mode returns the same (exact) correspondences:
+ *   "auto"   (default of the Python harness / bench) "mr" for batches larger than the
+ *            device's CU count, "lds" otherwise
  *   "lds"    (ring x azimuth-column) grid of the targets resident in LDS, one 1024-thread
- *            workgroup per scan, 3 lanes per query — the fast path for VLP-16 sized scans
- *   "lds1"   same grid in LDS, 384 threads, 1 lane per query
- *   "binned" the grid in global memory (any cloud size; automatic fallback of "lds*")
+ *            workgroup per scan and CU, 3 lanes per query — shortest latency for one scan
+ *   "mr"     multi-resident: the low part of the grid in LDS, the rest in a sorted global
+ *            copy, 512 threads, 1 lane per query, two scans per CU — batch throughput
+ *   "lds1"   whole grid in LDS, 384 threads, 1 lane per query
+ *   "binned" the grid in global memory (any cloud size; automatic fallback of the above)
  *   "brute"  all-pairs search + the literal index walk (any input; the fallback for
  *            clouds that are not ring-sorted or carry ring ids >= 16)                   */
 int lins_set_search(lins_ctx* ctx, const char* mode);

@@ -28,7 +28,7 @@ constexpr int kAzSurf = 128;         // azimuth columns per ring, surf targets
 constexpr int kAzCorner = 64;        // azimuth columns per ring, corner targets
 constexpr int kMaxRing = LINS_MAX_RING;
 
-enum { SEARCH_BRUTE = 0, SEARCH_BINNED = 1, SEARCH_LDS = 2, SEARCH_LDS3 = 3, SEARCH_LDS2 = 4 };
+enum { SEARCH_BRUTE = 0, SEARCH_BINNED = 1, SEARCH_LDS = 2, SEARCH_LDS3 = 3, SEARCH_MR = 4, SEARCH_AUTO = 5 };
 
 struct ScanDesc {  // one IESKF problem in the device arena (offsets in points)
   int off_surf_q, n_surf_q;

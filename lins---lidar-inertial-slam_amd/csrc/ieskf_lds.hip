@@ -1,1150 +1,56 @@
-// ieskf_lds.hip — the LDS-resident IESKF kernel: the fast path for VLP-16 sized scans.
-//
-// One 1024-thread workgroup (16 wave64, one per CU: it declares ~159 KB of the CU's
-// 160 KB LDS) owns one scan pair for the whole iterated update.  Both target clouds of
-// the scan are counting-sorted ONCE into (ring x azimuth-column) grids that live in
-// LDS as SoA (x[], y[], z[] f32 + u16 original index): after that single coalesced
-// pass over the scan's ~125 KB in HBM, every iteration's correspondence search is LDS
-// traffic only — the candidate windows are staged in LDS, not re-gathered from L2.
-//
-//   per iteration
-//     3 lanes / query   de-skew (f64, redundantly per lane) -> exact NN + index walk on
-//                       the LDS grid, the ring windows of one query split over its
-//                       three lanes and merged with wave shuffles on (distance, key)
-//     1 lane / query    plane / line residual + Jacobian (f64 -> f32) -> H row in LDS
-//     224 lanes         28 f64 sums, fixed-shape tree (8 strided groups -> ordered fold)
-//     <=42 lanes        6x6 pivoted elimination in LDS, dx
-//     wave 0            NaN / divergence / convergence, boxPlus, next constants
-//   16 waves x 21 queries = 336 queries per round = the VLP-16 caps (144 flat + 192 sharp).
-//
-// Scans that do not fit (more than kNpCap target points, ring ids >= 16, unsorted
-// rings) take the global-memory kernel in ieskf_kernels.hip — same results.
-
-#include <hip/hip_runtime.h>
-
-#include "ieskf_binned.h"
-#include "ieskf_device.h"
+// ieskf_lds.hip — full-residency instantiation of the LDS IESKF kernel (ieskf_lds_impl.h): the
+// whole scan (<= 8960 target points) in LDS, one workgroup per CU.  Two shapes:
+//   lanes = 3: 1024 threads, three lanes per query (shortest critical path per iteration: the
+//              single-scan latency path)
+//   lanes = 1: 384 threads, one lane per query  (fewest instructions issued per update)
+#define LINS_LDS_NS lds_full
+#define LINS_LDS_CAP 8960
+#define LINS_LDS_NMAX 8960
+#define LINS_LDS_REGREDUCE 0
+#define LINS_LDS_WAVES 16
+#define LINS_LDS_MINW 1
+#define LINS_LDS_BYTES 163840
+#include "ieskf_lds_impl.h"
 
 namespace lins {
 
-struct OutRec {
-  double residual_norm, update_norm;
-  int iters, converged, diverged, m_surf, m_corner, pad[3];
-};
+#define LINS_LAUNCH(NS, B, LN, PR)                                                                                  \
+  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, false, PR>), dim3(n), dim3(B), 0, stream, prm, descs, arena, sorted, \
+                     state_in, cov_in, (const double*)nullptr, 0, state_out, a6, (NS::OutRec*)out, idx_store, poses,  \
+                     scan_id_base, (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof)
+#define LINS_LAUNCH_PASS(NS, B, LN)                                                                                    \
+  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, true, false>), dim3(n), dim3(B), 0, stream, prm, descs, arena, sorted, \
+                     filt_state, (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr,           \
+                     (NS::OutRec*)nullptr, idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out,        \
+                     (long long*)nullptr)
 
-constexpr int kMaxLWaves = 16;
-constexpr int kNpCap = 8960;          // target points (surf + corner) resident in LDS
-constexpr int kSlotCap = 384;         // >= queries per round, row slots of 7 doubles
-constexpr int kCellsSurf = kRingsBinned * kAzSurf, kCellsCorner = kRingsBinned * kAzCorner;
+int lds_np_cap() { return lds_full::kNpMax; }
 
-__constant__ unsigned char kLPairA[28] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2,
-                                          2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6};
-__constant__ unsigned char kLPairB[28] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4,
-                                          5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6};
-
-struct LdsStore {
-  float px[kNpCap], py[kNpCap], pz[kNpCap];  // grid-sorted targets: surf cells, then corner cells
-  unsigned short pidx[kNpCap];               // original index inside its cloud
-  double slots[kSlotCap * 7];                // H rows; also the histogram scratch of the build
-  unsigned short cell_end[kCellsSurf + kCellsCorner];  // exclusive end (absolute position) per cell
-  double P[324];
-  IterConst ic;
-  double filt[19];
-  double sums[28];
-  double partial[kMaxLWaves * 28];  // one partial 28-vector per wave
-  double aug[3][42];  // one staging copy of [N | z] per solving wave
-  double w[6];
-  double dx[18];
-  double res_prev, res_last, upd_norm;
-  float2 az_edge[kAzSurf + 1];
-  float2 el_ang[2][kRingsBinned];    // elevation wedge of each ring as angles (lo - slack, hi + slack);
-                                     // an empty ring gets (+inf, -inf): never within reach
-  int el_bits[2][kRingsBinned][2];
-  int ring_start[2][kRingsBinned + 1];  // per cloud, in (original) index space
-  int piv[6], used[6];
-  int scan_tmp[kMaxLWaves + 4];
-  int m_surf, m_corner, iter, conv, div, pad;
-  long long prof_acc[16];  // phase profile accumulators of the PROF variant (written by thread 0)
-  int dbg[4];  // [0] certificate disagreements (verify mode) [1] NN searches skipped [2] walks skipped
-};
-static_assert(sizeof(LdsStore) <= 163840, "LDS budget of one CU");
-
-// The one LDS block of the workgroup.  File scope so that out-of-line device functions address
-// it as LDS (ds_* instructions) instead of through a generic pointer.
-__shared__ LdsStore g_lds;
-
-struct LCloud {  // one target cloud's grid (all pointers into LDS)
-  const unsigned short* cell_end;  // this cloud's cells (absolute positions)
-  const int* ring_start;
-  const float2* el_ang;
-  int naz, stride, base, n;
-};
-
-// polar view of a de-skewed query, computed once and shared by both search passes
-struct QueryPolar {
-  float rho, qn3, el, inv_unused;
-  int a0_surf_or_corner;
-};
-
-// Running best of a search: (distance, tie key) packed so that ONE unsigned 64-bit compare
-// is the reference's "strict < , first seen wins" rule: distances are non-negative floats
-// (their bit patterns order like the values, NaN above everything), the tie key is the
-// original index (pass 1: lowest index wins) or the visit rank (pass 2).  Initialised to
-// (threshold, 0): a candidate must be strictly closer than the threshold (SE:851, 856).
-struct Best {
-  unsigned long long k;   // winner: (distance bits, tie key); pos < 0: none yet (k = threshold sentinel)
-  int pos, ring;
-  unsigned long long k2;  // runner-up, kept with its identity so that a near-tie can be re-decided
-  int pos2, ring2;        //   later from two distance evaluations instead of a search
-  float omin;             // smallest squared distance of every OTHER candidate seen
-  __device__ __forceinline__ float d() const { return __uint_as_float((unsigned)(k >> 32)); }
-  __device__ __forceinline__ int key() const { return (int)(unsigned)k; }
-};
-__device__ __forceinline__ Best best_init(float thr) {
-  return Best{(unsigned long long)__float_as_uint(thr) << 32, -1, -1, ~0ull, -1, -1, INFINITY};
-}
-__device__ __forceinline__ unsigned long long pack_key(float d, int key) {
-  return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)key;
-}
-// insert candidate (k, pos, ring) into the top-2 list; equal keys are the same point seen again
-__device__ __forceinline__ void insert_key(Best& b, unsigned long long k, int pos, int ring) {
-  if (k < b.k) {
-    if (b.pos2 >= 0) b.omin = fminf(b.omin, __uint_as_float((unsigned)(b.k2 >> 32)));
-    b.k2 = b.k, b.pos2 = b.pos, b.ring2 = b.ring;  // (a dethroned sentinel stays a sentinel: pos2 < 0)
-    b.k = k, b.pos = pos, b.ring = ring;
-  } else if (k > b.k) {
-    if (k < b.k2) {
-      if (b.pos2 >= 0) b.omin = fminf(b.omin, __uint_as_float((unsigned)(b.k2 >> 32)));
-      b.k2 = k, b.pos2 = pos, b.ring2 = ring;
-    } else if (k > b.k2) {
-      b.omin = fminf(b.omin, __uint_as_float((unsigned)(k >> 32)));
-    }
-  }
-}
-__device__ __forceinline__ void consider(Best& b, float d, int key, int pos, int ring) {
-  insert_key(b, pack_key(d, key), pos, ring);
-}
-__device__ __forceinline__ void merge_from_lane(Best& b, int src_lane) {
-  unsigned lo = __shfl((unsigned)b.k, src_lane), hi = __shfl((unsigned)(b.k >> 32), src_lane);
-  unsigned lo2 = __shfl((unsigned)b.k2, src_lane), hi2 = __shfl((unsigned)(b.k2 >> 32), src_lane);
-  int pos = __shfl(b.pos, src_lane), ring = __shfl(b.ring, src_lane);
-  int pos2 = __shfl(b.pos2, src_lane), ring2 = __shfl(b.ring2, src_lane);
-  float om = __shfl(b.omin, src_lane);
-  b.omin = fminf(b.omin, om);
-  if (pos >= 0) insert_key(b, ((unsigned long long)hi << 32) | lo, pos, ring);
-  if (pos2 >= 0) insert_key(b, ((unsigned long long)hi2 << 32) | lo2, pos2, ring2);
-}
-
-// ---- certificates: skipping a search that provably returns the same answer -----------------
-// After a search run with its pruning bound inflated by `margin` metres, every candidate other
-// than the winner is at least  lb = min(sqrt(omin), sqrt(d_best) + margin)  away from the query
-// (scanned ones: measured; pruned ones: beyond the inflated bound).  If the de-skewed query has
-// since moved by `drift`, any other candidate is still at least lb - drift away, so while
-//     dist(query, winner)  <  lb - drift        (with slack for the f32 roundings)
-// the winner is the unique strict minimum of the reference's comparison and the search can be
-// skipped.  With no winner (nothing inside the search radius) the same test against the radius
-// certifies that there is still none.
-__device__ __forceinline__ float cert_lb(const Best& b, float thr, float margin) {
-  return fminf(sqrtf(b.omin), sqrtf(b.pos >= 0 ? b.d() : thr) + margin);
-}
-__device__ __forceinline__ bool certified(float d_now, float lb, float drift) {
-  return sqrtf(d_now) * (1.f + 4e-6f) + 2e-6f < (lb - drift * (1.f + 4e-6f)) * (1.f - 4e-6f);
-}
-
-// ---- columns / windows on the LDS grid ----------------------------------------------------
-// All lanes of a wave run the SAME code on different (ring, column-range) data: every
-// scan goes through scan_cols(), whose point loop exists once per call site, so splitting
-// a query's ring windows over three lanes is real parallelism, not serialised branches.
-template <class F>
-__device__ __forceinline__ void scan_cols(const LdsStore& L, const LCloud& c, int r, int lo, int hi, F f) {
-  int s0 = 0, e0 = 0, s1 = 0, e1 = 0;
-  if (lo <= hi) {
-    const int naz = c.naz, row = r * naz;
-    int len = hi - lo;
-    if (len >= naz - 1) lo = 0, len = naz - 1;  // at most naz columns
-    lo %= naz;
-    if (lo < 0) lo += naz;
-    hi = lo + len;
-    const int c0 = row + lo, c1 = row + (hi < naz ? hi : naz - 1);
-    s0 = c0 ? (int)c.cell_end[c0 - 1] : c.base;
-    e0 = (int)c.cell_end[c1];
-    if (hi >= naz) {  // wrapped tail: columns 0 .. hi-naz
-      s1 = row ? (int)c.cell_end[row - 1] : c.base;
-      e1 = (int)c.cell_end[row + hi - naz];
-    }
-  }
-#pragma unroll 1
-  for (int k = 0; k < 2; ++k) {
-    const int s = k ? s1 : s0, e = k ? e1 : e0;
-#pragma unroll 2
-    for (int p = s; p < e; ++p) f(L.px[p], L.py[p], L.pz[p], (int)L.pidx[p], p);
-  }
-}
-
-// How many columns either side of a0 can hold a point within sqrt(bound) of the query:
-// a point at azimuth difference D from the query is at least rho*sin(D) away (rho for
-// D >= 90 deg), so D <= asin(sqrt(bound)/rho); the query sits anywhere inside its own
-// column, hence the +2 (one for its offset, one for rounding) — a superset, never less.
-// asin(s) <= s + (pi/2 - 1) s^3 on [0, 1] (every term of asin's series beyond s is <= its
-// coefficient times s^3, and the coefficients sum to pi/2 - 1): a cheap upper bound is all the
-// pruning needs — a slightly wider window never changes the result.
-__device__ __forceinline__ float asin_ub(float s) { return s + 0.5707964f * s * s * s; }
-
-__device__ __forceinline__ int reach(const LCloud& c, float rho, float sqrt_bound) {
-  const int half = c.naz / 2;
-  float s = (sqrt_bound * (1.f + 1e-6f) + kSlack * rho + 1e-6f) / rho;  // rho == 0 -> inf/nan -> all columns
-  if (!(s < 1.f)) return half;
-  int k = (int)(asin_ub(s) * (1.f + 1e-6f) * ((float)c.naz * (0.5f / kPiF))) + 2;
-  return k < half ? k : half;
-}
-
-__device__ __forceinline__ bool ring_nonempty(const LCloud& c, int r) {
-  return r >= 0 && r < kRingsBinned && c.ring_start[r + 1] > c.ring_start[r];
-}
-
-// ring r can hold a point within sqrt(bound) of the query only if the query's elevation
-// is within delta = asin(sqrt(bound)/|q|) of the ring's elevation wedge (a point at
-// elevation difference g < 90 deg is at least |q| sin g away, |q| beyond that)
-__device__ __forceinline__ float reach_elev(float qn3, float sqrt_bound) {
-  float s = (sqrt_bound * (1.f + 1e-6f) + kSlack * qn3 + 1e-6f) / qn3;
-  return s < 1.f ? asin_ub(s) * (1.f + 1e-6f) + kSlack : 4.f;  // 4 rad > any elevation difference
-}
-__device__ __forceinline__ bool ring_in_reach(const LCloud& c, int r, float el_q, float delta) {
-  const float2 w = c.el_ang[r];  // one 8-byte LDS read; empty rings fail both tests
-  return el_q >= w.x - delta && el_q <= w.y + delta;
-}
-
-// ---- pass 1: exact NN; with LANES = 3 the ring windows of a query are split over its lanes
-template <int LANES>
-__device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float sx, float sy, float sz,
-                                       const QueryPolar& qp, float thr, float margin, int rq, int role, int lane_base,
-                                       int warm_pos, int warm_ring) {
-  Best b = best_init(thr);
-  // Warm start (iterations >= 1): last iteration's nearest neighbour is still a candidate, and its
-  // distance to the re-de-skewed query bounds the search from the start — the seed scan is skipped
-  // and the windows are minimal.  It only tightens bounds; the exact arg-min is still taken over
-  // every cell that could beat it, so the result is the same as a cold search.
-  const bool warm = warm_pos >= 0;
-  if (warm)
-    consider(b, sqdist3(L.px[warm_pos], L.py[warm_pos], L.pz[warm_pos], sx, sy, sz), (int)L.pidx[warm_pos], warm_pos,
-             warm_ring);
-  const float rho = qp.rho, qn3 = qp.qn3, el_q = qp.el;
-  const int a0 = qp.a0_surf_or_corner;
-  rq = rq < 0 ? 0 : (rq >= kRingsBinned ? kRingsBinned - 1 : rq);
-  int rcur = rq;
-  auto f = [&](float x, float y, float z, int j, int p) { consider(b, sqdist3(x, y, z, sx, sy, sz), j, p, rcur); };
-  const bool own = ring_nonempty(c, rq);
-  // cold seed: columns a0-1..a0+1 of the query's own ring and of its two neighbours, one ring per
-  // lane, merged before the bound is fixed — a query that sits between rings (or whose own ring is
-  // empty there) still starts from a real neighbour instead of sweeping the whole search radius
-  {
-    const int rs = LANES == 1 ? rq : rq + (role == 0 ? 0 : (role == 1 ? 1 : -1));
-    const bool seed = !warm && ring_nonempty(c, rs);
-    rcur = rs;
-    scan_cols(L, c, rs, seed ? a0 - 1 : 1, seed ? a0 + 1 : 0, f);
-    if (LANES == 1) {
-#pragma unroll 1
-      for (int dr = -1; dr <= 1; dr += 2) {
-        const bool sd2 = !warm && ring_nonempty(c, rq + dr);
-        rcur = rq + dr;
-        scan_cols(L, c, rq + dr, sd2 ? a0 - 1 : 1, sd2 ? a0 + 1 : 0, f);
-      }
-    } else if (!warm) {  // (wave-uniform from iteration to iteration: cold only in iteration 0)
-      if (LANES == 3) {
-        merge_from_lane(b, lane_base + (role + 1) % 3);
-        merge_from_lane(b, lane_base + (role + 2) % 3);
-      } else {
-        merge_from_lane(b, lane_base + (role ^ 1));
-      }
-    }
-    rcur = rq;
-  }
-  const int cin = warm ? 0 : 2;  // first column either side that the seed has not covered
-  const float B = b.d();  // fixed bound for everything below (conservative: >= the final best)
-  const float sqrtB = sqrtf(B) + margin;  // pruning bound inflated by the certificate margin
-  const int K = reach(c, rho, sqrtB);
-  const float delta = reach_elev(qn3, sqrtB);
-  // This lane's tasks as a bit mask (bit i <-> task t = role + LANES i): task 0 = own ring right
-  // of the seed, 1 = own ring left of it, 2.. = the other rings rq+1, rq-1, rq+2, ...  The ring
-  // tests are independent LDS reads, issued together; only surviving tasks enter the scan loop.
-  constexpr int kTasks = 2 + 2 * (kRingsBinned - 1), kPerLane = (kTasks + LANES - 1) / LANES;
-  unsigned todo = 0;
-#pragma unroll
-  for (int i = 0; i < kPerLane; ++i) {
-    const int t = role + LANES * i;
-    const int k = t - 2, off = (k >> 1) + 1;
-    const int r = t < 2 ? rq : rq + ((k & 1) ? -off : off);
-    bool go;
-    if (t < 2)
-      go = own && K >= cin;
-    else
-      go = t < kTasks && r >= 0 && r < kRingsBinned && ring_in_reach(c, r < 0 ? 0 : (r >= kRingsBinned ? kRingsBinned - 1 : r), el_q, delta);
-    todo |= go ? (1u << i) : 0u;
-  }
-#pragma unroll 1
-  while (todo) {
-    const int i = __ffs(todo) - 1;
-    todo &= todo - 1;
-    const int t = role + LANES * i;
-    const int k = t - 2, off = (k >> 1) + 1;
-    const int r = t < 2 ? rq : rq + ((k & 1) ? -off : off);
-    rcur = r;
-    // own ring: right part (with the centre column when warm) / left part; other rings: whole window
-    scan_cols(L, c, r, t == 0 ? a0 + cin : a0 - K, t == 1 ? a0 - (warm ? 1 : 2) : a0 + K, f);
-  }
-  if (LANES == 3) {
-    merge_from_lane(b, lane_base + (role + 1) % 3);
-    merge_from_lane(b, lane_base + (role + 2) % 3);
-  } else if (LANES == 2) {
-    merge_from_lane(b, lane_base + (role ^ 1));
-  }
-  return b;
-}
-
-constexpr int kBackRankL = 0x40000000;
-
-struct WalkCtx {
-  int j1, f_hi, b_lo;
-};
-__device__ __forceinline__ bool walk_ring_has_candidates(const LCloud& c, const WalkCtx& w, int r) {
-  if (r < 0 || r >= kRingsBinned) return false;
-  const int rs = c.ring_start[r], re = c.ring_start[r + 1];
-  const bool fwd = (w.j1 + 1 > rs ? w.j1 + 1 : rs) < (w.f_hi < re ? w.f_hi : re);
-  const bool bwd = (w.b_lo > rs ? w.b_lo : rs) < (w.j1 < re ? w.j1 : re);
-  return fwd || bwd;
-}
-
-// candidate filter + visit rank of the index walk: forward part (j1, f_hi) in ascending
-// order first, then the backward part [b_lo, j1) in descending order
-__device__ __forceinline__ bool walk_rank(const WalkCtx& w, int j, int& rank) {
-  const bool fwd = (unsigned)(j - w.j1 - 1) < (unsigned)(w.f_hi > w.j1 + 1 ? w.f_hi - w.j1 - 1 : 0);
-  const bool bwd = (unsigned)(j - w.b_lo) < (unsigned)(w.j1 - w.b_lo);  // b_lo <= j1 always
-  rank = fwd ? j - w.j1 : kBackRankL + (w.j1 - j);
-  return fwd || bwd;
-}
-
-// index intervals of the walk around nearest neighbour j1 on ring rho (sorted cloud):
-// forward (j1, min(N_query, N_target, start[rho+3])), backward [start[rho-2], j1)
-__device__ __forceinline__ WalkCtx make_walk_ctx(const LCloud& c, int nq, int j1, int rho) {
-  const int fend = nq < c.n ? nq : c.n;
-  const int r_hi = rho + 3 < kRingsBinned ? rho + 3 : kRingsBinned;
-  const int r_lo = rho - 2 > 0 ? rho - 2 : 0;
-  return WalkCtx{j1, fend < c.ring_start[r_hi] ? fend : c.ring_start[r_hi], c.ring_start[r_lo]};
-}
-
-// One walk task: candidates of ring r for the running best `cur` (rank-keyed).  full:
-// seed window + both extensions with the tightened bound; !full: extensions only (the
-// seed of that ring was scanned by all lanes before).  Same code for every lane.
-// seed_first: scan the seed window first and tighten the bound; centre_done: columns a0-1..a0+1
-// were already scanned (by the all-lane class-2 seed) — otherwise the extensions include them.
-__device__ __forceinline__ void walk_task(const LdsStore& L, const LCloud& c, const WalkCtx& w, int r, bool seed_first,
-                                          bool centre_done, int a0, float sx, float sy, float sz, float rho_q,
-                                          float qn3, float el_q, float margin, Best& cur) {
-  bool go = walk_ring_has_candidates(c, w, r);
-  if (go) go = ring_in_reach(c, r, el_q, reach_elev(qn3, sqrtf(cur.d()) + margin));
-  auto f = [&](float x, float y, float z, int j, int p) {
-    int rank;
-    if (walk_rank(w, j, rank)) consider(cur, sqdist3(x, y, z, sx, sy, sz), rank, p, 0);
-  };
-  const bool seed = go && seed_first;
-  scan_cols(L, c, r, seed ? a0 - 1 : 1, seed ? a0 + 1 : 0, f);
-  const bool done = seed_first || centre_done;
-  // Widen progressively: the window needed for the current bound, but at most 4x the width already
-  // covered per round — when the seed window was empty the bound tightens as soon as the first real
-  // candidate shows up, instead of one sweep over the whole search radius.
-  int kk = done ? 1 : -1;  // columns a0-kk..a0+kk are covered (-1: nothing yet)
-  const int half = c.naz / 2;
-#pragma unroll 1
-  for (int round = 0; round < 8 && go; ++round) {
-    const int K = reach(c, rho_q, sqrtf(cur.d()) + margin);
-    if (K <= kk) break;
-    const int nk = kk < 1 ? K : (K < 4 * kk ? K : 4 * kk);  // (a bound from a warm candidate: one shot)
-    scan_cols(L, c, r, a0 + kk + 1, a0 + nk, f);
-    scan_cols(L, c, r, a0 - nk, a0 - (kk < 0 ? 1 : kk + 1), f);
-    kk = nk;
-    if (kk >= half) break;
-  }
-}
-
-// ---- pass 2 (SE:859-910 surf, SE:983-1024 corner) ----------------------------------------
-// surf:   class 2 = ring rho (second point), class 3 = rings rho+-1, rho+-2 (third point)
-// corner: class 2 = rings rho+-1, rho+-2 (second point on a different ring), no class 3
-template <int LANES>
-__device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, bool is_surf, int nq, float thr, int j1,
-                                         int rho, float sx, float sy, float sz, const QueryPolar& qp, float margin,
-                                         int role, int lane_base, int warm2, int warm3, Best& c2, Best& c3) {
-  const WalkCtx w = make_walk_ctx(c, nq, j1, rho);
-  c2 = best_init(thr);
-  c3 = best_init(thr);
-  const float rho_q = qp.rho, qn3 = qp.qn3, el_q = qp.el;
-  const int a0 = qp.a0_surf_or_corner;
-  // warm start: last iteration's second / third point (same nearest neighbour => same index
-  // intervals and classes) are candidates whose distances bound the walk from the start
-  auto warm_cand = [&](Best& b, int pos) {
-    int rank;
-    if (pos >= 0 && walk_rank(w, (int)L.pidx[pos], rank))
-      consider(b, sqdist3(L.px[pos], L.py[pos], L.pz[pos], sx, sy, sz), rank, pos, 0);
-  };
-  warm_cand(c2, warm2);
-  warm_cand(c3, warm3);
-  const bool w2 = c2.pos >= 0, w3 = c3.pos >= 0;
-  if (is_surf && !w2) {  // class-2 seed on ring rho: all lanes of the query
-    bool go = walk_ring_has_candidates(c, w, rho);
-    auto f = [&](float x, float y, float z, int j, int p) {
-      int rank;
-      if (walk_rank(w, j, rank)) consider(c2, sqdist3(x, y, z, sx, sy, sz), rank, p, 0);
-    };
-    scan_cols(L, c, rho, go ? a0 - 1 : 1, go ? a0 + 1 : 0, f);
-  }
-  // tasks (data, not code), dealt round-robin to the query's lanes:
-  //   surf    t0: rho (class 2, extensions)  t1: rho-1  t2: rho-2  t3: rho+1  t4: rho+2  (class 3)
-  //   corner  t0: rho-1  t1: rho+1  t2: rho-2  t3: rho+2
-  constexpr int kPerLane = (5 + LANES - 1) / LANES;
-#pragma unroll 1
-  for (int i = 0; i < kPerLane; ++i) {
-    const int t = role + LANES * i;
-    int dr;
-    if (is_surf)
-      dr = t == 0 ? 0 : (t == 1 ? -1 : (t == 2 ? -2 : (t == 3 ? 1 : (t == 4 ? 2 : 99))));
-    else
-      dr = t == 0 ? -1 : (t == 1 ? 1 : (t == 2 ? -2 : (t == 3 ? 2 : 99)));
-    const bool use2 = !is_surf || dr == 0;
-    const bool have_bound = use2 ? w2 : w3;  // a warm bound replaces the per-ring seed scan
-    const bool seed_first = !have_bound && (!is_surf || dr != 0);
-    const bool centre_done = is_surf && dr == 0 && !w2;
-    Best cur = use2 ? c2 : c3;
-    walk_task(L, c, w, rho + dr, seed_first, centre_done, a0, sx, sy, sz, rho_q, qn3, el_q, margin, cur);
-    if (use2)
-      c2 = cur;
-    else
-      c3 = cur;
-  }
-  if (LANES == 3) {
-    merge_from_lane(c2, lane_base + (role + 1) % 3);
-    merge_from_lane(c2, lane_base + (role + 2) % 3);
-    merge_from_lane(c3, lane_base + (role + 1) % 3);
-    merge_from_lane(c3, lane_base + (role + 2) % 3);
-  } else if (LANES == 2) {
-    merge_from_lane(c2, lane_base + (role ^ 1));
-    merge_from_lane(c3, lane_base + (role ^ 1));
-  }
-}
-
-// ---- grid build: both clouds of the scan, once -----------------------------------------------
-template <int BLOCK>
-__device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, const float4* __restrict__ arena,
-                                               int tid) {
-  constexpr int kLBlock = BLOCK;
-  unsigned* cnt = reinterpret_cast<unsigned*>(L.slots);  // kCellsSurf + kCellsCorner counters
-  constexpr int ncell = kCellsSurf + kCellsCorner;
-  for (int c = tid; c < ncell; c += kLBlock) cnt[c] = 0;
-  for (int a = tid; a <= kAzSurf; a += kLBlock) {
-    float th = -kPiF + (float)a * (2.f * kPiF / (float)kAzSurf);
-    L.az_edge[a] = make_float2(cosf(th), sinf(th));
-  }
-  if (tid < 2 * kRingsBinned) {
-    L.el_bits[tid / kRingsBinned][tid % kRingsBinned][0] = 0x7FFFFFFF;
-    L.el_bits[tid / kRingsBinned][tid % kRingsBinned][1] = (int)0x80000000;
-  }
-  __syncthreads();
-  const float4* ts = arena + sd.off_surf_t;
-  const float4* tc = arena + sd.off_corner_t;
-  const int n_all = sd.n_surf_t + sd.n_corner_t;
-  // each thread owns the points tid, tid + BLOCK, ...; the cell of each is kept in a register
-  // between the histogram pass and the scatter pass (no second atan2f, no second classification)
-  constexpr int kPerThread = (kNpCap + BLOCK - 1) / BLOCK;
-  int cell_of[kPerThread];
-#pragma unroll
-  for (int k = 0; k < kPerThread; ++k) {
-    const int j = tid + k * kLBlock;
-    cell_of[k] = -1;
-    if (j < n_all) {
-      const bool is_s = j < sd.n_surf_t;
-      float4 p = is_s ? ts[j] : tc[j - sd.n_surf_t];
-      int r = ring_of(p.w);
-      int cell = is_s ? r * kAzSurf + az_bin(p.x, p.y, kAzSurf) : kCellsSurf + r * kAzCorner + az_bin(p.x, p.y, kAzCorner);
-      cell_of[k] = cell;
-      atomicAdd(&cnt[cell], 1u);
-      int eb = ordered_int(atan2f(p.z, sqrtf(p.x * p.x + p.y * p.y)));
-      atomicMin(&L.el_bits[is_s ? 0 : 1][r][0], eb);
-      atomicMax(&L.el_bits[is_s ? 0 : 1][r][1], eb);
-    }
-  }
-  __syncthreads();
-  // exclusive scan over all cells: surf cells first, so corner positions start at n_surf_t
-  constexpr int per = (ncell + kLBlock - 1) / kLBlock;
-  const int c_lo = tid * per < ncell ? tid * per : ncell;
-  const int c_hi = c_lo + per < ncell ? c_lo + per : ncell;
-  int local = 0;
-  for (int c = c_lo; c < c_hi; ++c) local += (int)cnt[c];
-  int run = block_exclusive_scan(local, tid, L.scan_tmp);
-  for (int c = c_lo; c < c_hi; ++c) {
-    int n = (int)cnt[c];
-    cnt[c] = (unsigned)run;
-    run += n;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < kPerThread; ++k) {
-    const int j = tid + k * kLBlock;
-    if (cell_of[k] >= 0) {
-      const bool is_s = j < sd.n_surf_t;
-      const int jj = is_s ? j : j - sd.n_surf_t;
-      float4 p = is_s ? ts[jj] : tc[jj];  // (L2 hit: read a moment ago)
-      unsigned pos = atomicAdd(&cnt[cell_of[k]], 1u);  // order inside a cell is irrelevant (keyed ties)
-      L.px[pos] = p.x, L.py[pos] = p.y, L.pz[pos] = p.z;
-      L.pidx[pos] = (unsigned short)jj;
-    }
-  }
-  __syncthreads();  // cnt[c] is now the exclusive END of cell c
-  for (int c = tid; c < ncell; c += kLBlock) L.cell_end[c] = (unsigned short)cnt[c];
-  if (tid <= kRingsBinned) {
-    L.ring_start[0][tid] = tid == 0 ? 0 : (int)cnt[tid * kAzSurf - 1];
-    L.ring_start[1][tid] = (tid == 0 ? (int)cnt[kCellsSurf - 1] : (int)cnt[kCellsSurf + tid * kAzCorner - 1]) - sd.n_surf_t;
-  }
-  if (tid < 2 * kRingsBinned) {
-    int cl = tid / kRingsBinned, r = tid % kRingsBinned;
-    float lo = ordered_float(L.el_bits[cl][r][0]) - kSlack, hi = ordered_float(L.el_bits[cl][r][1]) + kSlack;
-    const bool empty = L.el_bits[cl][r][0] == 0x7FFFFFFF;  // no point touched the ring's min/max
-    L.el_ang[cl][r] = empty ? make_float2(INFINITY, -INFINITY) : make_float2(lo, hi);
-  }
-  __syncthreads();
-}
-
-// 6 x 6 pivoted elimination in LDS, cooperative over the block (see ieskf_kernels.hip)
-__device__ __forceinline__ void l_block_solve6(double* aug, int nc, double* sol, int* piv, int* used, int tid) {
-  if (tid < 6) used[tid] = 0;
-  __syncthreads();
-  for (int k = 0; k < 6; ++k) {
-    if (tid == 0) {
-      int p = -1;
-      double best = -1.0;
-      for (int i = 0; i < 6; ++i)
-        if (!used[i]) {
-          double v = fabs(aug[i * nc + k]);
-          if (p < 0 || v > best) best = v, p = i;
-        }
-      piv[k] = p;
-      used[p] = 1;
-    }
-    __syncthreads();
-    const int p = piv[k];
-    const int i = tid / nc, j = tid - i * nc;
-    if (i < 6 && !used[i] && j > k) {
-      double f = aug[i * nc + k] / aug[p * nc + k];
-      aug[i * nc + j] -= f * aug[p * nc + j];
-    }
-    __syncthreads();
-  }
-  const int nrhs = nc - 6;
-  if (tid < nrhs) {
-    const int col = 6 + tid;
-    double x[6];
-#pragma unroll
-    for (int k = 5; k >= 0; --k) {
-      const int p = piv[k];
-      double s = aug[p * nc + col];
-#pragma unroll
-      for (int j = k + 1; j < 6; ++j) s -= aug[p * nc + j] * x[j];
-      x[k] = s / aug[p * nc + k];
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) sol[k * nrhs + tid] = x[k];
-  }
-  __syncthreads();
-}
-
-// ---------------------------------------------------------------------------
-// 6x6 pivoted elimination, every lane of the wave redundantly in registers (the wave is
-// one instruction stream anyway): no shuffles, no LDS traffic, no barriers.  Fully
-// unrolled; row exchanges are value selects so nothing is dynamically indexed.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void reg_solve6(double (&a)[6][7], double (&x)[6]) {
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    int p = k;
-    double best = fabs(a[k][k]);
-#pragma unroll
-    for (int i = k + 1; i < 6; ++i) {
-      double v = fabs(a[i][k]);
-      if (v > best) best = v, p = i;
-    }
-#pragma unroll
-    for (int i = k + 1; i < 6; ++i) {
-      const bool sw = (p == i);
-#pragma unroll
-      for (int j = k; j < 7; ++j) {
-        double u = a[k][j], w = a[i][j];
-        a[k][j] = sw ? w : u;
-        a[i][j] = sw ? u : w;
-      }
-    }
-    const double inv = 1.0 / a[k][k];
-#pragma unroll
-    for (int i = k + 1; i < 6; ++i) {
-      const double f = a[i][k] * inv;
-#pragma unroll
-      for (int j = k + 1; j < 7; ++j) a[i][j] -= f * a[k][j];
-    }
-  }
-#pragma unroll
-  for (int i = 5; i >= 0; --i) {
-    double sacc = a[i][6];
-#pragma unroll
-    for (int k = i + 1; k < 6; ++k) sacc -= a[i][k] * x[k];
-    x[i] = sacc / a[i][i];
-  }
-}
-
-// Rinvleft(-phi)^T and phi from a unit quaternion without libm sin/cos: with
-// h = |phi|/2 the half angle, cos h = |w| / |q| and sin h = |v| / |q| exactly, so
-// s = h cot h needs only the atan2 that Quat2axis performs anyway (math_utils.h:75-88,
-// 304-321; differs from the sin/cos route in the last ulp only).
-__device__ __forceinline__ void phi_and_Gt(const Q4& q, V3& phi, M3& Gt) {
-  const double mag = sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
-  phi = V3{q.x, q.y, q.z};
-  Gt = M3{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
-  if (!(mag >= 1e-10)) return;  // Quat2axis leaves v unscaled; |phi| < 1e-10 => Rinvleft = I
-  const double ang = wrap_pi(2.0 * atan2(mag, q.w));
-  const V3 u = V3{q.x, q.y, q.z} / mag;
-  phi = ang * u;
-  const double theta = norm(phi);
-  if (theta < 1e-10) return;
-  const double h = theta / 2.0;
-  const double n = sqrt(q.w * q.w + mag * mag);
-  const double s = h * ((fabs(q.w) / n) / (mag / n));
-  const V3 a = V3{-phi.x, -phi.y, -phi.z} / theta;  // axis of -phi
-  const M3 k = skew(a);
-  const double av[3] = {a.x, a.y, a.z};
-  // Rinvleft(-phi) = s I + (1 - s) a a^T - h [a]x ; store the transpose
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int jj = 0; jj < 3; ++jj)
-      Gt.m[jj * 3 + i] = (s * (i == jj ? 1.0 : 0.0) + (1.0 - s) * av[i] * av[jj]) - h * k.m[i * 3 + jj];
-}
-
-// ---------------------------------------------------------------------------
-// The serial tail of one iteration, kept out of line: its register needs (a 6x7 system in
-// registers, the 19-state) are allocated on their own instead of inflating — and spilling —
-// the search loop it would otherwise be fused with.  Called by every thread (barriers inside).
-// ---------------------------------------------------------------------------
-__device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int iter, bool prof, long long& t3) {
-  LdsStore& L = g_lds;
-  const int lane = tid & 63, wave = tid >> 6;
-  // ---- solve + state update: waves 0-2, each redundantly, in registers ----------------------
-  // (sigma^2 I + A P_SS) w = g + A d_S  (push-through form of SE:542-549), dx = d - P[:,S] w,
-  // NaN / divergence / convergence tests and boxPlus (SE:552-580); after one barrier the three
-  // waves split the constants of the next iteration: wave 0 -> linState_, flags, R^T;
-  // wave 1 -> phi, Rinvleft(-phi)^T;  wave 2 -> x_filter (-) x_lin.
-  double lin[19];
-  double rn = 0, un = 0, res_prev = 0;
-  int div = 0, conv = 0;
-  if (wave < 3) {
-    if (lane < 42) {
-      const int i = lane / 7, j = lane % 7;
-      double v;
-      if (j < 6) {
-        v = (i == j ? prm.r2 : 0.0);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) v += sym6(L.sums, i, k) * L.P[sidx(k) * 18 + sidx(j)];
-      } else {
-        v = L.sums[21 + i];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) v += sym6(L.sums, i, k) * L.ic.d[sidx(k)];
-      }
-      L.aug[wave][lane] = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // one lane per wave eliminates (registers, unrolled); a single active lane keeps whatever the
-    // register allocator spills for the 6x7 system to 1/64 of the scratch traffic
-    if (lane == 0) {
-      double a[6][7], x6[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 7; ++j) a[i][j] = L.aug[wave][i * 7 + j];
-      reg_solve6(a, x6);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) L.aug[wave][k] = x6[k];  // the system is consumed: reuse its first row
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double wsol[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) wsol[k] = L.aug[wave][k];
-    double dxi = 0;
-    if (lane < 18) {
-      double sacc = 0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) sacc += L.P[lane * 18 + sidx(k)] * wsol[k];
-      dxi = L.ic.d[lane] - sacc;
-    }
-    if (prof) t3 = clock64();
-    // broadcast dx lane by lane and fold it straight into the state (no dx[18] array: this
-    // section runs under the search loop's 128-VGPR budget): additive blocks now, the
-    // attitude increment through the quaternion below (boxPlus, KF:71-81)
-#pragma unroll
-    for (int k = 0; k < 19; ++k) lin[k] = L.ic.lin[k];
-    double dth[3] = {0, 0, 0};
-    bool has_nan = false;
-    un = 0;
-#pragma unroll
-    for (int k = 0; k < 18; ++k) {
-      const double vk = __shfl(dxi, k);
-      has_nan = has_nan || isnan(vk);
-      un += vk * vk;
-      if (k >= 6 && k < 9)
-        dth[k - 6] = vk;
-      else
-        lin[k < 6 ? k : k + 1] += vk;  // p,v at 0..5; ba,bw,g at 10..18 (q occupies 6..9)
-    }
-    un = sqrt(un);
-    rn = sqrt(L.sums[27]);
-    res_prev = L.res_prev;
-    if (has_nan) {
-      div = 2, un = L.upd_norm;
-    } else if (rn > res_prev * 10) {
-      div = 1, un = L.upd_norm;
-    } else {
-      const Q4 qn = qnormalized(qmul(Q4{lin[6], lin[7], lin[8], lin[9]}, axis2quat(V3{dth[0], dth[1], dth[2]})));
-      lin[6] = qn.w, lin[7] = qn.x, lin[8] = qn.y, lin[9] = qn.z;
-      if (un <= 1e-2 && !prm.fixed_iters) conv = 1;
-      res_prev = rn;
-    }
-  }
-  __syncthreads();  // every reader of the old linearisation state is done
-  if (wave < 3 && !div) {
-    const Q4 q{lin[6], lin[7], lin[8], lin[9]};
-    // (static indices only: a lane-indexed register array would be spilled to scratch)
-    if (wave == 0) {
-      const M3 Rt = mtrans(qmat(q));
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 19; ++k) L.ic.lin[k] = lin[k];
-        L.ic.Rt = Rt;
-      }
-    } else if (wave == 1) {
-      V3 phi;
-      M3 Gt;
-      phi_and_Gt(q, phi, Gt);
-      if (lane == 0) L.ic.phi = phi, L.ic.Gt = Gt;
-    } else {
-      // boxMinus(filter, lin), KF:84-94
-      const Q4 qf{L.filt[6], L.filt[7], L.filt[8], L.filt[9]};
-      const V3 da = quat2axis(qmul(qinverse(q), qf));
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          L.ic.d[0 + k] = L.filt[0 + k] - lin[0 + k];
-          L.ic.d[3 + k] = L.filt[3 + k] - lin[3 + k];
-          L.ic.d[9 + k] = L.filt[10 + k] - lin[10 + k];
-          L.ic.d[12 + k] = L.filt[13 + k] - lin[13 + k];
-          L.ic.d[15 + k] = L.filt[16 + k] - lin[16 + k];
-        }
-        L.ic.d[6] = da.x, L.ic.d[7] = da.y, L.ic.d[8] = da.z;
-      }
-    }
-  }
-  if (tid == 0) {
-    L.res_last = rn, L.res_prev = res_prev, L.upd_norm = un;
-    L.conv = conv, L.div = div;
-    L.iter = iter + 1;
-  }
-  __syncthreads();
-}
-
-// ---------------------------------------------------------------------------
-// the kernel.  PASS_ONLY: one correspondence pass at a caller-supplied linearisation
-// state (lins_correspondences / lins_reduce_pass), dumping records / sums.
-// ---------------------------------------------------------------------------
-template <int BLOCK, int LANES, bool PASS_ONLY, bool PROF>
-__global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
-    DevParams prm, const ScanDesc* __restrict__ descs, const float4* __restrict__ arena,
-    const double* __restrict__ state_in, const double* __restrict__ cov_in, const double* __restrict__ lin_in,
-    int iter_arg, double* __restrict__ state_out, double* __restrict__ a6_out, OutRec* __restrict__ out,
-    int4* __restrict__ idx_store, lins_pose_record* __restrict__ poses, int scan_id_base,
-    lins_corr* __restrict__ dump, double* __restrict__ sums_out, int* __restrict__ counts_out,
-    long long* __restrict__ prof_buf) {
-  constexpr bool prof = PROF;  // phase profile compiled in only for the debug variant
-  constexpr int kLBlock = BLOCK, kQPerWave = 64 / LANES, kQPerRound = (BLOCK / 64) * kQPerWave;
-  static_assert(kQPerRound <= kSlotCap && BLOCK >= 256 && BLOCK / 64 <= kMaxLWaves, "block shape");
-  LdsStore& L = g_lds;
-  // optional phase profile: [0] setup+grid build [1] correspondence [2] reduction [3] solve [4] update [5] total
-  // accumulators live in LDS (thread 0 only) so that the profiled variant keeps the register
-  // allocation of the production one: [0] setup [1] corr [2] reduce [3] solve [4] update [5] total
-  // [6..9] thread 0's own de-skew / NN / walk / geometry  [10..15] per-iteration time of iterations 0..5
-  if (prof && threadIdx.x < 16) g_lds.prof_acc[threadIdx.x] = 0;
-  const long long t_begin = prof ? clock64() : 0;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int scan = blockIdx.x;
-  const ScanDesc sd = descs[scan];
-  const int total = sd.n_surf_q + sd.n_corner_q;
-  const float4* tg_unused = arena;
-  (void)tg_unused;
-
-  for (int k = tid; k < 324; k += kLBlock) L.P[k] = PASS_ONLY ? 0.0 : cov_in[(size_t)scan * 324 + k];
-  if (tid < 19) {
-    double v = state_in[(size_t)scan * 19 + tid];
-    L.filt[tid] = v;
-    L.ic.lin[tid] = PASS_ONLY ? lin_in[(size_t)scan * 19 + tid] : v;
-  }
-  if (tid < 28) L.sums[tid] = 0;
-  if (tid == 0) {
-    L.res_prev = 1e6, L.res_last = 0, L.upd_norm = 0;
-    L.iter = PASS_ONLY ? iter_arg : 0, L.conv = 0, L.div = 0, L.m_surf = 0, L.m_corner = 0;
-    L.dbg[0] = L.dbg[1] = L.dbg[2] = L.dbg[3] = 0;
-  }
-  __syncthreads();
-  if (tid < 64) {  // wave 0, lane-redundant: constants of the first iteration
-    IterConst ic;
-    double filt[19];
-    for (int k = 0; k < 19; ++k) ic.lin[k] = L.ic.lin[k], filt[k] = L.filt[k];
-    make_iter_const(filt, ic);
-    if (tid == 0) {
-      L.ic.phi = ic.phi, L.ic.Rt = ic.Rt, L.ic.Gt = ic.Gt;
-      for (int k = 0; k < 18; ++k) L.ic.d[k] = ic.d[k];
-    }
-  }
-  build_lds_grid<BLOCK>(L, sd, arena, tid);  // ends with a barrier
-  if (prof && tid == 0) L.prof_acc[0] = clock64() - t_begin;
-
-  const LCloud cs{L.cell_end, L.ring_start[0], &L.el_ang[0][0], kAzSurf, 1, 0, sd.n_surf_t};
-  const LCloud cc{L.cell_end + kCellsSurf, L.ring_start[1], &L.el_ang[1][0], kAzCorner,
-                  kAzSurf / kAzCorner, sd.n_surf_t, sd.n_corner_t};
-  const int role = lane % LANES, lane_base = lane - role, q_in_wave = lane / LANES;
-  const bool lane_used = lane < kQPerWave * LANES;
-  // last iteration's triplet of this lane's query (grid positions) for the warm start; only
-  // meaningful when the scan needs a single round (the lane <-> query mapping is then fixed)
-  int a1 = -1, b1c = -1, ra1 = -1, rb1 = -1;  // nearest neighbour: tracked winner / runner-up (+ their rings)
-  int a2 = -1, b2c = -1, a3 = -1, b3c = -1;    // second and third point: tracked winner / runner-up
-  int sel1 = -1;                               // last iteration's nearest neighbour
-  // certificates of those three selections (see cert_lb / certified): lower bounds of every other
-  // candidate's distance and the query positions they were established at
-  float lb1 = 0.f, lb2 = 0.f, lb3 = 0.f, certA[3] = {0.f, 0.f, 0.f}, certB[3] = {0.f, 0.f, 0.f};
-  bool have_cert = false;
-
-  for (;;) {
-    const int iter = L.iter;
-    if (!PASS_ONLY && (iter >= prm.num_iter || L.conv || L.div)) break;
-    __syncthreads();  // everyone has read the loop state before it is rewritten
-    if (tid == 0) L.m_surf = 0, L.m_corner = 0;
-
-    const bool do_search = PASS_ONLY || (iter % prm.icp_freq) == 0;
-    double acc = 0;
-    int ms = 0, mc = 0;
-    long long t0 = prof ? clock64() : 0, t1 = t0, t2 = t0, t3 = t0;
-    // Query -> lane layout.  When both kinds fit one round with the corner queries starting on
-    // a wave boundary, do that: no wave then mixes plane and line code paths.
-    const int surf_waves = (sd.n_surf_q + kQPerWave - 1) / kQPerWave;
-    const bool aligned = surf_waves * kQPerWave + sd.n_corner_q <= kQPerRound;
-    const int span = aligned ? surf_waves * kQPerWave + sd.n_corner_q : total;  // row slots in use
-    for (int base = 0; base < span; base += kQPerRound) {
-      const int vslot = base + wave * kQPerWave + q_in_wave;  // position in the (padded) layout
-      int slot = vslot;                                        // query index: surf first, then corner
-      bool active = lane_used && vslot < span;
-      if (aligned) {
-        if (wave < surf_waves)
-          active = active && vslot < sd.n_surf_q;
-        else
-          slot = vslot - surf_waves * kQPerWave + sd.n_surf_q;
-      }
-      double row[7] = {0, 0, 0, 0, 0, 0, 0};
-      if (active) {
-        const bool is_surf = slot < sd.n_surf_q;
-        const int qi = is_surf ? slot : slot - sd.n_surf_q;
-        const float4 q = arena[(is_surf ? sd.off_surf_q : sd.off_corner_q) + qi];
-        const LCloud& c = is_surf ? cs : cc;
-        V3 phi = L.ic.phi;
-        V3 t{L.ic.lin[0], L.ic.lin[1], L.ic.lin[2]};
-        QueryOut o;
-        long long s0 = prof ? clock64() : 0, s1 = s0, s2 = s0;
-        transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2]);
-        if (prof) {
-          s1 = clock64();
-          if (tid == 0) L.prof_acc[6] += s1 - s0;
-        }
-        o.accepted = 0;
-        o.c[0] = o.c[1] = o.c[2] = o.c[3] = 0.f;
-        int p1 = -1, p2 = -1, p3 = -1;  // grid positions of the three target points
-        if (do_search) {
-          const bool single_round = span <= kQPerRound;
-          if (!single_round) a1 = b1c = a2 = b2c = a3 = b3c = sel1 = -1, have_cert = false;
-          QueryPolar qp;
-          qp.rho = sqrtf(o.sel[0] * o.sel[0] + o.sel[1] * o.sel[1]);
-          qp.qn3 = sqrtf(qp.rho * qp.rho + o.sel[2] * o.sel[2]);
-          qp.el = atan2f(o.sel[2], qp.rho);
-          qp.inv_unused = 0.f;
-          qp.a0_surf_or_corner = az_bin(o.sel[0], o.sel[1], c.naz);
-          const float thr = prm.nearest_f;
-          const float margin = have_cert ? prm.margin_warm : prm.margin_cold;
-          auto dist_to = [&](int pos) { return sqdist3(L.px[pos], L.py[pos], L.pz[pos], o.sel[0], o.sel[1], o.sel[2]); };
-          auto drift_from = [&](const float* cp) {
-            float ex = o.sel[0] - cp[0], ey = o.sel[1] - cp[1], ez = o.sel[2] - cp[2];
-            return sqrtf(ex * ex + ey * ey + ez * ez);
-          };
-          // Per selection the last search left two tracked candidates — the winner A and the
-          // runner-up B (grid positions, -1 = absent) — and a lower bound lb for the distance of every
-          // other candidate.  While everybody else is certified to stay farther than the closer of
-          // A and B, the selection is re-decided between those two from their distances alone
-          // (same strict (distance, key) order as the search); otherwise the search runs again,
-          // warm-started from A.
-          const unsigned long long kNone = ~0ull;
-          const bool verify = (prm.pad & 8) != 0;  // test aid: search anyway and count disagreements
-          // --- nearest neighbour -----------------------------------------------------------------------
-          {
-            const float da = a1 >= 0 ? dist_to(a1) : INFINITY, db = b1c >= 0 ? dist_to(b1c) : INFINITY;
-            bool ok = have_cert && !(prm.pad & 16) && certified(fminf(fminf(da, db), thr), lb1, drift_from(certA));
-            const unsigned long long ka = da < thr ? pack_key(da, (int)L.pidx[a1]) : kNone;
-            const unsigned long long kb = db < thr ? pack_key(db, (int)L.pidx[b1c]) : kNone;
-            const bool flip = kb < ka;
-            const int pred = (flip ? kb : ka) == kNone ? -1 : (flip ? b1c : a1);
-            const bool said = ok;
-            if (verify) ok = false;
-            if (!ok) {
-              if ((prm.pad & 32) && __ffsll(__ballot(1)) - 1 == lane) atomicAdd(&L.dbg[3], 1 + (iter >= 3 ? 1000 : 0));
-              Best bb = best_init(thr);
-              if (!(prm.pad & 2))  // (profiling aid: LINS_DEBUG_SKIP=2 skips the search, 1 skips the walk)
-                bb = nn_lds<LANES>(L, c, o.sel[0], o.sel[1], o.sel[2], qp, thr, margin, ring_of(q.w), role, lane_base, a1,
-                                   ra1);
-              p1 = bb.pos;  // (a winner beat the threshold sentinel, so its distance is < thr, SE:851)
-              if (said && p1 != pred && role == 0) atomicAdd(&L.dbg[0], 1);
-              a1 = bb.pos, ra1 = bb.ring, b1c = bb.pos2, rb1 = bb.ring2;
-              lb1 = cert_lb(bb, thr, margin);
-              certA[0] = o.sel[0], certA[1] = o.sel[1], certA[2] = o.sel[2];
-            } else {
-              p1 = pred;
-              if (flip) {  // the runner-up took over: swap the two tracked candidates
-                const int tp = a1, tr = ra1;
-                a1 = b1c, ra1 = rb1, b1c = tp, rb1 = tr;
-              }
-              if (role == 0) atomicAdd(&L.dbg[1], 1);
-            }
-          }
-          const bool nn_changed = p1 != sel1;
-          sel1 = p1;
-          if (prof) {
-            s2 = clock64();
-            if (tid == 0) L.prof_acc[7] += s2 - s1;
-          }
-          // --- second / third point ------------------------------------------------------------------
-          if (p1 >= 0) {
-            const int j1 = (int)L.pidx[p1], rho1 = ra1;  // (p1 >= 0 => p1 is candidate A)
-            bool need_walk = nn_changed || !have_cert;
-            int pred2 = -1, pred3 = -1;
-            bool flip2 = false, flip3 = false, said23 = false;
-            if (!need_walk) {
-              const WalkCtx w = make_walk_ctx(c, is_surf ? sd.n_surf_q : sd.n_corner_q, j1, rho1);
-              const float dB = drift_from(certB);
-              auto judge = [&](int pa, int pb, float lb, int& pred, bool& flip) {
-                const float da = pa >= 0 ? dist_to(pa) : INFINITY, db = pb >= 0 ? dist_to(pb) : INFINITY;
-                int rka = 0, rkb = 0;
-                if (pa >= 0) walk_rank(w, (int)L.pidx[pa], rka);
-                if (pb >= 0) walk_rank(w, (int)L.pidx[pb], rkb);
-                const unsigned long long ka = da < thr ? pack_key(da, rka) : kNone;
-                const unsigned long long kb = db < thr ? pack_key(db, rkb) : kNone;
-                flip = kb < ka;
-                pred = (flip ? kb : ka) == kNone ? -1 : (flip ? pb : pa);
-                return certified(fminf(fminf(da, db), thr), lb, dB);
-              };
-              bool ok23 = judge(a2, b2c, lb2, pred2, flip2);
-              if (is_surf) ok23 = judge(a3, b3c, lb3, pred3, flip3) && ok23;
-              said23 = ok23;
-              need_walk = !ok23 || verify;
-            }
-            if (need_walk) {
-              if ((prm.pad & 32) && __ffsll(__ballot(1)) - 1 == lane) atomicAdd(&L.dbg[0], 1 + (iter >= 3 ? 1000 : 0));
-              Best c2 = best_init(thr), c3 = c2;
-              if (!(prm.pad & 1))
-                walk_lds<LANES>(L, c, is_surf, is_surf ? sd.n_surf_q : sd.n_corner_q, thr, j1, rho1, o.sel[0], o.sel[1],
-                                o.sel[2], qp, margin, role, lane_base, nn_changed ? -1 : a2, nn_changed ? -1 : a3, c2, c3);
-              if (said23 && (c2.pos != pred2 || (is_surf && c3.pos != pred3)) && role == 0) atomicAdd(&L.dbg[0], 1);
-              p2 = c2.pos, p3 = c3.pos;
-              a2 = c2.pos, b2c = c2.pos2, a3 = c3.pos, b3c = c3.pos2;
-              lb2 = cert_lb(c2, thr, margin), lb3 = cert_lb(c3, thr, margin);
-              certB[0] = o.sel[0], certB[1] = o.sel[1], certB[2] = o.sel[2];
-            } else {
-              p2 = pred2, p3 = pred3;
-              if (flip2) {
-                const int tp = a2;
-                a2 = b2c, b2c = tp;
-              }
-              if (flip3) {
-                const int tp = a3;
-                a3 = b3c, b3c = tp;
-              }
-              if (role == 0) atomicAdd(&L.dbg[2], 1);
-            }
-          }
-          have_cert = single_round;
-          if (prof && tid == 0) L.prof_acc[8] += clock64() - s2;
-          if (prm.icp_freq > 1 && role == 0) idx_store[sd.slot_base + slot] = make_int4(p1, p2, p3, 0);
-        } else {
-          int4 s = idx_store[sd.slot_base + slot];
-          p1 = s.x, p2 = s.y, p3 = s.z;
-        }
-        long long s3 = prof ? clock64() : 0;
-        if (role == 0) {
-          if (is_surf) {
-            if (p2 >= 0 && p3 >= 0)
-              surf_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], make_float4(L.px[p1], L.py[p1], L.pz[p1], 0.f),
-                       make_float4(L.px[p2], L.py[p2], L.pz[p2], 0.f), make_float4(L.px[p3], L.py[p3], L.pz[p3], 0.f),
-                       o);
-          } else if (p2 >= 0) {
-            corner_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], make_float4(L.px[p1], L.py[p1], L.pz[p1], 0.f),
-                       make_float4(L.px[p2], L.py[p2], L.pz[p2], 0.f), o);
-          }
-          if (o.accepted) {
-            V3 cv{(double)o.c[0], (double)o.c[1], (double)o.c[2]};
-            V3 u = cross(V3{(double)q.x, (double)q.y, (double)q.z}, mvec(L.ic.Rt, cv));
-            V3 a = mvec(L.ic.Gt, u);
-            row[0] = cv.x, row[1] = cv.y, row[2] = cv.z, row[3] = a.x, row[4] = a.y, row[5] = a.z;
-            row[6] = prm.lidar_scale * (double)o.c[3];
-            if (is_surf)
-              ++ms;
-            else
-              ++mc;
-          }
-          if (PASS_ONLY && dump) {
-            lins_corr r;
-            r.ind1 = p1 >= 0 ? (int)L.pidx[p1] : -1;
-            r.ind2 = p2 >= 0 ? (int)L.pidx[p2] : -1;
-            r.ind3 = (is_surf && p3 >= 0) ? (int)L.pidx[p3] : -1;
-            r.accepted = o.accepted;
-            for (int k = 0; k < 4; ++k) r.coeff[k] = o.c[k];
-            r.sel[0] = o.sel[0], r.sel[1] = o.sel[1], r.sel[2] = o.sel[2], r.sel[3] = q.w;
-            dump[sd.slot_base + slot] = r;
-          }
-        }
-        if (prof && tid == 0) L.prof_acc[9] += clock64() - s3;
-      }
-      if (lane_used && role == 0) {
-        const int local = wave * kQPerWave + q_in_wave;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) L.slots[local * 7 + k] = row[k];
-      }
-      __syncthreads();
-      if (prof) t1 = clock64();
-      // rows -> 28 sums, every wave takes part: half-wave h of wave w folds rows 2w+h, 2w+h+G, ...
-      // (G = 2 * waves) in order, the two halves are added, then the wave partials are folded in
-      // wave order.  The tree is fixed, so the sums are bit-reproducible from run to run.
-      const int nrows = span - base < kQPerRound ? span - base : kQPerRound;
-      {
-        constexpr int G = 2 * (BLOCK / 64);
-        const int k = lane & 31;
-        const int a = kLPairA[k < 28 ? k : 0], b = kLPairB[k < 28 ? k : 0];
-#pragma unroll 2
-        for (int r = 2 * wave + (lane >> 5); r < nrows; r += G) acc += L.slots[r * 7 + a] * L.slots[r * 7 + b];
-      }
-      __syncthreads();
-    }
-    acc += __shfl_down(acc, 32);
-    if (lane < 28) L.partial[wave * 28 + lane] = acc;
-    if (ms) atomicAdd(&L.m_surf, ms);
-    if (mc) atomicAdd(&L.m_corner, mc);
-    __syncthreads();
-    if (tid < 28) {
-      double sacc = 0;
-#pragma unroll
-      for (int g = 0; g < BLOCK / 64; ++g) sacc += L.partial[g * 28 + tid];
-      L.sums[tid] = sacc;
-    }
-    __syncthreads();
-    if (prof) t2 = clock64();
-    if (PASS_ONLY && (prm.pad & 4) && !L.conv) {
-      // test aid: repeat the pass with the warm start fed by the first one — a warm search at
-      // the same state must return the very same triplets (exercises the tightest bounds)
-      __syncthreads();
-      if (tid == 0) L.conv = 1;
-      continue;
-    }
-    if (PASS_ONLY) {
-      if (sums_out && tid < 28) sums_out[(size_t)scan * 28 + tid] = L.sums[tid];
-      if (counts_out && tid == 0) counts_out[scan * 2] = L.m_surf, counts_out[scan * 2 + 1] = L.m_corner;
-      return;
-    }
-
-    solve_and_update(prm, tid, iter, prof, t3);
-    if (prof) {
-      long long t4 = clock64();
-      if (tid == 0) {
-        L.prof_acc[1] += t1 - t0, L.prof_acc[2] += t2 - t1, L.prof_acc[3] += t3 - t2, L.prof_acc[4] += t4 - t3;
-        if (iter < 6) L.prof_acc[10 + iter] = t4 - t0;
-      }
-    }
-  }
-  if (prof && tid == 0) {
-    long long* prof_out = prof_buf;
-    L.prof_acc[5] = clock64() - t_begin;
-    for (int k = 0; k < 16; ++k) prof_out[(size_t)scan * 16 + k] = L.prof_acc[k];
-  }
-
-  // ---- hand-off to the Joseph kernel / the caller (SE:585-598) ---------------
-  const int div = L.div;
-  if (tid < 19) state_out[(size_t)scan * 19 + tid] = div ? L.filt[tid] : L.ic.lin[tid];
-  if (tid < 21) a6_out[(size_t)scan * 21 + tid] = L.sums[tid];
-  if (tid == 0) {
-    OutRec r;
-    r.residual_norm = L.res_last, r.update_norm = L.upd_norm;
-    r.iters = L.iter, r.converged = L.conv, r.diverged = div;
-    r.m_surf = L.m_surf, r.m_corner = L.m_corner;
-    r.pad[0] = L.dbg[0], r.pad[1] = (prm.pad & 32) ? L.dbg[3] : L.dbg[1], r.pad[2] = L.dbg[2];
-    out[scan] = r;
-  }
-  if (poses && tid < 32) {
-    lins_pose_record* pr = poses + scan;
-    const double* st = div ? L.filt : L.ic.lin;
-    if (tid < 19) pr->state[tid] = st[tid];
-    if (tid == 19) pr->residual_norm = L.res_last;
-    if (tid == 20) {
-      pr->iters = L.iter, pr->converged = L.conv, pr->diverged = div;
-      pr->m_surf = L.m_surf, pr->m_corner = L.m_corner, pr->scan_id = scan_id_base + scan;
-      pr->pad[0] = pr->pad[1] = 0;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-int lds_np_cap() { return kNpCap; }
-
-// Two shapes of the same kernel:
-//   lanes = 1: 384 threads, one lane per query  (fewest instructions issued per update)
-//   lanes = 3: 1024 threads, three lanes per query (shortest critical path per iteration)
 void launch_lds(hipStream_t stream, int n, const DevParams& prm, int lanes, const ScanDesc* descs,
                 const float4* arena, const double* state_in, const double* cov_in, double* state_out, double* a6,
                 void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof) {
-#define LINS_LAUNCH_LDS(B, LN, PR)                                                                              \
-  hipLaunchKernelGGL((ieskf_lds_kernel<B, LN, false, PR>), dim3(n), dim3(B), 0, stream, prm, descs, arena, state_in, \
-                     cov_in, (const double*)nullptr, 0, state_out, a6, (OutRec*)out, idx_store, poses, scan_id_base, \
-                     (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof)
+  float4* sorted = nullptr;
   if (lanes == 3) {
     if (prof)
-      LINS_LAUNCH_LDS(1024, 3, true);
+      LINS_LAUNCH(lds_full, 1024, 3, true);
     else
-      LINS_LAUNCH_LDS(1024, 3, false);
+      LINS_LAUNCH(lds_full, 1024, 3, false);
   } else {
     if (prof)
-      LINS_LAUNCH_LDS(384, 1, true);
+      LINS_LAUNCH(lds_full, 384, 1, true);
     else
-      LINS_LAUNCH_LDS(384, 1, false);
+      LINS_LAUNCH(lds_full, 384, 1, false);
   }
-#undef LINS_LAUNCH_LDS
 }
 
 void launch_lds_pass(hipStream_t stream, int n, const DevParams& prm, int lanes, const ScanDesc* descs,
                      const float4* arena, const double* lin_state, const double* filt_state, int iter,
                      int4* idx_store, lins_corr* dump, double* sums_out, int* counts_out) {
+  float4* sorted = nullptr;
   if (lanes == 3)
-    hipLaunchKernelGGL((ieskf_lds_kernel<1024, 3, true, false>), dim3(n), dim3(1024), 0, stream, prm, descs, arena, filt_state,
-                       (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr, (OutRec*)nullptr,
-                       idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out, (long long*)nullptr);
+    LINS_LAUNCH_PASS(lds_full, 1024, 3);
   else
-    hipLaunchKernelGGL((ieskf_lds_kernel<384, 1, true, false>), dim3(n), dim3(384), 0, stream, prm, descs, arena, filt_state,
-                       (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr, (OutRec*)nullptr,
-                       idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out, (long long*)nullptr);
+    LINS_LAUNCH_PASS(lds_full, 384, 1);
 }
 
 }  // namespace lins

@@ -1,0 +1,54 @@
+// ieskf_lds_mr.hip — "multi-resident" instantiation of the LDS IESKF kernel (ieskf_lds_impl.h): the
+// batch-throughput path.  512-thread workgroups (8 waves: two per SIMD, so the placement of a
+// workgroup's waves is balanced whatever SIMD the dispatcher starts on), one lane per query, whose
+// LDS holds only the first 4736 grid positions of the scan — the corner cloud and the low surf
+// rings, where nearly every search ends; the rest of the grid is a sorted copy in global memory
+// that the same loops fall through to.  At < 80 KB of LDS and 128 VGPRs two independent scans are
+// resident per CU and fill each other's barriers and serial tails (measured with the HW_ID /
+// wall-clock probe of the PROF variant, tools/residency.py).  Results are identical to the
+// full-residency kernel: the same loops run over the same grid, only the storage of a position
+// differs.
+//
+// Shapes that were measured and dropped: 384-thread workgroups (6 waves land 2,2,1,1 on the four
+// SIMDs, every workgroup starting on the same one, so a second / third workgroup only fits with
+// <= 128 / 80 VGPRs even when LDS would allow it); three workgroups per CU at 96 VGPRs (588 B of
+// scratch per lane: no faster than two).
+#define LINS_LDS_NS lds_mr
+#define LINS_LDS_CAP 4736
+#define LINS_LDS_NMAX 12288
+#define LINS_LDS_REGREDUCE 1
+#define LINS_LDS_WAVES 8
+#define LINS_LDS_MINW 4
+#define LINS_LDS_BYTES 80896
+#include "ieskf_lds_impl.h"
+
+namespace lins {
+
+#define LINS_LAUNCH(NS, B, LN, PR)                                                                                  \
+  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, false, PR>), dim3(n), dim3(B), 0, stream, prm, descs, arena, sorted, \
+                     state_in, cov_in, (const double*)nullptr, 0, state_out, a6, (NS::OutRec*)out, idx_store, poses,  \
+                     scan_id_base, (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof)
+#define LINS_LAUNCH_PASS(NS, B, LN)                                                                                    \
+  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, true, false>), dim3(n), dim3(B), 0, stream, prm, descs, arena, sorted, \
+                     filt_state, (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr,           \
+                     (NS::OutRec*)nullptr, idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out,        \
+                     (long long*)nullptr)
+
+int lds_mr_np_cap() { return lds_mr::kNpMax; }
+
+void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
+                   float4* sorted, const double* state_in, const double* cov_in, double* state_out, double* a6,
+                   void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof) {
+  if (prof)
+    LINS_LAUNCH(lds_mr, 512, 1, true);
+  else
+    LINS_LAUNCH(lds_mr, 512, 1, false);
+}
+
+void launch_lds_mr_pass(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
+                        float4* sorted, const double* lin_state, const double* filt_state, int iter,
+                        int4* idx_store, lins_corr* dump, double* sums_out, int* counts_out) {
+  LINS_LAUNCH_PASS(lds_mr, 512, 1);
+}
+
+}  // namespace lins

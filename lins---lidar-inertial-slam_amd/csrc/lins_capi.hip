@@ -28,6 +28,11 @@ void launch_lds(hipStream_t, int, const DevParams&, int, const ScanDesc*, const 
 void launch_lds_pass(hipStream_t, int, const DevParams&, int, const ScanDesc*, const float4*, const double*,
                      const double*, int, int4*, lins_corr*, double*, int*);
 int lds_np_cap();
+void launch_lds_mr(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, float4*, const double*,
+                   const double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*);
+void launch_lds_mr_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, float4*, const double*,
+                        const double*, int, int4*, lins_corr*, double*, int*);
+int lds_mr_np_cap();
 void launch_transform_to_end(hipStream_t, int, int, const void*, const float4*, float4*, float4*);
 size_t reproject_job_size();
 struct ReprojectJobHost {
@@ -78,6 +83,9 @@ struct lins_ctx {
   int* d_counts = nullptr;
   int n_uploaded = 0;
   bool lds_ok = false;  // every uploaded scan fits the LDS-resident kernel
+  bool mr_ok = false;   // ... the multi-resident (hybrid LDS / global) kernel
+  int n_cu = 256;       // compute units of the device ("auto": batches beyond this take the mr kernel)
+  int last_search = -1; // kernel family the last batch actually ran
   bool ran = false;
   uint64_t bytes_per_iter = 0;
   uint64_t total_iters = 0;
@@ -134,13 +142,20 @@ void make_dev_params(const lins_params& p, int search, DevParams& d) {
   if (const char* e = std::getenv("LINS_DEBUG_SKIP")) d.pad = std::atoi(e);  // profiling aid: 1 = skip walks, 2 = skip search
 }
 
+// "auto": one workgroup per CU is all a small batch can use — the 1024-thread kernel gives each
+// scan the shortest critical path; beyond that the multi-resident kernel keeps two scans per CU.
+int effective_search(const lins_ctx* ctx, int n) {
+  if (ctx->dprm.search != SEARCH_AUTO) return ctx->dprm.search;
+  return n > ctx->n_cu ? (int)SEARCH_MR : (int)SEARCH_LDS3;
+}
+
 int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
   if (!ctx || !in || n < 0) return LINS_E_ARG;
   if (n > ctx->max_batch) return LINS_E_CAPACITY;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   size_t off = 0, slots = 0;
   uint64_t bytes = 0;
-  bool lds_ok = true;
+  bool lds_ok = true, mr_ok = true;
   for (int s = 0; s < n; ++s) {
     const lins_scan_pair& p = in[s];
     if (p.n_surf_flat < 0 || p.n_corner_sharp < 0 || p.n_surf_last < 0 || p.n_corner_last < 0) return LINS_E_ARG;
@@ -172,6 +187,7 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
     d.off_corner_t = offs[3], d.n_corner_t = cnt[3];
     d.surf_sorted = ss, d.corner_sorted = cs;
     if (!ss || !cs || cnt[2] + cnt[3] > lds_np_cap()) lds_ok = false;
+    if (!ss || !cs || cnt[2] + cnt[3] > lds_mr_np_cap()) mr_ok = false;
     d.slot_base = (int)slots;
     d.pad = 0;
     slots += cnt[0] + cnt[1];
@@ -187,6 +203,7 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->n_uploaded = n;
   ctx->lds_ok = lds_ok;
+  ctx->mr_ok = mr_ok;
   ctx->ran = false;
   ctx->bytes_per_iter = bytes;
   return LINS_OK;
@@ -221,7 +238,7 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   if (!ctx) return LINS_E_ARG;
   ctx->device = device;
   ctx->prm = *params;
-  make_dev_params(*params, SEARCH_BRUTE, ctx->dprm);
+  make_dev_params(*params, SEARCH_AUTO, ctx->dprm);  // (ineligible clouds fall back to the exact exhaustive paths)
   ctx->max_batch = max_batch;
   ctx->max_targets = max_targets;
   ctx->arena_cap = (size_t)max_batch * (2 * align4(max_targets) + 2 * LINS_MAX_QUERY);
@@ -236,6 +253,10 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
     }                                                \
   } while (0)
   CREATE_TRY(hipSetDevice(device));
+  {
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) ctx->n_cu = ncu;
+  }
   CREATE_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   CREATE_TRY(hipEventCreate(&ctx->ev0));
   CREATE_TRY(hipEventCreate(&ctx->ev1));
@@ -309,6 +330,10 @@ int lins_set_search(lins_ctx* ctx, const char* mode) {
     ctx->dprm.search = SEARCH_LDS3;
   else if (!std::strcmp(mode, "lds1"))  // LDS-resident grid, 384 threads, 1 lane per query
     ctx->dprm.search = SEARCH_LDS;
+  else if (!std::strcmp(mode, "mr"))  // multi-resident: part of the grid in LDS, 2 scans per CU
+    ctx->dprm.search = SEARCH_MR;
+  else if (!std::strcmp(mode, "auto"))  // "mr" for batches larger than the CU count, "lds" otherwise
+    ctx->dprm.search = SEARCH_AUTO;
   else
     return LINS_E_ARG;
   return LINS_OK;
@@ -321,21 +346,30 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   if (ctx->n_uploaded <= 0) return LINS_E_STATE;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  const bool want_lds = ctx->dprm.search >= SEARCH_LDS;
-  if (want_lds && ctx->lds_ok) {
-    launch_lds(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->dprm.search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc, ctx->d_arena, ctx->d_state_in, ctx->d_cov_in,
-               ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx, (lins_pose_record*)d_poses, scan_id_base, ctx->d_prof);
+  const int search = effective_search(ctx, ctx->n_uploaded);
+  const bool want_lds = search >= SEARCH_LDS, want_mr = search == SEARCH_MR;
+  const bool use_mr = want_mr && ctx->mr_ok, use_lds = want_lds && !want_mr && ctx->lds_ok;
+  ctx->last_search = use_mr ? SEARCH_MR : (use_lds ? search : (want_lds ? (int)SEARCH_BINNED : search));
+  if (use_mr || use_lds) {
+    if (use_mr)
+      launch_lds_mr(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_binned, ctx->d_state_in,
+                    ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx, (lins_pose_record*)d_poses,
+                    scan_id_base, ctx->d_prof);
+    else
+      launch_lds(ctx->stream, ctx->n_uploaded, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc,
+                 ctx->d_arena, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx,
+                 (lins_pose_record*)d_poses, scan_id_base, ctx->d_prof);
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     launch_joseph(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_cov_in, ctx->d_a6, ctx->d_out, ctx->d_cov_out);
   } else {
     DevParams dp = ctx->dprm;
-    if (want_lds) dp.search = SEARCH_BINNED;  // a scan does not fit LDS: global-memory grid
+    dp.search = want_lds ? (int)SEARCH_BINNED : search;  // a scan does not fit LDS: global-memory grid
     launch_persistent(ctx->stream, ctx->n_uploaded, dp, ctx->d_desc, ctx->d_arena, ctx->d_state_in, ctx->d_cov_in,
                       ctx->d_state_out, ctx->d_cov_out, ctx->d_a6, ctx->d_out, ctx->d_idx,
                       (lins_pose_record*)d_poses, scan_id_base, ctx->d_binned, ctx->d_prof);
   }
   HIP_TRY(ctx, hipGetLastError());
-  if (!(want_lds && ctx->lds_ok)) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  if (!(use_mr || use_lds)) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
   ctx->ran = true;
   return LINS_OK;
@@ -504,14 +538,19 @@ static int run_pass(lins_ctx* ctx, const lins_scan_pair* in, const double* lin_s
   if (rc) return rc;
   ctx->n_uploaded = 0;  // the single-pass calls do not leave a runnable batch behind
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_lin, lin_state, 19 * 8, hipMemcpyHostToDevice, ctx->stream));
-  const bool want_lds = ctx->dprm.search >= SEARCH_LDS;
-  if (want_lds && ctx->lds_ok) {
-    launch_lds_pass(ctx->stream, 1, ctx->dprm, ctx->dprm.search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc, ctx->d_arena, ctx->d_lin, ctx->d_state_in, iter,
+  const int search = effective_search(ctx, 1);
+  const bool want_lds = search >= SEARCH_LDS, want_mr = search == SEARCH_MR;
+  if (want_mr && ctx->mr_ok) {
+    launch_lds_mr_pass(ctx->stream, 1, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_binned, ctx->d_lin,
+                       ctx->d_state_in, iter, ctx->d_idx, dump ? ctx->d_dump : nullptr, sums ? ctx->d_sums : nullptr,
+                       sums ? ctx->d_counts : nullptr);
+  } else if (want_lds && !want_mr && ctx->lds_ok) {
+    launch_lds_pass(ctx->stream, 1, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc, ctx->d_arena, ctx->d_lin, ctx->d_state_in, iter,
                     ctx->d_idx, dump ? ctx->d_dump : nullptr, sums ? ctx->d_sums : nullptr,
                     sums ? ctx->d_counts : nullptr);
   } else {
     DevParams dp = ctx->dprm;
-    if (want_lds) dp.search = SEARCH_BINNED;
+    dp.search = want_lds ? (int)SEARCH_BINNED : search;
     launch_pass(ctx->stream, 1, dp, ctx->d_desc, ctx->d_arena, ctx->d_lin, ctx->d_state_in, iter, ctx->d_idx,
                 dump ? ctx->d_dump : nullptr, sums ? ctx->d_sums : nullptr, sums ? ctx->d_counts : nullptr,
                 ctx->d_binned);

@@ -62,7 +62,7 @@ def ctx(pkg, ieskf):
     c.close()
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1", "mr", "auto"])
 @pytest.mark.parametrize("kind", ["lattice", "dup", "axis", "offgrid"])
 def test_adversarial_clouds_exact_indices(pkg, oracle, ctx, search, kind):
     ctx.set_search(search)
@@ -79,7 +79,7 @@ def test_adversarial_clouds_exact_indices(pkg, oracle, ctx, search, kind):
             assert_same_corr(corner, wc, f"{kind}/{trial}/it{it}/corner")
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1", "mr", "auto"])
 def test_forward_walk_is_bounded_by_query_count(pkg, oracle, ctx, search):
     """SE:859/983: the forward walk stops at j < N_query.  Few queries => forward part empty;
     many queries (> targets) => our min(N_query, N_target) guard."""
@@ -108,7 +108,7 @@ def test_forward_walk_is_bounded_by_query_count(pkg, oracle, ctx, search):
                 assert np.abs(got.state - want.state).max() <= 1e-6 * max(1.0, np.abs(want.state).max())
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1", "mr", "auto"])
 def test_mixed_batch_with_one_oversized_scan(pkg, oracle, ctx, search):
     """One scan too large for LDS sends the whole batch down the global-memory grid path."""
     ctx.set_search(search)
@@ -123,7 +123,7 @@ def test_mixed_batch_with_one_oversized_scan(pkg, oracle, ctx, search):
             assert np.abs(got.state - want.state).max() <= 1e-6 * max(1.0, np.abs(want.state).max())
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1", "mr", "auto"])
 def test_unsorted_rings_and_high_ring_ids_fall_back_exactly(pkg, oracle, ctx, search):
     ctx.set_search(search)
     prm = pkg.default_params()
@@ -136,7 +136,7 @@ def test_unsorted_rings_and_high_ring_ids_fall_back_exactly(pkg, oracle, ctx, se
         assert_same_corr(corner, wc, "corner")
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1", "mr", "auto"])
 def test_empty_and_ragged_inputs(pkg, oracle, ctx, search):
     ctx.set_search(search)
     prm = pkg.default_params(num_iter=5)
@@ -155,7 +155,7 @@ def test_empty_and_ragged_inputs(pkg, oracle, ctx, search):
     del prm
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1", "mr", "auto"])
 def test_maximum_sizes(pkg, oracle, ctx, search):
     """1024 queries per cloud (LINS_MAX_QUERY; > one 512-slot reduction round) and a
     full 16x1800 target cloud."""
@@ -281,3 +281,22 @@ def test_update_point_cloud_reprojection_matches_host(pkg, ieskf, host, pairs):
         assert none == [None, None] and np.array_equal(xyz2[0], xyz[0])
         # a context that has just re-projected can go straight back to IESKF updates
         assert c.update(pairs[0]).iters >= 1
+
+
+@pytest.mark.parametrize("search", ["lds", "lds1", "mr"])
+@pytest.mark.parametrize("shape", [(0, 400, 300), (0, 900, 3000), (700, 0, 5000), (500, 500, 9500)])
+def test_more_queries_than_one_round_of_lanes(pkg, oracle, ctx, search, shape):
+    """More queries than a workgroup has query slots (336 / 384 / 512): several rounds over the same
+    LDS grid, no state carried from round to round (regression: a 16/32-bit aliasing assumption in
+    the grid build once let later rounds read stale cell bounds).  The last shape also exceeds the
+    resident part of the multi-resident kernel's grid (hybrid LDS / global storage)."""
+    ctx.set_search(search)
+    prm = pkg.default_params()
+    rng = np.random.default_rng(7)
+    n_sq, n_cq, n_t = shape
+    pair = make_pair(pkg, rng, n_sq, n_cq, n_t, n_t // 4 if n_t > 4000 else n_t, "lattice")
+    for it in (0, 1):
+        surf, corner = ctx.correspondences(pair, pair.state, it)
+        ws, wc = oracle.correspondences(prm, pair, pair.state, it, oracle.NN_BRUTE)
+        assert_same_corr(surf, ws, "surf")
+        assert_same_corr(corner, wc, "corner")

@@ -48,7 +48,7 @@ def ctx(pkg, ieskf):
     c.close()
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1", "mr", "auto"])
 def test_correspondences_bit_exact_along_oracle_trajectory(pkg, oracle, ctx, pairs, search):
     """configs[1]: device A2+A3 at every linearisation state the oracle visits."""
     ctx.set_search(search)
@@ -62,7 +62,7 @@ def test_correspondences_bit_exact_along_oracle_trajectory(pkg, oracle, ctx, pai
             assert_corr_equal(corner, tr["corner"][k], f"iter{k}.corner")
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1", "mr", "auto"])
 def test_reduction_and_host_solve(pkg, ieskf, oracle, ctx, pairs, search):
     """configs[1]: on-device 28-sum reduction + host-side 18x18 solve == oracle dx."""
     ctx.set_search(search)
@@ -78,7 +78,7 @@ def test_reduction_and_host_solve(pkg, ieskf, oracle, ctx, pairs, search):
         assert np.abs(dx - tr["dx"][k]).max() <= 1e-8 * max(1.0, np.abs(tr["dx"][k]).max())
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1", "mr", "auto"])
 def test_full_ieskf_matches_oracle(pkg, oracle, ctx, pairs, search):
     """configs[2]: on-device reduction + solve + full loop, reference stop rule."""
     ctx.set_search(search)
@@ -110,7 +110,7 @@ def test_fixed_iteration_mode_and_batch(pkg, ieskf, oracle, pairs):
         assert c.last_kernel_ms() > 0
 
 
-@pytest.mark.parametrize("search", ["lds", "lds1"])
+@pytest.mark.parametrize("search", ["lds", "lds1", "mr", "auto"])
 def test_warm_started_search_returns_the_same_triplets(pkg, ieskf, oracle, pairs, search, monkeypatch):
     """Iterations >= 1 start the search from the previous iteration's triplet (bounds only).
     Debug flag 4 makes the single-pass kernel run the pass twice, the second time warm: the
@@ -126,7 +126,7 @@ def test_warm_started_search_returns_the_same_triplets(pkg, ieskf, oracle, pairs
                 assert_corr_equal(corner, tr["corner"][k], f"warm.iter{k}.corner")
 
 
-@pytest.mark.parametrize("search", ["lds", "lds1"])
+@pytest.mark.parametrize("search", ["lds", "lds1", "mr", "auto"])
 def test_search_certificates_never_disagree_with_a_real_search(pkg, ieskf, oracle, host, search, monkeypatch):
     """From iteration 1 on a query keeps its previous triplet when a certificate proves a search
     would return it again.  Debug flag 8 searches anyway and counts disagreements on device."""
