@@ -23,6 +23,7 @@
 //   LINS_LDS_CAP        grid positions resident in LDS
 //   LINS_LDS_NMAX       target points a scan may have (> CAP: hybrid LDS / global storage)
 //   LINS_LDS_REGREDUCE  1: rows -> 28 sums through register butterflies (no row slots in LDS)
+//   LINS_LDS_SCANBATCH  points whose LDS reads are in flight together in the scan loops
 //   LINS_LDS_WAVES      waves of the largest workgroup shape instantiated
 //   LINS_LDS_MINW       minimum waves per SIMD the register allocation must allow
 //   LINS_LDS_BYTES      LDS budget of one workgroup, checked at compile time
@@ -58,6 +59,7 @@ constexpr int kNpCap = LINS_LDS_CAP;   // grid positions (corner cloud first, th
 constexpr int kNpMax = LINS_LDS_NMAX;  // target points of an eligible scan
 constexpr bool kHybrid = kNpMax > kNpCap;  // positions >= kNpCap live in the sorted global copy
 constexpr bool kRegReduce = LINS_LDS_REGREDUCE != 0;
+constexpr int kScanBatch = LINS_LDS_SCANBATCH;  // points per trip of the scan loops
 constexpr int kSlotCap = 384;         // >= queries per round, row slots of 7 doubles
 constexpr int kCellsSurf = kRingsBinned * kAzSurf, kCellsCorner = kRingsBinned * kAzCorner;
 static_assert(kNpMax >= kNpCap && kNpMax <= 16384, "positions are u16, indices u16");
@@ -150,7 +152,8 @@ struct Best {
   __device__ __forceinline__ int key() const { return (int)(unsigned)k; }
 };
 __device__ __forceinline__ Best best_init(float thr) {
-  return Best{(unsigned long long)__float_as_uint(thr) << 32, -1, -1, ~0ull, -1, -1, INFINITY};
+  // (no runner-up yet: key (+inf, 0xFFFFFFFF), so that its distance word reads +inf)
+  return Best{(unsigned long long)__float_as_uint(thr) << 32, -1, -1, 0x7F800000FFFFFFFFull, -1, -1, INFINITY};
 }
 __device__ __forceinline__ unsigned long long pack_key(float d, int key) {
   return ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)key;
@@ -172,6 +175,15 @@ __device__ __forceinline__ void insert_key(Best& b, unsigned long long k, int po
 }
 __device__ __forceinline__ void consider(Best& b, float d, int key, int pos, int ring) {
   insert_key(b, pack_key(d, key), pos, ring);
+}
+// The scan loops' form of consider(): nearly every scanned point is farther than the current
+// runner-up and only lowers `omin` — one compare and a select, no branch; the 64-bit key logic runs
+// for the few that can enter the top two (ties on the runner-up's distance included).  `ok` masks
+// points that are not candidates at all (walk rank filter, batch padding).
+__device__ __forceinline__ void consider_scan(Best& b, bool ok, float d, int key, int pos, int ring) {
+  const bool cand = ok && d <= __uint_as_float((unsigned)(b.k2 >> 32));
+  b.omin = (ok && !cand) ? fminf(b.omin, d) : b.omin;
+  if (cand) insert_key(b, pack_key(d, key), pos, ring);
 }
 __device__ __forceinline__ void merge_from_lane(Best& b, int src_lane) {
   unsigned lo = __shfl((unsigned)b.k, src_lane), hi = __shfl((unsigned)(b.k >> 32), src_lane);
@@ -226,13 +238,26 @@ __device__ __forceinline__ void scan_cols(const LdsStore& L, const LCloud& c, in
   for (int k = 0; k < 2; ++k) {
     const int s = k ? s1 : s0, e = k ? e1 : e0;
     const int el = kHybrid ? (e < c.n_lds ? e : c.n_lds) : e;
-#pragma unroll 2
-    for (int p = s; p < el; ++p) f(L.px[p], L.py[p], L.pz[p], (int)L.pidx[p], p);
+    // kScanBatch points per trip, all their LDS reads issued before the first is consumed (the
+    // loop is latency bound: one dependent LDS round trip per trip instead of per point); the last
+    // trip re-reads the final point for its padding lanes and masks them
+#pragma unroll 1
+    for (int p = s; p < el; p += kScanBatch) {
+      float x[kScanBatch], y[kScanBatch], z[kScanBatch];
+      int j[kScanBatch];
+#pragma unroll
+      for (int u = 0; u < kScanBatch; ++u) {
+        const int pu = p + u < el ? p + u : el - 1;
+        x[u] = L.px[pu], y[u] = L.py[pu], z[u] = L.pz[pu], j[u] = (int)L.pidx[pu];
+      }
+#pragma unroll
+      for (int u = 0; u < kScanBatch; ++u) f(x[u], y[u], z[u], j[u], p + u, p + u < el);
+    }
     if (kHybrid) {
 #pragma unroll 1
       for (int p = s > c.n_lds ? s : c.n_lds; p < e; ++p) {
         const float4 g = c.gs[p];
-        f(g.x, g.y, g.z, __float_as_int(g.w), p);
+        f(g.x, g.y, g.z, __float_as_int(g.w), p, true);
       }
     }
   }
@@ -288,7 +313,9 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
   const int a0 = qp.a0_surf_or_corner;
   rq = rq < 0 ? 0 : (rq >= kRingsBinned ? kRingsBinned - 1 : rq);
   int rcur = rq;
-  auto f = [&](float x, float y, float z, int j, int p) { consider(b, sqdist3(x, y, z, sx, sy, sz), j, p, rcur); };
+  auto f = [&](float x, float y, float z, int j, int p, bool ok) {
+    consider_scan(b, ok, sqdist3(x, y, z, sx, sy, sz), j, p, rcur);
+  };
   const bool own = ring_nonempty(c, rq);
   // cold seed: columns a0-1..a0+1 of the query's own ring and of its two neighbours, one ring per
   // lane, merged before the bound is fixed — a query that sits between rings (or whose own ring is
@@ -398,9 +425,10 @@ __device__ __forceinline__ void walk_task(const LdsStore& L, const LCloud& c, co
                                           float qn3, float el_q, float margin, Best& cur) {
   bool go = walk_ring_has_candidates(c, w, r);
   if (go) go = ring_in_reach(c, r, el_q, reach_elev(qn3, sqrtf(cur.d()) + margin));
-  auto f = [&](float x, float y, float z, int j, int p) {
+  auto f = [&](float x, float y, float z, int j, int p, bool ok) {
     int rank;
-    if (walk_rank(w, j, rank)) consider(cur, sqdist3(x, y, z, sx, sy, sz), rank, p, 0);
+    const bool in_walk = walk_rank(w, j, rank);
+    consider_scan(cur, ok && in_walk, sqdist3(x, y, z, sx, sy, sz), rank, p, 0);
   };
   const bool seed = go && seed_first;
   scan_cols(L, c, r, seed ? a0 - 1 : 1, seed ? a0 + 1 : 0, f);
@@ -445,9 +473,10 @@ __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, boo
   const bool w2 = c2.pos >= 0, w3 = c3.pos >= 0;
   if (is_surf && !w2) {  // class-2 seed on ring rho: all lanes of the query
     bool go = walk_ring_has_candidates(c, w, rho);
-    auto f = [&](float x, float y, float z, int j, int p) {
+    auto f = [&](float x, float y, float z, int j, int p, bool ok) {
       int rank;
-      if (walk_rank(w, j, rank)) consider(c2, sqdist3(x, y, z, sx, sy, sz), rank, p, 0);
+      const bool in_walk = walk_rank(w, j, rank);
+      consider_scan(c2, ok && in_walk, sqdist3(x, y, z, sx, sy, sz), rank, p, 0);
     };
     scan_cols(L, c, rho, go ? a0 - 1 : 1, go ? a0 + 1 : 0, f);
   }
@@ -855,6 +884,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   constexpr bool prof = PROF;  // phase profile compiled in only for the debug variant
   constexpr int kLBlock = BLOCK, kQPerWave = 64 / LANES, kQPerRound = (BLOCK / 64) * kQPerWave;
   static_assert((kRegReduce || kQPerRound <= kSlotCap) && BLOCK >= 256 && BLOCK / 64 <= kMaxLWaves, "block shape");
+  // (LANES > 1 is dispatched for single-round scans only, see effective_search() in lins_capi.hip)
   LdsStore& L = g_lds;
   // optional phase profile: [0] setup+grid build [1] correspondence [2] reduction [3] solve [4] update [5] total
   // accumulators live in LDS (thread 0 only) so that the profiled variant keeps the register

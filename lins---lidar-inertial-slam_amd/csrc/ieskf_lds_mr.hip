@@ -16,6 +16,7 @@
 #define LINS_LDS_NS lds_mr
 #define LINS_LDS_CAP 4736
 #define LINS_LDS_NMAX 12288
+#define LINS_LDS_SCANBATCH 4
 #define LINS_LDS_REGREDUCE 1
 #define LINS_LDS_WAVES 8
 #define LINS_LDS_MINW 4

@@ -86,6 +86,7 @@ struct lins_ctx {
   bool mr_ok = false;   // ... the multi-resident (hybrid LDS / global) kernel
   int n_cu = 256;       // compute units of the device ("auto": batches beyond this take the mr kernel)
   int last_search = -1; // kernel family the last batch actually ran
+  bool lds3_ok = false; // every uploaded scan has at most 336 queries (one round of the 3-lane shape)
   bool ran = false;
   uint64_t bytes_per_iter = 0;
   uint64_t total_iters = 0;
@@ -144,9 +145,13 @@ void make_dev_params(const lins_params& p, int search, DevParams& d) {
 
 // "auto": one workgroup per CU is all a small batch can use — the 1024-thread kernel gives each
 // scan the shortest critical path; beyond that the multi-resident kernel keeps two scans per CU.
+// The 3-lane shape is the single-round kernel: query sets beyond its 336 slots (more than a VLP-16
+// front-end can emit) take the 1-lane shapes, whose several-rounds path is the tested one.
 int effective_search(const lins_ctx* ctx, int n) {
-  if (ctx->dprm.search != SEARCH_AUTO) return ctx->dprm.search;
-  return n > ctx->n_cu ? (int)SEARCH_MR : (int)SEARCH_LDS3;
+  int s = ctx->dprm.search;
+  if (s == SEARCH_AUTO) s = n > ctx->n_cu ? (int)SEARCH_MR : (int)SEARCH_LDS3;
+  if (s == SEARCH_LDS3 && !ctx->lds3_ok) s = SEARCH_LDS;
+  return s;
 }
 
 int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
@@ -155,7 +160,7 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   size_t off = 0, slots = 0;
   uint64_t bytes = 0;
-  bool lds_ok = true, mr_ok = true;
+  bool lds_ok = true, mr_ok = true, lds3_ok = true;
   for (int s = 0; s < n; ++s) {
     const lins_scan_pair& p = in[s];
     if (p.n_surf_flat < 0 || p.n_corner_sharp < 0 || p.n_surf_last < 0 || p.n_corner_last < 0) return LINS_E_ARG;
@@ -188,6 +193,7 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
     d.surf_sorted = ss, d.corner_sorted = cs;
     if (!ss || !cs || cnt[2] + cnt[3] > lds_np_cap()) lds_ok = false;
     if (!ss || !cs || cnt[2] + cnt[3] > lds_mr_np_cap()) mr_ok = false;
+    if (cnt[0] + cnt[1] > 336) lds3_ok = false;  // (16 waves x 21 query slots = the VLP-16 caps, 144 flat + 192 sharp)
     d.slot_base = (int)slots;
     d.pad = 0;
     slots += cnt[0] + cnt[1];
@@ -204,6 +210,7 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
   ctx->n_uploaded = n;
   ctx->lds_ok = lds_ok;
   ctx->mr_ok = mr_ok;
+  ctx->lds3_ok = lds3_ok;
   ctx->ran = false;
   ctx->bytes_per_iter = bytes;
   return LINS_OK;

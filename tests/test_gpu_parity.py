@@ -159,3 +159,22 @@ def test_search_certificates_never_disagree_with_a_real_search(pkg, ieskf, oracl
             assert np.abs(got.state[:3] - w.state[:3]).max() <= POS_TOL
             assert np.abs(got.cov - w.cov).max() <= COV_REL * np.abs(w.cov).max()
     del C
+
+
+def test_kernel_shapes_agree_on_a_batch_larger_than_the_cu_count(pkg, ieskf, host):
+    """320 scans (> 256 CUs: "auto" takes the multi-resident kernel, several workgroups per CU):
+    every kernel shape must accept the same rows in every scan and land on the same state — the
+    searches are exact, only the summation order of the 28 sums differs between the shapes."""
+    prm = pkg.default_params(num_iter=10, fixed_iters=1)
+    batch = host.synth_batch(320, start=2000)
+    out = {}
+    for search in ("lds", "lds1", "mr", "auto", "binned"):
+        with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384, search=search) as c:
+            out[search] = c.update_batch(batch)
+    ref = out["binned"]
+    for search, res in out.items():
+        for k, (r, w) in enumerate(zip(res, ref)):
+            assert (r.iters, r.diverged, r.converged, r.m_surf, r.m_corner) == \
+                   (w.iters, w.diverged, w.converged, w.m_surf, w.m_corner), (search, k)
+            assert np.abs(r.state - w.state).max() <= 1e-9 * max(1.0, np.abs(w.state).max()), (search, k)
+            assert np.abs(r.cov - w.cov).max() <= 1e-9 * np.abs(w.cov).max(), (search, k)
