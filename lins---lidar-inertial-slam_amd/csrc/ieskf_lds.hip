@@ -6,7 +6,9 @@
 #define LINS_LDS_NS lds_full
 #define LINS_LDS_CAP 8960
 #define LINS_LDS_NMAX 8960
+#ifndef LINS_LDS_SCANBATCH
 #define LINS_LDS_SCANBATCH 4
+#endif
 #define LINS_LDS_REGREDUCE 0
 #define LINS_LDS_WAVES 16
 #define LINS_LDS_MINW 1

@@ -16,7 +16,9 @@
 #define LINS_LDS_NS lds_mr
 #define LINS_LDS_CAP 4736
 #define LINS_LDS_NMAX 12288
-#define LINS_LDS_SCANBATCH 4
+#ifndef LINS_LDS_SCANBATCH
+#define LINS_LDS_SCANBATCH 2  // (measured: 1 -> 7.9, 2 -> 8.1, 3 -> 8.0, 4 -> 7.75, 8 -> 7.1 M it/s at 128 VGPRs)
+#endif
 #define LINS_LDS_REGREDUCE 1
 #define LINS_LDS_WAVES 8
 #define LINS_LDS_MINW 4
