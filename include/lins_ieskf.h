@@ -53,6 +53,7 @@ extern "C" {
 #define LINS_E_INPUT (-4)     /* cloud violates the input contract (NaN, ring id)  */
 #define LINS_E_NODEVICE (-5)  /* no usable gfx950 device                           */
 #define LINS_E_STATE (-6)     /* call sequence error (run before upload, ...)      */
+#define LINS_E_UNSUPPORTED (-7) /* this input cannot take the requested device path (nothing was run) */
 
 typedef struct lins_point {
   float x, y, z, intensity;
@@ -191,6 +192,19 @@ int lins_correspondences(lins_ctx* ctx, const lins_scan_pair* in,
 int lins_reduce_pass(lins_ctx* ctx, const lins_scan_pair* in,
                      const double* lin_state, int iter, double* sums28,
                      int32_t* m_surf, int32_t* m_corner);
+
+/* --- next row: the ICP fallback on the device --------------------------- */
+/* estimateTransform / calculateTransformation (SE:1163-1320), the fallback performIESKF takes
+ * when the filter diverges (SE:585-592): up to NUM_ITER rounds of {correspondences at the current
+ * pose, 6-DoF Gauss-Newton step with the degeneracy projection of round 0, stop at 0.1 deg /
+ * 0.1 cm}, all inside one kernel per scan (same grid and searches as the IESKF kernel).
+ * in[].state = the pose to start from (the filter's); out[].state = that state with position and
+ * attitude replaced, out[].cov = in[].cov, out[].iters / converged = rounds run / stop rule hit.
+ * Returns LINS_E_UNSUPPORTED, with nothing run, when a scan cannot take the grid kernels
+ * (unsorted rings, ring ids >= 16, > 12288 target points) or ICP_FREQ != 1 —
+ * lins_host_perform_ieskf() then runs the same Gauss-Newton step on the host over
+ * lins_correspondences().                                                                   */
+int lins_icp_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins_result* out);
 
 /* --- next row after the update: updatePointCloud's re-projection --------- */
 /* transformToEnd (SE:1083-1101) of whole clouds with the scan's final relative pose

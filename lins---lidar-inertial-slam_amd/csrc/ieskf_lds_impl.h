@@ -45,6 +45,7 @@
 
 #include "ieskf_binned.h"
 #include "ieskf_device.h"
+#include "icp_math.h"
 
 namespace lins {
 namespace LINS_LDS_NS {
@@ -803,6 +804,36 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
 }
 
 // ---------------------------------------------------------------------------
+// Serial tail of one ICP iteration (estimateTransform's loop body after the correspondences,
+// SE:1170-1195): needs >= 10 plane and >= 5 line rows, else the iteration is spent without a step
+// (SE:1175-1184); Gauss-Newton step + degeneracy projection + stop rule in icp_math.h.  A handful
+// of 6x6 factorizations per divergence: one lane, arrays in scratch — clarity over speed.
+// ---------------------------------------------------------------------------
+__device__ __noinline__ void icp_solve_and_update(int tid, int iter) {
+  LdsStore& L = g_lds;
+  if (tid == 0) {
+    int conv = 0;
+    if (L.m_surf >= 10 && L.m_corner >= 5) {
+      double JTJ[36], JTb[6], x[6];
+      for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j < 6; ++j) JTJ[i * 6 + j] = L.sums[i <= j ? tri6(i, j) : tri6(j, i)];
+        JTb[i] = L.sums[21 + i];
+      }
+      icp_gn_solve(JTJ, JTb, iter, x);
+      double t[3] = {L.ic.lin[0], L.ic.lin[1], L.ic.lin[2]};
+      Q4 q{L.ic.lin[6], L.ic.lin[7], L.ic.lin[8], L.ic.lin[9]};
+      conv = icp_apply(x, t, q) ? 1 : 0;
+      L.ic.lin[0] = t[0], L.ic.lin[1] = t[1], L.ic.lin[2] = t[2];
+      L.ic.lin[6] = q.w, L.ic.lin[7] = q.x, L.ic.lin[8] = q.y, L.ic.lin[9] = q.z;
+      L.ic.phi = quat2axis(q);
+    }
+    L.conv = conv;
+    L.iter = iter + 1;
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
 // rows -> 28 sums inside a wave without LDS: every lane forms the 28 products of its own row
 // (21 of H^T H, 6 of H^T r, r^T r; all zero for an unused lane), then five halving butterflies
 // (xor 32, 16, 8, 4, 2) in which a lane pair splits the sums it still carries — one keeps the lower
@@ -869,7 +900,7 @@ __device__ __forceinline__ double wave_reduce_rows(const double (&row)[7], int l
 // the kernel.  PASS_ONLY: one correspondence pass at a caller-supplied linearisation
 // state (lins_correspondences / lins_reduce_pass), dumping records / sums.
 // ---------------------------------------------------------------------------
-template <int BLOCK, int LANES, bool PASS_ONLY, bool PROF>
+template <int BLOCK, int LANES, bool PASS_ONLY, bool PROF, bool ICP = false>
 #if LINS_LDS_MINW > 1
 __global__ __launch_bounds__(BLOCK, LINS_LDS_MINW) void ieskf_lds_kernel(
 #else
@@ -901,7 +932,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   float4* const gs = kHybrid ? sorted + sd.off_surf_t : nullptr;
   const int n_all_t = sd.n_surf_t + sd.n_corner_t, n_lds = n_all_t < kNpCap ? n_all_t : kNpCap;
 
-  for (int k = tid; k < 324; k += kLBlock) L.P[k] = PASS_ONLY ? 0.0 : cov_in[(size_t)scan * 324 + k];
+  for (int k = tid; k < 324; k += kLBlock) L.P[k] = (PASS_ONLY || ICP) ? 0.0 : cov_in[(size_t)scan * 324 + k];
   if (tid < 19) {
     double v = state_in[(size_t)scan * 19 + tid];
     L.filt[tid] = v;
@@ -1159,11 +1190,15 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
             corner_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], pt4(p1), pt4(p2), o);
           }
           if (o.accepted) {
-            V3 cv{(double)o.c[0], (double)o.c[1], (double)o.c[2]};
-            V3 u = cross(V3{(double)q.x, (double)q.y, (double)q.z}, mvec(L.ic.Rt, cv));
-            V3 a = mvec(L.ic.Gt, u);
-            row[0] = cv.x, row[1] = cv.y, row[2] = cv.z, row[3] = a.x, row[4] = a.y, row[5] = a.z;
-            row[6] = prm.lidar_scale * (double)o.c[3];
+            if (ICP) {  // Gauss-Newton row of the fallback (SE:1246-1257): [c^T(-R(s phi)[p]x), c^T | -0.05 res]
+              icp_row(prm.inv_period, phi, q.x, q.y, q.z, q.w, o.c, row, row[6]);
+            } else {
+              V3 cv{(double)o.c[0], (double)o.c[1], (double)o.c[2]};
+              V3 u = cross(V3{(double)q.x, (double)q.y, (double)q.z}, mvec(L.ic.Rt, cv));
+              V3 a = mvec(L.ic.Gt, u);
+              row[0] = cv.x, row[1] = cv.y, row[2] = cv.z, row[3] = a.x, row[4] = a.y, row[5] = a.z;
+              row[6] = prm.lidar_scale * (double)o.c[3];
+            }
             if (is_surf)
               ++ms;
             else
@@ -1246,7 +1281,10 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       return;
     }
 
-    solve_and_update(prm, tid, iter, prof, t3);
+    if (ICP)
+      icp_solve_and_update(tid, iter);
+    else
+      solve_and_update(prm, tid, iter, prof, t3);
     if (prof) {
       long long t4 = clock64();
       if (tid == 0) {
@@ -1267,8 +1305,12 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 
   // ---- hand-off to the Joseph kernel / the caller (SE:585-598) ---------------
   const int div = L.div;
-  if (tid < 19) state_out[(size_t)scan * 19 + tid] = div ? L.filt[tid] : L.ic.lin[tid];
-  if (tid < 21) a6_out[(size_t)scan * 21 + tid] = L.sums[tid];
+  if (ICP) {  // filterState with rn_, qbn_ replaced (SE:590-592); the covariance is the caller's, un-updated
+    if (tid < 19) state_out[(size_t)scan * 19 + tid] = (tid < 3 || (tid >= 6 && tid < 10)) ? L.ic.lin[tid] : L.filt[tid];
+  } else {
+    if (tid < 19) state_out[(size_t)scan * 19 + tid] = div ? L.filt[tid] : L.ic.lin[tid];
+    if (tid < 21) a6_out[(size_t)scan * 21 + tid] = L.sums[tid];
+  }
   if (tid == 0) {
     OutRec r;
     r.residual_norm = L.res_last, r.update_norm = L.upd_norm;

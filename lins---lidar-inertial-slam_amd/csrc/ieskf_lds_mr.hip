@@ -48,6 +48,16 @@ void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDe
     LINS_LAUNCH(lds_mr, 512, 1, false);
 }
 
+// ICP / Gauss-Newton fallback (estimateTransform, SE:1163-1320) on the same grid and searches:
+// state_in = the pose to start from (the filter's), state_out = that state with rn_, qbn_ replaced
+void launch_lds_mr_icp(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
+                       float4* sorted, const double* state_in, double* state_out, void* out, int4* idx_store) {
+  hipLaunchKernelGGL((lds_mr::ieskf_lds_kernel<512, 1, false, false, true>), dim3(n), dim3(512), 0, stream, prm, descs,
+                     arena, sorted, state_in, state_in /*unused: no covariance on this path*/, (const double*)nullptr, 0,
+                     state_out, (double*)nullptr, (lds_mr::OutRec*)out, idx_store, (lins_pose_record*)nullptr, 0,
+                     (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, (long long*)nullptr);
+}
+
 void launch_lds_mr_pass(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
                         float4* sorted, const double* lin_state, const double* filt_state, int iter,
                         int4* idx_store, lins_corr* dump, double* sums_out, int* counts_out) {

@@ -33,6 +33,8 @@ void launch_lds_mr(hipStream_t, int, const DevParams&, const ScanDesc*, const fl
 void launch_lds_mr_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, float4*, const double*,
                         const double*, int, int4*, lins_corr*, double*, int*);
 int lds_mr_np_cap();
+void launch_lds_mr_icp(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, float4*, const double*, double*,
+                       void*, int4*);
 void launch_transform_to_end(hipStream_t, int, int, const void*, const float4*, float4*, float4*);
 size_t reproject_job_size();
 struct ReprojectJobHost {
@@ -229,6 +231,7 @@ const char* lins_strerror(int code) {
     case LINS_E_INPUT: return "cloud violates the input contract (non-finite value or ring id out of range)";
     case LINS_E_NODEVICE: return "no usable gfx950 device";
     case LINS_E_STATE: return "call sequence error";
+    case LINS_E_UNSUPPORTED: return "input cannot take the requested device path";
     default: return "unknown error";
   }
 }
@@ -533,6 +536,36 @@ int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins
   if (n == 0) return LINS_OK;
   if ((rc = lins_batch_run(ctx, nullptr, 0))) return rc;
   return lins_batch_download(ctx, n, out);
+}
+
+/* The ICP / Gauss-Newton fallback of SE:585-592 (estimateTransform, SE:1163-1320) on the device:
+ * n scans from the poses in in[].state, out[].state = that state with position and attitude
+ * replaced, out[].cov = in[].cov (un-updated), out[].iters / converged = rounds run / stop rule hit.
+ * LINS_E_UNSUPPORTED (nothing run) when a scan cannot take the grid kernels (unsorted rings, ring
+ * ids >= 16, > 12288 target points) or ICP_FREQ != 1: lins_host_perform_ieskf() then falls back to
+ * the host Gauss-Newton step over lins_correspondences().                                        */
+int lins_icp_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins_result* out) {
+  if (!ctx || n < 0 || (n && (!in || !out))) return LINS_E_ARG;
+  int rc = upload(ctx, n, in);
+  if (rc) return rc;
+  ctx->n_uploaded = 0;  // not an IESKF batch
+  if (n == 0) return LINS_OK;
+  if (!ctx->mr_ok || ctx->prm.icp_freq != 1) return LINS_E_UNSUPPORTED;
+  launch_lds_mr_icp(ctx->stream, n, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_binned, ctx->d_state_in,
+                    ctx->d_state_out, ctx->d_out, ctx->d_idx);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state_out, (size_t)n * 19 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)n * sizeof(OutRecHost), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int s = 0; s < n; ++s) {
+    lins_result& r = out[s];
+    std::memset(&r, 0, sizeof r);
+    std::memcpy(r.state, ctx->h_state + (size_t)s * 19, sizeof r.state);
+    std::memcpy(r.cov, in[s].cov, sizeof r.cov);
+    const OutRecHost& o = ctx->h_out[s];
+    r.iters = o.iters, r.converged = o.converged, r.m_surf = o.m_surf, r.m_corner = o.m_corner;
+  }
+  return LINS_OK;
 }
 
 int lins_ieskf_update(lins_ctx* ctx, const lins_scan_pair* in, lins_result* out) {

@@ -20,7 +20,7 @@ EXPORTS = [
     "lins_ieskf_update", "lins_ieskf_update_batch", "lins_batch_upload", "lins_batch_run", "lins_sync",
     "lins_batch_download", "lins_last_kernel_ms", "lins_batch_bytes_per_iter", "lins_batch_total_iters",
     "lins_correspondences", "lins_reduce_pass", "lins_host_perform_ieskf", "lins_transform_to_end_batch",
-    "lins_last_reproject_stats",
+    "lins_last_reproject_stats", "lins_icp_update_batch",
 ]
 
 
@@ -68,6 +68,7 @@ def lib():
                                        C.POINTER(C.c_int32)]
         L.lins_host_perform_ieskf.argtypes = [vp, C.POINTER(Params), C.POINTER(ScanPairC), C.POINTER(ResultC),
                                               C.POINTER(C.c_int32)]
+        L.lins_icp_update_batch.argtypes = [vp, C.c_int, C.POINTER(ScanPairC), C.POINTER(ResultC)]
         L.lins_transform_to_end_batch.argtypes = [vp, C.c_int, C.POINTER(ReprojectJob)]
         L.lins_last_reproject_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
         for name in EXPORTS:
@@ -136,6 +137,14 @@ class IeskfContext:
         used = C.c_int32(0)
         self._check(lib().lins_host_perform_ieskf(self._h, C.byref(self.params), C.byref(c), C.byref(r), C.byref(used)))
         return Result(r), bool(used.value)
+
+    def icp_update_batch(self, pairs):
+        """estimateTransform (the ICP fallback) on the device, from each pair's state pose."""
+        arr = pairs_to_c(pairs)
+        res = (ResultC * len(pairs))()
+        self._check(lib().lins_icp_update_batch(self._h, len(pairs), arr, res))
+        self._n = 0
+        return [Result(r) for r in res]
 
     # -- staged batch form -------------------------------------------------------------
     def upload(self, pairs):

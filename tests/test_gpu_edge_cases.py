@@ -230,6 +230,50 @@ def test_icp_matches_oracle(pkg, ieskf, oracle, pairs):
     del C
 
 
+def test_device_icp_matches_oracle_and_the_host_path(pkg, ieskf, oracle, host, monkeypatch):
+    """the whole ICP fallback (SE:1163-1320) in one kernel per scan == the oracle's
+    estimateTransform, from perturbed poses (so that several Gauss-Newton rounds run, the first with
+    the degeneracy projection), and == the split path (device correspondences + host GN step)."""
+    prm = pkg.default_params(num_iter=30)
+    rng = np.random.default_rng(11)
+    batch = []
+    for p in host.synth_batch(12, start=300):
+        st = p.state.copy()
+        st[0:3] += rng.normal(0, 0.15, 3)
+        dq = np.array([1.0, *rng.normal(0, 0.01, 3)])
+        w, x, y, z = st[6:10]
+        a, b, c, d = dq / np.linalg.norm(dq)
+        st[6:10] = [w * a - x * b - y * c - z * d, w * b + x * a + y * d - z * c, w * c - x * d + y * a + z * b,
+                    w * d + x * c - y * b + z * a]
+        batch.append(pkg.ScanPair(p.surf_flat, p.corner_sharp, p.surf_last, p.corner_last, st, p.cov))
+    with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384) as c:
+        got = c.icp_update_batch(batch)
+        rounds = []
+        for pair, g in zip(batch, got):
+            t, q, iters = oracle.icp(prm, pair, pair.state[0:3], pair.state[6:10], oracle.NN_KDTREE)
+            assert g.iters == iters and g.diverged == 0
+            assert np.abs(g.state[0:3] - t).max() <= 1e-6 and np.abs(g.state[6:10] - q).max() <= 1e-7
+            keep = [3, 4, 5] + list(range(10, 19))
+            assert np.array_equal(g.state[keep], pair.state[keep]) and np.array_equal(g.cov, pair.cov)
+            rounds.append(iters)
+        assert max(rounds) >= 2
+        # the split path (what ineligible clouds take) lands on the same pose
+        nan_cov = np.full((18, 18), np.nan)  # NaN covariance => the filter diverges => fallback (SE:552-563)
+        bad = pkg.ScanPair(batch[0].surf_flat, batch[0].corner_sharp, batch[0].surf_last, batch[0].corner_last,
+                           batch[0].state, nan_cov)
+        dev, used = c.perform_ieskf(bad)
+        assert used and dev.diverged == 2
+        monkeypatch.setenv("LINS_ICP_HOST", "1")
+        hst, used = c.perform_ieskf(bad)
+        monkeypatch.delenv("LINS_ICP_HOST")
+        assert used and np.abs(dev.state - hst.state).max() <= 1e-9
+        assert np.abs(dev.state[0:3] - got[0].state[0:3]).max() <= 1e-12
+    # ICP_FREQ != 1 and clouds off the grid are refused, not silently approximated
+    with ieskf.IeskfContext(pkg.default_params(icp_freq=2), max_batch=1, max_targets=16384) as c:
+        with pytest.raises(ieskf.LinsError, match="-7"):
+            c.icp_update_batch(batch[:1])
+
+
 def test_abi_error_behaviour(pkg, ieskf):
     prm = pkg.default_params()
     rng = np.random.default_rng(1)
