@@ -122,6 +122,18 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
+    # device-copy ceiling of this box: a streaming float4 copy inside the context's arenas,
+    # measured after the timed region (it overwrites the uploaded clouds)
+    copy_gbs = None
+    if rank == 0:
+        import ctypes as C
+
+        L = ieskf.lib()
+        L.lins_debug_stream_copy.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
+        g_ = C.c_double(0)
+        if L.lins_debug_stream_copy(ctx._h, 1 << 30, 5, C.byref(g_)) == 0:
+            copy_gbs = g_.value
+
     iters_local = ctx.total_iters()
     bytes_iter_local = ctx.bytes_per_iter()  # sum over scans of B_iter
     stats = torch.tensor([elapsed, float(iters_local)], dtype=torch.float64, device="cuda")
@@ -185,6 +197,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic_from_profiles(args.search),
+                "copy_ceiling_GBs": copy_gbs,  # measured stream-copy rate (read + write) on this box
+                "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
                 "alg_bytes_per_launch": alg_bytes,
                 "kernel_ms": k_ms,
                 "bytes_per_iter_mean": bytes_iter_local / len(pairs),

@@ -682,6 +682,14 @@ void launch_transform_to_end(hipStream_t stream, int n_jobs, int max_n, const vo
 }
 size_t reproject_job_size() { return sizeof(ReprojectJob); }
 
+// device-copy ceiling probe (lins_debug_stream_copy): what a pure streaming kernel reaches on this box
+__global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ in, float4* __restrict__ out, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+void launch_stream_copy(hipStream_t stream, const float4* in, float4* out, size_t n) {
+  hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 16), dim3(256), 0, stream, in, out, n);
+}
+
 size_t out_rec_size() { return sizeof(OutRec); }
 
 }  // namespace lins

@@ -37,6 +37,7 @@ void launch_lds_mr_icp(hipStream_t, int, const DevParams&, const ScanDesc*, cons
                        void*, int4*);
 void launch_transform_to_end(hipStream_t, int, int, const void*, const float4*, float4*, float4*);
 size_t reproject_job_size();
+void launch_stream_copy(hipStream_t, const float4*, float4*, size_t);
 struct ReprojectJobHost {
   long long off;
   int n, has_yzx;
@@ -402,10 +403,34 @@ int lins_debug_phase_profile(lins_ctx* ctx, int enable, long long* out, int n_sc
   }
   if (!enable && ctx->d_prof) {
     (void)hipFree(ctx->d_prof);
-  (void)hipFree(ctx->d_aux);
-  (void)hipFree(ctx->d_jobs);
     ctx->d_prof = nullptr;
   }
+  return LINS_OK;
+}
+
+/* Measurement aid ("measure a device-copy ceiling with a stream kernel and report
+ * against both"): a grid-stride float4 copy of `bytes` bytes inside the context's point arenas,
+ * timed with HIP events on the context's stream; *gbs = (read + written bytes) / time of the best
+ * of `reps` launches.  An uploaded batch stays valid (only the scratch arena is written).       */
+int lins_debug_stream_copy(lins_ctx* ctx, uint64_t bytes, int reps, double* gbs) {
+  if (!ctx || !gbs || reps < 1) return LINS_E_ARG;
+  const size_t cap = ctx->arena_cap * sizeof(float4);
+  if (bytes > cap) bytes = cap;
+  const size_t n4 = bytes / sizeof(float4);
+  if (!n4) return LINS_E_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  float best = 1e30f;  // (source = the cloud arena, untouched; destination = the sorted-copy arena, scratch)
+  for (int r = 0; r < reps + 1; ++r) {  // (first launch: warm-up)
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    launch_stream_copy(ctx->stream, ctx->d_arena, ctx->d_binned, n4);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev2));
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev2));
+    if (r && ms < best) best = ms;
+  }
+  *gbs = 2.0 * (double)(n4 * sizeof(float4)) / ((double)best * 1e-3) / 1e9;
   return LINS_OK;
 }
 
