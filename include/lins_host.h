@@ -76,6 +76,37 @@ typedef struct lins_features {
 int lins_frontend_extract(const lins_point* raw, int n_raw, double scan_period,
                           lins_features* out);
 
+/* ---- front-end, in the reference's two stages ------------------------------ */
+/* What image_projection_node publishes and StateEstimator::processPCL consumes: the segmented
+ * cloud (sensor_msgs/PointCloud2 of PointXYZI, ring-major, ascending column, intensity =
+ * row + col / 10000, IP:234) + cloud_msgs/cloud_info (cloud_info.msg:1-12).                  */
+typedef struct lins_segmented_scan {
+  const lins_point* cloud;
+  const float* range;       /* segmentedCloudRange      */
+  const uint32_t* col;      /* segmentedCloudColInd     */
+  const uint8_t* ground;    /* segmentedCloudGroundFlag */
+  int32_t n;
+  int32_t start_ring[LINS_LINE_NUM], end_ring[LINS_LINE_NUM];  /* startRingIndex / endRingIndex */
+  float start_ori, end_ori, ori_diff;                          /* startOrientation, ...         */
+  int32_t n_outlier;
+} lins_segmented_scan;
+
+/* image_projection_node (IP:191-415) on the host: caller-allocated arrays of LINS_CLOUD_MAX
+ * entries, `out` is pointed at them.                                                          */
+int lins_frontend_segment(const lins_point* raw, int n_raw, lins_point* cloud, float* range, uint32_t* col,
+                          uint8_t* ground, lins_segmented_scan* out);
+/* StateEstimator's feature stage (undistortPcl .. extractFeatures, SE:619-827) on the host — the
+ * CPU restatement the device version is checked against.                                      */
+int lins_frontend_extract_segmented(const lins_segmented_scan* in, double scan_period, lins_features* out);
+/* The same stage on the device (csrc/frontend_kernels.hip): n scans, one
+ * workgroup each; out[k]'s four arrays are caller-allocated with the capacities of lins_features.
+ * Identical picks and clouds (the relative-time tag within 1 ulp of f32 where atan2f differs).   */
+int lins_extract_features_batch(lins_ctx* ctx, int n, const lins_segmented_scan* in, double scan_period,
+                                lins_features* out);
+/* HIP-event time (ms) of the front-end kernel of the last call and its algorithmic bytes
+ * (25 B read per segmented point + 16 B per emitted feature point).                            */
+int lins_last_frontend_stats(lins_ctx* ctx, float* kernel_ms, uint64_t* bytes);
+
 /* transformToEnd for every point, with the scan's final relative pose
  * (t = linState_.rn_, q = linState_.qbn_ as w,x,y,z). In-place allowed.       */
 void lins_transform_to_end(const double* t, const double* q_wxyz, double scan_period,

@@ -11,8 +11,8 @@
 //   transformToEnd          StateEstimator.hpp:1083-1101
 // Constants: parameters.h:79-92, exp_port.yaml:9-13.
 //
-// Sequential greedy logic — stays on the host; it is
-// here to FEED the hot path with realistically shaped inputs.
+// This is the CPU restatement: it FEEDS the hot path with realistically shaped inputs and is
+// what the device front-end (frontend_kernels.hip, lins_extract_features_batch) is checked against.
 
 #include <algorithm>
 #include <cfloat>
@@ -293,8 +293,11 @@ void extract(const Segmented& seg, double scan_period, lins_features* out) {
       int ep = (seg.start_ring[i] * (5 - j) + seg.end_ring[i] * (j + 1)) / 6 - 1;
       if (sp >= ep) continue;
       if (sp < 0 || ep >= n) continue;  // guard
-      std::sort(smooth.begin() + sp, smooth.begin() + ep,
-                [](const Smooth& a, const Smooth& b) { return a.value < b.value; });
+      // (the reference's comparator looks at the value only, which leaves equal curvatures in an
+      // unspecified order; ties are broken by index here and in the device kernel)
+      std::sort(smooth.begin() + sp, smooth.begin() + ep, [](const Smooth& a, const Smooth& b) {
+        return a.value < b.value || (a.value == b.value && a.ind < b.ind);
+      });
       int largest = 0;
       for (int k = ep; k >= sp; --k) {
         int ind = smooth[k].ind;
@@ -346,6 +349,37 @@ int lins_frontend_extract(const lins_point* raw, int n_raw, double scan_period, 
     return LINS_E_ARG;
   Segmented seg;
   project_and_segment(raw, n_raw, seg);
+  extract(seg, scan_period, out);
+  return LINS_OK;
+}
+
+int lins_frontend_segment(const lins_point* raw, int n_raw, lins_point* cloud, float* range, uint32_t* col,
+                          uint8_t* ground, lins_segmented_scan* out) {
+  if (!raw || !cloud || !range || !col || !ground || !out || n_raw < 2) return LINS_E_ARG;
+  Segmented seg;
+  project_and_segment(raw, n_raw, seg);
+  const int n = (int)seg.cloud.size();
+  if (n > LINS_CLOUD_MAX) return LINS_E_CAPACITY;
+  for (int i = 0; i < n; ++i) cloud[i] = seg.cloud[i], range[i] = seg.range[i], col[i] = seg.col[i], ground[i] = seg.ground[i];
+  out->cloud = cloud, out->range = range, out->col = col, out->ground = ground, out->n = n;
+  for (int r = 0; r < kRows; ++r) out->start_ring[r] = seg.start_ring[r], out->end_ring[r] = seg.end_ring[r];
+  out->start_ori = seg.start_ori, out->end_ori = seg.end_ori, out->ori_diff = seg.ori_diff;
+  out->n_outlier = seg.n_outlier;
+  return LINS_OK;
+}
+
+int lins_frontend_extract_segmented(const lins_segmented_scan* in, double scan_period, lins_features* out) {
+  if (!in || !out || in->n < 0 || in->n > LINS_CLOUD_MAX) return LINS_E_ARG;
+  if (!out->corner_sharp || !out->corner_less_sharp || !out->surf_flat || !out->surf_less_flat)
+    return LINS_E_ARG;
+  Segmented seg;
+  seg.cloud.assign(in->cloud, in->cloud + in->n);
+  seg.range.assign(in->range, in->range + in->n);
+  seg.col.assign(in->col, in->col + in->n);
+  seg.ground.assign(in->ground, in->ground + in->n);
+  for (int r = 0; r < kRows; ++r) seg.start_ring[r] = in->start_ring[r], seg.end_ring[r] = in->end_ring[r];
+  seg.start_ori = in->start_ori, seg.end_ori = in->end_ori, seg.ori_diff = in->ori_diff;
+  seg.n_outlier = in->n_outlier;
   extract(seg, scan_period, out);
   return LINS_OK;
 }

@@ -15,6 +15,7 @@
 #include <string>
 #include <vector>
 
+#include "../../include/lins_host.h"
 #include "ieskf_device.h"
 
 namespace lins {
@@ -38,6 +39,16 @@ void launch_lds_mr_icp(hipStream_t, int, const DevParams&, const ScanDesc*, cons
 void launch_transform_to_end(hipStream_t, int, int, const void*, const float4*, float4*, float4*);
 size_t reproject_job_size();
 void launch_stream_copy(hipStream_t, const float4*, float4*, size_t);
+void launch_frontend(hipStream_t, int, const void*, const float4*, const float*, const unsigned*, const unsigned char*,
+                     double, float4*, float*, int*, float4*, float4*, float4*, float4*, int*);
+size_t fe_scan_size();
+int fe_pick_stride();
+struct FeScanHost {
+  long long off;
+  int n;
+  int start_ring[16], end_ring[16];
+  float start_ori, end_ori, ori_diff;
+};
 struct ReprojectJobHost {
   long long off;
   int n, has_yzx;
@@ -77,6 +88,19 @@ struct lins_ctx {
   void* d_jobs = nullptr;
   float reproject_ms = 0.f;
   uint64_t reproject_bytes = 0;
+  // feature front-end (lins_extract_features_batch): device buffers, allocated on first use for fe_cap scans
+  struct Frontend {
+    int cap = 0;
+    void* d_scans = nullptr;
+    float4 *d_cloud = nullptr, *d_und = nullptr, *d_sharp = nullptr, *d_less_sharp = nullptr, *d_flat = nullptr,
+           *d_less_flat = nullptr;
+    float *d_range = nullptr, *d_diff = nullptr;
+    unsigned* d_col = nullptr;
+    unsigned char* d_ground = nullptr;
+    int *d_picks = nullptr, *d_counts = nullptr;
+    float ms = 0.f;
+    uint64_t bytes = 0;
+  } fe;
   long long* d_prof = nullptr;  // optional per-workgroup phase profile (lins_debug_phase_profile)
   double* d_a6 = nullptr;  // upper triangle of the last iteration's H^T H, per scan
   void* d_out = nullptr;
@@ -155,6 +179,14 @@ int effective_search(const lins_ctx* ctx, int n) {
   if (s == SEARCH_AUTO) s = n > ctx->n_cu ? (int)SEARCH_MR : (int)SEARCH_LDS3;
   if (s == SEARCH_LDS3 && !ctx->lds3_ok) s = SEARCH_LDS;
   return s;
+}
+
+void fe_free(lins_ctx* ctx) {
+  auto& f = ctx->fe;
+  void* ptrs[] = {f.d_scans, f.d_cloud, f.d_und, f.d_sharp, f.d_less_sharp, f.d_flat, f.d_less_flat, f.d_range,
+                  f.d_diff, f.d_col, f.d_ground, f.d_picks, f.d_counts};
+  for (void* p : ptrs) (void)hipFree(p);
+  f = lins_ctx::Frontend{};
 }
 
 int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
@@ -319,6 +351,7 @@ void lins_destroy(lins_ctx* ctx) {
   (void)hipFree(ctx->d_prof);
   (void)hipFree(ctx->d_aux);
   (void)hipFree(ctx->d_jobs);
+  fe_free(ctx);
   (void)hipFree(ctx->d_out);
   (void)hipFree(ctx->d_idx);
   (void)hipFree(ctx->d_dump);
@@ -431,6 +464,95 @@ int lins_debug_stream_copy(lins_ctx* ctx, uint64_t bytes, int reps, double* gbs)
     if (r && ms < best) best = ms;
   }
   *gbs = 2.0 * (double)(n4 * sizeof(float4)) / ((double)best * 1e-3) / 1e9;
+  return LINS_OK;
+}
+
+int lins_extract_features_batch(lins_ctx* ctx, int n, const lins_segmented_scan* in, double scan_period,
+                                lins_features* out) {
+  if (!ctx || n < 0 || (n && (!in || !out))) return LINS_E_ARG;
+  if (n == 0) return LINS_OK;
+  static_assert(sizeof(FeScanHost) == 152, "FeScan layout");
+  if (fe_scan_size() != sizeof(FeScanHost)) return LINS_E_STATE;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t N = LINS_CLOUD_MAX;
+  for (int k = 0; k < n; ++k) {
+    const lins_segmented_scan& s = in[k];
+    if (s.n < 0 || s.n > (int)N || (s.n && (!s.cloud || !s.range || !s.col || !s.ground))) return LINS_E_ARG;
+    if (!out[k].corner_sharp || !out[k].corner_less_sharp || !out[k].surf_flat || !out[k].surf_less_flat)
+      return LINS_E_ARG;
+    for (int r = 0; r < LINS_LINE_NUM; ++r)  // a sector must fit the per-wave sort network (a VLP-16 ring: <= 300)
+      if ((s.end_ring[r] - s.start_ring[r]) / 6 + 2 > 510) return LINS_E_UNSUPPORTED;
+    for (int i = 0; i < s.n; ++i) {
+      const lins_point& p = s.cloud[i];
+      if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z) || !std::isfinite(p.intensity) ||
+          !std::isfinite(s.range[i]) || s.col[i] >= (uint32_t)LINS_SCAN_NUM)
+        return LINS_E_INPUT;
+    }
+  }
+  auto& f = ctx->fe;
+  if (f.cap < n) {
+    fe_free(ctx);
+    const size_t c = (size_t)n;
+    HIP_TRY(ctx, hipMalloc(&f.d_scans, c * sizeof(FeScanHost)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_cloud, c * N * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_und, c * N * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_range, c * N * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_diff, c * N * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_col, c * N * sizeof(unsigned)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_ground, c * N));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_picks, c * fe_pick_stride() * sizeof(int)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_sharp, c * 192 * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_less_sharp, c * 1920 * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_flat, c * 384 * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_less_flat, c * N * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_counts, c * 4 * sizeof(int)));
+    f.cap = n;
+  }
+  std::vector<FeScanHost> hs(n);
+  uint64_t bytes = 0;
+  for (int k = 0; k < n; ++k) {
+    const lins_segmented_scan& s = in[k];
+    hs[k].off = (long long)((size_t)k * N), hs[k].n = s.n;
+    for (int r = 0; r < LINS_LINE_NUM; ++r) hs[k].start_ring[r] = s.start_ring[r], hs[k].end_ring[r] = s.end_ring[r];
+    hs[k].start_ori = s.start_ori, hs[k].end_ori = s.end_ori, hs[k].ori_diff = s.ori_diff;
+    if (!s.n) continue;
+    HIP_TRY(ctx, hipMemcpyAsync(f.d_cloud + hs[k].off, s.cloud, s.n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(f.d_range + hs[k].off, s.range, s.n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(f.d_col + hs[k].off, s.col, s.n * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(f.d_ground + hs[k].off, s.ground, s.n, hipMemcpyHostToDevice, ctx->stream));
+    bytes += (uint64_t)s.n * 25;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(f.d_scans, hs.data(), (size_t)n * sizeof(FeScanHost), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  launch_frontend(ctx->stream, n, f.d_scans, f.d_cloud, f.d_range, f.d_col, f.d_ground, scan_period, f.d_und, f.d_diff,
+                  f.d_picks, f.d_sharp, f.d_less_sharp, f.d_flat, f.d_less_flat, f.d_counts);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
+  std::vector<int> counts((size_t)n * 4);
+  HIP_TRY(ctx, hipMemcpyAsync(counts.data(), f.d_counts, counts.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < n; ++k) {
+    const int* c = &counts[(size_t)k * 4];
+    if (c[3] < 0) return LINS_E_UNSUPPORTED;  // a ring with more less-flat points than the voxel sort network holds
+    lins_features& o = out[k];
+    o.n_corner_sharp = c[0], o.n_corner_less_sharp = c[1], o.n_surf_flat = c[2], o.n_surf_less_flat = c[3];
+    o.n_segmented = in[k].n, o.n_outlier = in[k].n_outlier;
+    HIP_TRY(ctx, hipMemcpyAsync(o.corner_sharp, f.d_sharp + (size_t)k * 192, c[0] * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(o.corner_less_sharp, f.d_less_sharp + (size_t)k * 1920, c[1] * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(o.surf_flat, f.d_flat + (size_t)k * 384, c[2] * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(o.surf_less_flat, f.d_less_flat + (size_t)k * N, c[3] * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    bytes += 16ull * (c[0] + c[1] + c[2] + c[3]);
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipEventElapsedTime(&f.ms, ctx->ev0, ctx->ev2));
+  f.bytes = bytes;
+  return LINS_OK;
+}
+
+int lins_last_frontend_stats(lins_ctx* ctx, float* kernel_ms, uint64_t* bytes) {
+  if (!ctx) return LINS_E_ARG;
+  if (kernel_ms) *kernel_ms = ctx->fe.ms;
+  if (bytes) *bytes = ctx->fe.bytes;
   return LINS_OK;
 }
 

@@ -44,6 +44,72 @@ class Features(C.Structure):
     ]
 
 
+class SegmentedScanC(C.Structure):
+    """lins_segmented_scan: segmented cloud + cloud_msgs/cloud_info (include/lins_host.h)."""
+    _fields_ = [("cloud", C.POINTER(Point)), ("range", C.POINTER(C.c_float)), ("col", C.POINTER(C.c_uint32)),
+                ("ground", C.POINTER(C.c_uint8)), ("n", C.c_int32), ("start_ring", C.c_int32 * 16),
+                ("end_ring", C.c_int32 * 16), ("start_ori", C.c_float), ("end_ori", C.c_float),
+                ("ori_diff", C.c_float), ("n_outlier", C.c_int32)]
+
+
+class Segmented:
+    """numpy-owned segmented scan; .c is the ctypes view (pointers into the arrays kept alive here)."""
+
+    def __init__(self, cloud, rng, col, ground, c):
+        self.cloud, self.range, self.col, self.ground, self.c = cloud, rng, col, ground, c
+
+    @property
+    def n(self):
+        return self.c.n
+
+
+def _features_buffers():
+    cs, pcs = _buf(192)
+    cls, pcls = _buf(1920)
+    sf, psf = _buf(MAX_QUERY)
+    slf, pslf = _buf(CLOUD_MAX)
+    f = Features()
+    f.corner_sharp, f.corner_less_sharp, f.surf_flat, f.surf_less_flat = pcs, pcls, psf, pslf
+    return f, (cs, cls, sf, slf)
+
+
+def _features_dict(f, bufs):
+    cs, cls, sf, slf = bufs
+    return dict(corner_sharp=cs[: f.n_corner_sharp].copy(), corner_less_sharp=cls[: f.n_corner_less_sharp].copy(),
+                surf_flat=sf[: f.n_surf_flat].copy(), surf_less_flat=slf[: f.n_surf_less_flat].copy(),
+                n_segmented=f.n_segmented, n_outlier=f.n_outlier)
+
+
+def frontend_segment(raw):
+    """image_projection_node on the host: raw cloud -> segmented scan (lins_frontend_segment)."""
+    raw = np.ascontiguousarray(raw, dtype=np.float32).reshape(-1, 4)
+    cloud = np.zeros((CLOUD_MAX, 4), np.float32)
+    rng = np.zeros(CLOUD_MAX, np.float32)
+    col = np.zeros(CLOUD_MAX, np.uint32)
+    ground = np.zeros(CLOUD_MAX, np.uint8)
+    c = SegmentedScanC()
+    L = lib()
+    L.lins_frontend_segment.argtypes = [C.POINTER(Point), C.c_int, C.POINTER(Point), C.POINTER(C.c_float),
+                                        C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.POINTER(SegmentedScanC)]
+    rc = L.lins_frontend_segment(raw.ctypes.data_as(C.POINTER(Point)), len(raw), cloud.ctypes.data_as(C.POINTER(Point)),
+                                 rng.ctypes.data_as(C.POINTER(C.c_float)), col.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                 ground.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(c))
+    if rc != 0:
+        raise RuntimeError(f"lins_frontend_segment failed: {rc}")
+    return Segmented(cloud, rng, col, ground, c)
+
+
+def frontend_extract_segmented(seg, scan_period=0.1):
+    """StateEstimator's feature stage on the host (the CPU restatement of the device front-end)."""
+    f, bufs = _features_buffers()
+    L = lib()
+    L.lins_frontend_extract_segmented.argtypes = [C.POINTER(SegmentedScanC), C.c_double, C.POINTER(Features)]
+    rc = L.lins_frontend_extract_segmented(C.byref(seg.c), scan_period, C.byref(f))
+    if rc != 0:
+        raise RuntimeError(f"lins_frontend_extract_segmented failed: {rc}")
+    return _features_dict(f, bufs)
+
+
 class SynthPairC(C.Structure):
     _fields_ = [
         ("surf_flat", C.POINTER(Point)), ("n_surf_flat", C.c_int32),

@@ -20,7 +20,7 @@ EXPORTS = [
     "lins_ieskf_update", "lins_ieskf_update_batch", "lins_batch_upload", "lins_batch_run", "lins_sync",
     "lins_batch_download", "lins_last_kernel_ms", "lins_batch_bytes_per_iter", "lins_batch_total_iters",
     "lins_correspondences", "lins_reduce_pass", "lins_host_perform_ieskf", "lins_transform_to_end_batch",
-    "lins_last_reproject_stats", "lins_icp_update_batch",
+    "lins_last_reproject_stats", "lins_icp_update_batch", "lins_extract_features_batch", "lins_last_frontend_stats",
 ]
 
 
@@ -137,6 +137,33 @@ class IeskfContext:
         used = C.c_int32(0)
         self._check(lib().lins_host_perform_ieskf(self._h, C.byref(self.params), C.byref(c), C.byref(r), C.byref(used)))
         return Result(r), bool(used.value)
+
+    # -- StateEstimator's feature front-end on the device (undistortPcl .. extractFeatures) ----
+    def extract_features_batch(self, segs, scan_period=0.1):
+        """segs: list of host.Segmented.  Returns a list of dicts like host.frontend_extract()."""
+        import importlib
+
+        host = importlib.import_module(__package__ + ".host")
+        n = len(segs)
+        arr = (host.SegmentedScanC * n)(*[s.c for s in segs])
+        feats = (host.Features * n)()
+        keep = []
+        for k in range(n):
+            f, bufs = host._features_buffers()
+            feats[k] = f
+            keep.append(bufs)
+        L = lib()
+        L.lins_extract_features_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(host.SegmentedScanC), C.c_double,
+                                                  C.POINTER(host.Features)]
+        self._check(L.lins_extract_features_batch(self._h, n, arr, scan_period, feats))
+        return [host._features_dict(feats[k], keep[k]) for k in range(n)]
+
+    def frontend_stats(self):
+        ms, b = C.c_float(0), C.c_uint64(0)
+        L = lib()
+        L.lins_last_frontend_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
+        self._check(L.lins_last_frontend_stats(self._h, C.byref(ms), C.byref(b)))
+        return ms.value, b.value
 
     def icp_update_batch(self, pairs):
         """estimateTransform (the ICP fallback) on the device, from each pair's state pose."""

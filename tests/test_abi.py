@@ -29,12 +29,21 @@ def test_ieskf_library_exports_every_declared_symbol(ieskf):
     assert L.lins_strerror(0) == b"ok" and b"capacity" in L.lins_strerror(-3)
 
 
+DEVICE_SIDE_OF_HOST_HEADER = ("lins_host_perform_ieskf", "lins_extract_features_batch", "lins_last_frontend_stats")
+
+
 def test_host_library_exports_every_declared_symbol(host):
     L = host.lib()
     for name in declared("lins_host.h"):
-        if name == "lins_host_perform_ieskf":
-            continue  # lives in liblins_ieskf.so (it drives the GPU path)
+        if name in DEVICE_SIDE_OF_HOST_HEADER:
+            continue  # live in liblins_ieskf.so (they drive the GPU path)
         assert hasattr(L, name), f"liblins_host.so does not export {name}"
+
+
+def test_device_entries_of_the_host_header_are_in_the_hip_library(ieskf):
+    L = ieskf.lib()
+    for name in DEVICE_SIDE_OF_HOST_HEADER:
+        assert name in declared("lins_host.h") and hasattr(L, name), name
 
 
 def test_no_compute_without_a_device(pkg, ieskf):
