@@ -9,8 +9,8 @@
 // One 1024-thread workgroup per scan (16 waves = one wave per ring for the sequential greedy
 // part).  The per-point stencils read the range / column arrays coalesced in index order — the
 // organised cloud is ring-major; flags and columns of the whole scan live in LDS for the greedy
-// loops (latency bound, one lane per ring), the per-sector sort is a 512-key bitonic network per
-// wave in LDS, the per-ring VoxelGrid a 2048-key bitonic network over the whole workgroup.
+// picks, the per-sector sort is a 512-key and the per-ring VoxelGrid sort a 2048-key bitonic network
+// per wave with the keys in registers (wave shuffles across lanes).
 //
 // Sort keys carry the point index as tie-break ((|diffRange| bits, index): the reference's
 // std::sort leaves the order of equal curvatures unspecified; the host restatement uses the same
@@ -38,21 +38,22 @@ struct FeScan {  // device view of one lins_segmented_scan + its outputs
 };
 
 struct FeLds {
-  unsigned char flags[kFeMaxN + 16];   // bit 0 picked (cloudNeighborPicked); bits 1-2 cloudLabel: 0 = 0, 1 = 1 (less
-                                       // sharp), 2 = 2 (sharp), 3 = -1 (flat); bit 3 ground
-  unsigned short col[kFeMaxN + 16];
   union {
-    unsigned long long skey[kFeRows][kSectorCap];  // per wave: (|diffRange| bits << 32) | index
     struct {
-      unsigned long long vkey[kRingCap];  // (voxel index << 11) | order
-      float4 vpt[kRingCap];
-    } vox;
+      unsigned char flags[kFeMaxN + 16];  // bit 0 picked (cloudNeighborPicked); bits 1-2 cloudLabel: 0 = 0, 1 = 1 (less
+                                          // sharp), 2 = 2 (sharp), 3 = -1 (flat); bit 3 ground
+      unsigned short col[kFeMaxN + 16];
+      unsigned long long skey[kFeRows][kSectorCap];  // per wave: (|diffRange| bits << 32) | index
+    } a;                                              // stencils, masks, sector picks
+    unsigned short vso[kFeRows][kRingCap];            // VoxelGrid: per ring, sorted (run start << 15) | order
   };
-  int first_half_end;   // first point with ori - startOri > pi (halfPassed flips after it)
-  int bmin[3], bmax[3];  // ordered-int min / max of the ring's less-flat points
-  int scan_tmp[20];
-  int ring_m;           // less-flat points of the current ring
-  int out_base;         // less-flat points written so far
+  int first_half_end;      // first point with ori - startOri > pi (halfPassed flips after it)
+  int ring_m[kFeRows];     // less-flat points of each ring
+  int ring_base[kFeRows];  // where the ring's index list / temporary centroids start (its first sector's start)
+  int ring_bb[kFeRows][6]; // ordered-int min xyz, max xyz of the ring's less-flat points
+  int ring_out[kFeRows];   // voxels (= output points) of each ring
+  int ring_off[kFeRows + 1];
+  int bad;
 };
 static_assert(sizeof(FeLds) <= 160 * 1024, "LDS budget");
 
@@ -64,27 +65,40 @@ __device__ __forceinline__ int fe_ordered_int(float f) {
 }
 __device__ __forceinline__ float fe_ordered_float(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 
-// exclusive prefix sum of one value per thread over the block; total in *total (LDS)
-__device__ __forceinline__ int fe_block_scan(int v, int tid, int* tmp) {
-  const int lane = tid & 63, wave = tid >> 6;
-  int incl = v;
+// Bitonic sort of 64 * P keys by one wave, the keys in registers (lane l owns positions l P .. l P + P - 1):
+// compare-exchanges whose partner lies inside the lane's own block are register selects, the others
+// one wave shuffle per key (both lanes of a pair evaluate it and keep the min or the max) — no LDS
+// round trips, no fences.  Fully unrolled: every register index is a compile-time constant.
+template <int P>
+__device__ __forceinline__ void wave_bitonic_sort(unsigned long long (&v)[P], int lane) {
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    int nb = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += nb;
+  for (int k2 = 2; k2 <= 64 * P; k2 <<= 1) {
+#pragma unroll
+    for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+      if (j2 < P) {
+#pragma unroll
+        for (int u = 0; u < P; ++u)
+          if ((u & j2) == 0) {
+            const bool up = ((lane * P + u) & k2) == 0;
+            const unsigned long long a = v[u], b = v[u | j2];
+            const bool sw = (a > b) == up;
+            v[u] = sw ? b : a, v[u | j2] = sw ? a : b;
+          }
+      } else {
+        const int lm = j2 / P;
+        const bool lower = (lane & lm) == 0;
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+          const bool up = ((lane * P + u) & k2) == 0;
+          const unsigned lo = __shfl_xor((unsigned)v[u], lm), hi = __shfl_xor((unsigned)(v[u] >> 32), lm);
+          const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+          const bool keep_min = lower == up;
+          v[u] = keep_min ? (w < v[u] ? w : v[u]) : (w > v[u] ? w : v[u]);
+        }
+      }
+    }
   }
-  if (lane == 63) tmp[wave] = incl;
-  __syncthreads();
-  int off = 0, tot = 0;
-  for (int w = 0; w < kFeBlock / 64; ++w) {
-    if (w < wave) off += tmp[w];
-    tot += tmp[w];
-  }
-  __syncthreads();
-  tmp[18] = tot;  // (every thread writes the same value)
-  return off + incl - v;
 }
-
 
 __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     const FeScan* __restrict__ scans, const float4* __restrict__ cloud, const float* __restrict__ range,
@@ -93,6 +107,9 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     float4* __restrict__ out_less_sharp, float4* __restrict__ out_flat, float4* __restrict__ out_less_flat,
     int* __restrict__ out_counts) {
   FeLds& L = g_fe;
+#ifdef LINS_FE_PROF
+  long long fe_t0 = clock64();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int scan = blockIdx.x;
   const FeScan sc = scans[scan];
@@ -106,26 +123,37 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   int* pk = picks + (size_t)scan * kFeRows * 6 * kPickStride;
   const double kPi = 3.14159265358979323846;
 
-  if (tid == 0) L.first_half_end = n, L.out_base = 0;
+  if (tid == 0) L.first_half_end = n, L.bad = 0;
   for (int i = tid; i < n + 16; i += kFeBlock) {
-    L.flags[i] = i < n && gd[i] ? 8 : 0;
-    L.col[i] = i < n ? (unsigned short)cl[i] : 0;
+    L.a.flags[i] = i < n && gd[i] ? 8 : 0;
+    L.a.col[i] = i < n ? (unsigned short)cl[i] : 0;
   }
   __syncthreads();
 
+#ifdef LINS_FE_PROF
+  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("FE %d %lld\n", 0, t_ - fe_t0); fe_t0 = t_; }
+#endif
   // ---- undistortPcl, pass 1: where does halfPassed flip?  (SE:631-638: first-half adjustment) ----
   const double s_ori = (double)sc.start_ori, e_ori = (double)sc.end_ori;
-  for (int i = tid; i < n; i += kFeBlock) {
-    const float4 p = pts[i];
-    double ori = (double)(-atan2f(p.y, p.x));
-    if (ori < s_ori - kPi / 2)
-      ori += 2 * kPi;
-    else if (ori > s_ori + kPi * 3 / 2)
-      ori -= 2 * kPi;
-    if (ori - s_ori > kPi) atomicMin(&L.first_half_end, i);
+  {
+    int first = n;
+    for (int i = tid; i < n; i += kFeBlock) {
+      const float4 p = pts[i];
+      double ori = (double)(-atan2f(p.y, p.x));
+      if (ori < s_ori - kPi / 2)
+        ori += 2 * kPi;
+      else if (ori > s_ori + kPi * 3 / 2)
+        ori -= 2 * kPi;
+      if (ori - s_ori > kPi && i < first) first = i;
+    }
+    for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
+    if (lane == 0) atomicMin(&L.first_half_end, first);
   }
   __syncthreads();
   const int flip = L.first_half_end;
+#ifdef LINS_FE_PROF
+  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("FE %d %lld\n", 1, t_ - fe_t0); fe_t0 = t_; }
+#endif
   // ---- pass 2: relative time tag; smoothness stencil; masks -------------------------------------
   for (int i = tid; i < n; i += kFeBlock) {
     float4 p = pts[i];
@@ -151,7 +179,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           rg[i + 4] + rg[i + 5];
     df[i] = d;
   }
-  unsigned* fw = reinterpret_cast<unsigned*>(L.flags);  // (marks are idempotent bit sets: 32-bit LDS atomics)
+  unsigned* fw = reinterpret_cast<unsigned*>(L.a.flags);  // (marks are idempotent bit sets: 32-bit LDS atomics)
   auto mark = [&](int i) { atomicOr(&fw[i >> 2], 1u << ((i & 3) * 8)); };
   for (int i = tid; i < n; i += kFeBlock) {
     if (i >= 5 && i < n - 6) {  // markOccludedPoints (SE:680-713)
@@ -171,10 +199,13 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   }
   __syncthreads();
 
+#ifdef LINS_FE_PROF
+  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("FE %d %lld\n", 2, t_ - fe_t0); fe_t0 = t_; }
+#endif
   // ---- extractFeatures: one wave per ring, sectors in order (marks of one sector reach the next) ---
   {
     const int ring = wave;
-    unsigned long long* key = L.skey[ring];
+    unsigned long long* key = L.a.skey[ring];
     for (int j = 0; j < 6; ++j) {
       const int sp = (sc.start_ring[ring] * (6 - j) + sc.end_ring[ring] * j) / 6;
       const int ep = (sc.start_ring[ring] * (5 - j) + sc.end_ring[ring] * (j + 1)) / 6 - 1;
@@ -187,80 +218,128 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
       const int m = ep - sp;  // the sort covers [sp, ep) — ep itself keeps its place (SE:739-740)
       // cloudSmoothness[i].ind is i only where the stencil ran, [5, n - 5); elsewhere the value-initialised 0
       auto smooth_ind = [&](int i) { return (i >= 5 && i < n - 5) ? i : 0; };
-      for (int e = lane; e < kSectorCap; e += 64)
-        key[e] = e < m ? ((unsigned long long)__float_as_uint(fabsf(df[sp + e])) << 32) | (unsigned)smooth_ind(sp + e) : ~0ull;
-      // bitonic sort, ascending (wave-local: LDS accesses of one wave are ordered by the fences)
-      for (int k2 = 2; k2 <= kSectorCap; k2 <<= 1)
-        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          for (int e = lane; e < kSectorCap; e += 64) {
-            const int partner = e ^ j2;
-            if (partner > e) {
-              const unsigned long long a = key[e], b = key[partner];
-              const bool up = (e & k2) == 0;
-              if ((a > b) == up) key[e] = b, key[partner] = a;
-            }
-          }
+      bool ground_here = false;  // does any candidate of the plane loop exist at all?
+      {
+        constexpr int kP = kSectorCap / 64;
+        unsigned long long kv[kP];
+#pragma unroll
+        for (int u = 0; u < kP; ++u) {
+          const int e = lane * kP + u;
+          kv[u] = e < m ? ((unsigned long long)__float_as_uint(fabsf(df[sp + e])) << 32) | (unsigned)smooth_ind(sp + e) : ~0ull;
+          ground_here = ground_here || (e <= m && (L.a.flags[smooth_ind(sp + e)] & 8));
         }
+        wave_bitonic_sort<kP>(kv, lane);  // ascending
+#pragma unroll
+        for (int u = 0; u < kP; ++u) key[lane * kP + u] = kv[u];
+      }
+      const bool any_ground = __any(ground_here);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (lane == 0) {
+      {
+        // The greedy picks (SE:743-813) with the whole wave: 64 candidates at a time in visiting order
+        // (lane 0 first); the first lane that is still eligible under the CURRENT flags takes its pick
+        // and marks its neighbours, the lanes after it re-read their flags and the search resumes
+        // behind it — the sequential loop's outcome, one wave round per pick instead of one loop
+        // trip per candidate.  (A candidate that was not eligible when it was passed never becomes
+        // eligible: flags only gain bits.)
+        auto wave_sync = [&] {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
         auto sorted_ind = [&](int k) { return k == ep ? smooth_ind(ep) : (int)(unsigned)key[k - sp]; };
-        auto col_gap = [&](int a, int b) {
-          if (a < 0 || b < 0 || a >= n || b >= n) return 1000;
-          const int g = (int)L.col[a] - (int)L.col[b];
-          return g < 0 ? -g : g;
-        };
-        auto mark_nbrs = [&](int ind) {
-          for (int l = 1; l <= 5; ++l) {
-            if (col_gap(ind + l, ind + l - 1) > 10) break;
-            L.flags[ind + l] |= 1;
-          }
-          for (int l = -1; l >= -5; --l) {
-            if (col_gap(ind + l, ind + l + 1) > 10) break;
-            L.flags[ind + l] |= 1;
-          }
-        };
-        auto curv_of = [&](int ind) {
-          const double d = (double)df[ind];
+        const float d_ep = fabsf(df[ep]);
+        auto curv_at = [&](int k) {  // cloudCurvature of the k-th element = the square of the sort key's value
+          const double d = (double)(k == ep ? d_ep : __uint_as_float((unsigned)(key[k - sp] >> 32)));
           return d * d;
         };
-        int n_sharp = 0, n_ls = 0, n_flat = 0, largest = 0;
-        for (int k = ep; k >= sp; --k) {  // edges: largest curvature first (SE:743-779)
-          const int ind = sorted_ind(k);
-          const unsigned char f = L.flags[ind];
-          if (!(f & 1) && curv_of(ind) > 0.5 && !(f & 8)) {
-            ++largest;
-            if (largest <= 2) {
-              L.flags[ind] = (unsigned char)((f & ~6) | (2 << 1));  // cloudLabel 2
-              spk[n_sharp++] = ind;
-              spk[2 + n_ls++] = ind;
-            } else if (largest <= 20) {
-              L.flags[ind] = (unsigned char)((f & ~6) | (1 << 1));  // cloudLabel 1
-              spk[2 + n_ls++] = ind;
-            } else {
+        auto col_gap = [&](int a, int b) {
+          if (a < 0 || b < 0 || a >= n || b >= n) return 1000;
+          const int g = (int)L.a.col[a] - (int)L.a.col[b];
+          return g < 0 ? -g : g;
+        };
+        // cloudNeighborPicked of the +-5 neighbours up to the first column gap > 10 (SE:764-779): lanes 0-4
+        // look forward, 5-9 backward, the break position comes from a ballot
+        auto mark_nbrs = [&](int ind) {
+          const bool fwd = lane < 5, bwd = lane >= 5 && lane < 10;
+          const int l = fwd ? lane + 1 : -(lane - 5 + 1);
+          const bool gap = (fwd || bwd) && col_gap(ind + l, ind + l + (fwd ? -1 : 1)) > 10;
+          const unsigned long long gm = __ballot(gap);
+          const int stop_f = __ffsll((long long)(gm & 0x1Full)), stop_b = __ffsll((long long)((gm >> 5) & 0x1Full));
+          const int reach_f = stop_f ? stop_f - 1 : 5, reach_b = stop_b ? stop_b - 1 : 5;  // neighbours marked per side
+          if (fwd && lane < reach_f) L.a.flags[ind + l] |= 1;
+          if (bwd && lane - 5 < reach_b) L.a.flags[ind + l] |= 1;
+        };
+        int n_sharp = 0, n_ls = 0, n_flat = 0;
+        // edges: largest curvature first, at most 2 sharp + 18 less sharp
+        bool stop = false;
+        for (int top = ep; top >= sp && !stop; top -= 64) {
+          const int k = top - lane;
+          const bool valid = k >= sp;
+          const int ind = valid ? sorted_ind(k) : 0;
+          const bool curv_ok = valid && curv_at(k) > 0.5;
+          // ascending order below ep: a failed curvature test fails for every later candidate too
+          if (__any(valid && k < ep && !curv_ok)) stop = true;
+          unsigned long long passed = 0;  // lanes at or before the last pick
+          for (;;) {
+            const unsigned char f = valid ? L.a.flags[ind] : (unsigned char)1;
+            const unsigned long long elig = __ballot(curv_ok && !(f & 1) && !(f & 8)) & ~passed;
+            if (!elig) break;
+            const int who = __ffsll((long long)elig) - 1;
+            const int pind = __shfl(ind, who);
+            if (lane == who) {
+              if (n_ls < 2) {
+                L.a.flags[ind] = (unsigned char)((f & ~6) | (2 << 1) | 1);  // cloudLabel 2, picked
+                spk[n_sharp] = ind;
+              } else {
+                L.a.flags[ind] = (unsigned char)((f & ~6) | (1 << 1) | 1);  // cloudLabel 1, picked
+              }
+              spk[2 + n_ls] = ind;
+            }
+            n_sharp += n_ls < 2 ? 1 : 0;
+            ++n_ls;
+            wave_sync();
+            mark_nbrs(pind);
+            wave_sync();
+            passed = (2ull << who) - 1ull;
+            if (n_ls >= 20) {  // the 21st eligible candidate would only end the loop (SE:757-759)
+              stop = true;
               break;
             }
-            L.flags[ind] |= 1;
-            mark_nbrs(ind);
           }
         }
-        int smallest = 0;
-        for (int k = sp; k <= ep; ++k) {  // planes: smallest curvature first, ground only (SE:782-813)
-          const int ind = sorted_ind(k);
-          const unsigned char f = L.flags[ind];
-          if (!(f & 1) && curv_of(ind) < 0.5 && (f & 8)) {
-            L.flags[ind] = (unsigned char)(f | (3 << 1));  // cloudLabel -1
-            spk[22 + n_flat++] = ind;
-            if (++smallest >= 4) break;
-            L.flags[ind] |= 1;
-            mark_nbrs(ind);
+        // planes: smallest curvature first, ground points only, at most 4; the 4th is not marked (SE:782-813)
+        stop = !any_ground;
+        for (int bot = sp; bot <= ep && !stop; bot += 64) {
+          const int k = bot + lane;
+          const bool valid = k <= ep;
+          const int ind = valid ? sorted_ind(k) : 0;
+          const bool curv_ok = valid && curv_at(k) < 0.5;
+          unsigned long long passed = 0;
+          for (;;) {
+            const unsigned char f = valid ? L.a.flags[ind] : (unsigned char)1;
+            const unsigned long long elig = __ballot(curv_ok && !(f & 1) && (f & 8)) & ~passed;
+            if (!elig) break;
+            const int who = __ffsll((long long)elig) - 1;
+            const int pind = __shfl(ind, who);
+            const bool last = n_flat + 1 >= 4;
+            if (lane == who) {
+              L.a.flags[ind] = (unsigned char)(f | (3 << 1) | (last ? 0 : 1));  // cloudLabel -1 (+ picked unless the 4th)
+              spk[22 + n_flat] = ind;
+            }
+            ++n_flat;
+            wave_sync();
+            if (last) {
+              stop = true;
+              break;
+            }
+            mark_nbrs(pind);
+            wave_sync();
+            passed = (2ull << who) - 1ull;
           }
         }
-        spk[26] = n_sharp, spk[27] = n_ls, spk[28] = n_flat;
+        if (lane == 0) spk[26] = n_sharp, spk[27] = n_ls, spk[28] = n_flat;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -270,14 +349,17 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   __threadfence_block();
   __syncthreads();
 
+#ifdef LINS_FE_PROF
+  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("FE %d %lld\n", 3, t_ - fe_t0); fe_t0 = t_; }
+#endif
   auto label_le0 = [&](int k) {  // cloudLabel <= 0: untouched (0) or flat (-1)
-    const int b = (L.flags[k] >> 1) & 3;
+    const int b = (L.a.flags[k] >> 1) & 3;
     return b == 0 || b == 3;
   };
 
   // ---- feature clouds in the reference's order: rings, sectors, pick order -------------------------
   {
-    int* cnt = reinterpret_cast<int*>(L.vox.vkey);  // [3][96] counts, then [3][96] exclusive offsets (region idle here)
+    int* cnt = reinterpret_cast<int*>(L.a.skey);  // [3][96] counts, then [3][96] exclusive offsets (sort buffers idle here)
     constexpr int kSec = kFeRows * 6;
     if (tid < kSec) {
       const int* spk = pk + tid * kPickStride;
@@ -307,130 +389,159 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     __syncthreads();
   }
 
-  // ---- less-flat cloud: per ring, every point of its sectors with label <= 0, VoxelGrid 0.2 m ------
+#ifdef LINS_FE_PROF
+  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("FE %d %lld\n", 4, t_ - fe_t0); fe_t0 = t_; }
+#endif
+  // ---- less-flat cloud: per ring, every point of its sectors with label <= 0 (SE:815-820) ... -----
+  // D0, one wave per ring: compact the kept points and take the bounding box VoxelGrid needs.
   float4* olf = out_less_flat + (size_t)scan * kFeMaxN;
-  for (int ring = 0; ring < kFeRows; ++ring) {
-    // the ring's sector spans, in order, concatenated: positions [lo_j, hi_j]
-    int my_k[2] = {-1, -1};
+  float4* lfp = const_cast<float4*>(pts);  // the uploaded copy of the input cloud is dead: it becomes the per-ring
+                                           // compact lists of kept points (read back coalesced, no index chasing)
+  {
+    const int ring = wave;
+    int m = 0, base = -1;
+    int mn[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    for (int j = 0; j < 6; ++j) {
+      const int sp = (sc.start_ring[ring] * (6 - j) + sc.end_ring[ring] * j) / 6;
+      const int ep = (sc.start_ring[ring] * (5 - j) + sc.end_ring[ring] * (j + 1)) / 6 - 1;
+      if (sp >= ep || sp < 0 || ep >= n || ep - sp > kSectorCap - 1) continue;
+      if (base < 0) base = sp;
+      for (int c0 = sp; c0 <= ep; c0 += 64) {
+        const int k = c0 + lane;
+        const bool keep = k <= ep && label_le0(k);
+        const unsigned long long mask = __ballot(keep);
+        if (keep) {
+          const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+          const float4 p = un[k];
+          lfp[base + m + pos] = p;
+          const int ox = fe_ordered_int(p.x), oy = fe_ordered_int(p.y), oz = fe_ordered_int(p.z);
+          mn[0] = min(mn[0], ox), mn[1] = min(mn[1], oy), mn[2] = min(mn[2], oz);
+          mx[0] = max(mx[0], ox), mx[1] = max(mx[1], oy), mx[2] = max(mx[2], oz);
+        }
+        m += __popcll(mask);
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      for (int o = 32; o > 0; o >>= 1) mn[a] = min(mn[a], __shfl_xor(mn[a], o)), mx[a] = max(mx[a], __shfl_xor(mx[a], o));
+    if (lane == 0) {
+      L.ring_m[ring] = m, L.ring_base[ring] = base < 0 ? 0 : base;
+      for (int a = 0; a < 3; ++a) L.ring_bb[ring][a] = mn[a], L.ring_bb[ring][3 + a] = mx[a];
+      if (m > kRingCap) L.bad = 1;  // cannot happen for a 16 x 1800 sensor; refuse rather than truncate silently
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (L.bad) {
+    if (tid == 0) out_counts[scan * 4 + 3] = -1;
+    return;
+  }
+#ifdef LINS_FE_PROF
+  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("FE %d %lld\n", 5, t_ - fe_t0); fe_t0 = t_; }
+#endif
+  // D1, pcl::VoxelGrid 0.2 m with all-field averaging, output ordered by voxel index (SE:189, 822-825):
+  // one wave per ring; 2048 keys (voxel index << 11 | order) sorted in registers, then only the order
+  // and a run-start bit per sorted position go to LDS (the flags / columns / sector buffers are dead).
+  // Sorted position e belongs to lane e / 32.
+  {
     {
-      // enumerate candidate indices of this ring: the union of its valid sectors is contiguous per sector;
-      // thread t takes candidates t and t + 1024 of the concatenation
-      int base = 0;
-      for (int j = 0; j < 6; ++j) {
-        const int sp = (sc.start_ring[ring] * (6 - j) + sc.end_ring[ring] * j) / 6;
-        const int ep = (sc.start_ring[ring] * (5 - j) + sc.end_ring[ring] * (j + 1)) / 6 - 1;
-        if (sp >= ep || sp < 0 || ep >= n || ep - sp > kSectorCap - 1) continue;
-        const int len = ep - sp + 1;
-        for (int u = 0; u < 2; ++u) {
-          const int c = tid + u * kFeBlock - base;
-          if (c >= 0 && c < len) my_k[u] = sp + c;
+      const int ring = wave;
+      const int m = L.ring_m[ring], base = L.ring_base[ring];
+      unsigned short* vs = L.vso[wave];
+      int nvox = 0;
+      if (m > 0) {
+        const float inv = 1.0f / 0.2f;
+        int minb[3], maxb[3];
+        for (int a = 0; a < 3; ++a) {
+          minb[a] = (int)floorf(fe_ordered_float(L.ring_bb[ring][a]) * inv);
+          maxb[a] = (int)floorf(fe_ordered_float(L.ring_bb[ring][3 + a]) * inv);
         }
-        base += len;
-      }
-    }
-    bool keep[2];
-    for (int u = 0; u < 2; ++u) {
-      keep[u] = my_k[u] >= 0 && label_le0(my_k[u]);
-
-    }
-    // order inside the ring = candidate order: thread t's first candidate precedes every candidate of
-    // higher threads, its second (t + 1024) follows all first candidates
-    const int first_cnt = keep[0] ? 1 : 0, second_cnt = keep[1] ? 1 : 0;
-    const int pos0 = fe_block_scan(first_cnt, tid, L.scan_tmp);
-    const int tot0 = L.scan_tmp[18];
-    __syncthreads();
-    const int pos1 = fe_block_scan(second_cnt, tid, L.scan_tmp);
-    const int m = tot0 + L.scan_tmp[18];
-    __syncthreads();
-    if (tid < 3) L.bmin[tid] = 0x7FFFFFFF, L.bmax[tid] = (int)0x80000000;
-    __syncthreads();
-    if (m > kRingCap) {  // cannot happen for a 16 x 1800 sensor; refuse rather than truncate silently
-      if (tid == 0) out_counts[scan * 4 + 3] = -1;
-      return;
-    }
-    for (int u = 0; u < 2; ++u)
-      if (keep[u]) {
-        const float4 p = un[my_k[u]];
-        const int pos = u == 0 ? pos0 : tot0 + pos1;
-        L.vox.vpt[pos] = p;
-        atomicMin(&L.bmin[0], fe_ordered_int(p.x)), atomicMax(&L.bmax[0], fe_ordered_int(p.x));
-        atomicMin(&L.bmin[1], fe_ordered_int(p.y)), atomicMax(&L.bmax[1], fe_ordered_int(p.y));
-        atomicMin(&L.bmin[2], fe_ordered_int(p.z)), atomicMax(&L.bmax[2], fe_ordered_int(p.z));
-      }
-    __syncthreads();
-    if (m > 0) {
-      const float inv = 1.0f / 0.2f;
-      int minb[3], maxb[3];
-      for (int a = 0; a < 3; ++a) {
-        minb[a] = (int)floorf(fe_ordered_float(L.bmin[a]) * inv);
-        maxb[a] = (int)floorf(fe_ordered_float(L.bmax[a]) * inv);
-      }
-      const long long dx = maxb[0] - minb[0] + 1, dy = maxb[1] - minb[1] + 1;
-      for (int e = tid; e < kRingCap; e += kFeBlock) {
-        unsigned long long k = ~0ull;
-        if (e < m) {
-          const float4 p = L.vox.vpt[e];
-          const long long ix = (long long)floorf(p.x * inv) - minb[0];
-          const long long iy = (long long)floorf(p.y * inv) - minb[1];
-          const long long iz = (long long)floorf(p.z * inv) - minb[2];
-          k = ((unsigned long long)(ix + iy * dx + iz * dx * dy) << 11) | (unsigned)e;
-        }
-        L.vox.vkey[e] = k;
-      }
-      // bitonic sort of 2048 keys over the block (stable: the order is part of the key)
-      for (int k2 = 2; k2 <= kRingCap; k2 <<= 1)
-        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-          __syncthreads();
-          for (int e = tid; e < kRingCap; e += kFeBlock) {
-            const int partner = e ^ j2;
-            if (partner > e) {
-              const unsigned long long a = L.vox.vkey[e], b = L.vox.vkey[partner];
-              const bool up = (e & k2) == 0;
-              if ((a > b) == up) L.vox.vkey[e] = b, L.vox.vkey[partner] = a;
+        const long long dx = maxb[0] - minb[0] + 1, dy = maxb[1] - minb[1] + 1;
+        int mine = 0;
+        {
+          constexpr int kP = kRingCap / 64;
+          unsigned long long kv[kP];
+#pragma unroll
+          for (int u = 0; u < kP; ++u) {
+            const int e = lane * kP + u;
+            unsigned long long k = ~0ull;
+            if (e < m) {
+              const float4 p = lfp[base + e];
+              const long long ix = (long long)floorf(p.x * inv) - minb[0];
+              const long long iy = (long long)floorf(p.y * inv) - minb[1];
+              const long long iz = (long long)floorf(p.z * inv) - minb[2];
+              k = ((unsigned long long)(ix + iy * dx + iz * dx * dy) << 11) | (unsigned)e;
             }
+            kv[u] = k;
+          }
+          wave_bitonic_sort<kP>(kv, lane);
+          // run starts: the voxel index differs from the predecessor's (the previous lane's last key for u = 0)
+          const unsigned plo = __shfl_up((unsigned)kv[kP - 1], 1), phi = __shfl_up((unsigned)(kv[kP - 1] >> 32), 1);
+          unsigned long long prev = ((unsigned long long)phi << 32) | plo;
+#pragma unroll
+          for (int u = 0; u < kP; ++u) {
+            const int e = lane * kP + u;
+            const bool start = e < m && (e == 0 || (prev >> 11) != (kv[u] >> 11));
+            vs[e] = (unsigned short)((start ? 0x8000u : 0u) | (unsigned)(kv[u] & 2047u));
+            mine += start ? 1 : 0;
+            prev = kv[u];
           }
         }
-      __syncthreads();
-      // one thread per voxel run: centroid of all four fields, f32 sums in stable order
-      int starts = 0;
-      float4 cen[2];
-      bool is_start[2] = {false, false};
-      for (int u = 0; u < 2; ++u) {
-        const int e = tid + u * kFeBlock;
-        if (e < m) {
-          const unsigned long long ke = L.vox.vkey[e] >> 11;
-          if (e == 0 || (L.vox.vkey[e - 1] >> 11) != ke) {
-            float sx = 0, sy = 0, sz = 0, si = 0;
-            int j = e;
-            while (j < m && (L.vox.vkey[j] >> 11) == ke) {
-              const float4 p = L.vox.vpt[(int)(L.vox.vkey[j] & 2047u)];
-              sx += p.x, sy += p.y, sz += p.z, si += p.w;
-              ++j;
-            }
-            const float cnt = (float)(j - e);
-            cen[u] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
-            is_start[u] = true;
-            ++starts;
-          }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // one centroid per run start — f32 sums of all four fields in stable (original) order — to the
+        // ring's temporary place in the output array, at the wave prefix of the start counts
+        constexpr int kPerLane = kRingCap / 64;
+        const int e0 = lane * kPerLane;
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int nb = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += nb;
+        }
+        nvox = __shfl(incl, 63);
+        int pos = incl - mine;
+        for (int u = 0; u < kPerLane; ++u) {
+          const int e = e0 + u;
+          if (e >= m || !(vs[e] & 0x8000u)) continue;
+          float sx = 0, sy = 0, sz = 0, si = 0;
+          int j = e;
+          do {
+            const float4 p = lfp[base + (int)(vs[j] & 2047u)];
+            sx += p.x, sy += p.y, sz += p.z, si += p.w;
+            ++j;
+          } while (j < m && !(vs[j] & 0x8000u));
+          const float cnt = (float)(j - e);
+          olf[base + pos++] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
         }
       }
-      // output order = voxel index order = sorted order: element e before e' if e < e'
-      const int p0 = fe_block_scan(is_start[0] ? 1 : 0, tid, L.scan_tmp);
-      const int t0 = L.scan_tmp[18];
-      __syncthreads();
-      const int p1 = fe_block_scan(is_start[1] ? 1 : 0, tid, L.scan_tmp);
-      const int t1 = L.scan_tmp[18];
-      __syncthreads();
-      const int ob = L.out_base;
-      if (is_start[0]) olf[ob + p0] = cen[0];
-      if (is_start[1]) olf[ob + t0 + p1] = cen[1];
-      __syncthreads();
-      if (tid == 0) L.out_base = ob + t0 + t1;
-      (void)starts;
+      if (lane == 0) L.ring_out[ring] = nvox;
     }
+    __threadfence_block();
     __syncthreads();
   }
-  if (tid == 0) out_counts[scan * 4 + 3] = L.out_base;
+#ifdef LINS_FE_PROF
+  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("FE %d %lld\n", 6, t_ - fe_t0); fe_t0 = t_; }
+#endif
+  // D2: close the gaps, ring by ring (a ring's final place never lies behind its temporary one)
+  if (tid == 0) {
+    int run = 0;
+    for (int r = 0; r < kFeRows; ++r) L.ring_off[r] = run, run += L.ring_out[r];
+    L.ring_off[kFeRows] = run;
+    out_counts[scan * 4 + 3] = run;
+  }
+  __syncthreads();
+  for (int r = 0; r < kFeRows; ++r) {
+    const int c = L.ring_out[r], src = L.ring_base[r], dst = L.ring_off[r];
+    float4 v[2];
+    for (int u = 0; u < 2; ++u)
+      if (tid + u * kFeBlock < c) v[u] = olf[src + tid + u * kFeBlock];
+    __syncthreads();
+    for (int u = 0; u < 2; ++u)
+      if (tid + u * kFeBlock < c) olf[dst + tid + u * kFeBlock] = v[u];
+    __syncthreads();
+  }
 }
 
 void launch_frontend(hipStream_t stream, int n_scans, const void* scans, const float4* cloud, const float* range,
