@@ -107,6 +107,27 @@ int lins_extract_features_batch(lins_ctx* ctx, int n, const lins_segmented_scan*
  * (25 B read per segmented point + 16 B per emitted feature point).                            */
 int lins_last_frontend_stats(lins_ctx* ctx, float* kernel_ms, uint64_t* bytes);
 
+/* ---- device-resident streams: front-end -> IESKF update -> re-projection, the clouds never leave HBM ----
+ * n independent streams (sensors / robots / replayed logs) advance one scan per call:
+ *   1. the feature stage (SE:619-827) of every stream's new segmented scan, into device slots;
+ *   2. performIESKF (SE:465-600) of the new sharp / flat clouds against the stream's RESIDENT less-sharp /
+ *      less-flat clouds of the previous scan, from the prior (state, covariance) the caller's StatePredictor
+ *      supplies; diverged filters take the device ICP fallback (SE:585-592);
+ *   3. updatePointCloud (SE:1116-1139): the new less-sharp / less-flat clouds re-projected to the scan end
+ *      with the final pose, in place — the next call's targets.
+ * A stream's first scan has nothing to match against: no update is run (out[k].iters = 0, state / covariance
+ * returned as given) and its clouds are re-projected with the pose in prior_state[k] (the caller's bootstrap
+ * guess, SE:331-425 uses the IMU-integrated one).  prior_state: n x 19, prior_cov: n x 324, feature_counts
+ * (optional): n x 4 = sharp, less sharp, flat, less flat.                                                   */
+int lins_streams_init(lins_ctx* ctx, int n_streams);   /* n_streams <= the context's max_batch */
+int lins_streams_step(lins_ctx* ctx, const lins_segmented_scan* scans, const double* prior_state,
+                      const double* prior_cov, double scan_period, lins_result* out, int32_t* feature_counts);
+/* HIP-event times (ms) of the three stages of the last step */
+int lins_streams_stats(lins_ctx* ctx, float* frontend_ms, float* update_ms, float* reproject_ms);
+/* test aid: a resident cloud of the last scan back to the host (which: 0 less sharp, 1 less flat);
+ * returns the point count                                                                            */
+int lins_streams_peek(lins_ctx* ctx, int stream, int which, lins_point* out, int cap);
+
 /* transformToEnd for every point, with the scan's final relative pose
  * (t = linState_.rn_, q = linState_.qbn_ as w,x,y,z). In-place allowed.       */
 void lins_transform_to_end(const double* t, const double* q_wxyz, double scan_period,

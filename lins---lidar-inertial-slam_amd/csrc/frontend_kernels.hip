@@ -35,6 +35,8 @@ struct FeScan {  // device view of one lins_segmented_scan + its outputs
   int n;
   int start_ring[kFeRows], end_ring[kFeRows];
   float start_ori, end_ori, ori_diff;
+  int pad;
+  long long o_sharp, o_less_sharp, o_flat, o_less_flat;  // where the four feature clouds go (points from `out`)
 };
 
 struct FeLds {
@@ -103,8 +105,7 @@ __device__ __forceinline__ void wave_bitonic_sort(unsigned long long (&v)[P], in
 __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     const FeScan* __restrict__ scans, const float4* __restrict__ cloud, const float* __restrict__ range,
     const unsigned* __restrict__ col, const unsigned char* __restrict__ ground, double scan_period,
-    float4* __restrict__ und, float* __restrict__ diff, int* __restrict__ picks, float4* __restrict__ out_sharp,
-    float4* __restrict__ out_less_sharp, float4* __restrict__ out_flat, float4* __restrict__ out_less_flat,
+    float4* __restrict__ und, float* __restrict__ diff, int* __restrict__ picks, float4* __restrict__ out,
     int* __restrict__ out_counts) {
   FeLds& L = g_fe;
 #ifdef LINS_FE_PROF
@@ -379,11 +380,11 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
       const int s2 = t / 26, k = t - s2 * 26;
       const int* spk = pk + s2 * kPickStride;
       if (k < 2) {
-        if (k < spk[26]) out_sharp[(size_t)scan * 192 + cnt[3 * kSec + s2] + k] = un[spk[k]];
+        if (k < spk[26]) out[sc.o_sharp + cnt[3 * kSec + s2] + k] = un[spk[k]];
       } else if (k < 22) {
-        if (k - 2 < spk[27]) out_less_sharp[(size_t)scan * 1920 + cnt[4 * kSec + s2] + (k - 2)] = un[spk[k]];
+        if (k - 2 < spk[27]) out[sc.o_less_sharp + cnt[4 * kSec + s2] + (k - 2)] = un[spk[k]];
       } else {
-        if (k - 22 < spk[28]) out_flat[(size_t)scan * 384 + cnt[5 * kSec + s2] + (k - 22)] = un[spk[k]];
+        if (k - 22 < spk[28]) out[sc.o_flat + cnt[5 * kSec + s2] + (k - 22)] = un[spk[k]];
       }
     }
     __syncthreads();
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
 #endif
   // ---- less-flat cloud: per ring, every point of its sectors with label <= 0 (SE:815-820) ... -----
   // D0, one wave per ring: compact the kept points and take the bounding box VoxelGrid needs.
-  float4* olf = out_less_flat + (size_t)scan * kFeMaxN;
+  float4* olf = out + sc.o_less_flat;
   float4* lfp = const_cast<float4*>(pts);  // the uploaded copy of the input cloud is dead: it becomes the per-ring
                                            // compact lists of kept points (read back coalesced, no index chasing)
   {
@@ -546,10 +547,9 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
 
 void launch_frontend(hipStream_t stream, int n_scans, const void* scans, const float4* cloud, const float* range,
                      const unsigned* col, const unsigned char* ground, double scan_period, float4* und, float* diff,
-                     int* picks, float4* out_sharp, float4* out_less_sharp, float4* out_flat, float4* out_less_flat,
-                     int* out_counts) {
+                     int* picks, float4* out, int* out_counts) {
   hipLaunchKernelGGL(frontend_kernel, dim3(n_scans), dim3(kFeBlock), 0, stream, (const FeScan*)scans, cloud, range, col,
-                     ground, scan_period, und, diff, picks, out_sharp, out_less_sharp, out_flat, out_less_flat, out_counts);
+                     ground, scan_period, und, diff, picks, out, out_counts);
 }
 size_t fe_scan_size() { return sizeof(FeScan); }
 int fe_pick_stride() { return kFeRows * 6 * kPickStride; }

@@ -682,6 +682,39 @@ void launch_transform_to_end(hipStream_t stream, int n_jobs, int max_n, const vo
 }
 size_t reproject_job_size() { return sizeof(ReprojectJob); }
 
+// updatePointCloud's re-projection for device-resident streams (lins_streams_step): the pose is read
+// from the update's output states on the device, the clouds are rewritten in place (SE:1122-1131)
+struct StreamCloud {
+  long long off;  // first point in the stream arena
+  int n, stream;  // points, index of the state to use
+};
+__global__ __launch_bounds__(256) void reproject_in_place_kernel(const StreamCloud* __restrict__ jobs,
+                                                                 const double* __restrict__ states, float4* __restrict__ arena,
+                                                                 double inv_period) {
+  const StreamCloud jb = jobs[blockIdx.y];
+  const double* st = states + (size_t)jb.stream * 19;
+  const V3 t{st[0], st[1], st[2]};
+  const Q4 q{st[6], st[7], st[8], st[9]};
+  const V3 phi = quat2axis(q);
+  const Q4 qinv = qinverse(q);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += gridDim.x * blockDim.x) {
+    const float4 pi = arena[jb.off + i];
+    const float frac = pi.w - (float)(int)pi.w;
+    const double s = inv_period * (double)frac;
+    const V3 p1 = qrot(axis2quat(s * phi), V3{(double)pi.x, (double)pi.y, (double)pi.z}) + s * t;
+    const V3 p2 = qrot(qinv, p1 - t);
+    arena[jb.off + i] = make_float4((float)p2.x, (float)p2.y, (float)p2.z, pi.w);
+  }
+}
+void launch_reproject_in_place(hipStream_t stream, int n_jobs, int max_n, const void* jobs, const double* states,
+                               float4* arena, double inv_period) {
+  int gx = (max_n + 255) / 256;
+  gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+  hipLaunchKernelGGL(reproject_in_place_kernel, dim3(gx, n_jobs), dim3(256), 0, stream, (const StreamCloud*)jobs, states,
+                     arena, inv_period);
+}
+size_t stream_cloud_size() { return sizeof(StreamCloud); }
+
 // device-copy ceiling probe (lins_debug_stream_copy): what a pure streaming kernel reaches on this box
 __global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ in, float4* __restrict__ out, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];

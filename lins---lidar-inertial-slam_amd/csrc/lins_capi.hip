@@ -40,7 +40,13 @@ void launch_transform_to_end(hipStream_t, int, int, const void*, const float4*, 
 size_t reproject_job_size();
 void launch_stream_copy(hipStream_t, const float4*, float4*, size_t);
 void launch_frontend(hipStream_t, int, const void*, const float4*, const float*, const unsigned*, const unsigned char*,
-                     double, float4*, float*, int*, float4*, float4*, float4*, float4*, int*);
+                     double, float4*, float*, int*, float4*, int*);
+void launch_reproject_in_place(hipStream_t, int, int, const void*, const double*, float4*, double);
+size_t stream_cloud_size();
+struct StreamCloudHost {
+  long long off;
+  int n, stream;
+};
 size_t fe_scan_size();
 int fe_pick_stride();
 struct FeScanHost {
@@ -48,6 +54,8 @@ struct FeScanHost {
   int n;
   int start_ring[16], end_ring[16];
   float start_ori, end_ori, ori_diff;
+  int pad;
+  long long o_sharp, o_less_sharp, o_flat, o_less_flat;
 };
 struct ReprojectJobHost {
   long long off;
@@ -92,8 +100,7 @@ struct lins_ctx {
   struct Frontend {
     int cap = 0;
     void* d_scans = nullptr;
-    float4 *d_cloud = nullptr, *d_und = nullptr, *d_sharp = nullptr, *d_less_sharp = nullptr, *d_flat = nullptr,
-           *d_less_flat = nullptr;
+    float4 *d_cloud = nullptr, *d_und = nullptr, *d_out = nullptr;  // d_out: per scan [192 | 1920 | 384 | LINS_CLOUD_MAX]
     float *d_range = nullptr, *d_diff = nullptr;
     unsigned* d_col = nullptr;
     unsigned char* d_ground = nullptr;
@@ -101,6 +108,16 @@ struct lins_ctx {
     float ms = 0.f;
     uint64_t bytes = 0;
   } fe;
+  // device-resident streams (lins_streams_step): per stream two feature slots (this scan's / the last
+  // scan's clouds) inside one arena, so that ScanDesc offsets address both
+  struct Streams {
+    int n = 0, cur = 0;           // slot the NEXT scan's features go to
+    float4 *d_arena = nullptr, *d_sorted = nullptr;
+    ScanDesc* d_desc = nullptr;
+    void* d_jobs = nullptr;
+    std::vector<int> last_counts;  // per stream: less sharp, less flat of the resident last scan (-1: none yet)
+    float update_ms = 0.f, frontend_ms = 0.f, reproject_ms = 0.f;
+  } st;
   long long* d_prof = nullptr;  // optional per-workgroup phase profile (lins_debug_phase_profile)
   double* d_a6 = nullptr;  // upper triangle of the last iteration's H^T H, per scan
   void* d_out = nullptr;
@@ -181,10 +198,15 @@ int effective_search(const lins_ctx* ctx, int n) {
   return s;
 }
 
+void streams_free(lins_ctx* ctx) {
+  auto& t = ctx->st;
+  (void)hipFree(t.d_arena), (void)hipFree(t.d_sorted), (void)hipFree(t.d_desc), (void)hipFree(t.d_jobs);
+  t = lins_ctx::Streams{};
+}
+
 void fe_free(lins_ctx* ctx) {
   auto& f = ctx->fe;
-  void* ptrs[] = {f.d_scans, f.d_cloud, f.d_und, f.d_sharp, f.d_less_sharp, f.d_flat, f.d_less_flat, f.d_range,
-                  f.d_diff, f.d_col, f.d_ground, f.d_picks, f.d_counts};
+  void* ptrs[] = {f.d_scans, f.d_cloud, f.d_und, f.d_out, f.d_range, f.d_diff, f.d_col, f.d_ground, f.d_picks, f.d_counts};
   for (void* p : ptrs) (void)hipFree(p);
   f = lins_ctx::Frontend{};
 }
@@ -352,6 +374,7 @@ void lins_destroy(lins_ctx* ctx) {
   (void)hipFree(ctx->d_aux);
   (void)hipFree(ctx->d_jobs);
   fe_free(ctx);
+  streams_free(ctx);
   (void)hipFree(ctx->d_out);
   (void)hipFree(ctx->d_idx);
   (void)hipFree(ctx->d_dump);
@@ -467,19 +490,37 @@ int lins_debug_stream_copy(lins_ctx* ctx, uint64_t bytes, int reps, double* gbs)
   return LINS_OK;
 }
 
-int lins_extract_features_batch(lins_ctx* ctx, int n, const lins_segmented_scan* in, double scan_period,
-                                lins_features* out) {
-  if (!ctx || n < 0 || (n && (!in || !out))) return LINS_E_ARG;
-  if (n == 0) return LINS_OK;
-  static_assert(sizeof(FeScanHost) == 152, "FeScan layout");
+// device buffers of the front-end for n scans (inputs, scratch, and the default output buffer d_out)
+static int fe_alloc(lins_ctx* ctx, int n) {
+  auto& f = ctx->fe;
+  if (f.cap >= n) return LINS_OK;
+  fe_free(ctx);
+  const size_t c = (size_t)n, N = LINS_CLOUD_MAX;
+  HIP_TRY(ctx, hipMalloc(&f.d_scans, c * sizeof(FeScanHost)));
+  HIP_TRY(ctx, hipMalloc((void**)&f.d_cloud, c * N * sizeof(float4)));
+  HIP_TRY(ctx, hipMalloc((void**)&f.d_und, c * N * sizeof(float4)));
+  HIP_TRY(ctx, hipMalloc((void**)&f.d_range, c * N * sizeof(float)));
+  HIP_TRY(ctx, hipMalloc((void**)&f.d_diff, c * N * sizeof(float)));
+  HIP_TRY(ctx, hipMalloc((void**)&f.d_col, c * N * sizeof(unsigned)));
+  HIP_TRY(ctx, hipMalloc((void**)&f.d_ground, c * N));
+  HIP_TRY(ctx, hipMalloc((void**)&f.d_picks, c * fe_pick_stride() * sizeof(int)));
+  HIP_TRY(ctx, hipMalloc((void**)&f.d_out, c * (192 + 1920 + 384 + N) * sizeof(float4)));
+  HIP_TRY(ctx, hipMalloc((void**)&f.d_counts, c * 4 * sizeof(int)));
+  f.cap = n;
+  return LINS_OK;
+}
+
+// Front-end stage shared by lins_extract_features_batch and lins_streams_step: validate, upload the
+// segmented scans, launch frontend_kernel with the feature clouds going to out_base + offs[k][0..3]
+// (sharp, less sharp, flat, less flat), bring the four counts per scan back (synchronises).
+static int fe_run(lins_ctx* ctx, int n, const lins_segmented_scan* in, double scan_period, float4* out_base,
+                  const long long (*offs)[4], std::vector<int>& counts) {
+  static_assert(sizeof(FeScanHost) == 192, "FeScan layout");
   if (fe_scan_size() != sizeof(FeScanHost)) return LINS_E_STATE;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t N = LINS_CLOUD_MAX;
   for (int k = 0; k < n; ++k) {
     const lins_segmented_scan& s = in[k];
     if (s.n < 0 || s.n > (int)N || (s.n && (!s.cloud || !s.range || !s.col || !s.ground))) return LINS_E_ARG;
-    if (!out[k].corner_sharp || !out[k].corner_less_sharp || !out[k].surf_flat || !out[k].surf_less_flat)
-      return LINS_E_ARG;
     for (int r = 0; r < LINS_LINE_NUM; ++r)  // a sector must fit the per-wave sort network (a VLP-16 ring: <= 300)
       if ((s.end_ring[r] - s.start_ring[r]) / 6 + 2 > 510) return LINS_E_UNSUPPORTED;
     for (int i = 0; i < s.n; ++i) {
@@ -489,32 +530,17 @@ int lins_extract_features_batch(lins_ctx* ctx, int n, const lins_segmented_scan*
         return LINS_E_INPUT;
     }
   }
+  int rc0 = fe_alloc(ctx, n);
+  if (rc0) return rc0;
   auto& f = ctx->fe;
-  if (f.cap < n) {
-    fe_free(ctx);
-    const size_t c = (size_t)n;
-    HIP_TRY(ctx, hipMalloc(&f.d_scans, c * sizeof(FeScanHost)));
-    HIP_TRY(ctx, hipMalloc((void**)&f.d_cloud, c * N * sizeof(float4)));
-    HIP_TRY(ctx, hipMalloc((void**)&f.d_und, c * N * sizeof(float4)));
-    HIP_TRY(ctx, hipMalloc((void**)&f.d_range, c * N * sizeof(float)));
-    HIP_TRY(ctx, hipMalloc((void**)&f.d_diff, c * N * sizeof(float)));
-    HIP_TRY(ctx, hipMalloc((void**)&f.d_col, c * N * sizeof(unsigned)));
-    HIP_TRY(ctx, hipMalloc((void**)&f.d_ground, c * N));
-    HIP_TRY(ctx, hipMalloc((void**)&f.d_picks, c * fe_pick_stride() * sizeof(int)));
-    HIP_TRY(ctx, hipMalloc((void**)&f.d_sharp, c * 192 * sizeof(float4)));
-    HIP_TRY(ctx, hipMalloc((void**)&f.d_less_sharp, c * 1920 * sizeof(float4)));
-    HIP_TRY(ctx, hipMalloc((void**)&f.d_flat, c * 384 * sizeof(float4)));
-    HIP_TRY(ctx, hipMalloc((void**)&f.d_less_flat, c * N * sizeof(float4)));
-    HIP_TRY(ctx, hipMalloc((void**)&f.d_counts, c * 4 * sizeof(int)));
-    f.cap = n;
-  }
   std::vector<FeScanHost> hs(n);
   uint64_t bytes = 0;
   for (int k = 0; k < n; ++k) {
     const lins_segmented_scan& s = in[k];
-    hs[k].off = (long long)((size_t)k * N), hs[k].n = s.n;
+    hs[k].off = (long long)((size_t)k * N), hs[k].n = s.n, hs[k].pad = 0;
     for (int r = 0; r < LINS_LINE_NUM; ++r) hs[k].start_ring[r] = s.start_ring[r], hs[k].end_ring[r] = s.end_ring[r];
     hs[k].start_ori = s.start_ori, hs[k].end_ori = s.end_ori, hs[k].ori_diff = s.ori_diff;
+    hs[k].o_sharp = offs[k][0], hs[k].o_less_sharp = offs[k][1], hs[k].o_flat = offs[k][2], hs[k].o_less_flat = offs[k][3];
     if (!s.n) continue;
     HIP_TRY(ctx, hipMemcpyAsync(f.d_cloud + hs[k].off, s.cloud, s.n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(f.d_range + hs[k].off, s.range, s.n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
@@ -525,28 +551,225 @@ int lins_extract_features_batch(lins_ctx* ctx, int n, const lins_segmented_scan*
   HIP_TRY(ctx, hipMemcpyAsync(f.d_scans, hs.data(), (size_t)n * sizeof(FeScanHost), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   launch_frontend(ctx->stream, n, f.d_scans, f.d_cloud, f.d_range, f.d_col, f.d_ground, scan_period, f.d_und, f.d_diff,
-                  f.d_picks, f.d_sharp, f.d_less_sharp, f.d_flat, f.d_less_flat, f.d_counts);
+                  f.d_picks, out_base, f.d_counts);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
-  std::vector<int> counts((size_t)n * 4);
+  counts.resize((size_t)n * 4);
   HIP_TRY(ctx, hipMemcpyAsync(counts.data(), f.d_counts, counts.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  for (int k = 0; k < n; ++k) {
-    const int* c = &counts[(size_t)k * 4];
-    if (c[3] < 0) return LINS_E_UNSUPPORTED;  // a ring with more less-flat points than the voxel sort network holds
-    lins_features& o = out[k];
-    o.n_corner_sharp = c[0], o.n_corner_less_sharp = c[1], o.n_surf_flat = c[2], o.n_surf_less_flat = c[3];
-    o.n_segmented = in[k].n, o.n_outlier = in[k].n_outlier;
-    HIP_TRY(ctx, hipMemcpyAsync(o.corner_sharp, f.d_sharp + (size_t)k * 192, c[0] * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(o.corner_less_sharp, f.d_less_sharp + (size_t)k * 1920, c[1] * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(o.surf_flat, f.d_flat + (size_t)k * 384, c[2] * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(o.surf_less_flat, f.d_less_flat + (size_t)k * N, c[3] * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
-    bytes += 16ull * (c[0] + c[1] + c[2] + c[3]);
-  }
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipEventElapsedTime(&f.ms, ctx->ev0, ctx->ev2));
+  for (int k = 0; k < n; ++k) {
+    if (counts[(size_t)k * 4 + 3] < 0) return LINS_E_UNSUPPORTED;  // a ring beyond the voxel sort network
+    bytes += 16ull * (counts[k * 4] + counts[k * 4 + 1] + counts[k * 4 + 2] + counts[k * 4 + 3]);
+  }
   f.bytes = bytes;
   return LINS_OK;
+}
+
+int lins_extract_features_batch(lins_ctx* ctx, int n, const lins_segmented_scan* in, double scan_period,
+                                lins_features* out) {
+  if (!ctx || n < 0 || (n && (!in || !out))) return LINS_E_ARG;
+  if (n == 0) return LINS_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  for (int k = 0; k < n; ++k)
+    if (!out[k].corner_sharp || !out[k].corner_less_sharp || !out[k].surf_flat || !out[k].surf_less_flat)
+      return LINS_E_ARG;
+  const long long per = 192 + 1920 + 384 + LINS_CLOUD_MAX;
+  std::vector<long long> offs((size_t)n * 4);
+  for (int k = 0; k < n; ++k) {
+    long long* o = &offs[(size_t)k * 4];
+    o[0] = k * per, o[1] = o[0] + 192, o[2] = o[1] + 1920, o[3] = o[2] + 384;
+  }
+  std::vector<int> counts;
+  int rc = fe_alloc(ctx, n);  // (first, so that the default output buffer exists)
+  if (rc) return rc;
+  rc = fe_run(ctx, n, in, scan_period, ctx->fe.d_out, reinterpret_cast<const long long(*)[4]>(offs.data()), counts);
+  if (rc) return rc;
+  auto& f = ctx->fe;
+  for (int k = 0; k < n; ++k) {
+    const int* c = &counts[(size_t)k * 4];
+    const long long* o = &offs[(size_t)k * 4];
+    lins_features& ft = out[k];
+    ft.n_corner_sharp = c[0], ft.n_corner_less_sharp = c[1], ft.n_surf_flat = c[2], ft.n_surf_less_flat = c[3];
+    ft.n_segmented = in[k].n, ft.n_outlier = in[k].n_outlier;
+    HIP_TRY(ctx, hipMemcpyAsync(ft.corner_sharp, f.d_out + o[0], c[0] * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ft.corner_less_sharp, f.d_out + o[1], c[1] * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ft.surf_flat, f.d_out + o[2], c[2] * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ft.surf_less_flat, f.d_out + o[3], c[3] * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LINS_OK;
+}
+
+// ---- device-resident streams: front-end -> IESKF update -> re-projection without the clouds leaving HBM ----
+namespace {
+// slot layout (points): [flat 512 | sharp 256 | less flat LINS_CLOUD_MAX | less sharp 1920]; the less-sharp cloud
+// follows the less-flat one so that the multi-resident kernel's sorted copy (positions 0 .. n_all) stays in the slot
+constexpr long long kSlotFlat = 0, kSlotSharp = 512, kSlotLessFlat = 768, kSlotLessSharp = 768 + LINS_CLOUD_MAX;
+constexpr long long kSlotSize = kSlotLessSharp + 1920;
+inline long long slot_base(int stream, int slot) { return ((long long)stream * 2 + slot) * kSlotSize; }
+}  // namespace
+
+int lins_streams_init(lins_ctx* ctx, int n_streams) {
+  if (!ctx || n_streams < 1) return LINS_E_ARG;
+  if (n_streams > ctx->max_batch) return LINS_E_CAPACITY;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  streams_free(ctx);
+  auto& t = ctx->st;
+  const size_t pts = (size_t)n_streams * 2 * kSlotSize;
+  if (pts >= (1ull << 31)) return LINS_E_CAPACITY;  // ScanDesc offsets are ints
+  HIP_TRY(ctx, hipMalloc((void**)&t.d_arena, pts * sizeof(float4)));
+  HIP_TRY(ctx, hipMalloc((void**)&t.d_sorted, pts * sizeof(float4)));
+  HIP_TRY(ctx, hipMalloc((void**)&t.d_desc, (size_t)n_streams * sizeof(ScanDesc)));
+  HIP_TRY(ctx, hipMalloc(&t.d_jobs, (size_t)n_streams * 2 * sizeof(StreamCloudHost)));
+  t.n = n_streams, t.cur = 0;
+  t.last_counts.assign((size_t)n_streams * 2, -1);
+  return LINS_OK;
+}
+
+int lins_streams_step(lins_ctx* ctx, const lins_segmented_scan* scans, const double* prior_state, const double* prior_cov,
+                      double scan_period, lins_result* out, int32_t* feature_counts) {
+  if (!ctx || !scans || !prior_state || !prior_cov || !out) return LINS_E_ARG;
+  auto& t = ctx->st;
+  if (t.n <= 0) return LINS_E_STATE;
+  if (stream_cloud_size() != sizeof(StreamCloudHost)) return LINS_E_STATE;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int n = t.n, cur = t.cur, last = cur ^ 1;
+  ctx->n_uploaded = 0, ctx->ran = false;  // the batch buffers are reused below
+  // 1. feature front-end, straight into this scan's slots
+  std::vector<long long> offs((size_t)n * 4);
+  for (int k = 0; k < n; ++k) {
+    long long* o = &offs[(size_t)k * 4];
+    const long long b = slot_base(k, cur);
+    o[0] = b + kSlotSharp, o[1] = b + kSlotLessSharp, o[2] = b + kSlotFlat, o[3] = b + kSlotLessFlat;
+  }
+  std::vector<int> counts;
+  int rc = fe_run(ctx, n, scans, scan_period, t.d_arena, reinterpret_cast<const long long(*)[4]>(offs.data()), counts);
+  if (rc) return rc;
+  t.frontend_ms = ctx->fe.ms;
+  // 2. IESKF update of every stream against its resident last scan (a stream's first scan: an update
+  //    with no rows, which leaves the given state — the bootstrap pose — untouched)
+  bool lds_ok = true, mr_ok = true, lds3_ok = true;
+  for (int k = 0; k < n; ++k) {
+    const int* c = &counts[(size_t)k * 4];  // sharp, less sharp, flat, less flat
+    const bool has_last = t.last_counts[(size_t)k * 2] >= 0;
+    ScanDesc& d = ctx->h_desc[k];
+    const long long bq = slot_base(k, cur), bt = slot_base(k, last);
+    d.off_surf_q = (int)(bq + kSlotFlat), d.n_surf_q = has_last ? c[2] : 0;
+    d.off_corner_q = (int)(bq + kSlotSharp), d.n_corner_q = has_last ? c[0] : 0;
+    d.off_surf_t = (int)(bt + kSlotLessFlat), d.n_surf_t = has_last ? t.last_counts[(size_t)k * 2 + 1] : 0;
+    d.off_corner_t = (int)(bt + kSlotLessSharp), d.n_corner_t = has_last ? t.last_counts[(size_t)k * 2] : 0;
+    d.surf_sorted = d.corner_sorted = 1;  // the front-end emits ring-major clouds with ring ids < 16
+    d.slot_base = k * LINS_MAX_QUERY, d.pad = 0;
+    const int n_all = d.n_surf_t + d.n_corner_t;
+    if (n_all > lds_np_cap()) lds_ok = false;
+    if (n_all > lds_mr_np_cap()) mr_ok = false;
+    if (d.n_surf_q + d.n_corner_q > 336) lds3_ok = false;
+  }
+  ctx->lds_ok = lds_ok, ctx->mr_ok = mr_ok, ctx->lds3_ok = lds3_ok;
+  std::memcpy(ctx->h_state, prior_state, (size_t)n * 19 * 8);
+  std::memcpy(ctx->h_cov, prior_cov, (size_t)n * 324 * 8);
+  HIP_TRY(ctx, hipMemcpyAsync(t.d_desc, ctx->h_desc, (size_t)n * sizeof(ScanDesc), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_state_in, ctx->h_state, (size_t)n * 19 * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_cov_in, ctx->h_cov, (size_t)n * 324 * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  {
+    const int search = effective_search(ctx, n);
+    const bool want_lds = search >= SEARCH_LDS, want_mr = search == SEARCH_MR;
+    const bool use_mr = want_mr && mr_ok, use_lds = want_lds && !want_mr && lds_ok;
+    if (use_mr || use_lds) {
+      if (use_mr)
+        launch_lds_mr(ctx->stream, n, ctx->dprm, t.d_desc, t.d_arena, t.d_sorted, ctx->d_state_in, ctx->d_cov_in,
+                      ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr);
+      else
+        launch_lds(ctx->stream, n, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, t.d_desc, t.d_arena, ctx->d_state_in,
+                   ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr);
+      launch_joseph(ctx->stream, n, ctx->dprm, ctx->d_cov_in, ctx->d_a6, ctx->d_out, ctx->d_cov_out);
+    } else {
+      DevParams dp = ctx->dprm;
+      dp.search = want_lds ? (int)SEARCH_BINNED : search;
+      launch_persistent(ctx->stream, n, dp, t.d_desc, t.d_arena, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out,
+                        ctx->d_cov_out, ctx->d_a6, ctx->d_out, ctx->d_idx, nullptr, 0, t.d_sorted, nullptr);
+    }
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state_out, (size_t)n * 19 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cov, ctx->d_cov_out, (size_t)n * 324 * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)n * sizeof(OutRecHost), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipEventElapsedTime(&t.update_ms, ctx->ev0, ctx->ev1));
+  for (int k = 0; k < n; ++k) {
+    lins_result& r = out[k];
+    std::memset(&r, 0, sizeof r);
+    std::memcpy(r.state, ctx->h_state + (size_t)k * 19, sizeof r.state);
+    std::memcpy(r.cov, ctx->h_cov + (size_t)k * 324, sizeof r.cov);
+    const OutRecHost& o = ctx->h_out[k];
+    const bool has_last = t.last_counts[(size_t)k * 2] >= 0;
+    r.residual_norm = o.residual_norm, r.update_norm = o.update_norm;
+    r.iters = has_last ? o.iters : 0, r.converged = has_last ? o.converged : 0, r.diverged = has_last ? o.diverged : 0;
+    r.m_surf = o.m_surf, r.m_corner = o.m_corner;
+    if (!has_last) {  // a stream's first scan: the given state and covariance, bit for bit (also as re-projection pose)
+      std::memcpy(r.state, prior_state + (size_t)k * 19, sizeof r.state);
+      std::memcpy(r.cov, prior_cov + (size_t)k * 324, sizeof r.cov);
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->d_state_out + (size_t)k * 19, ctx->d_state_in + (size_t)k * 19, 19 * 8,
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+    }
+  }
+  // 2b. diverged filters: the ICP fallback (SE:585-592) on the same resident clouds, pose into the state row
+  for (int k = 0; k < n; ++k) {
+    if (!out[k].diverged) continue;
+    if (!mr_ok || ctx->prm.icp_freq != 1) return LINS_E_UNSUPPORTED;
+    launch_lds_mr_icp(ctx->stream, 1, ctx->dprm, t.d_desc + k, t.d_arena, t.d_sorted, ctx->d_state_in + (size_t)k * 19,
+                      ctx->d_state_out + (size_t)k * 19, (char*)ctx->d_out + (size_t)k * sizeof(OutRecHost), ctx->d_idx);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(out[k].state, ctx->d_state_out + (size_t)k * 19, 19 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(out[k].cov, prior_cov + (size_t)k * 324, 324 * 8);  // Pk_ un-updated
+  }
+  // 3. updatePointCloud: this scan's less-sharp / less-flat clouds to the scan end with the final pose
+  //    (device-resident state rows), in place — they are the next step's targets
+  std::vector<StreamCloudHost> jobs((size_t)n * 2);
+  int max_n = 1;
+  for (int k = 0; k < n; ++k) {
+    const int* c = &counts[(size_t)k * 4];
+    const long long b = slot_base(k, cur);
+    jobs[(size_t)k * 2] = StreamCloudHost{b + kSlotLessSharp, c[1], k};
+    jobs[(size_t)k * 2 + 1] = StreamCloudHost{b + kSlotLessFlat, c[3], k};
+    max_n = std::max(max_n, std::max(c[1], c[3]));
+    t.last_counts[(size_t)k * 2] = c[1], t.last_counts[(size_t)k * 2 + 1] = c[3];
+    if (feature_counts) std::memcpy(feature_counts + (size_t)k * 4, c, 4 * sizeof(int));
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(t.d_jobs, jobs.data(), jobs.size() * sizeof(StreamCloudHost), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  launch_reproject_in_place(ctx->stream, 2 * n, max_n, t.d_jobs, ctx->d_state_out, t.d_arena,
+                            (double)(1.f / (float)scan_period));
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipEventElapsedTime(&t.reproject_ms, ctx->ev0, ctx->ev2));
+  t.cur = last;
+  return LINS_OK;
+}
+
+int lins_streams_stats(lins_ctx* ctx, float* frontend_ms, float* update_ms, float* reproject_ms) {
+  if (!ctx) return LINS_E_ARG;
+  if (frontend_ms) *frontend_ms = ctx->st.frontend_ms;
+  if (update_ms) *update_ms = ctx->st.update_ms;
+  if (reproject_ms) *reproject_ms = ctx->st.reproject_ms;
+  return LINS_OK;
+}
+
+/* test aid: one resident cloud of a stream back to the host (which: 0 less sharp, 1 less flat of the LAST scan) */
+int lins_streams_peek(lins_ctx* ctx, int stream, int which, lins_point* out, int cap) {
+  if (!ctx || !out || stream < 0 || stream >= ctx->st.n || which < 0 || which > 1) return LINS_E_ARG;
+  auto& t = ctx->st;
+  const int cnt = t.last_counts[(size_t)stream * 2 + which];
+  if (cnt < 0) return LINS_E_STATE;
+  if (cnt > cap) return LINS_E_CAPACITY;
+  const long long b = slot_base(stream, t.cur ^ 1) + (which ? kSlotLessFlat : kSlotLessSharp);
+  HIP_TRY(ctx, hipMemcpy(out, t.d_arena + b, (size_t)cnt * sizeof(float4), hipMemcpyDeviceToHost));
+  return cnt;
 }
 
 int lins_last_frontend_stats(lins_ctx* ctx, float* kernel_ms, uint64_t* bytes) {

@@ -21,6 +21,7 @@ EXPORTS = [
     "lins_batch_download", "lins_last_kernel_ms", "lins_batch_bytes_per_iter", "lins_batch_total_iters",
     "lins_correspondences", "lins_reduce_pass", "lins_host_perform_ieskf", "lins_transform_to_end_batch",
     "lins_last_reproject_stats", "lins_icp_update_batch", "lins_extract_features_batch", "lins_last_frontend_stats",
+    "lins_streams_init", "lins_streams_step", "lins_streams_stats", "lins_streams_peek",
 ]
 
 
@@ -164,6 +165,50 @@ class IeskfContext:
         L.lins_last_frontend_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
         self._check(L.lins_last_frontend_stats(self._h, C.byref(ms), C.byref(b)))
         return ms.value, b.value
+
+    # -- device-resident streams: front-end -> update -> re-projection per scan -----------
+    def streams_init(self, n):
+        L = lib()
+        L.lins_streams_init.argtypes = [C.c_void_p, C.c_int]
+        self._check(L.lins_streams_init(self._h, n))
+        self._streams = n
+
+    def streams_step(self, segs, prior_state, prior_cov, scan_period=0.1):
+        """segs: one host.Segmented per stream; prior_state (n,19), prior_cov (n,18,18).
+        Returns (results, feature_counts (n,4) = sharp, less sharp, flat, less flat)."""
+        import importlib
+
+        host = importlib.import_module(__package__ + ".host")
+        n = self._streams
+        assert len(segs) == n
+        arr = (host.SegmentedScanC * n)(*[s.c for s in segs])
+        ps = np.ascontiguousarray(prior_state, dtype=np.float64).reshape(n, 19)
+        pc = np.ascontiguousarray(prior_cov, dtype=np.float64).reshape(n, 324)
+        res = (ResultC * n)()
+        counts = np.zeros((n, 4), np.int32)
+        L = lib()
+        L.lins_streams_step.argtypes = [C.c_void_p, C.POINTER(host.SegmentedScanC), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_double), C.c_double, C.POINTER(ResultC), C.POINTER(C.c_int32)]
+        self._check(L.lins_streams_step(self._h, arr, ps.ctypes.data_as(C.POINTER(C.c_double)),
+                                        pc.ctypes.data_as(C.POINTER(C.c_double)), scan_period, res,
+                                        counts.ctypes.data_as(C.POINTER(C.c_int32))))
+        self._n = 0
+        return [Result(r) for r in res], counts
+
+    def streams_stats(self):
+        a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
+        L = lib()
+        L.lins_streams_stats.argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 3
+        self._check(L.lins_streams_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def streams_peek(self, stream, which):
+        buf = np.zeros((28800, 4), np.float32)
+        L = lib()
+        L.lins_streams_peek.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        n = L.lins_streams_peek(self._h, stream, which, buf.ctypes.data, len(buf))
+        self._check(min(n, 0))
+        return buf[:n].copy()
 
     def icp_update_batch(self, pairs):
         """estimateTransform (the ICP fallback) on the device, from each pair's state pose."""

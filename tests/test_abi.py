@@ -29,7 +29,8 @@ def test_ieskf_library_exports_every_declared_symbol(ieskf):
     assert L.lins_strerror(0) == b"ok" and b"capacity" in L.lins_strerror(-3)
 
 
-DEVICE_SIDE_OF_HOST_HEADER = ("lins_host_perform_ieskf", "lins_extract_features_batch", "lins_last_frontend_stats")
+DEVICE_SIDE_OF_HOST_HEADER = ("lins_host_perform_ieskf", "lins_extract_features_batch", "lins_last_frontend_stats",
+                              "lins_streams_init", "lins_streams_step", "lins_streams_stats", "lins_streams_peek")
 
 
 def test_host_library_exports_every_declared_symbol(host):

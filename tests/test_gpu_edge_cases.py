@@ -369,3 +369,44 @@ def test_device_front_end_matches_the_host_restatement(pkg, ieskf, host):
             tol = np.maximum(np.spacing(np.abs(w[k][:, 3])).astype(np.float64), 1e-8) * (1 if k != "surf_less_flat" else 2)
             assert (err <= tol).all() and (err > 0).mean() <= 0.1, (k, err.max())
         assert g["n_segmented"] == w["n_segmented"] and g["n_outlier"] == w["n_outlier"]
+
+
+def test_device_resident_streams_reproduce_the_staged_path(pkg, ieskf, host):
+    """Two scans per stream through lins_streams_step (front-end -> update -> re-projection, clouds
+    resident in HBM) == the staged path on the same data: host front-end, host re-projection of the
+    first scan's clouds with the bootstrap pose, lins_ieskf_update_batch on the resulting pairs."""
+    n = 6
+    pairs = host.synth_batch(n, start=40)  # built by the host from the same two raw scans per index
+    seg0 = [host.frontend_segment(host.synth_raw_scan(40 + i, 0)) for i in range(n)]
+    seg1 = [host.frontend_segment(host.synth_raw_scan(40 + i, 1)) for i in range(n)]
+    boot = np.zeros((n, 19))
+    for i, p in enumerate(pairs):  # bootstrap pose = what the synthetic pairs re-project the first scan with
+        boot[i, 0:3], boot[i, 6:10] = p.meta["true_t"], p.meta["true_q"]
+    cov0 = np.tile(np.eye(18)[None] * 1e-4, (n, 1, 1))
+    prm = pkg.default_params(num_iter=30)
+    with ieskf.IeskfContext(prm, max_batch=n, max_targets=16384) as c:
+        want = c.update_batch(pairs)
+        c.streams_init(n)
+        r0, cnt0 = c.streams_step(seg0, boot, cov0)
+        for i, r in enumerate(r0):  # first scan: nothing to match, state handed back
+            assert r.iters == 0 and np.array_equal(r.state, boot[i])
+        for i, p in enumerate(pairs):  # the resident clouds are the pair's targets (re-projected first-scan clouds)
+            for which, ref in ((0, p.corner_last), (1, p.surf_last)):
+                got = c.streams_peek(i, which)
+                assert got.shape == ref.shape
+                # bit-equal except where a time tag / a trig call differs in its last bit (device vs host libm)
+                err = np.abs(got[:, :3].astype(np.float64) - ref[:, :3])
+                # (one f32 step of a ring-15 time tag moves a point at 50 m by ~2e-5 m through the de-skew)
+                assert err.max(initial=0) <= 5e-5 and (err > 0).mean() <= 2e-2 and np.abs(got[:, 3] - ref[:, 3]).max() <= 4e-6
+        r1, cnt1 = c.streams_step(seg1, np.stack([p.state for p in pairs]), np.stack([p.cov for p in pairs]))
+        fe_ms, up_ms, rp_ms = c.streams_stats()
+        assert fe_ms > 0 and up_ms > 0 and rp_ms > 0
+        for i, (g, w, p) in enumerate(zip(r1, want, pairs)):
+            assert tuple(cnt1[i][[2, 0]]) == (len(p.surf_flat), len(p.corner_sharp))
+            assert (g.iters, g.converged, g.diverged, g.m_surf, g.m_corner) == \
+                   (w.iters, w.converged, w.diverged, w.m_surf, w.m_corner), i
+            assert np.abs(g.state[:3] - w.state[:3]).max() <= 1e-6 and np.abs(g.state[6:10] - w.state[6:10]).max() <= 1e-7
+            assert np.abs(g.cov - w.cov).max() <= 1e-6 * np.abs(w.cov).max()
+        # third step on the same context (slots swap back): still runs, poses stay finite
+        r2, _ = c.streams_step(seg0, np.stack([p.state for p in pairs]), np.stack([p.cov for p in pairs]))
+        assert all(np.isfinite(r.state).all() for r in r2)

@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""Stage times of the device-resident pipeline (lins_streams_step): front-end -> IESKF update -> re-projection."""
+import importlib, os, sys, time
+from concurrent.futures import ThreadPoolExecutor
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "lins---lidar-inertial-slam_amd"
+pkg = importlib.import_module(PKG); host = importlib.import_module(PKG + ".host"); ieskf = importlib.import_module(PKG + ".ieskf")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+with ThreadPoolExecutor(16) as ex:
+    pairs = list(ex.map(host.synth_pair, range(n)))
+    seg0 = list(ex.map(lambda i: host.frontend_segment(host.synth_raw_scan(i, 0)), range(n)))
+    seg1 = list(ex.map(lambda i: host.frontend_segment(host.synth_raw_scan(i, 1)), range(n)))
+boot = np.zeros((n, 19))
+for i, p in enumerate(pairs):
+    boot[i, 0:3], boot[i, 6:10] = p.meta["true_t"], p.meta["true_q"]
+st = np.stack([p.state for p in pairs]); cv = np.stack([p.cov for p in pairs])
+with ieskf.IeskfContext(pkg.default_params(num_iter=10, fixed_iters=1), max_batch=n, max_targets=16384) as c:
+    c.streams_init(n)
+    c.streams_step(seg0, boot, np.tile(np.eye(18)[None] * 1e-4, (n, 1, 1)))
+    best = None
+    for rep in range(3):
+        t0 = time.perf_counter()
+        res, cnt = c.streams_step(seg1 if rep % 2 == 0 else seg0, st, cv)
+        wall = time.perf_counter() - t0
+        fe, up, rp = c.streams_stats()
+        if best is None or fe + up + rp < sum(best[:3]):
+            best = (fe, up, rp, wall)
+    fe, up, rp, wall = best
+    its = sum(r.iters for r in res)
+    print(f"streams: {n} streams, one scan each: front-end {fe:.3f} ms + update {up:.3f} ms ({its} iterations) + re-projection {rp:.3f} ms "
+          f"= {fe + up + rp:.3f} ms on device => {n / (fe + up + rp) * 1e3:.0f} scans/s; wall incl. segmented-cloud upload + validation {wall * 1e3:.1f} ms")
