@@ -201,9 +201,9 @@ int lins_reduce_pass(lins_ctx* ctx, const lins_scan_pair* in,
  * in[].state = the pose to start from (the filter's); out[].state = that state with position and
  * attitude replaced, out[].cov = in[].cov, out[].iters / converged = rounds run / stop rule hit.
  * Returns LINS_E_UNSUPPORTED, with nothing run, when a scan cannot take the grid kernels
- * (unsorted rings, ring ids >= 16, > 12288 target points) or ICP_FREQ != 1 —
+ * (unsorted rings, ring ids >= 16, > 12288 target points; with ICP_FREQ > 1 also > 512 queries) —
  * lins_host_perform_ieskf() then runs the same Gauss-Newton step on the host over
- * lins_correspondences().                                                                   */
+ * lins_correspondences() (which searches on every round).                                  */
 int lins_icp_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins_result* out);
 
 /* --- next row after the update: updatePointCloud's re-projection --------- */

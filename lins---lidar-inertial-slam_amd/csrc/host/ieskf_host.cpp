@@ -69,7 +69,7 @@ extern "C" int lins_host_perform_ieskf(lins_ctx* ctx, const lins_params* prm, co
     }
     if (rc != LINS_E_UNSUPPORTED) return rc;
   }
-  // clouds the grid kernels cannot take / ICP_FREQ != 1: device correspondences + host Gauss-Newton
+  // clouds the grid kernels cannot take: device correspondences + host Gauss-Newton
   double lin[LINS_STATE_DIM];
   std::memcpy(lin, in->state, sizeof lin);
   double t[3] = {lin[0], lin[1], lin[2]};

@@ -1005,6 +1005,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     const int surf_waves = (sd.n_surf_q + kQPerWave - 1) / kQPerWave;
     const bool aligned = surf_waves * kQPerWave + sd.n_corner_q <= kQPerRound;
     const int span = aligned ? surf_waves * kQPerWave + sd.n_corner_q : total;  // row slots in use
+    int4 held = make_int4(0, 0, 0, -1);  // (ICP, ICP_FREQ > 1, single round) a corner triplet waiting for the plane-row count
     for (int base = 0; base < span; base += kQPerRound) {
       const int vslot = base + wave * kQPerWave + q_in_wave;  // position in the (padded) layout
       int slot = vslot;                                        // query index: surf first, then corner
@@ -1172,7 +1173,14 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           }
           have_cert = single_round;
           if (prof && tid == 0) L.prof_acc[8] += clock64() - s2;
-          if (prm.icp_freq > 1 && role == 0) idx_store[sd.slot_base + slot] = make_int4(p1, p2, p3, 0);
+          if (prm.icp_freq > 1 && role == 0) {
+            // ICP mode: estimateTransform searches the corners only after >= 10 plane rows were accepted
+            // (SE:1175-1178) — a corner triplet is committed after the reduction, once that count is known
+            if (ICP && !is_surf)
+              held = make_int4(p1, p2, p3, sd.slot_base + slot);
+            else
+              idx_store[sd.slot_base + slot] = make_int4(p1, p2, p3, 0);
+          }
         } else {
           int4 s = idx_store[sd.slot_base + slot];
           p1 = s.x, p2 = s.y, p3 = s.z;
@@ -1281,6 +1289,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       return;
     }
 
+    if (ICP && held.w >= 0 && L.m_surf >= 10) idx_store[held.w] = make_int4(held.x, held.y, held.z, 0);
     if (ICP)
       icp_solve_and_update(tid, iter);
     else

@@ -912,15 +912,23 @@ int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins
  * n scans from the poses in in[].state, out[].state = that state with position and attitude
  * replaced, out[].cov = in[].cov (un-updated), out[].iters / converged = rounds run / stop rule hit.
  * LINS_E_UNSUPPORTED (nothing run) when a scan cannot take the grid kernels (unsorted rings, ring
- * ids >= 16, > 12288 target points) or ICP_FREQ != 1: lins_host_perform_ieskf() then falls back to
- * the host Gauss-Newton step over lins_correspondences().                                        */
+ * ids >= 16, > 12288 target points): lins_host_perform_ieskf() then falls back to the host
+ * Gauss-Newton step over lins_correspondences().                                                */
 int lins_icp_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins_result* out) {
   if (!ctx || n < 0 || (n && (!in || !out))) return LINS_E_ARG;
   int rc = upload(ctx, n, in);
   if (rc) return rc;
   ctx->n_uploaded = 0;  // not an IESKF batch
   if (n == 0) return LINS_OK;
-  if (!ctx->mr_ok || ctx->prm.icp_freq != 1) return LINS_E_UNSUPPORTED;
+  if (!ctx->mr_ok) return LINS_E_UNSUPPORTED;
+  if (ctx->prm.icp_freq != 1) {
+    // stored triplets are reused between searches: a scan starts with empty ones, as the oracle does (the
+    // reference's arrays keep whatever the previous scan left, SE:206-211), and the deferred corner commit
+    // needs every query of a scan in one round of the 512-lane kernel
+    for (int s = 0; s < n; ++s)
+      if (in[s].n_surf_flat + in[s].n_corner_sharp > 512) return LINS_E_UNSUPPORTED;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_idx, 0xFF, ctx->slot_cap * sizeof(int4), ctx->stream));
+  }
   launch_lds_mr_icp(ctx->stream, n, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_binned, ctx->d_state_in,
                     ctx->d_state_out, ctx->d_out, ctx->d_idx);
   HIP_TRY(ctx, hipGetLastError());

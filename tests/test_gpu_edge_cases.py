@@ -268,10 +268,23 @@ def test_device_icp_matches_oracle_and_the_host_path(pkg, ieskf, oracle, host, m
         monkeypatch.delenv("LINS_ICP_HOST")
         assert used and np.abs(dev.state - hst.state).max() <= 1e-9
         assert np.abs(dev.state[0:3] - got[0].state[0:3]).max() <= 1e-12
-    # ICP_FREQ != 1 and clouds off the grid are refused, not silently approximated
-    with ieskf.IeskfContext(pkg.default_params(icp_freq=2), max_batch=1, max_targets=16384) as c:
+    # ICP_FREQ > 1: triplets are reused between searches; corners are searched (and their triplets
+    # replaced) only on rounds that accepted >= 10 plane rows (SE:1175-1178) — incl. a scan with too few
+    few = pkg.ScanPair(batch[1].surf_flat[:6], batch[1].corner_sharp, batch[1].surf_last, batch[1].corner_last,
+                       batch[1].state, batch[1].cov)
+    for freq in (2, 3):
+        p2 = pkg.default_params(num_iter=12, icp_freq=freq)
+        with ieskf.IeskfContext(p2, max_batch=4, max_targets=16384) as c:
+            for pair, g in zip(batch[:3] + [few], c.icp_update_batch(batch[:3] + [few])):
+                t, q, iters = oracle.icp(p2, pair, pair.state[0:3], pair.state[6:10], oracle.NN_KDTREE)
+                assert g.iters == iters
+                assert np.abs(g.state[0:3] - t).max() <= 1e-6 and np.abs(g.state[6:10] - q).max() <= 1e-7
+    # clouds off the grid are refused, not silently approximated
+    off = pkg.ScanPair(batch[0].surf_flat, batch[0].corner_sharp, batch[0].surf_last[::-1].copy(), batch[0].corner_last,
+                       batch[0].state, batch[0].cov)
+    with ieskf.IeskfContext(prm, max_batch=1, max_targets=16384) as c:
         with pytest.raises(ieskf.LinsError, match="-7"):
-            c.icp_update_batch(batch[:1])
+            c.icp_update_batch([off])
 
 
 def test_abi_error_behaviour(pkg, ieskf):
