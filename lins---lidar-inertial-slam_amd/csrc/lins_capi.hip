@@ -11,7 +11,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
 #include <new>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -105,6 +108,12 @@ struct lins_ctx {
     unsigned* d_col = nullptr;
     unsigned char* d_ground = nullptr;
     int *d_picks = nullptr, *d_counts = nullptr;
+    // pinned host staging of the packed inputs (grow-only, h_cap points)
+    size_t h_cap = 0;
+    float4* h_cloud = nullptr;
+    float* h_range = nullptr;
+    unsigned* h_col = nullptr;
+    unsigned char* h_ground = nullptr;
     float ms = 0.f;
     uint64_t bytes = 0;
   } fe;
@@ -208,16 +217,40 @@ void fe_free(lins_ctx* ctx) {
   auto& f = ctx->fe;
   void* ptrs[] = {f.d_scans, f.d_cloud, f.d_und, f.d_out, f.d_range, f.d_diff, f.d_col, f.d_ground, f.d_picks, f.d_counts};
   for (void* p : ptrs) (void)hipFree(p);
+  (void)hipHostFree(f.h_cloud), (void)hipHostFree(f.h_range), (void)hipHostFree(f.h_col), (void)hipHostFree(f.h_ground);
   f = lins_ctx::Frontend{};
+}
+
+// Run fn(k) for k in [0, n) on up to 16 host threads (validation + packing of a batch is memory-bound
+// scalar work: 1024 scans = 8 M points); returns the smallest-index non-zero result.
+template <class F>
+int parallel_scans(int n, F fn) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int T = std::max(1, std::min({16, (int)(hw ? hw : 1), n / 8}));
+  std::vector<int> rc(n, 0);
+  if (T <= 1) {
+    for (int k = 0; k < n; ++k) rc[k] = fn(k);
+  } else {
+    std::atomic<int> next{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; ++t)
+      pool.emplace_back([&] {
+        for (int k; (k = next.fetch_add(1)) < n;) rc[k] = fn(k);
+      });
+    for (auto& th : pool) th.join();
+  }
+  for (int k = 0; k < n; ++k)
+    if (rc[k]) return rc[k];
+  return 0;
 }
 
 int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
   if (!ctx || !in || n < 0) return LINS_E_ARG;
   if (n > ctx->max_batch) return LINS_E_CAPACITY;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // pass 1 (serial, cheap): argument checks and the arena layout
   size_t off = 0, slots = 0;
   uint64_t bytes = 0;
-  bool lds_ok = true, mr_ok = true, lds3_ok = true;
   for (int s = 0; s < n; ++s) {
     const lins_scan_pair& p = in[s];
     if (p.n_surf_flat < 0 || p.n_corner_sharp < 0 || p.n_surf_last < 0 || p.n_corner_last < 0) return LINS_E_ARG;
@@ -226,38 +259,54 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
       return LINS_E_ARG;
     if (p.n_surf_flat > LINS_MAX_QUERY || p.n_corner_sharp > LINS_MAX_QUERY) return LINS_E_CAPACITY;
     if (p.n_surf_last > ctx->max_targets || p.n_corner_last > ctx->max_targets) return LINS_E_CAPACITY;
-    bool ss = true, cs = true;
-    int rc;
-    if ((rc = check_cloud(p.surf_flat, p.n_surf_flat, nullptr))) return rc;
-    if ((rc = check_cloud(p.corner_sharp, p.n_corner_sharp, nullptr))) return rc;
-    if ((rc = check_cloud(p.surf_less_flat_last, p.n_surf_last, &ss))) return rc;
-    if ((rc = check_cloud(p.corner_less_sharp_last, p.n_corner_last, &cs))) return rc;
     ScanDesc& d = ctx->h_desc[s];
-    const lins_point* src[4] = {p.surf_flat, p.corner_sharp, p.surf_less_flat_last, p.corner_less_sharp_last};
-    int cnt[4] = {p.n_surf_flat, p.n_corner_sharp, p.n_surf_last, p.n_corner_last};
+    const int cnt[4] = {p.n_surf_flat, p.n_corner_sharp, p.n_surf_last, p.n_corner_last};
     int offs[4];
     for (int c = 0; c < 4; ++c) {
       if (off + align4(cnt[c]) > ctx->arena_cap) return LINS_E_CAPACITY;
       offs[c] = (int)off;
-      if (cnt[c]) std::memcpy(ctx->h_arena + off, src[c], sizeof(lins_point) * cnt[c]);
-      for (size_t k = cnt[c]; k < align4(cnt[c]); ++k) ctx->h_arena[off + k] = make_float4(0, 0, 0, 0);
       off += align4(cnt[c]);
     }
     d.off_surf_q = offs[0], d.n_surf_q = cnt[0];
     d.off_corner_q = offs[1], d.n_corner_q = cnt[1];
     d.off_surf_t = offs[2], d.n_surf_t = cnt[2];
     d.off_corner_t = offs[3], d.n_corner_t = cnt[3];
-    d.surf_sorted = ss, d.corner_sorted = cs;
-    if (!ss || !cs || cnt[2] + cnt[3] > lds_np_cap()) lds_ok = false;
-    if (!ss || !cs || cnt[2] + cnt[3] > lds_mr_np_cap()) mr_ok = false;
-    if (cnt[0] + cnt[1] > 336) lds3_ok = false;  // (16 waves x 21 query slots = the VLP-16 caps, 144 flat + 192 sharp)
     d.slot_base = (int)slots;
     d.pad = 0;
     slots += cnt[0] + cnt[1];
     if (slots > ctx->slot_cap) return LINS_E_CAPACITY;
+    bytes += 16ull * (cnt[0] + cnt[1] + cnt[2] + cnt[3]) + 8 * 19 + 8 * 28;
+  }
+  // pass 2 (threaded): input contract + packing into the pinned staging arena
+  const int rc = parallel_scans(n, [&](int s) -> int {
+    const lins_scan_pair& p = in[s];
+    ScanDesc& d = ctx->h_desc[s];
+    bool ss = true, cs = true;
+    int r;
+    if ((r = check_cloud(p.surf_flat, p.n_surf_flat, nullptr))) return r;
+    if ((r = check_cloud(p.corner_sharp, p.n_corner_sharp, nullptr))) return r;
+    if ((r = check_cloud(p.surf_less_flat_last, p.n_surf_last, &ss))) return r;
+    if ((r = check_cloud(p.corner_less_sharp_last, p.n_corner_last, &cs))) return r;
+    d.surf_sorted = ss, d.corner_sorted = cs;
+    const lins_point* src[4] = {p.surf_flat, p.corner_sharp, p.surf_less_flat_last, p.corner_less_sharp_last};
+    const int cnt[4] = {d.n_surf_q, d.n_corner_q, d.n_surf_t, d.n_corner_t};
+    const int offs[4] = {d.off_surf_q, d.off_corner_q, d.off_surf_t, d.off_corner_t};
+    for (int c = 0; c < 4; ++c) {
+      if (cnt[c]) std::memcpy(ctx->h_arena + offs[c], src[c], sizeof(lins_point) * cnt[c]);
+      for (size_t k = cnt[c]; k < align4(cnt[c]); ++k) ctx->h_arena[offs[c] + k] = make_float4(0, 0, 0, 0);
+    }
     std::memcpy(ctx->h_state + (size_t)s * 19, p.state, sizeof p.state);
     std::memcpy(ctx->h_cov + (size_t)s * 324, p.cov, sizeof p.cov);
-    bytes += 16ull * (cnt[0] + cnt[1] + cnt[2] + cnt[3]) + 8 * 19 + 8 * 28;
+    return 0;
+  });
+  if (rc) return rc;
+  bool lds_ok = true, mr_ok = true, lds3_ok = true;
+  for (int s = 0; s < n; ++s) {
+    const ScanDesc& d = ctx->h_desc[s];
+    const bool grid = d.surf_sorted && d.corner_sorted;
+    if (!grid || d.n_surf_t + d.n_corner_t > lds_np_cap()) lds_ok = false;
+    if (!grid || d.n_surf_t + d.n_corner_t > lds_mr_np_cap()) mr_ok = false;
+    if (d.n_surf_q + d.n_corner_q > 336) lds3_ok = false;  // (16 waves x 21 query slots = the VLP-16 caps, 144 flat + 192 sharp)
   }
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_arena, ctx->h_arena, off * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_desc, ctx->h_desc, (size_t)n * sizeof(ScanDesc), hipMemcpyHostToDevice, ctx->stream));
@@ -518,35 +567,58 @@ static int fe_run(lins_ctx* ctx, int n, const lins_segmented_scan* in, double sc
   static_assert(sizeof(FeScanHost) == 192, "FeScan layout");
   if (fe_scan_size() != sizeof(FeScanHost)) return LINS_E_STATE;
   const size_t N = LINS_CLOUD_MAX;
+  // pass 1 (serial): argument checks, packed layout (each scan's arrays start on a multiple of 4 points)
+  std::vector<FeScanHost> hs(n);
+  size_t total = 0;
+  uint64_t bytes = 0;
   for (int k = 0; k < n; ++k) {
     const lins_segmented_scan& s = in[k];
     if (s.n < 0 || s.n > (int)N || (s.n && (!s.cloud || !s.range || !s.col || !s.ground))) return LINS_E_ARG;
     for (int r = 0; r < LINS_LINE_NUM; ++r)  // a sector must fit the per-wave sort network (a VLP-16 ring: <= 300)
       if ((s.end_ring[r] - s.start_ring[r]) / 6 + 2 > 510) return LINS_E_UNSUPPORTED;
+    hs[k].off = (long long)total, hs[k].n = s.n, hs[k].pad = 0;
+    for (int r = 0; r < LINS_LINE_NUM; ++r) hs[k].start_ring[r] = s.start_ring[r], hs[k].end_ring[r] = s.end_ring[r];
+    hs[k].start_ori = s.start_ori, hs[k].end_ori = s.end_ori, hs[k].ori_diff = s.ori_diff;
+    hs[k].o_sharp = offs[k][0], hs[k].o_less_sharp = offs[k][1], hs[k].o_flat = offs[k][2], hs[k].o_less_flat = offs[k][3];
+    total += align4(s.n);
+    bytes += (uint64_t)s.n * 25;
+  }
+  int rc0 = fe_alloc(ctx, n);
+  if (rc0) return rc0;
+  auto& f = ctx->fe;
+  if (f.h_cap < total) {
+    (void)hipHostFree(f.h_cloud), (void)hipHostFree(f.h_range), (void)hipHostFree(f.h_col), (void)hipHostFree(f.h_ground);
+    f.h_cloud = nullptr, f.h_range = nullptr, f.h_col = nullptr, f.h_ground = nullptr, f.h_cap = 0;
+    HIP_TRY(ctx, hipHostMalloc((void**)&f.h_cloud, total * sizeof(float4)));
+    HIP_TRY(ctx, hipHostMalloc((void**)&f.h_range, total * sizeof(float)));
+    HIP_TRY(ctx, hipHostMalloc((void**)&f.h_col, total * sizeof(unsigned)));
+    HIP_TRY(ctx, hipHostMalloc((void**)&f.h_ground, total));
+    f.h_cap = total;
+  }
+  // pass 2 (threaded): input contract + packing into the pinned staging
+  const int rcv = parallel_scans(n, [&](int k) -> int {
+    const lins_segmented_scan& s = in[k];
+    const size_t o = (size_t)hs[k].off;
     for (int i = 0; i < s.n; ++i) {
       const lins_point& p = s.cloud[i];
       if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z) || !std::isfinite(p.intensity) ||
           !std::isfinite(s.range[i]) || s.col[i] >= (uint32_t)LINS_SCAN_NUM)
         return LINS_E_INPUT;
     }
-  }
-  int rc0 = fe_alloc(ctx, n);
-  if (rc0) return rc0;
-  auto& f = ctx->fe;
-  std::vector<FeScanHost> hs(n);
-  uint64_t bytes = 0;
-  for (int k = 0; k < n; ++k) {
-    const lins_segmented_scan& s = in[k];
-    hs[k].off = (long long)((size_t)k * N), hs[k].n = s.n, hs[k].pad = 0;
-    for (int r = 0; r < LINS_LINE_NUM; ++r) hs[k].start_ring[r] = s.start_ring[r], hs[k].end_ring[r] = s.end_ring[r];
-    hs[k].start_ori = s.start_ori, hs[k].end_ori = s.end_ori, hs[k].ori_diff = s.ori_diff;
-    hs[k].o_sharp = offs[k][0], hs[k].o_less_sharp = offs[k][1], hs[k].o_flat = offs[k][2], hs[k].o_less_flat = offs[k][3];
-    if (!s.n) continue;
-    HIP_TRY(ctx, hipMemcpyAsync(f.d_cloud + hs[k].off, s.cloud, s.n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(f.d_range + hs[k].off, s.range, s.n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(f.d_col + hs[k].off, s.col, s.n * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(f.d_ground + hs[k].off, s.ground, s.n, hipMemcpyHostToDevice, ctx->stream));
-    bytes += (uint64_t)s.n * 25;
+    if (s.n) {
+      std::memcpy(f.h_cloud + o, s.cloud, s.n * sizeof(float4));
+      std::memcpy(f.h_range + o, s.range, s.n * sizeof(float));
+      std::memcpy(f.h_col + o, s.col, s.n * sizeof(unsigned));
+      std::memcpy(f.h_ground + o, s.ground, s.n);
+    }
+    return 0;
+  });
+  if (rcv) return rcv;
+  if (total) {
+    HIP_TRY(ctx, hipMemcpyAsync(f.d_cloud, f.h_cloud, total * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(f.d_range, f.h_range, total * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(f.d_col, f.h_col, total * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(f.d_ground, f.h_ground, total, hipMemcpyHostToDevice, ctx->stream));
   }
   HIP_TRY(ctx, hipMemcpyAsync(f.d_scans, hs.data(), (size_t)n * sizeof(FeScanHost), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
