@@ -957,22 +957,6 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   }
   build_lds_grid<BLOCK>(L, sd, arena, gs, tid);  // ends with a barrier
   if (prof && tid == 0) L.prof_acc[0] = clock64() - t_begin;
-#ifdef LINS_LDS_CHECK
-  auto lds_checksum = [&](unsigned* out5) {
-    unsigned h[5] = {0, 0, 0, 0, 0};
-    for (int p2_ = tid; p2_ < n_lds; p2_ += kLBlock) {
-      h[0] ^= __float_as_uint(L.px[p2_]) * (2u * p2_ + 1u), h[1] ^= __float_as_uint(L.py[p2_]) * (2u * p2_ + 1u);
-      h[2] ^= __float_as_uint(L.pz[p2_]) * (2u * p2_ + 1u), h[3] ^= (unsigned)L.pidx[p2_] * (2u * p2_ + 1u);
-    }
-    for (int c_ = tid; c_ < kCellsCorner + kCellsSurf; c_ += kLBlock) h[4] ^= (unsigned)L.cell_end[c_] * (2u * c_ + 1u);
-    for (int k = 0; k < 5; ++k) atomicXor(&out5[k], h[k]);
-  };
-  __shared__ unsigned chk[10];
-  if (tid < 10) chk[tid] = 0;
-  __syncthreads();
-  lds_checksum(chk);
-  __syncthreads();
-#endif
 
   const LCloud cs{L.cell_end + kCellsCorner, L.ring_start[0], &L.el_ang[0][0], kAzSurf, 1, sd.n_corner_t, sd.n_surf_t,
                   gs, n_lds};
@@ -1021,16 +1005,6 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         a1 = b1c = ra1 = rb1 = a2 = b2c = a3 = b3c = sel1 = -1, have_cert = false;
         lb1 = lb2 = lb3 = 0.f;
       }
-#ifdef LINS_LDS_CHECK2
-      {
-        const unsigned long long want_m = __ballot(active);
-        if (active) {
-          const unsigned long long got_m = __ballot(1);
-          if (got_m != want_m && lane == (int)__ffsll(got_m) - 1)
-            printf("exec mismatch scan %d base %d wave %d want %llx got %llx\n", scan, base, wave, want_m, got_m);
-        }
-      }
-#endif
       if (active) {
         const bool is_surf = slot < sd.n_surf_q;
         const int qi = is_surf ? slot : slot - sd.n_surf_q;
@@ -1089,20 +1063,6 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
                 bb = nn_lds<LANES>(L, c, o.sel[0], o.sel[1], o.sel[2], qp, thr, margin, ring_of(q.w), role, lane_base, a1,
                                    ra1);
               p1 = bb.pos;  // (a winner beat the threshold sentinel, so its distance is < thr, SE:851)
-#ifdef LINS_LDS_CHECK3
-              if (role == 0) {
-                unsigned long long kb = (unsigned long long)__float_as_uint(thr) << 32;
-                int pb = -1;
-                for (int pp = c.base; pp < c.base + c.n; ++pp) {
-                  unsigned long long kk = pack_key(pt_sqdist(L, c, pp, o.sel[0], o.sel[1], o.sel[2]), pt_idx(L, c, pp));
-                  if (kk < kb) kb = kk, pb = pp;
-                }
-                if (pb != bb.pos)
-                  printf("NN mismatch base %d slot %d lane %d: got pos %d d %g (idx %d) true pos %d d %g idx %d | rq %d a0 %d el %g rho %g\n",
-                         base, slot, lane, bb.pos, bb.d(), bb.pos >= 0 ? pt_idx(L, c, bb.pos) : -1, pb,
-                         __uint_as_float((unsigned)(kb >> 32)), (int)(unsigned)kb, ring_of(q.w), qp.a0_surf_or_corner, qp.el, qp.rho);
-              }
-#endif
               if (said && p1 != pred && role == 0) atomicAdd(&L.dbg[0], 1);
               a1 = bb.pos, ra1 = bb.ring, b1c = bb.pos2, rb1 = bb.ring2;
               lb1 = cert_lb(bb, thr, margin);
@@ -1275,14 +1235,6 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       if (tid == 0) L.conv = 1;
       continue;
     }
-#ifdef LINS_LDS_CHECK
-    __syncthreads();
-    lds_checksum(chk + 5);
-    __syncthreads();
-    if (tid == 0)
-      for (int k = 0; k < 5; ++k)
-        if (chk[k] != chk[5 + k]) printf("LDS array %d changed (scan %d iter %d)\n", k, scan, iter);
-#endif
     if (PASS_ONLY) {
       if (sums_out && tid < 28) sums_out[(size_t)scan * 28 + tid] = L.sums[tid];
       if (counts_out && tid == 0) counts_out[scan * 2] = L.m_surf, counts_out[scan * 2 + 1] = L.m_corner;

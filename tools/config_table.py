@@ -26,7 +26,7 @@ sec, its = oracle.bench(prm, [pair] * reps, oracle.FORM_DENSE, oracle.NN_KDTREE,
 cpu1 = its / sec
 print(f"| 1. single scan, CPU oracle, 10 iters | {cpu1:.0f} | n/a (one scan) | n/a | n/a | self |")
 
-with ieskf.IeskfContext(prm, max_batch=1, max_targets=16384, search="lds") as ctx:
+with ieskf.IeskfContext(prm, max_batch=1, max_targets=16384, search="auto") as ctx:
     # configs[1]: device correspondences + reduction, host 18x18 solve, per iteration
     want, tr = oracle.ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_BRUTE, trace=True)
     lin = pair.state.copy()
@@ -63,7 +63,7 @@ with ieskf.IeskfContext(prm, max_batch=1, max_targets=16384, search="lds") as ct
 
 with ThreadPoolExecutor(16) as ex:
     pairs = list(ex.map(host.synth_pair, range(1024)))
-with ieskf.IeskfContext(prm, max_batch=1024, max_targets=16384, search="lds") as ctx:
+with ieskf.IeskfContext(prm, max_batch=1024, max_targets=16384, search="auto") as ctx:
     ctx.upload(pairs)
     ks = []
     for _ in range(10):
