@@ -128,6 +128,10 @@ int lins_streams_stats(lins_ctx* ctx, float* frontend_ms, float* update_ms, floa
  * returns the point count                                                                            */
 int lins_streams_peek(lins_ctx* ctx, int stream, int which, lins_point* out, int cap);
 
+/* the front-end's atan2 (csrc/lins_math.h: a fixed f32 operation sequence shared bit for bit by the host
+ * restatement and the device kernels; within 2 ulp(pi/4) of the true value)                        */
+float lins_host_atan2f(float y, float x);
+
 /* transformToEnd for every point, with the scan's final relative pose
  * (t = linState_.rn_, q = linState_.qbn_ as w,x,y,z). In-place allowed.       */
 void lins_transform_to_end(const double* t, const double* q_wxyz, double scan_period,

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     int first = n;
     for (int i = tid; i < n; i += kFeBlock) {
       const float4 p = pts[i];
-      double ori = (double)(-atan2f(p.y, p.x));
+      double ori = (double)(-lins_atan2f(p.y, p.x));
       if (ori < s_ori - kPi / 2)
         ori += 2 * kPi;
       else if (ori > s_ori + kPi * 3 / 2)
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   // ---- pass 2: relative time tag; smoothness stencil; masks -------------------------------------
   for (int i = tid; i < n; i += kFeBlock) {
     float4 p = pts[i];
-    double ori = (double)(-atan2f(p.y, p.x));
+    double ori = (double)(-lins_atan2f(p.y, p.x));
     if (i <= flip) {
       if (ori < s_ori - kPi / 2)
         ori += 2 * kPi;

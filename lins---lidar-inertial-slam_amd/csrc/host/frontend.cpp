@@ -54,8 +54,8 @@ void project_and_segment(const lins_point* raw, int n, Segmented& seg) {
   std::vector<int> label(kCells, 0);
 
   // findStartEndAngle (IP:191-203) — including the y(last)/x(second-to-last) mix
-  seg.start_ori = -std::atan2(raw[0].y, raw[0].x);
-  seg.end_ori = -std::atan2(raw[n - 1].y, raw[n - 2].x) + 2 * M_PI;
+  seg.start_ori = -lins_atan2f(raw[0].y, raw[0].x);
+  seg.end_ori = -lins_atan2f(raw[n - 1].y, raw[n - 2].x) + 2 * M_PI;
   if (seg.end_ori - seg.start_ori > 3 * M_PI)
     seg.end_ori -= 2 * M_PI;
   else if (seg.end_ori - seg.start_ori < M_PI)
@@ -65,11 +65,11 @@ void project_and_segment(const lins_point* raw, int n, Segmented& seg) {
   // projectPointCloud (IP:205-241)
   for (int i = 0; i < n; ++i) {
     lins_point p = raw[i];
-    float vert = std::atan2(p.z, std::sqrt(p.x * p.x + p.y * p.y)) * 180 / M_PI;
+    float vert = lins_atan2f(p.z, std::sqrt(p.x * p.x + p.y * p.y)) * 180 / M_PI;
     float rowf = (vert + kAngBottom) / kAngResY;
     if (rowf < 0 || rowf >= kRows) continue;
     int row = (int)rowf;
-    float horizon = std::atan2(p.x, p.y) * 180 / M_PI;
+    float horizon = lins_atan2f(p.x, p.y) * 180 / M_PI;
     int colm = (int)(-std::round((horizon - 90.0) / kAngResX) + kCols / 2);
     if (colm >= kCols) colm -= kCols;
     if (colm < 0 || colm >= kCols) continue;
@@ -88,7 +88,7 @@ void project_and_segment(const lins_point* raw, int n, Segmented& seg) {
         continue;
       }
       float dx = full[up].x - full[lo].x, dy = full[up].y - full[lo].y, dz = full[up].z - full[lo].z;
-      float angle = std::atan2(dz, std::sqrt(dx * dx + dy * dy)) * 180 / M_PI;
+      float angle = lins_atan2f(dz, std::sqrt(dx * dx + dy * dy)) * 180 / M_PI;
       if (std::fabs(angle - kSensorMountAngle) <= 10) ground[lo] = 1, ground[up] = 1;
     }
   for (int c = 0; c < kCells; ++c)
@@ -122,7 +122,7 @@ void project_and_segment(const lins_point* raw, int n, Segmented& seg) {
           if (label[tcell] != 0) continue;
           float d1 = std::max(range[cell], range[tcell]), d2 = std::min(range[cell], range[tcell]);
           float alpha = d[0] == 0 ? kSegmentAlphaX : kSegmentAlphaY;
-          float angle = std::atan2(d2 * std::sin(alpha), d1 - d2 * std::cos(alpha));
+          float angle = lins_atan2f(d2 * std::sin(alpha), d1 - d2 * std::cos(alpha));
           if (angle > kSegmentTheta) {
             queue[qe++] = tcell;
             label[tcell] = label_count;
@@ -220,7 +220,7 @@ void extract(const Segmented& seg, double scan_period, lins_features* out) {
   bool half_passed = false;
   for (int i = 0; i < n; ++i) {
     lins_point p = seg.cloud[i];
-    double ori = -std::atan2(p.y, p.x);
+    double ori = -lins_atan2f(p.y, p.x);
     if (!half_passed) {
       if (ori < seg.start_ori - M_PI / 2)
         ori += 2 * M_PI;
@@ -383,6 +383,8 @@ int lins_frontend_extract_segmented(const lins_segmented_scan* in, double scan_p
   extract(seg, scan_period, out);
   return LINS_OK;
 }
+
+float lins_host_atan2f(float y, float x) { return lins_atan2f(y, x); }
 
 void lins_transform_to_end(const double* t, const double* q, double scan_period, const lins_point* in,
                            int n, lins_point* out) {

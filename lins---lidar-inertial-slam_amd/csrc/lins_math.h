@@ -99,6 +99,29 @@ LINS_HD V3 rowmul(V3 r, const M3& a) {  // (r^T A)^T
           r.x * a.m[2] + r.y * a.m[5] + r.z * a.m[8]};
 }
 
+// atan2 in f32 with a FIXED operation sequence (one division, a degree-9 odd polynomial after the
+// classic two-octant reduction; <= 2 ulp of pi/4 from the true value): the feature front-end bins points by
+// angle and tags them with angle-derived times, so the host restatement and the device kernels must
+// agree to the bit — libm's and ocml's atan2f do not.  Same sign / quadrant conventions as atan2
+// (atan2(+-0, x < 0) = +-pi, atan2(0, 0) = 0).
+LINS_HD float lins_atan2f(float y, float x) {
+  const float ax = x < 0.f ? -x : x, ay = y < 0.f ? -y : y;
+  const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+  float r = 0.f;
+  if (mx > 0.f) {
+    float a = mn / mx, base = 0.f;  // a in [0, 1]
+    if (a > 0.41421356f) {          // tan(pi/8): atan(a) = pi/4 + atan((a - 1) / (a + 1))
+      base = 0.78539816f;
+      a = (a - 1.f) / (a + 1.f);
+    }
+    const float z = a * a;
+    r = base + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * a + a);
+    if (ay > ax) r = 1.57079633f - r;
+  }
+  if (x < 0.f) r = 3.14159265f - r;
+  return y < 0.f ? -r : ((y == 0.f && 1.f / y < 0.f) ? -r : r);
+}
+
 LINS_HD double wrap_pi(double x) {
   const double pi = 3.14159265358979323846;
   while (x >= pi) x -= 2.0 * pi;

@@ -362,8 +362,8 @@ def test_more_queries_than_one_round_of_lanes(pkg, oracle, ctx, search, shape):
 def test_device_front_end_matches_the_host_restatement(pkg, ieskf, host):
     """undistortPcl .. extractFeatures (SE:619-827) on the device == the host
     restatement on the same segmented scans: identical picks (same points, same order, same counts),
-    coordinates bit-equal, the relative-time tag within 1 ulp of f32 on a vanishing fraction
-    (ocml vs libm atan2f).  Includes the scans the IESKF fixtures are made of."""
+    every field bit-equal (both sides use the fixed-sequence lins_atan2f for the time tags).  Includes the
+    scans the IESKF fixtures are made of."""
     segs = [host.frontend_segment(host.synth_raw_scan(idx, k)) for idx in range(3) for k in (0, 1)]
     want = [host.frontend_extract_segmented(s) for s in segs]
     with ieskf.IeskfContext(pkg.default_params(), max_batch=1, max_targets=1024) as c:
@@ -375,12 +375,7 @@ def test_device_front_end_matches_the_host_restatement(pkg, ieskf, host):
     for g, w in zip(got + again, want + want[:2]):
         for k in ("corner_sharp", "corner_less_sharp", "surf_flat", "surf_less_flat"):
             assert g[k].shape == w[k].shape, (k, g[k].shape, w[k].shape)
-            assert np.array_equal(g[k][:, :3], w[k][:, :3]), k
-            # relative-time tag: atan2f differs by <= 1 ulp between ocml and libm => <= 4e-9 on the tag
-            # (0.1 s x 2.4e-7 rad / 2 pi), i.e. nothing, or one f32 rounding step of ring + tag
-            err = np.abs(g[k][:, 3].astype(np.float64) - w[k][:, 3].astype(np.float64))
-            tol = np.maximum(np.spacing(np.abs(w[k][:, 3])).astype(np.float64), 1e-8) * (1 if k != "surf_less_flat" else 2)
-            assert (err <= tol).all() and (err > 0).mean() <= 0.1, (k, err.max())
+            assert np.array_equal(g[k], w[k]), k  # coordinates AND time tags, bit for bit (shared lins_atan2f)
         assert g["n_segmented"] == w["n_segmented"] and g["n_outlier"] == w["n_outlier"]
 
 
