@@ -95,6 +95,12 @@ typedef struct lins_segmented_scan {
  * entries, `out` is pointed at them.                                                          */
 int lins_frontend_segment(const lins_point* raw, int n_raw, lins_point* cloud, float* range, uint32_t* col,
                           uint8_t* ground, lins_segmented_scan* out);
+/* The same stage on the device (csrc/segment_kernels.hip): n raw clouds in firing order; out[k]'s four array
+ * pointers must point at caller-allocated arrays of LINS_CLOUD_MAX entries (they are written).  Identical
+ * to lins_frontend_segment() — the BFS labelling is restated as an order-free min-label propagation.    */
+int lins_segment_batch(lins_ctx* ctx, int n, const lins_point* const* raw, const int32_t* n_raw,
+                       lins_segmented_scan* out);
+int lins_last_segment_ms(lins_ctx* ctx, float* kernel_ms);
 /* StateEstimator's feature stage (undistortPcl .. extractFeatures, SE:619-827) on the host — the
  * CPU restatement the device version is checked against.                                      */
 int lins_frontend_extract_segmented(const lins_segmented_scan* in, double scan_period, lins_features* out);
@@ -122,6 +128,10 @@ int lins_last_frontend_stats(lins_ctx* ctx, float* kernel_ms, uint64_t* bytes);
 int lins_streams_init(lins_ctx* ctx, int n_streams);   /* n_streams <= the context's max_batch */
 int lins_streams_step(lins_ctx* ctx, const lins_segmented_scan* scans, const double* prior_state,
                       const double* prior_cov, double scan_period, lins_result* out, int32_t* feature_counts);
+/* the same step from RAW clouds (firing order): the image_projection stage (IP:191-415) runs on the device
+ * too (lins_last_segment_ms reports its kernel time) and hands the segmented scan to the front-end in HBM */
+int lins_streams_step_raw(lins_ctx* ctx, const lins_point* const* raw, const int32_t* n_raw, const double* prior_state,
+                          const double* prior_cov, double scan_period, lins_result* out, int32_t* feature_counts);
 /* HIP-event times (ms) of the three stages of the last step */
 int lins_streams_stats(lins_ctx* ctx, float* frontend_ms, float* update_ms, float* reproject_ms);
 /* test aid: a resident cloud of the last scan back to the host (which: 0 less sharp, 1 less flat);

@@ -46,6 +46,13 @@ void launch_frontend(hipStream_t, int, const void*, const float4*, const float*,
                      double, float4*, float*, int*, float4*, int*);
 void launch_reproject_in_place(hipStream_t, int, int, const void*, const double*, float4*, double);
 size_t stream_cloud_size();
+void launch_segment(hipStream_t, int, const void*, const float4*, float, float, float, float, float, int*, float4*, float*,
+                    int*, int*, void*, float4*, float*, unsigned*, unsigned char*, int*);
+size_t sg_raw_size();
+struct SgRawHost {
+  long long off;
+  int n, pad;
+};
 struct StreamCloudHost {
   long long off;
   int n, stream;
@@ -116,6 +123,14 @@ struct lins_ctx {
     unsigned char* h_ground = nullptr;
     float ms = 0.f;
     uint64_t bytes = 0;
+    // image_projection stage (lins_segment_batch / the raw-cloud streams path): raw points + per-cell scratch
+    int sg_cap = 0;
+    size_t raw_cap = 0, h_raw_cap = 0;
+    float4 *d_raw = nullptr, *d_full = nullptr, *h_raw = nullptr;
+    void* d_raws = nullptr;
+    float* d_rangemat = nullptr;
+    int *d_cellidx = nullptr, *d_segcount = nullptr, *d_segrows = nullptr, *d_outliers = nullptr;
+    float sg_ms = 0.f;
   } fe;
   // device-resident streams (lins_streams_step): per stream two feature slots (this scan's / the last
   // scan's clouds) inside one arena, so that ScanDesc offsets address both
@@ -217,6 +232,9 @@ void fe_free(lins_ctx* ctx) {
   auto& f = ctx->fe;
   void* ptrs[] = {f.d_scans, f.d_cloud, f.d_und, f.d_out, f.d_range, f.d_diff, f.d_col, f.d_ground, f.d_picks, f.d_counts};
   for (void* p : ptrs) (void)hipFree(p);
+  void* sg[] = {f.d_raw, f.d_full, f.d_raws, f.d_rangemat, f.d_cellidx, f.d_segcount, f.d_segrows, f.d_outliers};
+  for (void* p : sg) (void)hipFree(p);
+  (void)hipHostFree(f.h_raw);
   (void)hipHostFree(f.h_cloud), (void)hipHostFree(f.h_range), (void)hipHostFree(f.h_col), (void)hipHostFree(f.h_ground);
   f = lins_ctx::Frontend{};
 }
@@ -559,6 +577,8 @@ static int fe_alloc(lins_ctx* ctx, int n) {
   return LINS_OK;
 }
 
+static int fe_launch(lins_ctx* ctx, int n, double scan_period, float4* out_base, std::vector<int>& counts, uint64_t bytes);
+
 // Front-end stage shared by lins_extract_features_batch and lins_streams_step: validate, upload the
 // segmented scans, launch frontend_kernel with the feature clouds going to out_base + offs[k][0..3]
 // (sharp, less sharp, flat, less flat), bring the four counts per scan back (synchronises).
@@ -621,6 +641,13 @@ static int fe_run(lins_ctx* ctx, int n, const lins_segmented_scan* in, double sc
     HIP_TRY(ctx, hipMemcpyAsync(f.d_ground, f.h_ground, total, hipMemcpyHostToDevice, ctx->stream));
   }
   HIP_TRY(ctx, hipMemcpyAsync(f.d_scans, hs.data(), (size_t)n * sizeof(FeScanHost), hipMemcpyHostToDevice, ctx->stream));
+  return fe_launch(ctx, n, scan_period, out_base, counts, bytes);
+}
+
+// the front-end kernel over the n scans described by f.d_scans (filled by the host path above or by the
+// segmentation kernel); brings the four counts per scan back (synchronises)
+static int fe_launch(lins_ctx* ctx, int n, double scan_period, float4* out_base, std::vector<int>& counts, uint64_t bytes) {
+  auto& f = ctx->fe;
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   launch_frontend(ctx->stream, n, f.d_scans, f.d_cloud, f.d_range, f.d_col, f.d_ground, scan_period, f.d_und, f.d_diff,
                   f.d_picks, out_base, f.d_counts);
@@ -635,6 +662,117 @@ static int fe_run(lins_ctx* ctx, int n, const lins_segmented_scan* in, double sc
     bytes += 16ull * (counts[k * 4] + counts[k * 4 + 1] + counts[k * 4 + 2] + counts[k * 4 + 3]);
   }
   f.bytes = bytes;
+  return LINS_OK;
+}
+
+// image_projection stage on the device: n raw clouds -> the front-end's device input buffers (f.d_cloud /
+// d_range / d_col / d_ground at k * LINS_CLOUD_MAX) and the head of each FeScan (n, ring indices, orientations);
+// offs = where the front-end will later put the four feature clouds of each scan
+static int sg_run(lins_ctx* ctx, int n, const lins_point* const* raw, const int32_t* n_raw, const long long (*offs)[4]) {
+  static_assert(sizeof(SgRawHost) == 16, "SgRaw layout");
+  if (sg_raw_size() != sizeof(SgRawHost)) return LINS_E_STATE;
+  const size_t N = LINS_CLOUD_MAX;
+  size_t total = 0;
+  std::vector<SgRawHost> hr(n);
+  for (int k = 0; k < n; ++k) {
+    if (!raw[k] || n_raw[k] < 2 || n_raw[k] > 65536) return LINS_E_ARG;
+    hr[k] = SgRawHost{(long long)total, n_raw[k], 0};
+    total += align4(n_raw[k]);
+  }
+  int rc = fe_alloc(ctx, n);
+  if (rc) return rc;
+  auto& f = ctx->fe;
+  if (f.sg_cap < n) {
+    void* old[] = {f.d_full, f.d_raws, f.d_rangemat, f.d_cellidx, f.d_segcount, f.d_segrows, f.d_outliers};
+    for (void* p : old) (void)hipFree(p);
+    f.d_full = nullptr, f.d_raws = nullptr, f.d_rangemat = nullptr, f.d_cellidx = nullptr, f.d_segcount = nullptr;
+    f.d_segrows = nullptr, f.d_outliers = nullptr, f.sg_cap = 0;
+    const size_t c = (size_t)n;
+    HIP_TRY(ctx, hipMalloc(&f.d_raws, c * sizeof(SgRawHost)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_full, c * N * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_rangemat, c * N * sizeof(float)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_cellidx, c * N * sizeof(int)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_segcount, c * N * sizeof(int)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_segrows, c * N * sizeof(int)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_outliers, c * sizeof(int)));
+    f.sg_cap = n;
+  }
+  if (f.raw_cap < total) {
+    (void)hipFree(f.d_raw);
+    f.d_raw = nullptr, f.raw_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_raw, total * sizeof(float4)));
+    f.raw_cap = total;
+  }
+  if (f.h_raw_cap < total) {
+    (void)hipHostFree(f.h_raw);
+    f.h_raw = nullptr, f.h_raw_cap = 0;
+    HIP_TRY(ctx, hipHostMalloc((void**)&f.h_raw, total * sizeof(float4)));
+    f.h_raw_cap = total;
+  }
+  const int rcv = parallel_scans(n, [&](int k) -> int {
+    const lins_point* p = raw[k];
+    for (int i = 0; i < n_raw[k]; ++i)  // (no-return points may be NaN in a real driver's cloud: they never project)
+      if (std::isinf(p[i].x) || std::isinf(p[i].y) || std::isinf(p[i].z)) return LINS_E_INPUT;
+    std::memcpy(f.h_raw + hr[k].off, p, (size_t)n_raw[k] * sizeof(float4));
+    return 0;
+  });
+  if (rcv) return rcv;
+  std::vector<FeScanHost> hs(n);
+  for (int k = 0; k < n; ++k) {
+    std::memset(&hs[k], 0, sizeof hs[k]);
+    hs[k].off = (long long)((size_t)k * N);
+    hs[k].o_sharp = offs[k][0], hs[k].o_less_sharp = offs[k][1], hs[k].o_flat = offs[k][2], hs[k].o_less_flat = offs[k][3];
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(f.d_raw, f.h_raw, total * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(f.d_raws, hr.data(), (size_t)n * sizeof(SgRawHost), hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(f.d_scans, hs.data(), (size_t)n * sizeof(FeScanHost), hipMemcpyHostToDevice, ctx->stream));
+  // segmentAlphaX / Y and segmentTheta as the host restatement forms them (parameters.h:88-92)
+  const float ax = (float)(0.2f / 180.0 * M_PI), ay = (float)(2.0f / 180.0 * M_PI);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  launch_segment(ctx->stream, n, f.d_raws, f.d_raw, std::sin(ax), std::cos(ax), std::sin(ay), std::cos(ay), 1.0472f,
+                 f.d_cellidx, f.d_full, f.d_rangemat, f.d_segcount, f.d_segrows, f.d_scans, f.d_cloud, f.d_range, f.d_col,
+                 f.d_ground, f.d_outliers);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
+  return LINS_OK;
+}
+
+int lins_segment_batch(lins_ctx* ctx, int n, const lins_point* const* raw, const int32_t* n_raw, lins_segmented_scan* out) {
+  if (!ctx || n < 0 || (n && (!raw || !n_raw || !out))) return LINS_E_ARG;
+  if (n == 0) return LINS_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  for (int k = 0; k < n; ++k)
+    if (!out[k].cloud || !out[k].range || !out[k].col || !out[k].ground) return LINS_E_ARG;
+  std::vector<long long> offs((size_t)n * 4, 0);
+  int rc = sg_run(ctx, n, raw, n_raw, reinterpret_cast<const long long(*)[4]>(offs.data()));
+  if (rc) return rc;
+  auto& f = ctx->fe;
+  std::vector<FeScanHost> hs(n);
+  std::vector<int> outl(n);
+  HIP_TRY(ctx, hipMemcpyAsync(hs.data(), f.d_scans, (size_t)n * sizeof(FeScanHost), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(outl.data(), f.d_outliers, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipEventElapsedTime(&f.sg_ms, ctx->ev0, ctx->ev2));
+  const size_t N = LINS_CLOUD_MAX;
+  for (int k = 0; k < n; ++k) {
+    lins_segmented_scan& o = out[k];
+    o.n = hs[k].n;
+    for (int r = 0; r < LINS_LINE_NUM; ++r) o.start_ring[r] = hs[k].start_ring[r], o.end_ring[r] = hs[k].end_ring[r];
+    o.start_ori = hs[k].start_ori, o.end_ori = hs[k].end_ori, o.ori_diff = hs[k].ori_diff;
+    o.n_outlier = outl[k];
+    const size_t b = (size_t)k * N;
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<lins_point*>(o.cloud), f.d_cloud + b, o.n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<float*>(o.range), f.d_range + b, o.n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint32_t*>(o.col), f.d_col + b, o.n * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(const_cast<uint8_t*>(o.ground), f.d_ground + b, o.n, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return LINS_OK;
+}
+
+int lins_last_segment_ms(lins_ctx* ctx, float* kernel_ms) {
+  if (!ctx || !kernel_ms) return LINS_E_ARG;
+  *kernel_ms = ctx->fe.sg_ms;
   return LINS_OK;
 }
 
@@ -699,9 +837,26 @@ int lins_streams_init(lins_ctx* ctx, int n_streams) {
   return LINS_OK;
 }
 
+static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, const lins_point* const* raw,
+                             const int32_t* n_raw, const double* prior_state, const double* prior_cov, double scan_period,
+                             lins_result* out, int32_t* feature_counts);
+
 int lins_streams_step(lins_ctx* ctx, const lins_segmented_scan* scans, const double* prior_state, const double* prior_cov,
                       double scan_period, lins_result* out, int32_t* feature_counts) {
-  if (!ctx || !scans || !prior_state || !prior_cov || !out) return LINS_E_ARG;
+  if (!scans) return LINS_E_ARG;
+  return streams_step_impl(ctx, scans, nullptr, nullptr, prior_state, prior_cov, scan_period, out, feature_counts);
+}
+
+int lins_streams_step_raw(lins_ctx* ctx, const lins_point* const* raw, const int32_t* n_raw, const double* prior_state,
+                          const double* prior_cov, double scan_period, lins_result* out, int32_t* feature_counts) {
+  if (!raw || !n_raw) return LINS_E_ARG;
+  return streams_step_impl(ctx, nullptr, raw, n_raw, prior_state, prior_cov, scan_period, out, feature_counts);
+}
+
+static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, const lins_point* const* raw,
+                             const int32_t* n_raw, const double* prior_state, const double* prior_cov, double scan_period,
+                             lins_result* out, int32_t* feature_counts) {
+  if (!ctx || !prior_state || !prior_cov || !out) return LINS_E_ARG;
   auto& t = ctx->st;
   if (t.n <= 0) return LINS_E_STATE;
   if (stream_cloud_size() != sizeof(StreamCloudHost)) return LINS_E_STATE;
@@ -716,7 +871,16 @@ int lins_streams_step(lins_ctx* ctx, const lins_segmented_scan* scans, const dou
     o[0] = b + kSlotSharp, o[1] = b + kSlotLessSharp, o[2] = b + kSlotFlat, o[3] = b + kSlotLessFlat;
   }
   std::vector<int> counts;
-  int rc = fe_run(ctx, n, scans, scan_period, t.d_arena, reinterpret_cast<const long long(*)[4]>(offs.data()), counts);
+  int rc;
+  if (scans) {
+    rc = fe_run(ctx, n, scans, scan_period, t.d_arena, reinterpret_cast<const long long(*)[4]>(offs.data()), counts);
+  } else {  // raw clouds: the image_projection stage on the device feeds the front-end where its output lies
+    rc = sg_run(ctx, n, raw, n_raw, reinterpret_cast<const long long(*)[4]>(offs.data()));
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipEventElapsedTime(&ctx->fe.sg_ms, ctx->ev0, ctx->ev2));
+    rc = fe_launch(ctx, n, scan_period, t.d_arena, counts, 0);
+  }
   if (rc) return rc;
   t.frontend_ms = ctx->fe.ms;
   // 2. IESKF update of every stream against its resident last scan (a stream's first scan: an update

@@ -21,7 +21,8 @@ EXPORTS = [
     "lins_batch_download", "lins_last_kernel_ms", "lins_batch_bytes_per_iter", "lins_batch_total_iters",
     "lins_correspondences", "lins_reduce_pass", "lins_host_perform_ieskf", "lins_transform_to_end_batch",
     "lins_last_reproject_stats", "lins_icp_update_batch", "lins_extract_features_batch", "lins_last_frontend_stats",
-    "lins_streams_init", "lins_streams_step", "lins_streams_stats", "lins_streams_peek",
+    "lins_streams_init", "lins_streams_step", "lins_streams_stats", "lins_streams_peek", "lins_segment_batch",
+    "lins_last_segment_ms", "lins_streams_step_raw",
 ]
 
 
@@ -139,6 +140,46 @@ class IeskfContext:
         self._check(lib().lins_host_perform_ieskf(self._h, C.byref(self.params), C.byref(c), C.byref(r), C.byref(used)))
         return Result(r), bool(used.value)
 
+    # -- image_projection_node on the device: raw clouds -> segmented scans --------------------
+    def segment_batch(self, raws):
+        """raws: list of (n,4) f32 raw clouds in firing order.  Returns a list of host.Segmented."""
+        import importlib
+
+        host = importlib.import_module(__package__ + ".host")
+        n = len(raws)
+        raws = [np.ascontiguousarray(r, dtype=np.float32).reshape(-1, 4) for r in raws]
+        ptrs = (C.POINTER(host.Point) * n)(*[r.ctypes.data_as(C.POINTER(host.Point)) for r in raws])
+        counts = (C.c_int32 * n)(*[len(r) for r in raws])
+        out = (host.SegmentedScanC * n)()
+        keep = []
+        for k in range(n):
+            cloud = np.zeros((host.CLOUD_MAX, 4), np.float32)
+            rng = np.zeros(host.CLOUD_MAX, np.float32)
+            col = np.zeros(host.CLOUD_MAX, np.uint32)
+            ground = np.zeros(host.CLOUD_MAX, np.uint8)
+            out[k].cloud = cloud.ctypes.data_as(C.POINTER(host.Point))
+            out[k].range = rng.ctypes.data_as(C.POINTER(C.c_float))
+            out[k].col = col.ctypes.data_as(C.POINTER(C.c_uint32))
+            out[k].ground = ground.ctypes.data_as(C.POINTER(C.c_uint8))
+            keep.append((cloud, rng, col, ground))
+        L = lib()
+        L.lins_segment_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(host.Point)), C.POINTER(C.c_int32),
+                                         C.POINTER(host.SegmentedScanC)]
+        self._check(L.lins_segment_batch(self._h, n, ptrs, counts, out))
+        res = []
+        for k in range(n):
+            c = host.SegmentedScanC()
+            C.memmove(C.byref(c), C.byref(out[k]), C.sizeof(c))
+            res.append(host.Segmented(*keep[k], c))
+        return res
+
+    def segment_ms(self):
+        ms = C.c_float(0)
+        L = lib()
+        L.lins_last_segment_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        self._check(L.lins_last_segment_ms(self._h, C.byref(ms)))
+        return ms.value
+
     # -- StateEstimator's feature front-end on the device (undistortPcl .. extractFeatures) ----
     def extract_features_batch(self, segs, scan_period=0.1):
         """segs: list of host.Segmented.  Returns a list of dicts like host.frontend_extract()."""
@@ -192,6 +233,30 @@ class IeskfContext:
         self._check(L.lins_streams_step(self._h, arr, ps.ctypes.data_as(C.POINTER(C.c_double)),
                                         pc.ctypes.data_as(C.POINTER(C.c_double)), scan_period, res,
                                         counts.ctypes.data_as(C.POINTER(C.c_int32))))
+        self._n = 0
+        return [Result(r) for r in res], counts
+
+    def streams_step_raw(self, raws, prior_state, prior_cov, scan_period=0.1):
+        """Like streams_step, from raw clouds (firing order): image projection / segmentation on the device too."""
+        import importlib
+
+        host = importlib.import_module(__package__ + ".host")
+        n = self._streams
+        assert len(raws) == n
+        raws = [np.ascontiguousarray(r, dtype=np.float32).reshape(-1, 4) for r in raws]
+        ptrs = (C.POINTER(host.Point) * n)(*[r.ctypes.data_as(C.POINTER(host.Point)) for r in raws])
+        cnts = (C.c_int32 * n)(*[len(r) for r in raws])
+        ps = np.ascontiguousarray(prior_state, dtype=np.float64).reshape(n, 19)
+        pc = np.ascontiguousarray(prior_cov, dtype=np.float64).reshape(n, 324)
+        res = (ResultC * n)()
+        counts = np.zeros((n, 4), np.int32)
+        L = lib()
+        L.lins_streams_step_raw.argtypes = [C.c_void_p, C.POINTER(C.POINTER(host.Point)), C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(ResultC),
+                                            C.POINTER(C.c_int32)]
+        self._check(L.lins_streams_step_raw(self._h, ptrs, cnts, ps.ctypes.data_as(C.POINTER(C.c_double)),
+                                            pc.ctypes.data_as(C.POINTER(C.c_double)), scan_period, res,
+                                            counts.ctypes.data_as(C.POINTER(C.c_int32))))
         self._n = 0
         return [Result(r) for r in res], counts
 

@@ -30,7 +30,8 @@ def test_ieskf_library_exports_every_declared_symbol(ieskf):
 
 
 DEVICE_SIDE_OF_HOST_HEADER = ("lins_host_perform_ieskf", "lins_extract_features_batch", "lins_last_frontend_stats",
-                              "lins_streams_init", "lins_streams_step", "lins_streams_stats", "lins_streams_peek")
+                              "lins_streams_init", "lins_streams_step", "lins_streams_stats", "lins_streams_peek",
+                              "lins_segment_batch", "lins_last_segment_ms", "lins_streams_step_raw")
 
 
 def test_host_library_exports_every_declared_symbol(host):

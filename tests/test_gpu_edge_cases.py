@@ -415,6 +415,39 @@ def test_device_resident_streams_reproduce_the_staged_path(pkg, ieskf, host):
                    (w.iters, w.converged, w.diverged, w.m_surf, w.m_corner), i
             assert np.abs(g.state[:3] - w.state[:3]).max() <= 1e-6 and np.abs(g.state[6:10] - w.state[6:10]).max() <= 1e-7
             assert np.abs(g.cov - w.cov).max() <= 1e-6 * np.abs(w.cov).max()
+        # the same two steps from RAW clouds (image projection on the device too): identical results, bit for bit
+        c.streams_init(n)
+        raw0 = [host.synth_raw_scan(40 + i, 0) for i in range(n)]
+        raw1 = [host.synth_raw_scan(40 + i, 1) for i in range(n)]
+        c.streams_step_raw(raw0, boot, cov0)
+        r1r, cnt1r = c.streams_step_raw(raw1, np.stack([p.state for p in pairs]), np.stack([p.cov for p in pairs]))
+        assert np.array_equal(cnt1r, cnt1)
+        for a, b in zip(r1r, r1):
+            assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov) and a.iters == b.iters
         # third step on the same context (slots swap back): still runs, poses stay finite
         r2, _ = c.streams_step(seg0, np.stack([p.state for p in pairs]), np.stack([p.cov for p in pairs]))
         assert all(np.isfinite(r.state).all() for r in r2)
+
+
+def test_device_segmentation_matches_the_host_restatement(pkg, ieskf, host):
+    """image_projection_node (IP:191-415) on the device == the host restatement, bit for bit: projection
+    (last point owns a cell), ground flags, the BFS labelling restated as a min-label propagation over the
+    reference's directed neighbour table (validity of every segment), emission order, ring indices,
+    orientations, outlier count — and the feature stage fed from it yields the same feature clouds."""
+    raws = [host.synth_raw_scan(idx, k) for idx in (0, 1, 2, 7) for k in (0, 1)]
+    want = [host.frontend_segment(r) for r in raws]
+    with ieskf.IeskfContext(pkg.default_params(), max_batch=1, max_targets=1024) as c:
+        got = c.segment_batch(raws)
+        assert c.segment_ms() > 0
+        for g, w in zip(got, want):
+            assert g.n == w.n and g.c.n_outlier == w.c.n_outlier
+            assert list(g.c.start_ring) == list(w.c.start_ring) and list(g.c.end_ring) == list(w.c.end_ring)
+            assert (g.c.start_ori, g.c.end_ori, g.c.ori_diff) == (w.c.start_ori, w.c.end_ori, w.c.ori_diff)
+            n = w.n
+            assert np.array_equal(g.cloud[:n], w.cloud[:n]) and np.array_equal(g.range[:n], w.range[:n])
+            assert np.array_equal(g.col[:n], w.col[:n]) and np.array_equal(g.ground[:n], w.ground[:n])
+        feats = c.extract_features_batch(got)
+    for f, w in zip(feats, want):
+        ref = host.frontend_extract_segmented(w)
+        for k in ("corner_sharp", "corner_less_sharp", "surf_flat", "surf_less_flat"):
+            assert np.array_equal(f[k], ref[k]), k

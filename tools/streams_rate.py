@@ -10,8 +10,10 @@ pkg = importlib.import_module(PKG); host = importlib.import_module(PKG + ".host"
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 with ThreadPoolExecutor(16) as ex:
     pairs = list(ex.map(host.synth_pair, range(n)))
-    seg0 = list(ex.map(lambda i: host.frontend_segment(host.synth_raw_scan(i, 0)), range(n)))
-    seg1 = list(ex.map(lambda i: host.frontend_segment(host.synth_raw_scan(i, 1)), range(n)))
+    raw0 = list(ex.map(lambda i: host.synth_raw_scan(i, 0), range(n)))
+    raw1 = list(ex.map(lambda i: host.synth_raw_scan(i, 1), range(n)))
+    seg0 = list(ex.map(host.frontend_segment, raw0))
+    seg1 = list(ex.map(host.frontend_segment, raw1))
 boot = np.zeros((n, 19))
 for i, p in enumerate(pairs):
     boot[i, 0:3], boot[i, 6:10] = p.meta["true_t"], p.meta["true_q"]
@@ -31,3 +33,17 @@ with ieskf.IeskfContext(pkg.default_params(num_iter=10, fixed_iters=1), max_batc
     its = sum(r.iters for r in res)
     print(f"streams: {n} streams, one scan each: front-end {fe:.3f} ms + update {up:.3f} ms ({its} iterations) + re-projection {rp:.3f} ms "
           f"= {fe + up + rp:.3f} ms on device => {n / (fe + up + rp) * 1e3:.0f} scans/s; wall incl. segmented-cloud upload + validation {wall * 1e3:.1f} ms")
+    # the same from raw clouds: image projection / segmentation on the device as well
+    c.streams_init(n)
+    c.streams_step_raw(raw0, boot, np.tile(np.eye(18)[None] * 1e-4, (n, 1, 1)))
+    best = None
+    for rep in range(3):
+        t0 = time.perf_counter()
+        res, cnt = c.streams_step_raw(raw1 if rep % 2 == 0 else raw0, st, cv)
+        wall = time.perf_counter() - t0
+        fe, up, rp = c.streams_stats(); sg = c.segment_ms()
+        if best is None or sg + fe + up + rp < sum(best[:4]):
+            best = (sg, fe, up, rp, wall)
+    sg, fe, up, rp, wall = best
+    print(f"streams from raw clouds: projection + segmentation {sg:.3f} ms + front-end {fe:.3f} ms + update {up:.3f} ms + re-projection {rp:.3f} ms "
+          f"= {sg + fe + up + rp:.3f} ms on device => {n / (sg + fe + up + rp) * 1e3:.0f} scans/s; wall incl. raw-cloud upload {wall * 1e3:.1f} ms")
