@@ -88,6 +88,10 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
                                                            unsigned* __restrict__ out_col, unsigned char* __restrict__ out_ground,
                                                            int* __restrict__ out_outliers) {
   SgLds& L = g_sg;
+#ifdef LINS_SG_PROF
+  long long sg_t0 = clock64();
+  int sg_sweeps = 0;
+#endif
   const int tid = threadIdx.x, scan = blockIdx.x;
   const SgRaw rw = raws[scan];
   const float4* pts = raw + rw.off;
@@ -104,7 +108,11 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
   if (tid == 0) L.n_outlier = 0;
   __syncthreads();
 
+#ifdef LINS_SG_PROF
+  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("SG %d %lld\n", 0, t_ - sg_t0); sg_t0 = t_; }
+#endif
   // ---- projectPointCloud (IP:205-241): the LAST point that falls into a cell owns it -------------
+#pragma unroll 4
   for (int i = tid; i < n; i += kSgBlock) {
     const float4 p = pts[i];
     const float vert = (float)((double)(lins_atan2f(p.z, sqrtf(p.x * p.x + p.y * p.y)) * 180) / kPi);
@@ -119,6 +127,7 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
   }
   __threadfence_block();
   __syncthreads();
+#pragma unroll 4
   for (int c = tid; c < kSgCells; c += kSgBlock) {
     const int i = ci[c];
     float4 p = make_float4(NAN, NAN, NAN, -1.f);
@@ -134,6 +143,9 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
   __threadfence_block();
   __syncthreads();
 
+#ifdef LINS_SG_PROF
+  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("SG %d %lld\n", 1, t_ - sg_t0); sg_t0 = t_; }
+#endif
   // ---- groundRemoval (IP:243-278): one thread per column, rows bottom-up (a row is rewritten by the next) ----
   for (int c = tid; c < kSgCells; c += kSgBlock) L.ground[c] = 0;
   __syncthreads();
@@ -151,7 +163,11 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
     }
   __syncthreads();
 
+#ifdef LINS_SG_PROF
+  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("SG %d %lld\n", 2, t_ - sg_t0); sg_t0 = t_; }
+#endif
   // ---- adjacency of labelComponents (IP:336-415) as three edge bits per eligible cell ------------------
+#pragma unroll 4
   for (int c = tid; c < kSgCells; c += kSgBlock) {
     const bool elig = !(L.ground[c] == 1 || rm[c] == FLT_MAX);
     L.edges[c] = elig ? 0x80 : 0;
@@ -165,6 +181,7 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
     if (tc >= kSgCols) tc = 0;
     return r * kSgCols + tc;
   };
+#pragma unroll 4
   for (int c = tid; c < kSgCells; c += kSgBlock) {
     if (!(L.edges[c] & 0x80)) continue;
     unsigned char e = 0x80;
@@ -182,6 +199,9 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
   }
   __syncthreads();
 
+#ifdef LINS_SG_PROF
+  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("SG %d %lld\n", 3, t_ - sg_t0); sg_t0 = t_; }
+#endif
   // ---- min-label propagation: pull over the in-edges, own run of cells in raster order, until stable ----
   constexpr int kRun = (kSgCells + kSgBlock - 1) / kSgBlock;  // 29 cells per thread
   const int c_lo = tid * kRun < kSgCells ? tid * kRun : kSgCells;
@@ -215,11 +235,18 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
     }
     if (ch) L.changed = 1;
     __syncthreads();
+#ifdef LINS_SG_PROF
+    ++sg_sweeps;
+#endif
     if (!L.changed) break;
     __syncthreads();
   }
 
+#ifdef LINS_SG_PROF
+  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("SG %d %lld\n", 4, t_ - sg_t0); sg_t0 = t_; }
+#endif
   // ---- segment validity (IP:398-406): size, and rows of the cells that were pushed as neighbours -------
+#pragma unroll 4
   for (int c = tid; c < kSgCells; c += kSgBlock) {
     if (!(L.edges[c] & 0x80)) continue;
     const int s = L.label[c];
@@ -229,6 +256,9 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
   __threadfence_block();
   __syncthreads();
 
+#ifdef LINS_SG_PROF
+  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("SG %d %lld\n", 5, t_ - sg_t0); sg_t0 = t_; }
+#endif
   // ---- cloudSegmentation emission (IP:292-321): ring-major, ascending column -----------------------------
   auto decide = [&](int c, bool& is_ground) {  // emitted? (also counts the outliers of invalid segments)
     const int i = c / kSgCols, j = c - i * kSgCols;
@@ -281,6 +311,9 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
     fo->start_ring[tid] = L.ring_count[tid] - 1 + 5;
     fo->end_ring[tid] = L.ring_count[tid + 1] - 1 - 5;
   }
+#ifdef LINS_SG_PROF
+  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("SG %d %lld sweeps %d\n", 6, t_ - sg_t0, sg_sweeps); }
+#endif
   if (tid == 0) {
     fo->n = total;
     // findStartEndAngle (IP:191-203), including the y(last) / x(second-to-last) mix
