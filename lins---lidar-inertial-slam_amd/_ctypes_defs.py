@@ -170,3 +170,38 @@ class Result:
             f"Result(iters={self.iters}, conv={self.converged}, div={self.diverged}, "
             f"m=({self.m_surf},{self.m_corner}), p={self.state[:3]}, |r|={self.residual_norm:.4g})"
         )
+
+
+# ---- scan-to-map row (include/lins_map.h) -------------------------------------------------
+class MapProblemC(C.Structure):
+    _fields_ = [("map_corner", C.POINTER(Point)), ("map_surf", C.POINTER(Point)), ("scan_corner", C.POINTER(Point)),
+                ("scan_surf", C.POINTER(Point)), ("n_map_corner", C.c_int32), ("n_map_surf", C.c_int32),
+                ("n_scan_corner", C.c_int32), ("n_scan_surf", C.c_int32), ("transform", C.c_float * 6),
+                ("reserved", C.c_int32 * 2)]
+
+
+class MapResultC(C.Structure):
+    _fields_ = [("transform", C.c_float * 6), ("iters", C.c_int32), ("converged", C.c_int32),
+                ("degenerate", C.c_int32), ("n_sel", C.c_int32)]
+
+
+MAP_CORR_DTYPE = np.dtype([("ind", np.int32, 5), ("accepted", np.int32), ("coeff", np.float32, 4),
+                           ("sel", np.float32, 3), ("sq5", np.float32)])
+
+
+class MapProblem:
+    """numpy-owned scan-to-map problem; as_c() gives the ctypes view."""
+
+    def __init__(self, map_corner, map_surf, scan_corner, scan_surf, transform):
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 4)
+        self.map_corner, self.map_surf, self.scan_corner, self.scan_surf = f(map_corner), f(map_surf), f(scan_corner), f(scan_surf)
+        self.transform = np.asarray(transform, dtype=np.float32).copy()
+
+    def as_c(self):
+        c = MapProblemC()
+        pp = lambda a: a.ctypes.data_as(C.POINTER(Point))
+        c.map_corner, c.map_surf, c.scan_corner, c.scan_surf = pp(self.map_corner), pp(self.map_surf), pp(self.scan_corner), pp(self.scan_surf)
+        c.n_map_corner, c.n_map_surf = len(self.map_corner), len(self.map_surf)
+        c.n_scan_corner, c.n_scan_surf = len(self.scan_corner), len(self.scan_surf)
+        c.transform[:] = [float(v) for v in self.transform]
+        return c

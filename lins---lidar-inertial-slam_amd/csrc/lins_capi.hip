@@ -20,6 +20,7 @@
 
 #include "../../include/lins_host.h"
 #include "ieskf_device.h"
+#include "lins_ctx_priv.h"
 
 namespace lins {
 void launch_persistent(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const double*,
@@ -142,6 +143,8 @@ struct lins_ctx {
     std::vector<int> last_counts;  // per stream: less sharp, less flat of the resident last scan (-1: none yet)
     float update_ms = 0.f, frontend_ms = 0.f, reproject_ms = 0.f;
   } st;
+  void* map_state = nullptr;  // scan-to-map row (lins_map_capi.hip), freed through map_state_free
+  void (*map_state_free)(void*) = nullptr;
   long long* d_prof = nullptr;  // optional per-workgroup phase profile (lins_debug_phase_profile)
   double* d_a6 = nullptr;  // upper triangle of the last iteration's H^T H, per scan
   void* d_out = nullptr;
@@ -160,6 +163,20 @@ struct lins_ctx {
   uint64_t total_iters = 0;
   std::string hip_err;
 };
+
+namespace lins {
+hipStream_t ctx_stream(lins_ctx* ctx) { return ctx->stream; }
+int ctx_device(lins_ctx* ctx) { return ctx->device; }
+int ctx_fail_hip(lins_ctx* ctx, hipError_t e, const char* what) {
+  if (ctx) ctx->hip_err = std::string(what) + ": " + hipGetErrorString(e);
+  return LINS_E_HIP;
+}
+void** ctx_map_slot(lins_ctx* ctx, void (*free_fn)(void*)) {
+  ctx->map_state_free = free_fn;
+  return &ctx->map_state;
+}
+void ctx_events(lins_ctx* ctx, hipEvent_t* a, hipEvent_t* b) { *a = ctx->ev0, *b = ctx->ev2; }
+}  // namespace lins
 
 namespace {
 
@@ -442,6 +459,7 @@ void lins_destroy(lins_ctx* ctx) {
   (void)hipFree(ctx->d_jobs);
   fe_free(ctx);
   streams_free(ctx);
+  if (ctx->map_state && ctx->map_state_free) ctx->map_state_free(ctx->map_state);
   (void)hipFree(ctx->d_out);
   (void)hipFree(ctx->d_idx);
   (void)hipFree(ctx->d_dump);

@@ -1,0 +1,160 @@
+// map_kernels.hip — scan-to-map correspondences on the device: cornerOptimization /
+// surfOptimization (LM:1351-1521) and the rows + normal-equation sums of LMOptimization (LM:1543-1584).
+//
+// The local map (1e4 .. 1e5 points per cloud) is bucketed into 1 m cells of the integer lattice
+// (host-built counting sort, once per problem: the reference rebuilds its kd-trees per scan too,
+// LM:1637-1638).  A correspondence only counts when the FIFTH neighbour is closer than 1 m
+// (pointSearchSqDis[4] < 1.0, LM:1360 / 1464), so the exact 5-NN it needs lies in the 27 cells around
+// the query's cell: one thread per query scans those cells, keeps the five smallest
+// (squared distance, index) keys — the order FLANN's result is restated with — and runs the
+// eigen- / plane-fit of map_math.h in registers.  The accepted rows go straight into the 21 + 6 sums
+// of A^T A, A^T b (f64, fixed-shape tree per block; the host adds the per-block partials in order).
+#include <hip/hip_runtime.h>
+
+#include "map_math.h"
+
+namespace lins {
+
+struct MapGrid {  // one cloud of one problem
+  long long off_pts;    // first sorted point (x, y, z, original index bits) in the point arena
+  long long off_cells;  // first of (ncell + 1) cell starts in the cell arena (positions relative to off_pts)
+  int cmin[3], cdim[3];
+};
+struct MapDev {  // one problem
+  MapGrid g[2];      // 0 corner map, 1 surf map
+  long long off_q;   // queries: corner scan points, then surf scan points
+  long long off_rec; // lins_map_corr records, same order
+  int n_q[2];
+  int active;        // 0: finished / precondition not met — its blocks return at once
+  int pad;
+};
+struct MapRound {
+  MapAssoc as;
+  MapTrig tg;
+  float pad;
+};
+
+constexpr int kMapBlock = 256;
+
+__global__ __launch_bounds__(kMapBlock) void map_corr_kernel(const MapDev* __restrict__ probs, const MapRound* __restrict__ rounds,
+                                                             const float4* __restrict__ pts, const int* __restrict__ cells,
+                                                             const float4* __restrict__ queries, lins_map_corr* __restrict__ recs,
+                                                             double* __restrict__ partials, int blocks_per_problem) {
+  const int prob = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const MapDev pd = probs[prob];
+  double* out = partials + ((size_t)prob * blocks_per_problem + blockIdx.x) * 28;
+  if (!pd.active) {
+    if (tid < 28) out[tid] = 0.0;
+    return;
+  }
+  const MapRound rd = rounds[prob];
+  const int q = blockIdx.x * kMapBlock + tid, nq = pd.n_q[0] + pd.n_q[1];
+  double v[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) v[k] = 0.0;
+  if (q < nq) {
+    const int which = q < pd.n_q[0] ? 0 : 1;
+    const MapGrid g = pd.g[which];
+    const float4 po = queries[pd.off_q + q];
+    float sx, sy, sz;
+    map_associate(rd.as, po.x, po.y, po.z, sx, sy, sz);
+    // the five smallest keys (squared-distance bits << 32 | original index): distances are >= 0, so the
+    // unsigned 64-bit order is the (distance, index) order; pos = where the point sits in the sorted map
+    const unsigned long long kNoKey = ((unsigned long long)0x7F800000u << 32) | 0xFFFFFFFFull;
+    unsigned long long key[5] = {kNoKey, kNoKey, kNoKey, kNoKey, kNoKey};
+    int pos[5] = {-1, -1, -1, -1, -1};
+    const int cx = (int)floorf(sx) - g.cmin[0], cy = (int)floorf(sy) - g.cmin[1], cz = (int)floorf(sz) - g.cmin[2];
+    const float4* gp = pts + g.off_pts;
+    const int* gc = cells + g.off_cells;
+    for (int dz = -1; dz <= 1; ++dz)
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int iz = cz + dz, iy = cy + dy;
+        if (iz < 0 || iz >= g.cdim[2] || iy < 0 || iy >= g.cdim[1]) continue;
+        // the three x-neighbours are consecutive cells: one contiguous span of points
+        int x0 = cx - 1, x1 = cx + 1;
+        x0 = x0 < 0 ? 0 : x0, x1 = x1 >= g.cdim[0] ? g.cdim[0] - 1 : x1;
+        if (x0 > x1) continue;
+        const int row = (iz * g.cdim[1] + iy) * g.cdim[0];
+        const int s = gc[row + x0], e = gc[row + x1 + 1];
+        for (int p = s; p < e; ++p) {
+          const float4 t = gp[p];
+          const float ddx = sx - t.x, ddy = sy - t.y, ddz = sz - t.z;
+          const float d = (ddx * ddx + ddy * ddy) + ddz * ddz;
+          unsigned long long ck = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(t.w);
+          if (!(ck < key[4])) continue;
+          int cp = p;  // insertion, unrolled so that the arrays stay in registers
+#pragma unroll
+          for (int k = 0; k < 5; ++k) {
+            const bool before = ck < key[k];
+            const unsigned long long tk = key[k];
+            const int tp = pos[k];
+            key[k] = before ? ck : tk, pos[k] = before ? cp : tp;
+            ck = before ? tk : ck, cp = before ? tp : cp;
+          }
+        }
+      }
+    lins_map_corr r;
+    r.sel[0] = sx, r.sel[1] = sy, r.sel[2] = sz;
+    r.accepted = 0;
+    r.coeff[0] = r.coeff[1] = r.coeff[2] = r.coeff[3] = 0.f;
+    const float sq5 = __uint_as_float((unsigned)(key[4] >> 32));
+    if (sq5 < 1.0) {
+      float px[5], py[5], pz[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        const float4 t = gp[pos[k]];
+        px[k] = t.x, py[k] = t.y, pz[k] = t.z;
+        r.ind[k] = (int)(unsigned)key[k];
+      }
+      r.sq5 = sq5;
+      float c[4];
+      r.accepted = which == 0 ? map_corner_fit(px, py, pz, sx, sy, sz, c) : map_surf_fit(px, py, pz, sx, sy, sz, c);
+      r.coeff[0] = c[0], r.coeff[1] = c[1], r.coeff[2] = c[2], r.coeff[3] = c[3];
+      if (r.accepted) {
+        float row[6], b;
+        map_lm_row(rd.tg, po.x, po.y, po.z, c, row, b);
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = i; j < 6; ++j) v[t++] = (double)row[i] * (double)row[j];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[21 + i] = (double)row[i] * (double)b;
+        v[27] = 1.0;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) r.ind[k] = -1;
+      r.sq5 = INFINITY;
+    }
+    recs[pd.off_rec + q] = r;
+  }
+  // 28 sums: wave butterfly, then the four waves in order
+  __shared__ double wsum[kMapBlock / 64][28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) {
+    double x = v[k];
+    for (int o = 32; o > 0; o >>= 1) {
+      const int lo = __shfl_xor(__double2loint(x), o), hi = __shfl_xor(__double2hiint(x), o);
+      x += __hiloint2double(hi, lo);
+    }
+    if (lane == 0) wsum[wave][k] = x;
+  }
+  __syncthreads();
+  if (tid < 28) {
+    double s = 0.0;
+    for (int w = 0; w < kMapBlock / 64; ++w) s += wsum[w][tid];
+    out[tid] = s;
+  }
+}
+
+void launch_map_corr(hipStream_t stream, int n_problems, int blocks_per_problem, const void* probs, const void* rounds,
+                     const float4* pts, const int* cells, const float4* queries, lins_map_corr* recs, double* partials) {
+  hipLaunchKernelGGL(map_corr_kernel, dim3(blocks_per_problem, n_problems), dim3(kMapBlock), 0, stream, (const MapDev*)probs,
+                     (const MapRound*)rounds, pts, cells, queries, recs, partials, blocks_per_problem);
+}
+size_t map_dev_size() { return sizeof(MapDev); }
+size_t map_round_size() { return sizeof(MapRound); }
+int map_block() { return kMapBlock; }
+
+}  // namespace lins

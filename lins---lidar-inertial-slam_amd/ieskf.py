@@ -22,7 +22,8 @@ EXPORTS = [
     "lins_correspondences", "lins_reduce_pass", "lins_host_perform_ieskf", "lins_transform_to_end_batch",
     "lins_last_reproject_stats", "lins_icp_update_batch", "lins_extract_features_batch", "lins_last_frontend_stats",
     "lins_streams_init", "lins_streams_step", "lins_streams_stats", "lins_streams_peek", "lins_segment_batch",
-    "lins_last_segment_ms", "lins_streams_step_raw",
+    "lins_last_segment_ms", "lins_streams_step_raw", "lins_map_correspondences", "lins_scan2map_batch",
+    "lins_last_map_stats",
 ]
 
 
@@ -139,6 +140,37 @@ class IeskfContext:
         used = C.c_int32(0)
         self._check(lib().lins_host_perform_ieskf(self._h, C.byref(self.params), C.byref(c), C.byref(r), C.byref(used)))
         return Result(r), bool(used.value)
+
+    # -- scan-to-map row (include/lins_map.h) -----------------------------------------------------
+    def map_correspondences(self, problem):
+        from ._ctypes_defs import MAP_CORR_DTYPE, MapProblemC
+
+        c = problem.as_c()
+        corner = np.zeros(len(problem.scan_corner), dtype=MAP_CORR_DTYPE)
+        surf = np.zeros(len(problem.scan_surf), dtype=MAP_CORR_DTYPE)
+        L = lib()
+        L.lins_map_correspondences.argtypes = [C.c_void_p, C.POINTER(MapProblemC), C.c_void_p, C.c_void_p]
+        self._check(L.lins_map_correspondences(self._h, C.byref(c), corner.ctypes.data, surf.ctypes.data))
+        return corner, surf
+
+    def scan2map_batch(self, problems):
+        from ._ctypes_defs import MapProblemC, MapResultC
+
+        n = len(problems)
+        arr = (MapProblemC * n)(*[p.as_c() for p in problems])
+        res = (MapResultC * n)()
+        L = lib()
+        L.lins_scan2map_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(MapProblemC), C.POINTER(MapResultC)]
+        self._check(L.lins_scan2map_batch(self._h, n, arr, res))
+        return [dict(transform=np.array(r.transform[:], dtype=np.float32), iters=r.iters, converged=r.converged,
+                     degenerate=r.degenerate, n_sel=r.n_sel) for r in res]
+
+    def map_stats(self):
+        ms, q = C.c_float(0), C.c_uint64(0)
+        L = lib()
+        L.lins_last_map_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
+        self._check(L.lins_last_map_stats(self._h, C.byref(ms), C.byref(q)))
+        return ms.value, q.value
 
     # -- image_projection_node on the device: raw clouds -> segmented scans --------------------
     def segment_batch(self, raws):

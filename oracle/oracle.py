@@ -181,3 +181,26 @@ def bench(prm, pairs, form=FORM_DENSE, mode=NN_KDTREE, threads=1):
     rc = lib().oracle_bench(C.byref(prm), len(pairs), arr, form, mode, threads, C.byref(sec), C.byref(its))
     assert rc == 0, rc
     return sec.value, its.value
+
+
+# ---- scan-to-map row (oracle/map_oracle.cpp) ------------------------------------------------
+def map_correspondences(problem):
+    c = problem.as_c()
+    corner = np.zeros(len(problem.scan_corner), dtype=_defs.MAP_CORR_DTYPE)
+    surf = np.zeros(len(problem.scan_surf), dtype=_defs.MAP_CORR_DTYPE)
+    L = lib()
+    L.oracle_map_correspondences.argtypes = [C.POINTER(_defs.MapProblemC), C.c_void_p, C.c_void_p]
+    rc = L.oracle_map_correspondences(C.byref(c), corner.ctypes.data, surf.ctypes.data)
+    assert rc == 0, rc
+    return corner, surf
+
+
+def scan2map(problem):
+    c = problem.as_c()
+    r = _defs.MapResultC()
+    L = lib()
+    L.oracle_scan2map.argtypes = [C.POINTER(_defs.MapProblemC), C.POINTER(_defs.MapResultC)]
+    rc = L.oracle_scan2map(C.byref(c), C.byref(r))
+    assert rc == 0, rc
+    return dict(transform=np.array(r.transform[:], dtype=np.float32), iters=r.iters, converged=r.converged,
+                degenerate=r.degenerate, n_sel=r.n_sel)

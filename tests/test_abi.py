@@ -24,7 +24,7 @@ def test_headers_declare_the_expected_surface():
 
 def test_ieskf_library_exports_every_declared_symbol(ieskf):
     L = ieskf.lib()  # loads liblins_ieskf.so (cross-compiled for gfx950; loading needs no GPU)
-    for name in declared("lins_ieskf.h") + ["lins_host_perform_ieskf"]:
+    for name in declared("lins_ieskf.h") + declared("lins_map.h") + ["lins_host_perform_ieskf"]:
         assert hasattr(L, name), f"liblins_ieskf.so does not export {name}"
     assert L.lins_strerror(0) == b"ok" and b"capacity" in L.lins_strerror(-3)
 
