@@ -25,6 +25,12 @@ with ieskf.IeskfContext(pkg.default_params(num_iter=30), max_batch=n, max_target
         c.extract_features_batch(segs)
         c.transform_to_end([p.surf_last for p in pairs] + [p.corner_last for p in pairs],
                            [(np.array([0.3, 0.1, 0.0]), np.array([0.9999, 0.01, 0.0, 0.01]) / np.linalg.norm([0.9999, 0.01, 0.0, 0.01]))] * (2 * n))
+    sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
+    from map_synth import make_problem
+    defs = importlib.import_module(PKG + "._ctypes_defs")
+    probs = [make_problem(defs, 100 + i, n_map_surf=30000, n_map_corner=4000, n_scan_surf=1500, n_scan_corner=400)[0] for i in range(32)]
+    for _ in range(3):
+        c.scan2map_batch(probs)
     print("ICP rounds per scan: mean", np.mean([x.iters for x in r]), "converged", sum(x.converged for x in r), "of", n)
 PY
 cd /tmp && export TMPDIR=/tmp && rm -rf $out/aux_kt && rocprofv3 --kernel-trace --stats -d $out/aux_kt -- python /tmp/aux_run.py > $out/aux_kt.log 2>&1
