@@ -986,15 +986,32 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     long long t0 = prof ? clock64() : 0, t1 = t0, t2 = t0, t3 = t0;
     // Query -> lane layout.  When both kinds fit one round with the corner queries starting on
     // a wave boundary, do that: no wave then mixes plane and line code paths.
-    const int surf_waves = (sd.n_surf_q + kQPerWave - 1) / kQPerWave;
+    int surf_waves = (sd.n_surf_q + kQPerWave - 1) / kQPerWave;
     const bool aligned = surf_waves * kQPerWave + sd.n_corner_q <= kQPerRound;
-    const int span = aligned ? surf_waves * kQPerWave + sd.n_corner_q : total;  // row slots in use
+    // One lane per query: a wave runs the union of its lanes' search paths, so its time grows with
+    // the number of active lanes — spread the queries over ALL waves instead of filling them one by
+    // one: plane queries (the costlier kind: two walks over five rings) evenly over the first
+    // kSpreadSurf waves, line queries evenly over the rest.
+    constexpr int kWaves = BLOCK / 64, kSpreadSurf = (kWaves * 5 + 4) / 8;
+    int spread_s = 0, spread_c = 0;  // queries per wave of either kind (0 = not spread)
+    if (LANES == 1) {
+      const int ws = (prm.pad >> 8) & 15 ? (prm.pad >> 8) & 15 : kSpreadSurf, wc = kWaves - ws;
+      const int ps = (sd.n_surf_q + ws - 1) / ws, pc = wc > 0 ? (sd.n_corner_q + wc - 1) / wc : 65;
+      if (ws < kWaves && ps <= 64 && pc <= 64) spread_s = ps, spread_c = pc, surf_waves = ws;
+    }
+    const bool spread = LANES == 1 && (spread_s | spread_c) != 0;
+    const int span = spread ? kQPerRound : (aligned ? surf_waves * kQPerWave + sd.n_corner_q : total);  // row slots in use
     int4 held = make_int4(0, 0, 0, -1);  // (ICP, ICP_FREQ > 1, single round) a corner triplet waiting for the plane-row count
     for (int base = 0; base < span; base += kQPerRound) {
       const int vslot = base + wave * kQPerWave + q_in_wave;  // position in the (padded) layout
       int slot = vslot;                                        // query index: surf first, then corner
       bool active = lane_used && vslot < span;
-      if (aligned) {
+      if (spread) {
+        if (wave < surf_waves)
+          slot = wave * spread_s + lane, active = lane < spread_s && slot < sd.n_surf_q;
+        else
+          slot = sd.n_surf_q + (wave - surf_waves) * spread_c + lane, active = lane < spread_c && slot < total;
+      } else if (aligned) {
         if (wave < surf_waves)
           active = active && vslot < sd.n_surf_q;
         else
