@@ -5,9 +5,9 @@
 // (host-built counting sort, once per problem: the reference rebuilds its kd-trees per scan too,
 // LM:1637-1638).  A correspondence only counts when the FIFTH neighbour is closer than 1 m
 // (pointSearchSqDis[4] < 1.0, LM:1360 / 1464), so the exact 5-NN it needs lies in the 27 cells around
-// the query's cell: one thread per query scans those cells, keeps the five smallest
-// (squared distance, index) keys — the order FLANN's result is restated with — and runs the
-// eigen- / plane-fit of map_math.h in registers.  The accepted rows go straight into the 21 + 6 sums
+// the query's cell: kMapLanes lanes per query scan those cells, each keeps the five smallest
+// (squared distance, index) keys it saw — the order FLANN's result is restated with — the lists are
+// merged by shuffles, and the query runs the eigen- / plane-fit of map_math.h in registers.  The accepted rows go straight into the 21 + 6 sums
 // of A^T A, A^T b (f64, fixed-shape tree per block; the host adds the per-block partials in order).
 #include <hip/hip_runtime.h>
 
@@ -35,6 +35,8 @@ struct MapRound {
 };
 
 constexpr int kMapBlock = 256;
+constexpr int kMapLanes = 8;  // lanes per query: they share the scan of its 27 cells, then merge their five-best lists
+constexpr int kMapQPerBlock = kMapBlock / kMapLanes;
 
 __global__ __launch_bounds__(kMapBlock) void map_corr_kernel(const MapDev* __restrict__ probs, const MapRound* __restrict__ rounds,
                                                              const float4* __restrict__ pts, const int* __restrict__ cells,
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(kMapBlock) void map_corr_kernel(const MapDev* __res
     return;
   }
   const MapRound rd = rounds[prob];
-  const int q = blockIdx.x * kMapBlock + tid, nq = pd.n_q[0] + pd.n_q[1];
+  const int q = blockIdx.x * kMapQPerBlock + tid / kMapLanes, sub = tid % kMapLanes, nq = pd.n_q[0] + pd.n_q[1];
   double v[28];
 #pragma unroll
   for (int k = 0; k < 28; ++k) v[k] = 0.0;
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(kMapBlock) void map_corr_kernel(const MapDev* __res
         if (x0 > x1) continue;
         const int row = (iz * g.cdim[1] + iy) * g.cdim[0];
         const int s = gc[row + x0], e = gc[row + x1 + 1];
-        for (int p = s; p < e; ++p) {
+        for (int p = s + sub; p < e; p += kMapLanes) {  // (a group's lanes read consecutive points)
           const float4 t = gp[p];
           const float ddx = sx - t.x, ddy = sy - t.y, ddz = sz - t.z;
           const float d = (ddx * ddx + ddy * ddy) + ddz * ddz;
@@ -93,6 +95,29 @@ __global__ __launch_bounds__(kMapBlock) void map_corr_kernel(const MapDev* __res
           }
         }
       }
+    // fold the lanes' lists: after log2(kMapLanes) exchanges every lane of the query holds the same five best
+    // (the lists are disjoint — every point was scanned by exactly one lane — so nothing is inserted twice)
+#pragma unroll
+    for (int m = 1; m < kMapLanes; m <<= 1) {
+      unsigned long long ok[5];
+      int op[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) ok[k] = __shfl_xor(key[k], m), op[k] = __shfl_xor(pos[k], m);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        unsigned long long ck = ok[i];
+        int cp = op[i];
+        if (!(ck < key[4])) continue;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const bool before = ck < key[k];
+          const unsigned long long tk = key[k];
+          const int tp = pos[k];
+          key[k] = before ? ck : tk, pos[k] = before ? cp : tp;
+          ck = before ? tk : ck, cp = before ? tp : cp;
+        }
+      }
+    }
     lins_map_corr r;
     r.sel[0] = sx, r.sel[1] = sy, r.sel[2] = sz;
     r.accepted = 0;
@@ -110,7 +135,7 @@ __global__ __launch_bounds__(kMapBlock) void map_corr_kernel(const MapDev* __res
       float c[4];
       r.accepted = which == 0 ? map_corner_fit(px, py, pz, sx, sy, sz, c) : map_surf_fit(px, py, pz, sx, sy, sz, c);
       r.coeff[0] = c[0], r.coeff[1] = c[1], r.coeff[2] = c[2], r.coeff[3] = c[3];
-      if (r.accepted) {
+      if (r.accepted && sub == 0) {  // (the fit ran on every lane of the query, identically: one of them counts)
         float row[6], b;
         map_lm_row(rd.tg, po.x, po.y, po.z, c, row, b);
         int t = 0;
@@ -127,14 +152,14 @@ __global__ __launch_bounds__(kMapBlock) void map_corr_kernel(const MapDev* __res
       for (int k = 0; k < 5; ++k) r.ind[k] = -1;
       r.sq5 = INFINITY;
     }
-    recs[pd.off_rec + q] = r;
+    if (sub == 0) recs[pd.off_rec + q] = r;
   }
   // 28 sums: wave butterfly, then the four waves in order
   __shared__ double wsum[kMapBlock / 64][28];
 #pragma unroll
   for (int k = 0; k < 28; ++k) {
     double x = v[k];
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 32; o >= kMapLanes; o >>= 1) {  // (only lane 0 of a query carries a row)
       const int lo = __shfl_xor(__double2loint(x), o), hi = __shfl_xor(__double2hiint(x), o);
       x += __hiloint2double(hi, lo);
     }
@@ -155,6 +180,6 @@ void launch_map_corr(hipStream_t stream, int n_problems, int blocks_per_problem,
 }
 size_t map_dev_size() { return sizeof(MapDev); }
 size_t map_round_size() { return sizeof(MapRound); }
-int map_block() { return kMapBlock; }
+int map_block() { return kMapQPerBlock; }  // queries per block
 
 }  // namespace lins
