@@ -47,8 +47,8 @@ void launch_frontend(hipStream_t, int, const void*, const float4*, const float*,
                      double, float4*, float*, int*, float4*, int*);
 void launch_reproject_in_place(hipStream_t, int, int, const void*, const double*, float4*, double);
 size_t stream_cloud_size();
-void launch_segment(hipStream_t, int, const void*, const float4*, float, float, float, float, float, int*, float4*, float*,
-                    int*, int*, void*, float4*, float*, unsigned*, unsigned char*, int*);
+void launch_segment(hipStream_t, int, const void*, const float4*, float, float, float, float, float, unsigned long long*, int*, void*, float4*,
+                    float*, unsigned*, unsigned char*, int*);
 size_t sg_raw_size();
 struct SgRawHost {
   long long off;
@@ -127,10 +127,10 @@ struct lins_ctx {
     // image_projection stage (lins_segment_batch / the raw-cloud streams path): raw points + per-cell scratch
     int sg_cap = 0;
     size_t raw_cap = 0, h_raw_cap = 0;
-    float4 *d_raw = nullptr, *d_full = nullptr, *h_raw = nullptr;
+    float4 *d_raw = nullptr, *h_raw = nullptr;
     void* d_raws = nullptr;
-    float* d_rangemat = nullptr;
-    int *d_cellidx = nullptr, *d_segcount = nullptr, *d_segrows = nullptr, *d_outliers = nullptr;
+    unsigned long long* d_cellidx = nullptr;
+    int *d_segrows = nullptr, *d_outliers = nullptr;
     float sg_ms = 0.f;
   } fe;
   // device-resident streams (lins_streams_step): per stream two feature slots (this scan's / the last
@@ -249,7 +249,7 @@ void fe_free(lins_ctx* ctx) {
   auto& f = ctx->fe;
   void* ptrs[] = {f.d_scans, f.d_cloud, f.d_und, f.d_out, f.d_range, f.d_diff, f.d_col, f.d_ground, f.d_picks, f.d_counts};
   for (void* p : ptrs) (void)hipFree(p);
-  void* sg[] = {f.d_raw, f.d_full, f.d_raws, f.d_rangemat, f.d_cellidx, f.d_segcount, f.d_segrows, f.d_outliers};
+  void* sg[] = {f.d_raw, f.d_raws, f.d_cellidx, f.d_segrows, f.d_outliers};
   for (void* p : sg) (void)hipFree(p);
   (void)hipHostFree(f.h_raw);
   (void)hipHostFree(f.h_cloud), (void)hipHostFree(f.h_range), (void)hipHostFree(f.h_col), (void)hipHostFree(f.h_ground);
@@ -701,16 +701,12 @@ static int sg_run(lins_ctx* ctx, int n, const lins_point* const* raw, const int3
   if (rc) return rc;
   auto& f = ctx->fe;
   if (f.sg_cap < n) {
-    void* old[] = {f.d_full, f.d_raws, f.d_rangemat, f.d_cellidx, f.d_segcount, f.d_segrows, f.d_outliers};
+    void* old[] = {f.d_raws, f.d_cellidx, f.d_segrows, f.d_outliers};
     for (void* p : old) (void)hipFree(p);
-    f.d_full = nullptr, f.d_raws = nullptr, f.d_rangemat = nullptr, f.d_cellidx = nullptr, f.d_segcount = nullptr;
-    f.d_segrows = nullptr, f.d_outliers = nullptr, f.sg_cap = 0;
+    f.d_raws = nullptr, f.d_cellidx = nullptr, f.d_segrows = nullptr, f.d_outliers = nullptr, f.sg_cap = 0;
     const size_t c = (size_t)n;
     HIP_TRY(ctx, hipMalloc(&f.d_raws, c * sizeof(SgRawHost)));
-    HIP_TRY(ctx, hipMalloc((void**)&f.d_full, c * N * sizeof(float4)));
-    HIP_TRY(ctx, hipMalloc((void**)&f.d_rangemat, c * N * sizeof(float)));
-    HIP_TRY(ctx, hipMalloc((void**)&f.d_cellidx, c * N * sizeof(int)));
-    HIP_TRY(ctx, hipMalloc((void**)&f.d_segcount, c * N * sizeof(int)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_cellidx, c * N * sizeof(unsigned long long)));
     HIP_TRY(ctx, hipMalloc((void**)&f.d_segrows, c * N * sizeof(int)));
     HIP_TRY(ctx, hipMalloc((void**)&f.d_outliers, c * sizeof(int)));
     f.sg_cap = n;
@@ -748,8 +744,7 @@ static int sg_run(lins_ctx* ctx, int n, const lins_point* const* raw, const int3
   const float ax = (float)(0.2f / 180.0 * M_PI), ay = (float)(2.0f / 180.0 * M_PI);
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   launch_segment(ctx->stream, n, f.d_raws, f.d_raw, std::sin(ax), std::cos(ax), std::sin(ay), std::cos(ay), 1.0472f,
-                 f.d_cellidx, f.d_full, f.d_rangemat, f.d_segcount, f.d_segrows, f.d_scans, f.d_cloud, f.d_range, f.d_col,
-                 f.d_ground, f.d_outliers);
+                 f.d_cellidx, f.d_segrows, f.d_scans, f.d_cloud, f.d_range, f.d_col, f.d_ground, f.d_outliers);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
   return LINS_OK;

@@ -49,15 +49,21 @@ struct SgConsts {
 };
 
 struct SgLds {
-  signed char ground[kSgCells];    // groundMat: 0, 1, -1
-  unsigned char edges[kSgCells];   // bit 0 right, bit 1 "+255", bit 2 down; bit 7 eligible (labelMat == 0 at the start)
-  unsigned short label[kSgCells];  // smallest raster index that reaches the cell (0xFFFF: not eligible)
+  unsigned char flags[kSgCells];  // bit 0 right, bit 1 "+255", bit 2 down edge; bit 3 groundMat == 1; bit 7 eligible (labelMat == 0)
+  union {
+    float range[kSgCells];  // rangeMat — until the adjacency is built
+    struct {
+      unsigned short label[kSgCells];  // smallest raster index that reaches the cell (0xFFFF: not eligible)
+      unsigned cnt2[kSgCells / 2];     // cells per label, two u16 counters per word (a count never exceeds 28 800)
+    } seg;                             // — afterwards
+    unsigned short emitted[kSgCells];  // the emitted cells in output order — once validity is decided
+  } u;
   int changed;
   int scan_tmp[20];
   int ring_count[kSgRows + 1];
   int n_outlier;
 };
-static_assert(sizeof(SgLds) <= 160 * 1024, "LDS budget");
+static_assert(sizeof(SgLds) <= 160 * 1024 && kSgCells % 2 == 0, "LDS budget");
 __shared__ SgLds g_sg;
 
 __device__ __forceinline__ int sg_block_scan(int v, int tid, int* tmp) {  // exclusive; total in tmp[18]
@@ -80,37 +86,40 @@ __device__ __forceinline__ int sg_block_scan(int v, int tid, int* tmp) {  // exc
   return off + incl - v;
 }
 
+// The range image lives in LDS (rangeMat first, the labels and their counters in the same bytes once the
+// adjacency is built); the only per-scan global scratch is the cell -> point index (the projection's atomicMax
+// target) and the row masks of the small segments.  fullCloud is never materialised: a cell's point is read
+// back through its index where the reference reads fullCloud (ground removal, emission).
 __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restrict__ raws, const float4* __restrict__ raw,
-                                                           SgConsts k, int* __restrict__ cellidx, float4* __restrict__ full,
-                                                           float* __restrict__ rangeMat, int* __restrict__ seg_count,
-                                                           int* __restrict__ seg_rows, unsigned char* __restrict__ fe_scans,
-                                                           float4* __restrict__ out_cloud, float* __restrict__ out_range,
-                                                           unsigned* __restrict__ out_col, unsigned char* __restrict__ out_ground,
-                                                           int* __restrict__ out_outliers) {
+                                                           SgConsts k, unsigned long long* __restrict__ cellidx, int* __restrict__ seg_rows,
+                                                           unsigned char* __restrict__ fe_scans, float4* __restrict__ out_cloud,
+                                                           float* __restrict__ out_range, unsigned* __restrict__ out_col,
+                                                           unsigned char* __restrict__ out_ground, int* __restrict__ out_outliers) {
   SgLds& L = g_sg;
 #ifdef LINS_SG_PROF
   long long sg_t0 = clock64();
   int sg_sweeps = 0;
+  long long sg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SG_MARK(id) \
+  { long long t_ = clock64(); sg_t[id] = t_ - sg_t0; sg_t0 = t_; }
+#else
+#define SG_MARK(id)
 #endif
   const int tid = threadIdx.x, scan = blockIdx.x;
   const SgRaw rw = raws[scan];
   const float4* pts = raw + rw.off;
   const int n = rw.n;
-  int* ci = cellidx + (size_t)scan * kSgCells;
-  float4* fl = full + (size_t)scan * kSgCells;
-  float* rm = rangeMat + (size_t)scan * kSgCells;
-  int* cnt = seg_count + (size_t)scan * kSgCells;
+  // per cell: (1 + index of the point that owns it) << 32 | its range bits; 0 = no return
+  unsigned long long* ci = cellidx + (size_t)scan * kSgCells;
   int* rws = seg_rows + (size_t)scan * kSgCells;
   FeScanOut* fo = reinterpret_cast<FeScanOut*>(fe_scans + (size_t)scan * kFeScanStride);
   const double kPi = 3.14159265358979323846;
 
-  for (int c = tid; c < kSgCells; c += kSgBlock) ci[c] = -1, cnt[c] = 0, rws[c] = 0;
+  for (int c = tid; c < kSgCells; c += kSgBlock) ci[c] = 0ull, rws[c] = 0, L.flags[c] = 0;
   if (tid == 0) L.n_outlier = 0;
   __syncthreads();
+  SG_MARK(0)
 
-#ifdef LINS_SG_PROF
-  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("SG %d %lld\n", 0, t_ - sg_t0); sg_t0 = t_; }
-#endif
   // ---- projectPointCloud (IP:205-241): the LAST point that falls into a cell owns it -------------
 #pragma unroll 4
   for (int i = tid; i < n; i += kSgBlock) {
@@ -123,57 +132,49 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
     int colm = (int)(-round(((double)horizon - 90.0) / (double)0.2f) + kSgCols / 2);
     if (colm >= kSgCols) colm -= kSgCols;
     if (colm < 0 || colm >= kSgCols) continue;
-    atomicMax(&ci[colm + row * kSgCols], i);
+    const float range = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
+    atomicMax(&ci[colm + row * kSgCols], ((unsigned long long)(unsigned)(i + 1) << 32) | __float_as_uint(range));
   }
   __threadfence_block();
   __syncthreads();
-#pragma unroll 4
+  // rangeMat (FLT_MAX: no return) into LDS
+#pragma unroll 8
   for (int c = tid; c < kSgCells; c += kSgBlock) {
-    const int i = ci[c];
-    float4 p = make_float4(NAN, NAN, NAN, -1.f);
-    float r = FLT_MAX;
-    if (i >= 0) {
-      p = pts[i];
-      r = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
-      const int row = c / kSgCols, colm = c - row * kSgCols;
-      p.w = (float)((double)(float)row + (double)(float)colm / 10000.0);
-    }
-    fl[c] = p, rm[c] = r;
+    const unsigned long long key = ci[c];
+    L.u.range[c] = (key >> 32) ? __uint_as_float((unsigned)key) : FLT_MAX;
   }
-  __threadfence_block();
   __syncthreads();
+  SG_MARK(1)
 
-#ifdef LINS_SG_PROF
-  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("SG %d %lld\n", 1, t_ - sg_t0); sg_t0 = t_; }
-#endif
   // ---- groundRemoval (IP:243-278): one thread per column, rows bottom-up (a row is rewritten by the next) ----
-  for (int c = tid; c < kSgCells; c += kSgBlock) L.ground[c] = 0;
-  __syncthreads();
-  for (int j = tid; j < kSgCols; j += kSgBlock)
+  for (int j = tid; j < kSgCols; j += kSgBlock) {
+    int gi[kSgGroundScanInd + 1];
+#pragma unroll
+    for (int i = 0; i <= kSgGroundScanInd; ++i) gi[i] = (int)(ci[j + i * kSgCols] >> 32) - 1;
+    float4 gp[kSgGroundScanInd + 1];
+#pragma unroll
+    for (int i = 0; i <= kSgGroundScanInd; ++i) gp[i] = pts[gi[i] >= 0 ? gi[i] : 0];
+    int g[kSgGroundScanInd + 1];
+#pragma unroll
+    for (int i = 0; i <= kSgGroundScanInd; ++i) g[i] = 0;
+#pragma unroll
     for (int i = 0; i < kSgGroundScanInd; ++i) {
-      const int lo = j + i * kSgCols, up = j + (i + 1) * kSgCols;
-      const float4 a = fl[lo], b = fl[up];
-      if (a.w == -1.f || b.w == -1.f) {
-        L.ground[lo] = -1;
+      if (gi[i] < 0 || gi[i + 1] < 0) {  // fullCloud intensity -1: no point in one of the two cells
+        g[i] = -1;
         continue;
       }
-      const float dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;
+      const float dx = gp[i + 1].x - gp[i].x, dy = gp[i + 1].y - gp[i].y, dz = gp[i + 1].z - gp[i].z;
       const float angle = (float)((double)(lins_atan2f(dz, sqrtf(dx * dx + dy * dy)) * 180) / kPi);
-      if (fabsf(angle - 0.0f) <= 10) L.ground[lo] = 1, L.ground[up] = 1;
+      if (fabsf(angle - 0.0f) <= 10) g[i] = 1, g[i + 1] = 1;
     }
-  __syncthreads();
-
-#ifdef LINS_SG_PROF
-  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("SG %d %lld\n", 2, t_ - sg_t0); sg_t0 = t_; }
-#endif
-  // ---- adjacency of labelComponents (IP:336-415) as three edge bits per eligible cell ------------------
-#pragma unroll 4
-  for (int c = tid; c < kSgCells; c += kSgBlock) {
-    const bool elig = !(L.ground[c] == 1 || rm[c] == FLT_MAX);
-    L.edges[c] = elig ? 0x80 : 0;
-    L.label[c] = elig ? (unsigned short)c : (unsigned short)0xFFFF;
+#pragma unroll
+    for (int i = 0; i <= kSgGroundScanInd; ++i)
+      if (g[i] == 1) L.flags[j + i * kSgCols] = 8;
   }
   __syncthreads();
+  SG_MARK(2)
+
+  // ---- adjacency of labelComponents (IP:336-415) as three edge bits per eligible cell ------------------
   auto target = [&](int c, int dir) {  // dir 0: (0, +1)   1: (0, +255)   2: (+1, 0);  -1 if outside
     const int r = c / kSgCols, col = c - r * kSgCols;
     if (dir == 2) return r + 1 < kSgRows ? c + kSgCols : -1;
@@ -181,28 +182,33 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
     if (tc >= kSgCols) tc = 0;
     return r * kSgCols + tc;
   };
-#pragma unroll 4
+  // eligible = labelMat 0 at the start: not ground, has a return (bit 3 is final here, the range image too)
+  auto eligible = [&](int c) { return !((L.flags[c] & 8) || L.u.range[c] == FLT_MAX); };
+#pragma unroll 2
   for (int c = tid; c < kSgCells; c += kSgBlock) {
-    if (!(L.edges[c] & 0x80)) continue;
+    if (!eligible(c)) continue;
     unsigned char e = 0x80;
-    const float rc = rm[c];
+    const float rc = L.u.range[c];
+#pragma unroll
     for (int dir = 0; dir < 3; ++dir) {
       const int t = target(c, dir);
-      if (t < 0 || !(L.edges[t] & 0x80)) continue;
-      const float rt = rm[t];
+      if (t < 0 || !eligible(t)) continue;
+      const float rt = L.u.range[t];
       const float d1 = fmaxf(rc, rt), d2 = fminf(rc, rt);
       const float sa = dir == 2 ? k.sin_ay : k.sin_ax, ca = dir == 2 ? k.cos_ay : k.cos_ax;
       const float angle = lins_atan2f(d2 * sa, d1 - d2 * ca);
       if (angle > k.theta) e |= (unsigned char)(1 << dir);
     }
-    L.edges[c] = e;  // (only this thread writes the low bits of its cells; bit 7 is read by others and unchanged)
+    L.flags[c] = e;  // (an eligible cell has bit 3 clear; others read only bit 3 of this byte, which stays 0)
   }
+  __syncthreads();  // the range image is dead from here: its bytes become the labels and their counters
+  for (int c = tid; c < kSgCells; c += kSgBlock) L.u.seg.label[c] = (L.flags[c] & 0x80) ? (unsigned short)c : (unsigned short)0xFFFF;
+  for (int w = tid; w < kSgCells / 2; w += kSgBlock) L.u.seg.cnt2[w] = 0;
   __syncthreads();
+  SG_MARK(3)
 
-#ifdef LINS_SG_PROF
-  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("SG %d %lld\n", 3, t_ - sg_t0); sg_t0 = t_; }
-#endif
   // ---- min-label propagation: pull over the in-edges, own run of cells in raster order, until stable ----
+  unsigned short* label = L.u.seg.label;
   constexpr int kRun = (kSgCells + kSgBlock - 1) / kSgBlock;  // 29 cells per thread
   const int c_lo = tid * kRun < kSgCells ? tid * kRun : kSgCells;
   const int c_hi = c_lo + kRun < kSgCells ? c_lo + kRun : kSgCells;
@@ -213,25 +219,25 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
     {  // column 0 of ring r collects the "+255" edges of every column whose col + 255 passes 1800: one wave per ring
       const int r = tid >> 6, lane = tid & 63;
       const int c0 = r * kSgCols;
-      if (r < kSgRows && (L.edges[c0] & 0x80)) {
+      if (r < kSgRows && (L.flags[c0] & 0x80)) {
         unsigned best = 0xFFFFu;
         for (int cc = kSgCols - 255 + lane; cc < kSgCols; cc += 64)
-          if (L.edges[c0 + cc] & 2) best = min(best, (unsigned)L.label[c0 + cc]);
+          if (L.flags[c0 + cc] & 2) best = min(best, (unsigned)label[c0 + cc]);
         for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
-        if (lane == 0 && best < L.label[c0]) L.label[c0] = (unsigned short)best, ch = true;
+        if (lane == 0 && best < label[c0]) label[c0] = (unsigned short)best, ch = true;
       }
     }
     __syncthreads();
     for (int c = c_lo; c < c_hi; ++c) {
-      if (!(L.edges[c] & 0x80)) continue;
+      if (!(L.flags[c] & 0x80)) continue;
       const int r = c / kSgCols, col = c - r * kSgCols;
-      unsigned short best = L.label[c];
+      unsigned short best = label[c];
       // in-edges: (r, col - 1) right [col 0: (r, 1799)], (r, col - 255) "+255" [col >= 255], (r - 1, col) down
       const int pl = col ? c - 1 : c + kSgCols - 1;
-      if (L.edges[pl] & 1) best = min(best, L.label[pl]);
-      if (col >= 255 && (L.edges[c - 255] & 2)) best = min(best, L.label[c - 255]);
-      if (r > 0 && (L.edges[c - kSgCols] & 4)) best = min(best, L.label[c - kSgCols]);
-      if (best != L.label[c]) L.label[c] = best, ch = true;
+      if (L.flags[pl] & 1) best = min(best, label[pl]);
+      if (col >= 255 && (L.flags[c - 255] & 2)) best = min(best, label[c - 255]);
+      if (r > 0 && (L.flags[c - kSgCols] & 4)) best = min(best, label[c - kSgCols]);
+      if (best != label[c]) label[c] = best, ch = true;
     }
     if (ch) L.changed = 1;
     __syncthreads();
@@ -241,69 +247,68 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
     if (!L.changed) break;
     __syncthreads();
   }
+  SG_MARK(4)
 
-#ifdef LINS_SG_PROF
-  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("SG %d %lld\n", 4, t_ - sg_t0); sg_t0 = t_; }
-#endif
   // ---- segment validity (IP:398-406): size, and rows of the cells that were pushed as neighbours -------
-#pragma unroll 4
-  for (int c = tid; c < kSgCells; c += kSgBlock) {
-    if (!(L.edges[c] & 0x80)) continue;
-    const int s = L.label[c];
-    atomicAdd(&cnt[s], 1);
-    if (c != s) atomicOr(&rws[s], 1 << (c / kSgCols));
-  }
+  auto count_of = [&](int s) { return (int)((L.u.seg.cnt2[s >> 1] >> ((s & 1) * 16)) & 0xFFFFu); };
+  for (int c = tid; c < kSgCells; c += kSgBlock)
+    if (L.flags[c] & 0x80) {
+      const int s = label[c];
+      atomicAdd(&L.u.seg.cnt2[s >> 1], 1u << ((s & 1) * 16));
+    }
+  __syncthreads();
+  // the row test only decides segments of 5 .. 29 cells: only those touch the global row masks
+  for (int c = tid; c < kSgCells; c += kSgBlock)
+    if (L.flags[c] & 0x80) {
+      const int s = label[c];
+      if (c != s) {
+        const int np = count_of(s);
+        if (np >= 5 && np < 30) atomicOr(&rws[s], 1 << (c / kSgCols));
+      }
+    }
   __threadfence_block();
   __syncthreads();
+  SG_MARK(5)
 
-#ifdef LINS_SG_PROF
-  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("SG %d %lld\n", 5, t_ - sg_t0); sg_t0 = t_; }
-#endif
   // ---- cloudSegmentation emission (IP:292-321): ring-major, ascending column -----------------------------
-  auto decide = [&](int c, bool& is_ground) {  // emitted? (also counts the outliers of invalid segments)
-    const int i = c / kSgCols, j = c - i * kSgCols;
-    is_ground = false;
-    if (L.edges[c] & 0x80) {
-      const int s = L.label[c], np = cnt[s];
-      const bool feasible = np >= 30 || (np >= 5 && __popc(rws[s]) >= 3);
-      if (!feasible) {
-        if (i > kSgGroundScanInd && j % 5 == 0) atomicAdd(&L.n_outlier, 1);
-        return false;
-      }
-      return true;
-    }
-    if (L.ground[c] == 1) {
-      is_ground = true;
-      return !(j % 5 != 0 && j > 5 && j < kSgCols - 5);
-    }
-    return false;
+  auto feasible = [&](int c) {
+    const int s = label[c], np = count_of(s);
+    return np >= 30 || (np >= 5 && __popc(rws[s]) >= 3);
   };
   int mine = 0;
+  unsigned emit_mask = 0;  // bit k: cell c_lo + k is emitted (kRun <= 32)
+  static_assert(kRun <= 32, "emit mask");
   for (int c = c_lo; c < c_hi; ++c) {
-    bool g;
-    mine += decide(c, g) ? 1 : 0;
+    const int i = c / kSgCols, j = c - i * kSgCols;
+    bool emit = false;
+    if (L.flags[c] & 0x80) {
+      emit = feasible(c);
+      if (!emit && i > kSgGroundScanInd && j % 5 == 0) atomicAdd(&L.n_outlier, 1);
+    } else if (L.flags[c] & 8) {
+      emit = !(j % 5 != 0 && j > 5 && j < kSgCols - 5);
+    }
+    if (emit) ++mine, emit_mask |= 1u << (c - c_lo);
   }
-  // (decide() counted outliers once here; the second pass below must not count again)
   const int base = sg_block_scan(mine, tid, L.scan_tmp);
   const int total = L.scan_tmp[18];
   const size_t ob = (size_t)fo->off;
+  // (sg_block_scan's barriers: every thread is done with the labels and counters — their bytes take the list)
   int pos = base;
   for (int c = c_lo; c < c_hi; ++c) {
+    if (c % kSgCols == 0) L.ring_count[c / kSgCols] = pos;  // points emitted before ring i
+    if (emit_mask & (1u << (c - c_lo))) L.u.emitted[pos++] = (unsigned short)c;
+  }
+  __syncthreads();
+  // the output, one thread per emitted point: coalesced stores, independent gathers
+#pragma unroll 4
+  for (int o = tid; o < total; o += kSgBlock) {
+    const int c = L.u.emitted[o];
     const int i = c / kSgCols, j = c - i * kSgCols;
-    if (j == 0) L.ring_count[i] = pos;  // points emitted before ring i
-    bool emit = false, is_ground = false;
-    if (L.edges[c] & 0x80) {
-      const int s = L.label[c], np = cnt[s];
-      emit = np >= 30 || (np >= 5 && __popc(rws[s]) >= 3);
-    } else if (L.ground[c] == 1) {
-      is_ground = true;
-      emit = !(j % 5 != 0 && j > 5 && j < kSgCols - 5);
-    }
-    if (emit) {
-      out_cloud[ob + pos] = fl[c], out_range[ob + pos] = rm[c], out_col[ob + pos] = (unsigned)j;
-      out_ground[ob + pos] = is_ground ? 1 : 0;
-      ++pos;
-    }
+    const unsigned long long key = ci[c];
+    float4 p = pts[(int)(key >> 32) - 1];
+    p.w = (float)((double)(float)i + (double)(float)j / 10000.0);  // fullCloud intensity (IP:234)
+    out_cloud[ob + o] = p, out_range[ob + o] = __uint_as_float((unsigned)key), out_col[ob + o] = (unsigned)j;
+    out_ground[ob + o] = (L.flags[c] & 8) ? 1 : 0;
   }
   if (tid == 0) L.ring_count[kSgRows] = total;
   __syncthreads();
@@ -312,7 +317,10 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
     fo->end_ring[tid] = L.ring_count[tid + 1] - 1 - 5;
   }
 #ifdef LINS_SG_PROF
-  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("SG %d %lld sweeps %d\n", 6, t_ - sg_t0, sg_sweeps); }
+  SG_MARK(6)
+  if (tid == 0 && (scan & 255) == 0)
+    printf("SG scan %d: init %lld project+range %lld ground %lld adjacency %lld labels %lld (%d sweeps) validity %lld emission %lld\n", scan,
+           sg_t[0], sg_t[1], sg_t[2], sg_t[3], sg_t[4], sg_sweeps, sg_t[5], sg_t[6]);
 #endif
   if (tid == 0) {
     fo->n = total;
@@ -329,13 +337,11 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
 }
 
 void launch_segment(hipStream_t stream, int n_scans, const void* raws, const float4* raw, float sin_ax, float cos_ax,
-                    float sin_ay, float cos_ay, float theta, int* cellidx, float4* full, float* rangeMat, int* seg_count,
-                    int* seg_rows, void* fe_scans, float4* out_cloud, float* out_range, unsigned* out_col,
-                    unsigned char* out_ground, int* out_outliers) {
+                    float sin_ay, float cos_ay, float theta, unsigned long long* cellidx, int* seg_rows, void* fe_scans, float4* out_cloud,
+                    float* out_range, unsigned* out_col, unsigned char* out_ground, int* out_outliers) {
   SgConsts k{sin_ax, cos_ax, sin_ay, cos_ay, theta};
-  hipLaunchKernelGGL(segment_kernel, dim3(n_scans), dim3(kSgBlock), 0, stream, (const SgRaw*)raws, raw, k, cellidx, full,
-                     rangeMat, seg_count, seg_rows, (unsigned char*)fe_scans, out_cloud, out_range, out_col, out_ground,
-                     out_outliers);
+  hipLaunchKernelGGL(segment_kernel, dim3(n_scans), dim3(kSgBlock), 0, stream, (const SgRaw*)raws, raw, k, cellidx, seg_rows,
+                     (unsigned char*)fe_scans, out_cloud, out_range, out_col, out_ground, out_outliers);
 }
 size_t sg_raw_size() { return sizeof(SgRaw); }
 
