@@ -71,8 +71,19 @@ __device__ __forceinline__ float fe_ordered_float(int i) { return __int_as_float
 // compare-exchanges whose partner lies inside the lane's own block are register selects, the others
 // one wave shuffle per key (both lanes of a pair evaluate it and keep the min or the max) — no LDS
 // round trips, no fences.  Fully unrolled: every register index is a compile-time constant.
-template <int P>
-__device__ __forceinline__ void wave_bitonic_sort(unsigned long long (&v)[P], int lane) {
+template <int N>
+struct FeInt {
+  static constexpr int value = N;
+};
+
+__device__ __forceinline__ unsigned long long fe_shfl_xor(unsigned long long v, int m) {
+  const unsigned lo = __shfl_xor((unsigned)v, m), hi = __shfl_xor((unsigned)(v >> 32), m);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned fe_shfl_xor(unsigned v, int m) { return __shfl_xor(v, m); }
+
+template <int P, class K>
+__device__ __forceinline__ void wave_bitonic_sort(K (&v)[P], int lane) {
 #pragma unroll
   for (int k2 = 2; k2 <= 64 * P; k2 <<= 1) {
 #pragma unroll
@@ -82,7 +93,7 @@ __device__ __forceinline__ void wave_bitonic_sort(unsigned long long (&v)[P], in
         for (int u = 0; u < P; ++u)
           if ((u & j2) == 0) {
             const bool up = ((lane * P + u) & k2) == 0;
-            const unsigned long long a = v[u], b = v[u | j2];
+            const K a = v[u], b = v[u | j2];
             const bool sw = (a > b) == up;
             v[u] = sw ? b : a, v[u | j2] = sw ? a : b;
           }
@@ -92,8 +103,7 @@ __device__ __forceinline__ void wave_bitonic_sort(unsigned long long (&v)[P], in
 #pragma unroll
         for (int u = 0; u < P; ++u) {
           const bool up = ((lane * P + u) & k2) == 0;
-          const unsigned lo = __shfl_xor((unsigned)v[u], lm), hi = __shfl_xor((unsigned)(v[u] >> 32), lm);
-          const unsigned long long w = ((unsigned long long)hi << 32) | lo;
+          const K w = fe_shfl_xor(v[u], lm);
           const bool keep_min = lower == up;
           v[u] = keep_min ? (w < v[u] ? w : v[u]) : (w > v[u] ? w : v[u]);
         }
@@ -109,7 +119,11 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     int* __restrict__ out_counts) {
   FeLds& L = g_fe;
 #ifdef LINS_FE_PROF
-  long long fe_t0 = clock64();
+  long long fe_t0 = clock64(), fe_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define FE_MARK(id) \
+  { long long t_ = clock64(); fe_t[id] = t_ - fe_t0; fe_t0 = t_; }
+#else
+#define FE_MARK(id)
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int scan = blockIdx.x;
@@ -131,9 +145,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   }
   __syncthreads();
 
-#ifdef LINS_FE_PROF
-  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("FE %d %lld\n", 0, t_ - fe_t0); fe_t0 = t_; }
-#endif
+  FE_MARK(0)
   // ---- undistortPcl, pass 1: where does halfPassed flip?  (SE:631-638: first-half adjustment) ----
   const double s_ori = (double)sc.start_ori, e_ori = (double)sc.end_ori;
   {
@@ -152,9 +164,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   }
   __syncthreads();
   const int flip = L.first_half_end;
-#ifdef LINS_FE_PROF
-  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("FE %d %lld\n", 1, t_ - fe_t0); fe_t0 = t_; }
-#endif
+  FE_MARK(1)
   // ---- pass 2: relative time tag; smoothness stencil; masks -------------------------------------
   for (int i = tid; i < n; i += kFeBlock) {
     float4 p = pts[i];
@@ -200,9 +210,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   }
   __syncthreads();
 
-#ifdef LINS_FE_PROF
-  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("FE %d %lld\n", 2, t_ - fe_t0); fe_t0 = t_; }
-#endif
+  FE_MARK(2)
   // ---- extractFeatures: one wave per ring, sectors in order (marks of one sector reach the next) ---
   {
     const int ring = wave;
@@ -220,19 +228,28 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
       // cloudSmoothness[i].ind is i only where the stencil ran, [5, n - 5); elsewhere the value-initialised 0
       auto smooth_ind = [&](int i) { return (i >= 5 && i < n - 5) ? i : 0; };
       bool ground_here = false;  // does any candidate of the plane loop exist at all?
-      {
-        constexpr int kP = kSectorCap / 64;
+      // the sort network is sized to the sector: 64 x kP keys, the smallest that holds [sp, ep] (a VLP-16 sector
+      // of a segmented ring has ~150 points: two or four keys per lane instead of eight)
+      auto sort_sector = [&](auto tag) {
+        constexpr int kP = decltype(tag)::value;
         unsigned long long kv[kP];
 #pragma unroll
         for (int u = 0; u < kP; ++u) {
           const int e = lane * kP + u;
           kv[u] = e < m ? ((unsigned long long)__float_as_uint(fabsf(df[sp + e])) << 32) | (unsigned)smooth_ind(sp + e) : ~0ull;
-          ground_here = ground_here || (e <= m && (L.a.flags[smooth_ind(sp + e)] & 8));
+          ground_here = ground_here || (e <= m && (g_fe.a.flags[smooth_ind(sp + e)] & 8));
         }
-        wave_bitonic_sort<kP>(kv, lane);  // ascending
+        wave_bitonic_sort<kP, unsigned long long>(kv, lane);  // ascending
 #pragma unroll
         for (int u = 0; u < kP; ++u) key[lane * kP + u] = kv[u];
-      }
+      };
+      static_assert(kSectorCap == 512, "sort sizes below");
+      if (m < 128)
+        sort_sector(FeInt<2>{});
+      else if (m < 256)
+        sort_sector(FeInt<4>{});
+      else
+        sort_sector(FeInt<8>{});
       const bool any_ground = __any(ground_here);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -350,9 +367,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   __threadfence_block();
   __syncthreads();
 
-#ifdef LINS_FE_PROF
-  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("FE %d %lld\n", 3, t_ - fe_t0); fe_t0 = t_; }
-#endif
+  FE_MARK(3)
   auto label_le0 = [&](int k) {  // cloudLabel <= 0: untouched (0) or flat (-1)
     const int b = (L.a.flags[k] >> 1) & 3;
     return b == 0 || b == 3;
@@ -390,9 +405,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     __syncthreads();
   }
 
-#ifdef LINS_FE_PROF
-  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("FE %d %lld\n", 4, t_ - fe_t0); fe_t0 = t_; }
-#endif
+  FE_MARK(4)
   // ---- less-flat cloud: per ring, every point of its sectors with label <= 0 (SE:815-820) ... -----
   // D0, one wave per ring: compact the kept points and take the bounding box VoxelGrid needs.
   float4* olf = out + sc.o_less_flat;
@@ -437,9 +450,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     if (tid == 0) out_counts[scan * 4 + 3] = -1;
     return;
   }
-#ifdef LINS_FE_PROF
-  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("FE %d %lld\n", 5, t_ - fe_t0); fe_t0 = t_; }
-#endif
+  FE_MARK(5)
   // D1, pcl::VoxelGrid 0.2 m with all-field averaging, output ordered by voxel index (SE:189, 822-825):
   // one wave per ring; 2048 keys (voxel index << 11 | order) sorted in registers, then only the order
   // and a run-start bit per sorted position go to LDS (the flags / columns / sector buffers are dead).
@@ -458,63 +469,82 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           maxb[a] = (int)floorf(fe_ordered_float(L.ring_bb[ring][3 + a]) * inv);
         }
         const long long dx = maxb[0] - minb[0] + 1, dy = maxb[1] - minb[1] + 1;
-        int mine = 0;
-        {
-          constexpr int kP = kRingCap / 64;
-          unsigned long long kv[kP];
+        // the sort network and the centroid loop are sized to the ring: 64 x kP positions, position e on lane e / kP
+        auto voxel_grid = [&](auto tag, auto key_zero) {
+          constexpr int kP = decltype(tag)::value;
+          using K = decltype(key_zero);  // 32-bit keys when (voxel index << 11 | order) fits: half the shuffles and compares
+          int mine = 0;
+          {
+            K kv[kP];
 #pragma unroll
-          for (int u = 0; u < kP; ++u) {
-            const int e = lane * kP + u;
-            unsigned long long k = ~0ull;
-            if (e < m) {
-              const float4 p = lfp[base + e];
-              const long long ix = (long long)floorf(p.x * inv) - minb[0];
-              const long long iy = (long long)floorf(p.y * inv) - minb[1];
-              const long long iz = (long long)floorf(p.z * inv) - minb[2];
-              k = ((unsigned long long)(ix + iy * dx + iz * dx * dy) << 11) | (unsigned)e;
+            for (int u = 0; u < kP; ++u) {
+              const int e = lane * kP + u;
+              K k = (K)~key_zero;
+              if (e < m) {
+                const float4 p = lfp[base + e];
+                const long long ix = (long long)floorf(p.x * inv) - minb[0];
+                const long long iy = (long long)floorf(p.y * inv) - minb[1];
+                const long long iz = (long long)floorf(p.z * inv) - minb[2];
+                k = (K)(((unsigned long long)(ix + iy * dx + iz * dx * dy) << 11) | (unsigned)e);
+              }
+              kv[u] = k;
             }
-            kv[u] = k;
-          }
-          wave_bitonic_sort<kP>(kv, lane);
-          // run starts: the voxel index differs from the predecessor's (the previous lane's last key for u = 0)
-          const unsigned plo = __shfl_up((unsigned)kv[kP - 1], 1), phi = __shfl_up((unsigned)(kv[kP - 1] >> 32), 1);
-          unsigned long long prev = ((unsigned long long)phi << 32) | plo;
+            wave_bitonic_sort<kP, K>(kv, lane);
+            // run starts: the voxel index differs from the predecessor's (the previous lane's last key for u = 0)
+            const unsigned plo = __shfl_up((unsigned)kv[kP - 1], 1), phi = __shfl_up((unsigned)((unsigned long long)kv[kP - 1] >> 32), 1);
+            K prev = (K)(((unsigned long long)phi << 32) | plo);
 #pragma unroll
+            for (int u = 0; u < kP; ++u) {
+              const int e = lane * kP + u;
+              const bool start = e < m && (e == 0 || (prev >> 11) != (kv[u] >> 11));
+              vs[e] = (unsigned short)((start ? 0x8000u : 0u) | (unsigned)(kv[u] & 2047u));
+              mine += start ? 1 : 0;
+              prev = kv[u];
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          // one centroid per run start — f32 sums of all four fields in stable (original) order — to the
+          // ring's temporary place in the output array, at the wave prefix of the start counts
+          const int e0 = lane * kP;
+          int incl = mine;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const int nb = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += nb;
+          }
+          nvox = __shfl(incl, 63);
+          int pos = incl - mine;
           for (int u = 0; u < kP; ++u) {
-            const int e = lane * kP + u;
-            const bool start = e < m && (e == 0 || (prev >> 11) != (kv[u] >> 11));
-            vs[e] = (unsigned short)((start ? 0x8000u : 0u) | (unsigned)(kv[u] & 2047u));
-            mine += start ? 1 : 0;
-            prev = kv[u];
+            const int e = e0 + u;
+            if (e >= m || !(vs[e] & 0x8000u)) continue;
+            float sx = 0, sy = 0, sz = 0, si = 0;
+            int j = e;
+            do {
+              const float4 p = lfp[base + (int)(vs[j] & 2047u)];
+              sx += p.x, sy += p.y, sz += p.z, si += p.w;
+              ++j;
+            } while (j < m && !(vs[j] & 0x8000u));
+            const float cnt = (float)(j - e);
+            olf[base + pos++] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
           }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // one centroid per run start — f32 sums of all four fields in stable (original) order — to the
-        // ring's temporary place in the output array, at the wave prefix of the start counts
-        constexpr int kPerLane = kRingCap / 64;
-        const int e0 = lane * kPerLane;
-        int incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-          const int nb = __shfl_up(incl, o, 64);
-          if (lane >= o) incl += nb;
-        }
-        nvox = __shfl(incl, 63);
-        int pos = incl - mine;
-        for (int u = 0; u < kPerLane; ++u) {
-          const int e = e0 + u;
-          if (e >= m || !(vs[e] & 0x8000u)) continue;
-          float sx = 0, sy = 0, sz = 0, si = 0;
-          int j = e;
-          do {
-            const float4 p = lfp[base + (int)(vs[j] & 2047u)];
-            sx += p.x, sy += p.y, sz += p.z, si += p.w;
-            ++j;
-          } while (j < m && !(vs[j] & 0x8000u));
-          const float cnt = (float)(j - e);
-          olf[base + pos++] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+        };
+        static_assert(kRingCap == 2048, "sort sizes below");
+        const long long dz = maxb[2] - minb[2] + 1;
+        const bool narrow = dx * dy * dz < (1ll << 21) - 1;  // every key below the 32-bit padding value
+        if (narrow) {
+          if (m <= 512)
+            voxel_grid(FeInt<8>{}, 0u);
+          else if (m <= 1024)
+            voxel_grid(FeInt<16>{}, 0u);
+          else
+            voxel_grid(FeInt<32>{}, 0u);
+        } else {
+          if (m <= 1024)
+            voxel_grid(FeInt<16>{}, 0ull);
+          else
+            voxel_grid(FeInt<32>{}, 0ull);
         }
       }
       if (lane == 0) L.ring_out[ring] = nvox;
@@ -522,9 +552,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     __threadfence_block();
     __syncthreads();
   }
-#ifdef LINS_FE_PROF
-  if (tid == 0 && scan == 0) { long long t_ = clock64(); printf("FE %d %lld\n", 6, t_ - fe_t0); fe_t0 = t_; }
-#endif
+  FE_MARK(6)
   // D2: close the gaps, ring by ring (a ring's final place never lies behind its temporary one)
   if (tid == 0) {
     int run = 0;
@@ -543,6 +571,12 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
       if (tid + u * kFeBlock < c) olf[dst + tid + u * kFeBlock] = v[u];
     __syncthreads();
   }
+#ifdef LINS_FE_PROF
+  FE_MARK(7)
+  if (tid == 0 && (scan & 255) == 0)
+    printf("FE scan %d: load %lld flip %lld tags+stencil+masks %lld sort+picks %lld labels %lld compact %lld voxel grid %lld gaps %lld\n", scan, fe_t[0],
+           fe_t[1], fe_t[2], fe_t[3], fe_t[4], fe_t[5], fe_t[6], fe_t[7]);
+#endif
 }
 
 void launch_frontend(hipStream_t stream, int n_scans, const void* scans, const float4* cloud, const float* range,
