@@ -42,3 +42,30 @@ def make_problem(defs, seed, n_map_surf=20000, n_map_corner=3000, n_scan_surf=90
     T0 = T_true + np.concatenate([rng.normal(0, perturb[0], 3), rng.normal(0, perturb[1], 3)])
     pad = lambda a: np.concatenate([a, np.zeros((len(a), 1))], 1).astype(np.float32)
     return defs.MapProblem(pad(map_corner), pad(map_surf), pad(sc), pad(ss), T0.astype(np.float32)), T_true
+
+
+def make_corridor(defs, seed, n_map_surf=12000, n_map_corner=1500, n_scan_surf=900, n_scan_corner=200, noise=0.01):
+    """A corridor along x: floor and two side walls, edges along x only — nothing constrains the translation along
+    x, so LMOptimization's eigen-test must flag the problem as degenerate (LM:1589-1614)."""
+    rng = np.random.default_rng(seed)
+    L, W, H = 40.0, 4.0, 3.0
+    n3 = n_map_surf // 3
+    floor = np.stack([rng.uniform(-L / 2, L / 2, n3), rng.uniform(-W / 2, W / 2, n3), np.full(n3, -1.5)], 1)
+    wl = np.stack([rng.uniform(-L / 2, L / 2, n3), np.full(n3, -W / 2), rng.uniform(-1.5, -1.5 + H, n3)], 1)
+    n_r = n_map_surf - 2 * n3
+    wr = np.stack([rng.uniform(-L / 2, L / 2, n_r), np.full(n_r, W / 2), rng.uniform(-1.5, -1.5 + H, n_r)], 1)
+    map_surf = np.concatenate([floor, wl, wr]) + rng.normal(0, noise, (n_map_surf, 3))
+    per = n_map_corner // 4
+    edges = [np.stack([rng.uniform(-L / 2, L / 2, per), np.full(per, y), np.full(per, z)], 1)
+             for y in (-W / 2, W / 2) for z in (-1.5, -1.5 + H)]
+    map_corner = np.concatenate(edges) + rng.normal(0, noise / 2, (4 * per, 3))
+    T_true = np.concatenate([rng.normal(0, 0.02, 3), rng.normal(0, 0.2, 3)])
+    R = rot(*T_true[:3])
+    to_sensor = lambda pm: (pm - T_true[3:]) @ R
+    near = lambda a: a[np.abs(a[:, 0]) < L / 2 - 3]  # keep the scan away from the corridor's open ends
+    ms, mc = near(map_surf), near(map_corner)
+    ss = to_sensor(ms[rng.choice(len(ms), n_scan_surf, replace=False)]) + rng.normal(0, noise, (n_scan_surf, 3))
+    sc = to_sensor(mc[rng.choice(len(mc), n_scan_corner, replace=False)]) + rng.normal(0, noise, (n_scan_corner, 3))
+    T0 = T_true + np.concatenate([rng.normal(0, 0.005, 3), rng.normal(0, 0.03, 3)])
+    pad = lambda a: np.concatenate([a, np.zeros((len(a), 1))], 1).astype(np.float32)
+    return defs.MapProblem(pad(map_corner), pad(map_surf), pad(sc), pad(ss), T0.astype(np.float32)), T_true

@@ -76,3 +76,39 @@ def test_scan2map_batch_matches_the_oracle(oracle, ctx):
     for g, t in zip(got[:6], truths):
         assert np.abs(g["transform"][:3] - t[:3]).max() < 0.005 and np.abs(g["transform"][3:] - t[3:]).max() < 0.03
     assert got[6]["iters"] == 10 and got[7]["iters"] == 0
+
+
+def test_scan2map_flags_a_corridor_as_degenerate_like_the_oracle(oracle, ctx):
+    """LMOptimization's degeneracy projection (LM:1589-1614, eigenvalues below 100 on round 0): a corridor leaves
+    the translation along its axis unobservable — same flag, same rounds, same transform as the oracle."""
+    from map_synth import make_corridor
+    probs = [make_corridor(defs, 50 + k)[0] for k in range(3)]
+    got = ctx.scan2map_batch(probs)
+    for p, g in zip(probs, got):
+        w = oracle.scan2map(p)
+        assert w["degenerate"] == 1
+        assert (g["iters"], g["converged"], g["degenerate"], g["n_sel"]) == (w["iters"], w["converged"], w["degenerate"], w["n_sel"])
+        assert np.abs(g["transform"] - w["transform"]).max() <= 2e-5
+
+
+def test_scan2map_edge_cases(pkg, ieskf, oracle, ctx):
+    """empty batch; a scan without corner points; a scan without any point; a non-finite map point is an input
+    error, not a crash"""
+    assert ctx.scan2map_batch([]) == []
+    prob, _ = make_problem(defs, 61)
+    empty = np.zeros((0, 4), np.float32)
+    no_corner = defs.MapProblem(prob.map_corner, prob.map_surf, empty, prob.scan_surf, prob.transform)
+    no_points = defs.MapProblem(prob.map_corner, prob.map_surf, empty, empty, prob.transform)
+    got = ctx.scan2map_batch([no_corner, no_points])
+    for p, g in zip((no_corner, no_points), got):
+        w = oracle.scan2map(p)
+        assert (g["iters"], g["converged"], g["degenerate"], g["n_sel"]) == (w["iters"], w["converged"], w["degenerate"], w["n_sel"])
+        assert np.abs(g["transform"] - w["transform"]).max() <= 2e-5
+    gc, gs = ctx.map_correspondences(no_corner)
+    assert len(gc) == 0 and len(gs) == len(prob.scan_surf)
+    bad = prob.map_surf.copy()
+    bad[17, 1] = np.nan
+    with pytest.raises(ieskf.LinsError):
+        ctx.scan2map_batch([defs.MapProblem(prob.map_corner, bad, prob.scan_corner, prob.scan_surf, prob.transform)])
+    # the context is still usable afterwards
+    assert ctx.scan2map_batch([prob])[0]["iters"] > 0
