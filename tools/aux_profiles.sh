@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel stats of the rows around the update (ICP fallback, re-projection, feature front-end)
+# rocprofv3 kernel stats of the rows around the update (ICP fallback, re-projection, feature front-end, segmentation, scan-to-map)
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out
@@ -13,7 +13,8 @@ from concurrent.futures import ThreadPoolExecutor
 n = 256
 with ThreadPoolExecutor(16) as ex:
     pairs = list(ex.map(host.synth_pair, range(n)))
-    segs = list(ex.map(lambda i: host.frontend_segment(host.synth_raw_scan(i, 1)), range(n)))
+    raws = list(ex.map(lambda i: host.synth_raw_scan(i, 1), range(n)))
+    segs = list(ex.map(host.frontend_segment, raws))
 rng = np.random.default_rng(0)
 bad = []
 for p in pairs:
@@ -23,6 +24,7 @@ with ieskf.IeskfContext(pkg.default_params(num_iter=30), max_batch=n, max_target
     for _ in range(3):
         r = c.icp_update_batch(bad)
         c.extract_features_batch(segs)
+        c.segment_batch(raws)
         c.transform_to_end([p.surf_last for p in pairs] + [p.corner_last for p in pairs],
                            [(np.array([0.3, 0.1, 0.0]), np.array([0.9999, 0.01, 0.0, 0.01]) / np.linalg.norm([0.9999, 0.01, 0.0, 0.01]))] * (2 * n))
     sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
