@@ -457,20 +457,32 @@ __device__ __forceinline__ void walk_task(const LdsStore& L, const LCloud& c, co
 template <int LANES>
 __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, bool is_surf, int nq, float thr, int j1,
                                          int rho, float sx, float sy, float sz, const QueryPolar& qp, float margin,
-                                         int role, int lane_base, int warm2, int warm3, Best& c2, Best& c3) {
+                                         int role, int lane_base, int warm2, int warm3, bool check_class, Best& c2,
+                                         Best& c3) {
   const WalkCtx w = make_walk_ctx(c, nq, j1, rho);
   c2 = best_init(thr);
   c3 = best_init(thr);
   const float rho_q = qp.rho, qn3 = qp.qn3, el_q = qp.el;
   const int a0 = qp.a0_surf_or_corner;
-  // warm start: last iteration's second / third point (same nearest neighbour => same index
-  // intervals and classes) are candidates whose distances bound the walk from the start
-  auto warm_cand = [&](Best& b, int pos) {
+  // warm start: last iteration's second / third point are candidates whose distances bound the walk from the
+  // start.  Same nearest neighbour => same index intervals and classes; after the nearest neighbour moved
+  // (check_class) they still qualify when they lie in the new intervals and on a ring of the right class.
+  auto warm_cand = [&](Best& b, int pos, bool on_ring_rho) {
     int rank;
-    if (pos >= 0 && walk_rank(w, pt_idx(L, c, pos), rank)) consider(b, pt_sqdist(L, c, pos, sx, sy, sz), rank, pos, 0);
+    if (pos < 0) return;
+    const int j = pt_idx(L, c, pos);
+    if (!walk_rank(w, j, rank)) return;
+    if (check_class) {
+      int r = 0;  // ring of index j: the last ring that starts at or before it
+#pragma unroll
+      for (int step = kRingsBinned / 2; step > 0; step >>= 1)
+        if (c.ring_start[r + step] <= j) r += step;
+      if ((r == rho) != on_ring_rho) return;
+    }
+    consider(b, pt_sqdist(L, c, pos, sx, sy, sz), rank, pos, 0);
   };
-  warm_cand(c2, warm2);
-  warm_cand(c3, warm3);
+  warm_cand(c2, warm2, is_surf);  // second point: ring rho for planes, another ring for lines
+  warm_cand(c3, warm3, false);    // third point (planes only): another ring
   const bool w2 = c2.pos >= 0, w3 = c3.pos >= 0;
   if (is_surf && !w2) {  // class-2 seed on ring rho: all lanes of the query
     bool go = walk_ring_has_candidates(c, w, rho);
@@ -1129,7 +1141,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
               Best c2 = best_init(thr), c3 = c2;
               if (!(prm.pad & 1))
                 walk_lds<LANES>(L, c, is_surf, is_surf ? sd.n_surf_q : sd.n_corner_q, thr, j1, rho1, o.sel[0], o.sel[1],
-                                o.sel[2], qp, margin, role, lane_base, nn_changed ? -1 : a2, nn_changed ? -1 : a3, c2, c3);
+                                o.sel[2], qp, margin, role, lane_base, a2, a3, nn_changed, c2, c3);
               if (said23 && (c2.pos != pred2 || (is_surf && c3.pos != pred3)) && role == 0) atomicAdd(&L.dbg[0], 1);
               p2 = c2.pos, p3 = c3.pos;
               a2 = c2.pos, b2c = c2.pos2, a3 = c3.pos, b3c = c3.pos2;
