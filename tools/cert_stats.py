@@ -17,7 +17,7 @@ defs = importlib.import_module(PKG + "._ctypes_defs")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 batch = host.synth_batch(n)
 prm = pkg.default_params(num_iter=10, fixed_iters=1)
-with ieskf.IeskfContext(prm, max_batch=n, max_targets=16384, search="lds") as c:
+with ieskf.IeskfContext(prm, max_batch=n, max_targets=16384, search=(sys.argv[2] if len(sys.argv) > 2 else "mr")) as c:
     arr = defs.pairs_to_c(batch)
     res = (defs.ResultC * n)()
     assert ieskf.lib().lins_ieskf_update_batch(c._h, n, arr, res) == 0
