@@ -197,6 +197,20 @@ __device__ __forceinline__ void merge_from_lane(Best& b, int src_lane) {
   if (pos2 >= 0) insert_key(b, ((unsigned long long)hi2 << 32) | lo2, pos2, ring2);
 }
 
+// fold the partial results of a query's lanes (consecutive, starting at lane_base) into every one of them.
+// LANES = 3: the three-lane kernel; LANES = 0: ln lanes, a power of two chosen at run time.
+template <int LANES>
+__device__ __forceinline__ void merge_query_lanes(Best& b, int lane_base, int role, int ln) {
+  if (LANES == 3) {
+    merge_from_lane(b, lane_base + (role + 1) % 3);
+    merge_from_lane(b, lane_base + (role + 2) % 3);
+  } else if (LANES != 1) {
+    const int n = LANES ? LANES : ln;
+#pragma unroll 1
+    for (int m = 1; m < n; m <<= 1) merge_from_lane(b, lane_base + (role ^ m));
+  }
+}
+
 // ---- certificates: skipping a search that provably returns the same answer -----------------
 // After a search run with its pruning bound inflated by `margin` metres, every candidate other
 // than the winner is at least  lb = min(sqrt(omin), sqrt(d_best) + margin)  away from the query
@@ -300,8 +314,9 @@ __device__ __forceinline__ bool ring_in_reach(const LCloud& c, int r, float el_q
 // ---- pass 1: exact NN; with LANES = 3 the ring windows of a query are split over its lanes
 template <int LANES>
 __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float sx, float sy, float sz,
-                                       const QueryPolar& qp, float thr, float margin, int rq, int role, int lane_base,
-                                       int warm_pos, int warm_ring) {
+                                       const QueryPolar& qp, float thr, float margin, int rq, int ln, int role,
+                                       int lane_base, int warm_pos, int warm_ring) {
+  const int LN = LANES ? LANES : ln;  // lanes of this query (LANES = 0: a run-time power of two, wave-uniform)
   Best b = best_init(thr);
   // Warm start (iterations >= 1): last iteration's nearest neighbour is still a candidate, and its
   // distance to the re-de-skewed query bounds the search from the start — the seed scan is skipped
@@ -322,24 +337,19 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
   // lane, merged before the bound is fixed — a query that sits between rings (or whose own ring is
   // empty there) still starts from a real neighbour instead of sweeping the whole search radius
   {
-    const int rs = LANES == 1 ? rq : rq + (role == 0 ? 0 : (role == 1 ? 1 : -1));
-    const bool seed = !warm && ring_nonempty(c, rs);
+    const int rs = LN == 1 ? rq : rq + (role == 0 ? 0 : (role == 1 ? 1 : -1));
+    const bool seed = !warm && role < 3 && ring_nonempty(c, rs);
     rcur = rs;
     scan_cols(L, c, rs, seed ? a0 - 1 : 1, seed ? a0 + 1 : 0, f);
-    if (LANES == 1) {
+    if (LN == 1) {
 #pragma unroll 1
       for (int dr = -1; dr <= 1; dr += 2) {
         const bool sd2 = !warm && ring_nonempty(c, rq + dr);
         rcur = rq + dr;
         scan_cols(L, c, rq + dr, sd2 ? a0 - 1 : 1, sd2 ? a0 + 1 : 0, f);
       }
-    } else if (!warm) {  // (wave-uniform from iteration to iteration: cold only in iteration 0)
-      if (LANES == 3) {
-        merge_from_lane(b, lane_base + (role + 1) % 3);
-        merge_from_lane(b, lane_base + (role + 2) % 3);
-      } else {
-        merge_from_lane(b, lane_base + (role ^ 1));
-      }
+    } else if (!warm) {  // (the lanes of a query agree on `warm`)
+      merge_query_lanes<LANES>(b, lane_base, role, ln);
     }
     rcur = rq;
   }
@@ -351,11 +361,12 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
   // This lane's tasks as a bit mask (bit i <-> task t = role + LANES i): task 0 = own ring right
   // of the seed, 1 = own ring left of it, 2.. = the other rings rq+1, rq-1, rq+2, ...  The ring
   // tests are independent LDS reads, issued together; only surviving tasks enter the scan loop.
-  constexpr int kTasks = 2 + 2 * (kRingsBinned - 1), kPerLane = (kTasks + LANES - 1) / LANES;
+  constexpr int kTasks = 2 + 2 * (kRingsBinned - 1), kPerLane = LANES ? (kTasks + LANES - 1) / LANES : kTasks;
   unsigned todo = 0;
 #pragma unroll
   for (int i = 0; i < kPerLane; ++i) {
-    const int t = role + LANES * i;
+    const int t = role + LN * i;
+    if (LANES == 0 && t >= kTasks) break;
     const int k = t - 2, off = (k >> 1) + 1;
     const int r = t < 2 ? rq : rq + ((k & 1) ? -off : off);
     bool go;
@@ -369,20 +380,35 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
   while (todo) {
     const int i = __ffs(todo) - 1;
     todo &= todo - 1;
-    const int t = role + LANES * i;
+    const int t = role + LN * i;
     const int k = t - 2, off = (k >> 1) + 1;
     const int r = t < 2 ? rq : rq + ((k & 1) ? -off : off);
     rcur = r;
     // own ring: right part (with the centre column when warm) / left part; other rings: whole window
     scan_cols(L, c, r, t == 0 ? a0 + cin : a0 - K, t == 1 ? a0 - (warm ? 1 : 2) : a0 + K, f);
   }
-  if (LANES == 3) {
-    merge_from_lane(b, lane_base + (role + 1) % 3);
-    merge_from_lane(b, lane_base + (role + 2) % 3);
-  } else if (LANES == 2) {
-    merge_from_lane(b, lane_base + (role ^ 1));
-  }
+  merge_query_lanes<LANES>(b, lane_base, role, ln);
   return b;
+}
+
+// ---- wave-cooperative searches: which lanes need one, and who serves whom ------------------------
+constexpr int kCoopMaxLanes = 8;  // (measured on the batch workload: 2 -> 8.4, 4 -> 8.9, 8 -> 8.9, 16 -> 8.85 M it/s)
+struct CoopMap {
+  int n;          // searches needed in this wave
+  int rank;       // this lane's position in the permutation (needing lanes first, in lane order)
+  int owner_map;  // lane r holds the lane id of rank r
+};
+__device__ __forceinline__ CoopMap coop_map(bool need, int lane) {
+  const unsigned long long m = __ballot(need);
+  const int n = __popcll(m);
+  const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+  const int rank = need ? below : n + (lane - below);  // a permutation of 0..63: every lane receives exactly one push
+  return CoopMap{n, rank, __builtin_amdgcn_ds_permute(rank << 2, lane)};
+}
+// lanes per search when n searches share a wave: 64 / n rounded down to a power of two (1: everyone for himself)
+__device__ __forceinline__ int coop_lanes(int n, int cap) {
+  const int l = 1 << (31 - __clz(64 / n));
+  return l > cap ? cap : l;
 }
 
 constexpr int kBackRankL = 0x40000000;
@@ -457,8 +483,9 @@ __device__ __forceinline__ void walk_task(const LdsStore& L, const LCloud& c, co
 template <int LANES>
 __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, bool is_surf, int nq, float thr, int j1,
                                          int rho, float sx, float sy, float sz, const QueryPolar& qp, float margin,
-                                         int role, int lane_base, int warm2, int warm3, bool check_class, Best& c2,
-                                         Best& c3) {
+                                         int ln, int role, int lane_base, int warm2, int warm3, bool check_class,
+                                         Best& c2, Best& c3) {
+  const int LN = LANES ? LANES : ln;
   const WalkCtx w = make_walk_ctx(c, nq, j1, rho);
   c2 = best_init(thr);
   c3 = best_init(thr);
@@ -496,10 +523,11 @@ __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, boo
   // tasks (data, not code), dealt round-robin to the query's lanes:
   //   surf    t0: rho (class 2, extensions)  t1: rho-1  t2: rho-2  t3: rho+1  t4: rho+2  (class 3)
   //   corner  t0: rho-1  t1: rho+1  t2: rho-2  t3: rho+2
-  constexpr int kPerLane = (5 + LANES - 1) / LANES;
+  constexpr int kPerLane = LANES ? (5 + LANES - 1) / LANES : 5;
 #pragma unroll 1
   for (int i = 0; i < kPerLane; ++i) {
-    const int t = role + LANES * i;
+    const int t = role + LN * i;
+    if (LANES == 0 && t > 4) break;
     int dr;
     if (is_surf)
       dr = t == 0 ? 0 : (t == 1 ? -1 : (t == 2 ? -2 : (t == 3 ? 1 : (t == 4 ? 2 : 99))));
@@ -516,15 +544,8 @@ __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, boo
     else
       c3 = cur;
   }
-  if (LANES == 3) {
-    merge_from_lane(c2, lane_base + (role + 1) % 3);
-    merge_from_lane(c2, lane_base + (role + 2) % 3);
-    merge_from_lane(c3, lane_base + (role + 1) % 3);
-    merge_from_lane(c3, lane_base + (role + 2) % 3);
-  } else if (LANES == 2) {
-    merge_from_lane(c2, lane_base + (role ^ 1));
-    merge_from_lane(c3, lane_base + (role ^ 1));
-  }
+  merge_query_lanes<LANES>(c2, lane_base, role, ln);
+  merge_query_lanes<LANES>(c3, lane_base, role, ln);
 }
 
 // ---- grid build: both clouds of the scan, once -----------------------------------------------
@@ -985,6 +1006,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   // candidate's distance and the query positions they were established at
   float lb1 = 0.f, lb2 = 0.f, lb3 = 0.f, certA[3] = {0.f, 0.f, 0.f}, certB[3] = {0.f, 0.f, 0.f};
   bool have_cert = false;
+  bool searched = false;  // a search iteration has run: certificates and warm candidates exist (uniform)
 
   for (;;) {
     const int iter = L.iter;
@@ -1007,7 +1029,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     constexpr int kWaves = BLOCK / 64, kSpreadSurf = (kWaves * 5 + 4) / 8;
     int spread_s = 0, spread_c = 0;  // queries per wave of either kind (0 = not spread)
     if (LANES == 1) {
-      const int ws = (prm.pad >> 8) & 15 ? (prm.pad >> 8) & 15 : kSpreadSurf, wc = kWaves - ws;
+      const int ws = kSpreadSurf, wc = kWaves - ws;  // (measured: 4 or 5 of 8 waves for the plane queries, no difference)
       const int ps = (sd.n_surf_q + ws - 1) / ws, pc = wc > 0 ? (sd.n_corner_q + wc - 1) / wc : 65;
       if (ws < kWaves && ps <= 64 && pc <= 64) spread_s = ps, spread_c = pc, surf_waves = ws;
     }
@@ -1034,7 +1056,256 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         a1 = b1c = ra1 = rb1 = a2 = b2c = a3 = b3c = sel1 = -1, have_cert = false;
         lb1 = lb2 = lb3 = 0.f;
       }
-      if (active) {
+      if constexpr (LANES == 1) {
+        // ---- one owner lane per query, wave-cooperative searches --------------------------------------
+        // The owner de-skews its query and tests the certificates; the queries of the wave that do need a
+        // search are then served several lanes at a time (inputs and results travel by bpermute, no LDS
+        // and no barrier): a wave's search time follows the number of searches it really has to run, not
+        // the union of 64 independent control flows.
+        const bool is_surf = slot < sd.n_surf_q;
+        const int qi = is_surf ? slot : slot - sd.n_surf_q;
+        const LCloud& c = is_surf ? cs : cc;
+        const float thr = prm.nearest_f;
+        const bool single_round = span <= kQPerRound;
+        const bool warm_iter = single_round && searched;  // certificates / warm candidates exist (uniform)
+        const float margin = warm_iter ? prm.margin_warm : prm.margin_cold;
+        const bool verify = (prm.pad & 8) != 0;  // test aid: search anyway and count disagreements
+        // the cold iteration searches for every query: one lane each (more lanes per wave cost more than the shorter
+        // chains give back — measured); afterwards only the uncertified queries search, up to kCoopMaxLanes lanes each
+        const int coop_cap = warm_iter ? kCoopMaxLanes : 1;
+        const unsigned long long kNone = ~0ull;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        V3 phi = L.ic.phi;
+        QueryOut o;
+        o.accepted = 0;
+        o.c[0] = o.c[1] = o.c[2] = o.c[3] = 0.f;
+        o.sel[0] = o.sel[1] = o.sel[2] = 0.f;
+        QueryPolar qp = {0.f, 0.f, 0.f, 0.f, 0};
+        int p1 = -1, p2 = -1, p3 = -1;
+        long long s0 = prof ? clock64() : 0, s1 = s0, s2 = s0;
+        if (active) {
+          q = arena[(is_surf ? sd.off_surf_q : sd.off_corner_q) + qi];
+          V3 t{L.ic.lin[0], L.ic.lin[1], L.ic.lin[2]};
+          transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2]);
+        }
+        if (prof) {
+          s1 = clock64();
+          if (tid == 0) L.prof_acc[6] += s1 - s0;
+        }
+        auto dist_to = [&](int pos) { return pt_sqdist(L, c, pos, o.sel[0], o.sel[1], o.sel[2]); };
+        auto drift_from = [&](const float* cp) {
+          float ex = o.sel[0] - cp[0], ey = o.sel[1] - cp[1], ez = o.sel[2] - cp[2];
+          return sqrtf(ex * ex + ey * ey + ez * ez);
+        };
+        if (do_search) {
+          if (!single_round) a1 = b1c = a2 = b2c = a3 = b3c = sel1 = -1;
+          // --- nearest neighbour: certificate (owner) -----------------------------------------------------
+          // Per selection the last search left two tracked candidates — the winner A and the runner-up B
+          // (grid positions, -1 = absent) — and a lower bound lb for the distance of every other
+          // candidate.  While everybody else is certified to stay farther than the closer of A and B,
+          // the selection is re-decided between those two from their distances alone (same strict
+          // (distance, key) order as the search); otherwise the search runs again, warm-started from A.
+          bool need_nn = false, said = false, flip = false;
+          int pred = -1;
+          if (active) {
+            qp.rho = sqrtf(o.sel[0] * o.sel[0] + o.sel[1] * o.sel[1]);
+            qp.qn3 = sqrtf(qp.rho * qp.rho + o.sel[2] * o.sel[2]);
+            qp.el = atan2f(o.sel[2], qp.rho);
+            qp.a0_surf_or_corner = az_bin(o.sel[0], o.sel[1], c.naz);
+            const float da = a1 >= 0 ? dist_to(a1) : INFINITY, db = b1c >= 0 ? dist_to(b1c) : INFINITY;
+            bool ok = warm_iter && !(prm.pad & 16) && certified(fminf(fminf(da, db), thr), lb1, drift_from(certA));
+            const unsigned long long ka = da < thr ? pack_key(da, pt_idx(L, c, a1)) : kNone;
+            const unsigned long long kb = db < thr ? pack_key(db, pt_idx(L, c, b1c)) : kNone;
+            flip = kb < ka;
+            pred = (flip ? kb : ka) == kNone ? -1 : (flip ? b1c : a1);
+            said = ok;
+            if (verify) ok = false;
+            need_nn = !ok;
+          }
+          // --- nearest neighbour: the searches of this wave, coop_lanes() lanes each ---------------------------
+          {
+            const CoopMap cm = coop_map(need_nn, lane);
+            int r_pos = -1, r_ring = -1, r_pos2 = -1, r_ring2 = -1;
+            float r_lb = 0.f;
+            if (cm.n) {  // (wave-uniform)
+              // lanes per search: as many as the wave can give each of its cm.n searches, a power of two
+              const int ln = coop_lanes(cm.n, coop_cap);
+              const int wrole = lane & (ln - 1), wbase = lane - wrole, item = lane / ln;
+              bool valid = need_nn;
+              float isx = o.sel[0], isy = o.sel[1], isz = o.sel[2];
+              QueryPolar iq = qp;
+              int i_surf = is_surf, i_rq = ring_of(q.w), i_a1 = a1, i_ra1 = ra1;
+              if (ln > 1) {  // the inputs of search `item` travel from its owner to the ln lanes that serve it
+                valid = item < cm.n;
+                const int owner = __shfl(cm.owner_map, valid ? item : 0);
+                isx = __shfl(o.sel[0], owner), isy = __shfl(o.sel[1], owner), isz = __shfl(o.sel[2], owner);
+                iq.rho = __shfl(qp.rho, owner), iq.qn3 = __shfl(qp.qn3, owner), iq.el = __shfl(qp.el, owner);
+                iq.a0_surf_or_corner = __shfl(qp.a0_surf_or_corner, owner);
+                i_surf = __shfl((int)is_surf, owner), i_rq = __shfl(i_rq, owner);
+                i_a1 = __shfl(a1, owner), i_ra1 = __shfl(ra1, owner);
+              }
+              Best bb = best_init(thr);
+              if (valid && !(prm.pad & 2))  // (profiling aid: LINS_DEBUG_SKIP=2 skips the search, 1 skips the walk)
+                bb = nn_lds<0>(L, i_surf ? cs : cc, isx, isy, isz, iq, thr, margin, i_rq, ln, wrole, wbase, i_a1, i_ra1);
+              r_pos = bb.pos, r_ring = bb.ring, r_pos2 = bb.pos2, r_ring2 = bb.ring2, r_lb = cert_lb(bb, thr, margin);
+              if (ln > 1) {  // hand back: the owner of rank r reads the first lane of group r
+                const int src = (cm.rank * ln) & 63;
+                r_pos = __shfl(r_pos, src), r_ring = __shfl(r_ring, src);
+                r_pos2 = __shfl(r_pos2, src), r_ring2 = __shfl(r_ring2, src), r_lb = __shfl(r_lb, src);
+              }
+            }
+            if (need_nn) {
+              p1 = r_pos;  // (a winner beat the threshold sentinel, so its distance is < thr, SE:851)
+              if (said && p1 != pred) atomicAdd(&L.dbg[0], 1);
+              a1 = r_pos, ra1 = r_ring, b1c = r_pos2, rb1 = r_ring2;
+              lb1 = r_lb;
+              certA[0] = o.sel[0], certA[1] = o.sel[1], certA[2] = o.sel[2];
+            } else if (active) {
+              p1 = pred;
+              if (flip) {  // the runner-up took over: swap the two tracked candidates
+                const int tp = a1, tr = ra1;
+                a1 = b1c, ra1 = rb1, b1c = tp, rb1 = tr;
+              }
+              atomicAdd(&L.dbg[1], 1);
+            }
+          }
+          const bool nn_changed = p1 != sel1;
+          if (active) sel1 = p1;
+          if (prof) {
+            s2 = clock64();
+            if (tid == 0) L.prof_acc[7] += s2 - s1;
+          }
+          // --- second / third point: certificate (owner) --------------------------------------------------
+          bool need_walk = false, flip2 = false, flip3 = false, said23 = false;
+          int pred2 = -1, pred3 = -1, j1 = -1;
+          if (active && p1 >= 0) {
+            j1 = pt_idx(L, c, p1);  // (p1 >= 0 => p1 is candidate A, on ring ra1)
+            need_walk = nn_changed || !warm_iter;
+            if (!need_walk) {
+              const WalkCtx w = make_walk_ctx(c, is_surf ? sd.n_surf_q : sd.n_corner_q, j1, ra1);
+              const float dB = drift_from(certB);
+              auto judge = [&](int pa, int pb, float lb, int& pd, bool& fl) {
+                const float da = pa >= 0 ? dist_to(pa) : INFINITY, db = pb >= 0 ? dist_to(pb) : INFINITY;
+                int rka = 0, rkb = 0;
+                if (pa >= 0) walk_rank(w, pt_idx(L, c, pa), rka);
+                if (pb >= 0) walk_rank(w, pt_idx(L, c, pb), rkb);
+                const unsigned long long ka = da < thr ? pack_key(da, rka) : kNone;
+                const unsigned long long kb = db < thr ? pack_key(db, rkb) : kNone;
+                fl = kb < ka;
+                pd = (fl ? kb : ka) == kNone ? -1 : (fl ? pb : pa);
+                return certified(fminf(fminf(da, db), thr), lb, dB);
+              };
+              bool ok23 = judge(a2, b2c, lb2, pred2, flip2);
+              if (is_surf) ok23 = judge(a3, b3c, lb3, pred3, flip3) && ok23;
+              said23 = ok23;
+              need_walk = !ok23 || verify;
+            }
+          }
+          // --- second / third point: the walks of this wave --------------------------------------------------
+          {
+            const CoopMap cm = coop_map(need_walk, lane);
+            int r2 = -1, r2b = -1, r3 = -1, r3b = -1;
+            float r_lb2 = 0.f, r_lb3 = 0.f;
+            if (cm.n) {
+              const int ln = coop_lanes(cm.n, coop_cap);
+              const int wrole = lane & (ln - 1), wbase = lane - wrole, item = lane / ln;
+              bool valid = need_walk;
+              float isx = o.sel[0], isy = o.sel[1], isz = o.sel[2];
+              QueryPolar iq = qp;
+              int i_surf = is_surf, i_j1 = j1, i_rho1 = ra1, i_w2 = a2, i_w3 = a3, i_chk = nn_changed;
+              if (ln > 1) {
+                valid = item < cm.n;
+                const int owner = __shfl(cm.owner_map, valid ? item : 0);
+                isx = __shfl(o.sel[0], owner), isy = __shfl(o.sel[1], owner), isz = __shfl(o.sel[2], owner);
+                iq.rho = __shfl(qp.rho, owner), iq.qn3 = __shfl(qp.qn3, owner), iq.el = __shfl(qp.el, owner);
+                iq.a0_surf_or_corner = __shfl(qp.a0_surf_or_corner, owner);
+                i_surf = __shfl((int)is_surf, owner), i_j1 = __shfl(j1, owner), i_rho1 = __shfl(ra1, owner);
+                i_w2 = __shfl(a2, owner), i_w3 = __shfl(a3, owner), i_chk = __shfl((int)nn_changed, owner);
+              }
+              Best c2 = best_init(thr), c3 = c2;
+              if (valid && !(prm.pad & 1))
+                walk_lds<0>(L, i_surf ? cs : cc, i_surf != 0, i_surf ? sd.n_surf_q : sd.n_corner_q, thr, i_j1, i_rho1, isx, isy, isz,
+                            iq, margin, ln, wrole, wbase, i_w2, i_w3, i_chk != 0, c2, c3);
+              r2 = c2.pos, r2b = c2.pos2, r3 = c3.pos, r3b = c3.pos2;
+              r_lb2 = cert_lb(c2, thr, margin), r_lb3 = cert_lb(c3, thr, margin);
+              if (ln > 1) {
+                const int src = (cm.rank * ln) & 63;
+                r2 = __shfl(r2, src), r2b = __shfl(r2b, src), r3 = __shfl(r3, src), r3b = __shfl(r3b, src);
+                r_lb2 = __shfl(r_lb2, src), r_lb3 = __shfl(r_lb3, src);
+              }
+            }
+            if (need_walk) {
+              if (said23 && (r2 != pred2 || (is_surf && r3 != pred3))) atomicAdd(&L.dbg[0], 1);
+              p2 = r2, p3 = r3;
+              a2 = r2, b2c = r2b, a3 = r3, b3c = r3b;
+              lb2 = r_lb2, lb3 = r_lb3;
+              certB[0] = o.sel[0], certB[1] = o.sel[1], certB[2] = o.sel[2];
+            } else if (active && p1 >= 0) {
+              p2 = pred2, p3 = pred3;
+              if (flip2) {
+                const int tp = a2;
+                a2 = b2c, b2c = tp;
+              }
+              if (flip3) {
+                const int tp = a3;
+                a3 = b3c, b3c = tp;
+              }
+              atomicAdd(&L.dbg[2], 1);
+            }
+          }
+          if (prof && tid == 0) L.prof_acc[8] += clock64() - s2;
+          if (active && prm.icp_freq > 1) {
+            // ICP mode: estimateTransform searches the corners only after >= 10 plane rows were accepted
+            // (SE:1175-1178) — a corner triplet is committed after the reduction, once that count is known
+            if (ICP && !is_surf)
+              held = make_int4(p1, p2, p3, sd.slot_base + slot);
+            else
+              idx_store[sd.slot_base + slot] = make_int4(p1, p2, p3, 0);
+          }
+        } else if (active) {
+          int4 s = idx_store[sd.slot_base + slot];
+          p1 = s.x, p2 = s.y, p3 = s.z;
+        }
+        long long s3 = prof ? clock64() : 0;
+        if (active) {
+          auto pt4 = [&](int pos) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            pt_xyz(L, c, pos, v.x, v.y, v.z);
+            return v;
+          };
+          if (is_surf) {
+            if (p1 >= 0 && p2 >= 0 && p3 >= 0) surf_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], pt4(p1), pt4(p2), pt4(p3), o);
+          } else if (p1 >= 0 && p2 >= 0) {
+            corner_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], pt4(p1), pt4(p2), o);
+          }
+          if (o.accepted) {
+            if (ICP) {  // Gauss-Newton row of the fallback (SE:1246-1257): [c^T(-R(s phi)[p]x), c^T | -0.05 res]
+              icp_row(prm.inv_period, phi, q.x, q.y, q.z, q.w, o.c, row, row[6]);
+            } else {
+              V3 cv{(double)o.c[0], (double)o.c[1], (double)o.c[2]};
+              V3 u = cross(V3{(double)q.x, (double)q.y, (double)q.z}, mvec(L.ic.Rt, cv));
+              V3 a = mvec(L.ic.Gt, u);
+              row[0] = cv.x, row[1] = cv.y, row[2] = cv.z, row[3] = a.x, row[4] = a.y, row[5] = a.z;
+              row[6] = prm.lidar_scale * (double)o.c[3];
+            }
+            if (is_surf)
+              ++ms;
+            else
+              ++mc;
+          }
+          if (PASS_ONLY && dump) {
+            lins_corr r;
+            r.ind1 = p1 >= 0 ? pt_idx(L, c, p1) : -1;
+            r.ind2 = p2 >= 0 ? pt_idx(L, c, p2) : -1;
+            r.ind3 = (is_surf && p3 >= 0) ? pt_idx(L, c, p3) : -1;
+            r.accepted = o.accepted;
+            for (int k = 0; k < 4; ++k) r.coeff[k] = o.c[k];
+            r.sel[0] = o.sel[0], r.sel[1] = o.sel[1], r.sel[2] = o.sel[2], r.sel[3] = q.w;
+            dump[sd.slot_base + slot] = r;
+          }
+        }
+        if (prof && tid == 0) L.prof_acc[9] += clock64() - s3;
+      } else if (active) {
         const bool is_surf = slot < sd.n_surf_q;
         const int qi = is_surf ? slot : slot - sd.n_surf_q;
         const float4 q = arena[(is_surf ? sd.off_surf_q : sd.off_corner_q) + qi];
@@ -1089,8 +1360,8 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
               if ((prm.pad & 32) && __ffsll(__ballot(1)) - 1 == lane) atomicAdd(&L.dbg[3], 1 + (iter >= 3 ? 1000 : 0));
               Best bb = best_init(thr);
               if (!(prm.pad & 2))  // (profiling aid: LINS_DEBUG_SKIP=2 skips the search, 1 skips the walk)
-                bb = nn_lds<LANES>(L, c, o.sel[0], o.sel[1], o.sel[2], qp, thr, margin, ring_of(q.w), role, lane_base, a1,
-                                   ra1);
+                bb = nn_lds<LANES>(L, c, o.sel[0], o.sel[1], o.sel[2], qp, thr, margin, ring_of(q.w), LANES, role, lane_base,
+                                   a1, ra1);
               p1 = bb.pos;  // (a winner beat the threshold sentinel, so its distance is < thr, SE:851)
               if (said && p1 != pred && role == 0) atomicAdd(&L.dbg[0], 1);
               a1 = bb.pos, ra1 = bb.ring, b1c = bb.pos2, rb1 = bb.ring2;
@@ -1141,7 +1412,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
               Best c2 = best_init(thr), c3 = c2;
               if (!(prm.pad & 1))
                 walk_lds<LANES>(L, c, is_surf, is_surf ? sd.n_surf_q : sd.n_corner_q, thr, j1, rho1, o.sel[0], o.sel[1],
-                                o.sel[2], qp, margin, role, lane_base, a2, a3, nn_changed, c2, c3);
+                                o.sel[2], qp, margin, LANES, role, lane_base, a2, a3, nn_changed, c2, c3);
               if (said23 && (c2.pos != pred2 || (is_surf && c3.pos != pred3)) && role == 0) atomicAdd(&L.dbg[0], 1);
               p2 = c2.pos, p3 = c3.pos;
               a2 = c2.pos, b2c = c2.pos2, a3 = c3.pos, b3c = c3.pos2;
@@ -1239,6 +1510,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         __syncthreads();
       }
     }
+    if (do_search) searched = true;
     if (kRegReduce) {
       const int sidx28 = reduce_sum_index(lane);
       if (sidx28 >= 0) L.partial[wave * 28 + sidx28] = acc;
