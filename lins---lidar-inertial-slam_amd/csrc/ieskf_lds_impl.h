@@ -7,10 +7,13 @@
 //   mr    (ieskf_lds_mr.hip)  "multi-resident": only the first LINS_LDS_CAP grid positions (the
 //                             corner cloud and the low surf rings, where nearly every search
 //                             ends) live in LDS, the rest in a grid-sorted copy in global memory
-//                             that the same loops fall through to; 384 threads, one lane per
-//                             query, no row slots — several workgroups (= independent scans) fit
-//                             one CU and hide each other's barriers and serial tails (batch
-//                             throughput).
+//                             that the same loops fall through to; 512 threads, one OWNER lane
+//                             per query (the queries spread over all waves), no row slots — two
+//                             workgroups (= independent scans) fit one CU and hide each other's
+//                             barriers and serial tails (batch throughput).  After the cold
+//                             iteration only the queries whose certificates fail search, and a
+//                             wave serves each of those with up to kCoopMaxLanes of its lanes
+//                             (coop_map / coop_lanes below).
 //
 // One workgroup owns one scan pair for the whole iterated update.  Both target clouds of
 // the scan are counting-sorted ONCE into (ring x azimuth-column) grids kept as SoA

@@ -1,6 +1,7 @@
 // ieskf_lds_mr.hip — "multi-resident" instantiation of the LDS IESKF kernel (ieskf_lds_impl.h): the
 // batch-throughput path.  512-thread workgroups (8 waves: two per SIMD, so the placement of a
-// workgroup's waves is balanced whatever SIMD the dispatcher starts on), one lane per query, whose
+// workgroup's waves is balanced whatever SIMD the dispatcher starts on), one owner lane per query (the
+// searches of the warm iterations are served by several lanes, see ieskf_lds_impl.h), whose
 // LDS holds only the first 4736 grid positions of the scan — the corner cloud and the low surf
 // rings, where nearly every search ends; the rest of the grid is a sorted copy in global memory
 // that the same loops fall through to.  At < 80 KB of LDS and 128 VGPRs two independent scans are
