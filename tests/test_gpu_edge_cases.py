@@ -451,3 +451,42 @@ def test_device_segmentation_matches_the_host_restatement(pkg, ieskf, host):
         ref = host.frontend_extract_segmented(w)
         for k in ("corner_sharp", "corner_less_sharp", "surf_flat", "surf_less_flat"):
             assert np.array_equal(f[k], ref[k]), k
+
+
+def _wide_room_raw_scan(seed, r0=95.0, wobble=4.0):
+    """A raw 16 x 1800 cloud in firing order (columns from +179.8 deg clockwise, the 16 rings of a column together)
+    of a round hall of radius r0 + wobble cos(3 az) metres with a floor at z = -1.8: the beams meet the wall head-on,
+    so every column of the upper rings survives the segmentation — a sector has 300 points (the 512-key sort
+    network) — and the wall is far enough that a ring's VoxelGrid box exceeds 2^21 cells (the 64-bit voxel keys)."""
+    rng = np.random.default_rng(seed)
+    az = np.radians(179.83 - 0.2 * np.arange(1800))  # (off the column edges of IP:225)
+    el = np.radians(-15.0 + 2.0 * np.arange(16))
+    A, E = np.meshgrid(az, el, indexing="ij")  # (1800, 16): column-major firing order
+    t_wall = (r0 + wobble * np.cos(3 * A)) / np.cos(E)
+    with np.errstate(divide="ignore"):
+        t_ground = np.where(E < 0, 1.8 / -np.sin(E), np.inf)
+    t = np.minimum(t_wall, t_ground) + rng.normal(0, 0.02, A.shape)
+    pts = np.stack([t * np.cos(E) * np.cos(A), t * np.cos(E) * np.sin(A), t * np.sin(E), np.zeros_like(t)], -1)
+    return pts.reshape(-1, 4).astype(np.float32)
+
+
+def test_front_end_on_a_wide_hall_takes_the_large_sort_paths(pkg, ieskf, host):
+    """sectors of 300 points (512-key sector sort), rings of 1800 points whose voxel box needs 64-bit keys: the
+    device stages still equal the host restatement bit for bit"""
+    raws = [_wide_room_raw_scan(5), _wide_room_raw_scan(6, 60.0, 2.0)]
+    want = [host.frontend_segment(r) for r in raws]
+    assert max(int(e) - int(s) for w in want for s, e in zip(w.c.start_ring, w.c.end_ring)) > 1700
+    with ieskf.IeskfContext(pkg.default_params(), max_batch=1, max_targets=1024) as c:
+        got = c.segment_batch(raws)
+        for g, w in zip(got, want):
+            n = w.n
+            assert g.n == n and g.c.n_outlier == w.c.n_outlier
+            assert list(g.c.start_ring) == list(w.c.start_ring) and list(g.c.end_ring) == list(w.c.end_ring)
+            assert np.array_equal(g.cloud[:n], w.cloud[:n]) and np.array_equal(g.range[:n], w.range[:n])
+            assert np.array_equal(g.col[:n], w.col[:n]) and np.array_equal(g.ground[:n], w.ground[:n])
+        feats = c.extract_features_batch(got)
+    for f, w in zip(feats, want):
+        ref = host.frontend_extract_segmented(w)
+        assert len(ref["surf_less_flat"]) > 3000
+        for k in ("corner_sharp", "corner_less_sharp", "surf_flat", "surf_less_flat"):
+            assert np.array_equal(f[k], ref[k]), k
