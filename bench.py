@@ -97,17 +97,41 @@ def main():
     ctx = ieskf.IeskfContext(prm, device=local_rank, max_batch=len(pairs), max_targets=max(max_targets, 1024),
                              search=args.search)
     ctx.upload(pairs)
-    poses = torch.zeros(len(pairs) * 192, dtype=torch.uint8, device="cuda")
-    gathered = torch.zeros(world * len(pairs) * 192, dtype=torch.uint8, device="cuda") if use_dist else None
+    # The pose gather of step k is enqueued (RCCL's own stream) right after step k + 1's update has been launched and
+    # runs beside it: two pose / gather buffers alternate, a buffer is reused only after the gather that read it
+    # has completed, and the last gather is issued and waited for inside the timed region (barrier()).
+    poses = [torch.zeros(len(pairs) * 192, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    gathered_bufs = [torch.zeros(world * len(pairs) * 192, dtype=torch.uint8, device="cuda") for _ in range(2)] if use_dist else None
+    pending = [None, None]
+    ungathered = [None]  # buffer index of the newest step, whose poses are complete but not gathered yet
+    n_steps_done = [0]
+
+    def finish(b):
+        if pending[b] is not None:
+            pending[b].wait()                          # orders the collective before torch's current stream ...
+            torch.cuda.current_stream().synchronize()  # ... which the host then drains: the buffers are free
+            pending[b] = None
+
+    def gather_newest():
+        b = ungathered[0]
+        if use_dist and b is not None:
+            pending[b] = dist.all_gather_into_tensor(gathered_bufs[b], poses[b], async_op=True)
+            ungathered[0] = None
 
     def step():
-        ctx.run(poses.data_ptr(), lo)
-        ctx.sync()
+        b = n_steps_done[0] & 1
+        n_steps_done[0] += 1
         if use_dist:
-            dist.all_gather_into_tensor(gathered, poses)
+            finish(b)
+        ctx.run(poses[b].data_ptr(), lo)  # asynchronous launch
+        gather_newest()                   # the previous step's records travel while this update computes
+        ctx.sync()
+        ungathered[0] = b
 
     def barrier():
         if use_dist:
+            gather_newest()
+            finish(0), finish(1)
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -121,6 +145,7 @@ def main():
         kernel_ms.append(ctx.last_kernel_ms())
     barrier()
     elapsed = time.perf_counter() - t0
+    gathered = gathered_bufs[(n_steps_done[0] - 1) & 1] if use_dist else None  # the last step's gather
 
     # device-copy ceiling of this box: a streaming float4 copy inside the context's arenas,
     # measured after the timed region (it overwrites the uploaded clouds)
@@ -222,10 +247,19 @@ def main():
                 "all_cores": {"value": itn / secn, "cores": ncpu},
                 "reduced_6x6_form_1core": {"value": itr / secr, "cores": 1},
             }
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+    if out is not None:
+        # RCCL writes its version banner to the C stdout buffer, which would otherwise be flushed at exit — after a
+        # line printed from Python.  Drain it first: the JSON line is the last thing on stdout.
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
