@@ -251,6 +251,12 @@ def main():
         out = None
     ctx.close()
     if use_dist:
+        # every rank drains its C stdout (RCCL's banner) before rank 0 prints the result line
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        dist.barrier()
         dist.destroy_process_group()
     if out is not None:
         # RCCL writes its version banner to the C stdout buffer, which would otherwise be flushed at exit — after a
