@@ -229,7 +229,7 @@ def main():
                 "bytes_per_iter_mean": bytes_iter_local / len(pairs),
             },
         }
-        if not args.no_cpu and args.cpu_sample > 0:
+        if not args.no_cpu and args.cpu_sample > 0 and world == 1:  # (the CPU leg: single-GPU runs only)
             from oracle import oracle
 
             sample = pairs[: min(args.cpu_sample, len(pairs))]
