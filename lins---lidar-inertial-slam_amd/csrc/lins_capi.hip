@@ -47,7 +47,7 @@ void launch_frontend(hipStream_t, int, const void*, const float4*, const float*,
                      double, float4*, float*, int*, float4*, int*);
 void launch_reproject_in_place(hipStream_t, int, int, const void*, const double*, float4*, double);
 size_t stream_cloud_size();
-void launch_segment(hipStream_t, int, const void*, const float4*, float, float, float, float, float, unsigned long long*, int*, void*, float4*,
+void launch_segment(hipStream_t, int, const void*, const float4*, float, float, float, float, float, unsigned*, int*, void*, float4*,
                     float*, unsigned*, unsigned char*, int*);
 size_t sg_raw_size();
 struct SgRawHost {
@@ -129,7 +129,7 @@ struct lins_ctx {
     size_t raw_cap = 0, h_raw_cap = 0;
     float4 *d_raw = nullptr, *h_raw = nullptr;
     void* d_raws = nullptr;
-    unsigned long long* d_cellidx = nullptr;
+    unsigned* d_cellidx = nullptr;
     int *d_segrows = nullptr, *d_outliers = nullptr;
     float sg_ms = 0.f;
   } fe;
@@ -706,7 +706,7 @@ static int sg_run(lins_ctx* ctx, int n, const lins_point* const* raw, const int3
     f.d_raws = nullptr, f.d_cellidx = nullptr, f.d_segrows = nullptr, f.d_outliers = nullptr, f.sg_cap = 0;
     const size_t c = (size_t)n;
     HIP_TRY(ctx, hipMalloc(&f.d_raws, c * sizeof(SgRawHost)));
-    HIP_TRY(ctx, hipMalloc((void**)&f.d_cellidx, c * N * sizeof(unsigned long long)));
+    HIP_TRY(ctx, hipMalloc((void**)&f.d_cellidx, c * N * sizeof(unsigned)));
     HIP_TRY(ctx, hipMalloc((void**)&f.d_segrows, c * N * sizeof(int)));
     HIP_TRY(ctx, hipMalloc((void**)&f.d_outliers, c * sizeof(int)));
     f.sg_cap = n;

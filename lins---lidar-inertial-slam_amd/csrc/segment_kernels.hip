@@ -51,7 +51,8 @@ struct SgConsts {
 struct SgLds {
   unsigned char flags[kSgCells];  // bit 0 right, bit 1 "+255", bit 2 down edge; bit 3 groundMat == 1; bit 7 eligible (labelMat == 0)
   union {
-    float range[kSgCells];  // rangeMat — until the adjacency is built
+    unsigned own[kSgCells];  // 1 + index of the point that owns the cell (0: no return) — during the projection
+    float range[kSgCells];   // rangeMat — until the adjacency is built
     struct {
       unsigned short label[kSgCells];  // smallest raster index that reaches the cell (0xFFFF: not eligible)
       unsigned cnt2[kSgCells / 2];     // cells per label, two u16 counters per word (a count never exceeds 28 800)
@@ -86,12 +87,13 @@ __device__ __forceinline__ int sg_block_scan(int v, int tid, int* tmp) {  // exc
   return off + incl - v;
 }
 
-// The range image lives in LDS (rangeMat first, the labels and their counters in the same bytes once the
-// adjacency is built); the only per-scan global scratch is the cell -> point index (the projection's atomicMax
-// target) and the row masks of the small segments.  fullCloud is never materialised: a cell's point is read
+// The images live in LDS, in the same 115 KB one after the other: the owner image (the projection's atomicMax
+// target), rangeMat, then the labels + their counters, then the list of emitted cells.  The only per-scan global
+// scratch is a copy of the owner image (written once, read back by ground removal and the emission) and the row
+// masks of the small segments (zeroed at the segment roots only).  fullCloud is never materialised: a cell's point is read
 // back through its index where the reference reads fullCloud (ground removal, emission).
 __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restrict__ raws, const float4* __restrict__ raw,
-                                                           SgConsts k, unsigned long long* __restrict__ cellidx, int* __restrict__ seg_rows,
+                                                           SgConsts k, unsigned* __restrict__ cellidx, int* __restrict__ seg_rows,
                                                            unsigned char* __restrict__ fe_scans, float4* __restrict__ out_cloud,
                                                            float* __restrict__ out_range, unsigned* __restrict__ out_col,
                                                            unsigned char* __restrict__ out_ground, int* __restrict__ out_outliers) {
@@ -109,13 +111,13 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
   const SgRaw rw = raws[scan];
   const float4* pts = raw + rw.off;
   const int n = rw.n;
-  // per cell: (1 + index of the point that owns it) << 32 | its range bits; 0 = no return
-  unsigned long long* ci = cellidx + (size_t)scan * kSgCells;
+  // per cell: 1 + index of the point that owns it, 0 = no return (written once, from the LDS image the projection builds)
+  unsigned* ci = cellidx + (size_t)scan * kSgCells;
   int* rws = seg_rows + (size_t)scan * kSgCells;
   FeScanOut* fo = reinterpret_cast<FeScanOut*>(fe_scans + (size_t)scan * kFeScanStride);
   const double kPi = 3.14159265358979323846;
 
-  for (int c = tid; c < kSgCells; c += kSgBlock) ci[c] = 0ull, rws[c] = 0, L.flags[c] = 0;
+  for (int c = tid; c < kSgCells; c += kSgBlock) L.u.own[c] = 0u, L.flags[c] = 0;
   if (tid == 0) L.n_outlier = 0;
   __syncthreads();
   SG_MARK(0)
@@ -132,17 +134,32 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
     int colm = (int)(-round(((double)horizon - 90.0) / (double)0.2f) + kSgCols / 2);
     if (colm >= kSgCols) colm -= kSgCols;
     if (colm < 0 || colm >= kSgCols) continue;
-    const float range = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
-    atomicMax(&ci[colm + row * kSgCols], ((unsigned long long)(unsigned)(i + 1) << 32) | __float_as_uint(range));
+    atomicMax(&L.u.own[colm + row * kSgCols], (unsigned)(i + 1));
+  }
+  __syncthreads();
+  // the owner image goes to global memory (ground removal and the emission read it back), its LDS bytes become
+  // rangeMat (FLT_MAX: no return): every thread rewrites only the cells it has just read
+  constexpr int kFill = 8;
+  for (int c0 = tid; c0 < kSgCells; c0 += kSgBlock * kFill) {
+    unsigned o[kFill];
+#pragma unroll
+    for (int u = 0; u < kFill; ++u) {
+      const int c = c0 + u * kSgBlock;
+      o[u] = c < kSgCells ? L.u.own[c] : 0u;
+    }
+    float4 p[kFill];
+#pragma unroll
+    for (int u = 0; u < kFill; ++u) p[u] = pts[o[u] ? o[u] - 1 : 0];
+#pragma unroll
+    for (int u = 0; u < kFill; ++u) {
+      const int c = c0 + u * kSgBlock;
+      if (c < kSgCells) {
+        ci[c] = o[u];
+        L.u.range[c] = o[u] ? sqrtf(p[u].x * p[u].x + p[u].y * p[u].y + p[u].z * p[u].z) : FLT_MAX;
+      }
+    }
   }
   __threadfence_block();
-  __syncthreads();
-  // rangeMat (FLT_MAX: no return) into LDS
-#pragma unroll 8
-  for (int c = tid; c < kSgCells; c += kSgBlock) {
-    const unsigned long long key = ci[c];
-    L.u.range[c] = (key >> 32) ? __uint_as_float((unsigned)key) : FLT_MAX;
-  }
   __syncthreads();
   SG_MARK(1)
 
@@ -150,7 +167,7 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
   for (int j = tid; j < kSgCols; j += kSgBlock) {
     int gi[kSgGroundScanInd + 1];
 #pragma unroll
-    for (int i = 0; i <= kSgGroundScanInd; ++i) gi[i] = (int)(ci[j + i * kSgCols] >> 32) - 1;
+    for (int i = 0; i <= kSgGroundScanInd; ++i) gi[i] = (int)ci[j + i * kSgCols] - 1;
     float4 gp[kSgGroundScanInd + 1];
 #pragma unroll
     for (int i = 0; i <= kSgGroundScanInd; ++i) gp[i] = pts[gi[i] >= 0 ? gi[i] : 0];
@@ -255,7 +272,9 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
     if (L.flags[c] & 0x80) {
       const int s = label[c];
       atomicAdd(&L.u.seg.cnt2[s >> 1], 1u << ((s & 1) * 16));
+      if (s == c) rws[c] = 0;  // a segment's row mask lives at its root: zeroed here, not for all 28 800 cells
     }
+  __threadfence_block();
   __syncthreads();
   // the row test only decides segments of 5 .. 29 cells: only those touch the global row masks
   for (int c = tid; c < kSgCells; c += kSgBlock)
@@ -304,10 +323,10 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
   for (int o = tid; o < total; o += kSgBlock) {
     const int c = L.u.emitted[o];
     const int i = c / kSgCols, j = c - i * kSgCols;
-    const unsigned long long key = ci[c];
-    float4 p = pts[(int)(key >> 32) - 1];
+    float4 p = pts[(int)ci[c] - 1];
+    out_range[ob + o] = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);  // rangeMat's expression (IP:230)
     p.w = (float)((double)(float)i + (double)(float)j / 10000.0);  // fullCloud intensity (IP:234)
-    out_cloud[ob + o] = p, out_range[ob + o] = __uint_as_float((unsigned)key), out_col[ob + o] = (unsigned)j;
+    out_cloud[ob + o] = p, out_col[ob + o] = (unsigned)j;
     out_ground[ob + o] = (L.flags[c] & 8) ? 1 : 0;
   }
   if (tid == 0) L.ring_count[kSgRows] = total;
@@ -337,7 +356,7 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
 }
 
 void launch_segment(hipStream_t stream, int n_scans, const void* raws, const float4* raw, float sin_ax, float cos_ax,
-                    float sin_ay, float cos_ay, float theta, unsigned long long* cellidx, int* seg_rows, void* fe_scans, float4* out_cloud,
+                    float sin_ay, float cos_ay, float theta, unsigned* cellidx, int* seg_rows, void* fe_scans, float4* out_cloud,
                     float* out_range, unsigned* out_col, unsigned char* out_ground, int* out_outliers) {
   SgConsts k{sin_ax, cos_ax, sin_ay, cos_ay, theta};
   hipLaunchKernelGGL(segment_kernel, dim3(n_scans), dim3(kSgBlock), 0, stream, (const SgRaw*)raws, raw, k, cellidx, seg_rows,
