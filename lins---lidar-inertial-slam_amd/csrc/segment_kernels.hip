@@ -123,39 +123,79 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
   SG_MARK(0)
 
   // ---- projectPointCloud (IP:205-241): the LAST point that falls into a cell owns it -------------
-#pragma unroll 4
-  for (int i = tid; i < n; i += kSgBlock) {
-    const float4 p = pts[i];
+  // Clouds of up to kSgPts points per thread (a VLP-16 scan has 28 800) keep every point's cell in registers, so
+  // that the range image and, later, the output are written point by point with coalesced reads of the raw cloud
+  // (the raw cloud is in firing order, the images ring-major: gathering points cell by cell touches a 64-byte line
+  // per 16-byte point).  Larger clouds take the cell-by-cell path.
+  constexpr int kSgPts = 32;
+  const bool by_point = n <= kSgPts * kSgBlock;
+  int cell_of[kSgPts];
+  unsigned owner_mask = 0;  // bit k: this thread's k-th point owns its cell
+  auto cell_of_point = [&](const float4& p) {
     const float vert = (float)((double)(lins_atan2f(p.z, sqrtf(p.x * p.x + p.y * p.y)) * 180) / kPi);
     const float rowf = (vert + (15.0f + 0.1f)) / 2.0f;
-    if (rowf < 0 || rowf >= kSgRows) continue;
+    if (rowf < 0 || rowf >= kSgRows) return -1;
     const int row = (int)rowf;
     const float horizon = (float)((double)(lins_atan2f(p.x, p.y) * 180) / kPi);
     int colm = (int)(-round(((double)horizon - 90.0) / (double)0.2f) + kSgCols / 2);
     if (colm >= kSgCols) colm -= kSgCols;
-    if (colm < 0 || colm >= kSgCols) continue;
-    atomicMax(&L.u.own[colm + row * kSgCols], (unsigned)(i + 1));
+    if (colm < 0 || colm >= kSgCols) return -1;
+    return colm + row * kSgCols;
+  };
+  if (by_point) {
+#pragma unroll
+    for (int k = 0; k < kSgPts; ++k) {
+      const int i = tid + k * kSgBlock;
+      cell_of[k] = i < n ? cell_of_point(pts[i]) : -1;
+      if (cell_of[k] >= 0) atomicMax(&L.u.own[cell_of[k]], (unsigned)(i + 1));
+    }
+  } else {
+#pragma unroll 4
+    for (int i = tid; i < n; i += kSgBlock) {
+      const int cell = cell_of_point(pts[i]);
+      if (cell >= 0) atomicMax(&L.u.own[cell], (unsigned)(i + 1));
+    }
   }
   __syncthreads();
   // the owner image goes to global memory (ground removal and the emission read it back), its LDS bytes become
-  // rangeMat (FLT_MAX: no return): every thread rewrites only the cells it has just read
-  constexpr int kFill = 8;
-  for (int c0 = tid; c0 < kSgCells; c0 += kSgBlock * kFill) {
-    unsigned o[kFill];
-#pragma unroll
-    for (int u = 0; u < kFill; ++u) {
-      const int c = c0 + u * kSgBlock;
-      o[u] = c < kSgCells ? L.u.own[c] : 0u;
+  // rangeMat (FLT_MAX: no return)
+  if (by_point) {
+    for (int c = tid; c < kSgCells; c += kSgBlock) {
+      const unsigned o = L.u.own[c];
+      ci[c] = o;
+      if (!o) L.u.range[c] = FLT_MAX;
     }
-    float4 p[kFill];
+    __syncthreads();
+    // (a cell's word is rewritten by its owner only; the other points of that cell compare it with their own
+    // index + 1 and see either the owner's index or range bits — a range >= 0.1 m is no index — never their own)
 #pragma unroll
-    for (int u = 0; u < kFill; ++u) p[u] = pts[o[u] ? o[u] - 1 : 0];
+    for (int k = 0; k < kSgPts; ++k) {
+      const int c = cell_of[k], i = tid + k * kSgBlock;
+      if (c >= 0 && L.u.own[c] == (unsigned)(i + 1)) {
+        const float4 p = pts[i];
+        L.u.range[c] = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
+        owner_mask |= 1u << k;
+      }
+    }
+  } else {
+    constexpr int kFill = 8;
+    for (int c0 = tid; c0 < kSgCells; c0 += kSgBlock * kFill) {
+      unsigned o[kFill];
 #pragma unroll
-    for (int u = 0; u < kFill; ++u) {
-      const int c = c0 + u * kSgBlock;
-      if (c < kSgCells) {
-        ci[c] = o[u];
-        L.u.range[c] = o[u] ? sqrtf(p[u].x * p[u].x + p[u].y * p[u].y + p[u].z * p[u].z) : FLT_MAX;
+      for (int u = 0; u < kFill; ++u) {
+        const int c = c0 + u * kSgBlock;
+        o[u] = c < kSgCells ? L.u.own[c] : 0u;
+      }
+      float4 p[kFill];
+#pragma unroll
+      for (int u = 0; u < kFill; ++u) p[u] = pts[o[u] ? o[u] - 1 : 0];
+#pragma unroll
+      for (int u = 0; u < kFill; ++u) {
+        const int c = c0 + u * kSgBlock;
+        if (c < kSgCells) {
+          ci[c] = o[u];
+          L.u.range[c] = o[u] ? sqrtf(p[u].x * p[u].x + p[u].y * p[u].y + p[u].z * p[u].z) : FLT_MAX;
+        }
       }
     }
   }
@@ -315,19 +355,34 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
   int pos = base;
   for (int c = c_lo; c < c_hi; ++c) {
     if (c % kSgCols == 0) L.ring_count[c / kSgCols] = pos;  // points emitted before ring i
-    if (emit_mask & (1u << (c - c_lo))) L.u.emitted[pos++] = (unsigned short)c;
+    if (emit_mask & (1u << (c - c_lo))) {
+      if (by_point)
+        L.u.emitted[c] = (unsigned short)pos++, L.flags[c] |= 0x40;  // cell -> output position, bit 6: emitted
+      else
+        L.u.emitted[pos++] = (unsigned short)c;                       // output position -> cell
+    }
   }
   __syncthreads();
-  // the output, one thread per emitted point: coalesced stores, independent gathers
-#pragma unroll 4
-  for (int o = tid; o < total; o += kSgBlock) {
-    const int c = L.u.emitted[o];
+  auto put = [&](int o, int c, float4 p) {
     const int i = c / kSgCols, j = c - i * kSgCols;
-    float4 p = pts[(int)ci[c] - 1];
     out_range[ob + o] = sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);  // rangeMat's expression (IP:230)
     p.w = (float)((double)(float)i + (double)(float)j / 10000.0);  // fullCloud intensity (IP:234)
     out_cloud[ob + o] = p, out_col[ob + o] = (unsigned)j;
     out_ground[ob + o] = (L.flags[c] & 8) ? 1 : 0;
+  };
+  if (by_point) {  // every owner of an emitted cell writes its point: coalesced reads of the raw cloud
+#pragma unroll
+    for (int k = 0; k < kSgPts; ++k)
+      if ((owner_mask >> k) & 1u) {
+        const int c = cell_of[k];
+        if (L.flags[c] & 0x40) put((int)L.u.emitted[c], c, pts[tid + k * kSgBlock]);
+      }
+  } else {  // one thread per emitted point: coalesced stores, gathers of the owning points
+#pragma unroll 4
+    for (int o = tid; o < total; o += kSgBlock) {
+      const int c = L.u.emitted[o];
+      put(o, c, pts[(int)ci[c] - 1]);
+    }
   }
   if (tid == 0) L.ring_count[kSgRows] = total;
   __syncthreads();

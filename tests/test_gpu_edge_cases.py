@@ -490,3 +490,22 @@ def test_front_end_on_a_wide_hall_takes_the_large_sort_paths(pkg, ieskf, host):
         assert len(ref["surf_less_flat"]) > 3000
         for k in ("corner_sharp", "corner_less_sharp", "surf_flat", "surf_less_flat"):
             assert np.array_equal(f[k], ref[k]), k
+
+
+def test_segmentation_of_a_cloud_with_more_points_than_cells(pkg, ieskf, host):
+    """more raw points than the 28 800 cells (a driver that repeats packets): later points take over their cells
+    (IP:238-240), and the kernel's cell-by-cell path (clouds beyond 32 768 points) equals the host restatement"""
+    base = host.synth_raw_scan(3, 1)
+    rng = np.random.default_rng(11)
+    extra = base[rng.permutation(len(base))[:14000]].copy()
+    extra[:, :3] *= np.float32(1.01)  # the same directions, a little farther: other ranges in the same cells
+    raw = np.ascontiguousarray(np.concatenate([base, extra]))
+    assert len(raw) > 32768
+    want = host.frontend_segment(raw)
+    with ieskf.IeskfContext(pkg.default_params(), max_batch=1, max_targets=1024) as c:
+        g = c.segment_batch([raw, base])[0]
+    n = want.n
+    assert g.n == n and g.c.n_outlier == want.c.n_outlier
+    assert list(g.c.start_ring) == list(want.c.start_ring) and list(g.c.end_ring) == list(want.c.end_ring)
+    assert np.array_equal(g.cloud[:n], want.cloud[:n]) and np.array_equal(g.range[:n], want.range[:n])
+    assert np.array_equal(g.col[:n], want.col[:n]) and np.array_equal(g.ground[:n], want.ground[:n])
