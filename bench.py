@@ -46,6 +46,63 @@ def traffic_from_profiles(search):
         return None
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: re-exec under torch.distributed.run, one rank per
+    GPU on this node (the driver's own N > 1 command line does the same from outside and is honoured as is)."""
+    import socket
+    import subprocess
+
+    if not args.dry_run:
+        import torch
+
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs on this node, found {have}")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def dry_run(args, rank, world):
+    """No GPU, no kernels: the launcher + the benchmarked exchange step (dist.PoseGatherPipeline) over gloo with
+    synthetic pose records.  Test aid for the N > 1 plumbing (tests/test_dist.py); prints a line marked dry_run."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    dist_mod = importlib.import_module(PKG + ".dist")
+    defs = importlib.import_module(PKG + "._ctypes_defs")
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    n_total = args.batch * world
+    pipe = dist_mod.PoseGatherPipeline(n_total, rank, world, device="cpu")
+    for k in range(args.warmup + args.steps):
+        b, buf = pipe.begin_step()
+        rec = np.zeros(pipe.hi - pipe.lo, dtype=defs.POSE_DTYPE)
+        rec["scan_id"] = np.arange(pipe.lo, pipe.hi)
+        rec["iters"] = args.iters
+        rec["m_surf"] = k  # the step a record belongs to
+        buf[: rec.nbytes] = torch.from_numpy(rec.view(np.uint8).copy())
+        pipe.gather_newest()
+        pipe.end_step(b)
+    pipe.drain()
+    rec = pipe.records()
+    assert int(rec["iters"].sum()) == n_total * args.iters, "pose gather incomplete"
+    assert (rec["m_surf"] == args.warmup + args.steps - 1).all(), "pose gather returned a stale step"
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "records": int(len(rec)), "ordered": True}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,20 +113,25 @@ def main():
     ap.add_argument("--search", default=os.environ.get("LINS_SEARCH", "auto"))
     ap.add_argument("--cpu-sample", type=int, default=192, help="scans timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="launcher + pose gather only, gloo, no GPU (test aid)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.dry_run:
+        return dry_run(args, rank, world)
 
     import numpy as np
     import torch
 
     import __graft_entry__ as g
 
-    g.build(only_missing=True)
+    g.build()
     pkg = importlib.import_module(PKG)
     host = importlib.import_module(PKG + ".host")
     ieskf = importlib.import_module(PKG + ".ieskf")
@@ -77,6 +139,8 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the HIP path)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, this node has {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("LINS_FORCE_DIST") == "1"  # (force: exercise the RCCL path on 1 GPU)
     if use_dist:
@@ -97,41 +161,21 @@ def main():
     ctx = ieskf.IeskfContext(prm, device=local_rank, max_batch=len(pairs), max_targets=max(max_targets, 1024),
                              search=args.search)
     ctx.upload(pairs)
-    # The pose gather of step k is enqueued (RCCL's own stream) right after step k + 1's update has been launched and
-    # runs beside it: two pose / gather buffers alternate, a buffer is reused only after the gather that read it
-    # has completed, and the last gather is issued and waited for inside the timed region (barrier()).
-    poses = [torch.zeros(len(pairs) * 192, dtype=torch.uint8, device="cuda") for _ in range(2)]
-    gathered_bufs = [torch.zeros(world * len(pairs) * 192, dtype=torch.uint8, device="cuda") for _ in range(2)] if use_dist else None
-    pending = [None, None]
-    ungathered = [None]  # buffer index of the newest step, whose poses are complete but not gathered yet
-    n_steps_done = [0]
-
-    def finish(b):
-        if pending[b] is not None:
-            pending[b].wait()                          # orders the collective before torch's current stream ...
-            torch.cuda.current_stream().synchronize()  # ... which the host then drains: the buffers are free
-            pending[b] = None
-
-    def gather_newest():
-        b = ungathered[0]
-        if use_dist and b is not None:
-            pending[b] = dist.all_gather_into_tensor(gathered_bufs[b], poses[b], async_op=True)
-            ungathered[0] = None
+    # The exchange step (dist.PoseGatherPipeline, the code tests/test_dist.py drives under gloo): the pose gather of
+    # step k is enqueued (RCCL's own stream) right after step k + 1's update has been launched and runs beside it;
+    # the last gather is issued and completed inside the timed region (barrier()).
+    pipe = dist_mod.PoseGatherPipeline(args.batch * world, rank, world, device="cuda", enabled=use_dist)
 
     def step():
-        b = n_steps_done[0] & 1
-        n_steps_done[0] += 1
-        if use_dist:
-            finish(b)
-        ctx.run(poses[b].data_ptr(), lo)  # asynchronous launch
-        gather_newest()                   # the previous step's records travel while this update computes
+        b, buf = pipe.begin_step()
+        ctx.run(buf.data_ptr(), lo)  # asynchronous launch
+        pipe.gather_newest()         # the previous step's records travel while this update computes
         ctx.sync()
-        ungathered[0] = b
+        pipe.end_step(b)
 
     def barrier():
+        pipe.drain()
         if use_dist:
-            gather_newest()
-            finish(0), finish(1)
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -145,7 +189,6 @@ def main():
         kernel_ms.append(ctx.last_kernel_ms())
     barrier()
     elapsed = time.perf_counter() - t0
-    gathered = gathered_bufs[(n_steps_done[0] - 1) & 1] if use_dist else None  # the last step's gather
 
     # device-copy ceiling of this box: a streaming float4 copy inside the context's arenas,
     # measured after the timed region (it overwrites the uploaded clouds)
@@ -172,9 +215,7 @@ def main():
         elapsed_max, iters_all = elapsed, float(iters_local)
 
     if use_dist:  # the gathered pose records must be complete and in scan order (outside the timed region)
-        defs = importlib.import_module(PKG + "._ctypes_defs")
-        rec = np.frombuffer(gathered.cpu().numpy().tobytes(), dtype=defs.POSE_DTYPE)
-        assert np.array_equal(rec["scan_id"], np.arange(world * len(pairs))), "pose gather out of order"
+        rec = pipe.records()  # (raises when out of order)
         assert int(rec["iters"].sum()) == int(iters_all), "pose gather incomplete"
 
     if rank == 0:

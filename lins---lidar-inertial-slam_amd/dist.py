@@ -59,3 +59,81 @@ def gather_pose_records(local_bytes, n_total, group=None):
     rec = np.concatenate(parts)
     assert np.array_equal(rec["scan_id"], np.arange(n_total)), "pose records out of order"
     return rec
+
+
+class PoseGatherPipeline:
+    """The benchmarked exchange step: a double-buffered, asynchronous all-gather of the ranks' pose records.
+
+    Step k's update writes its records into pose buffer k & 1; their gather is enqueued right after step
+    k + 1's update has been launched and travels while that update computes (RCCL's own stream on the GPU
+    box).  A buffer is handed out again only after the gather that read it has completed, and drain()
+    issues and completes the last one.  Shards may be ragged by one record: every rank's buffer is padded
+    to the largest shard (all_gather_into_tensor wants equal pieces) and `records()` cuts the padding out.
+
+    Device-agnostic: CUDA tensors + "nccl" in bench.py, CPU tensors + "gloo" in tests/test_dist.py.
+    With world == 1 and no process group it degenerates to two local buffers and no collective."""
+
+    def __init__(self, n_total, rank, world, device="cpu", group=None, enabled=None):
+        import torch
+
+        self.torch = torch
+        self.n_total, self.rank, self.world, self.group = n_total, rank, world, group
+        self.spans = [shard_range(n_total, r, world) for r in range(world)]
+        self.lo, self.hi = self.spans[rank]
+        self.max_n = max(b - a for a, b in self.spans)
+        self.enabled = (world > 1) if enabled is None else enabled
+        self.cuda = torch.device(device).type == "cuda"
+        nbytes = max(self.max_n, 1) * RECORD_BYTES
+        self.poses = [torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(2)]
+        self.gathered = [torch.zeros(world * nbytes, dtype=torch.uint8, device=device) for _ in range(2)] if self.enabled else None
+        self.pending = [None, None]
+        self.ungathered = None  # buffer of the newest finished step, not gathered yet
+        self.steps = 0
+
+    def _finish(self, b):
+        if self.pending[b] is not None:
+            self.pending[b].wait()  # orders the collective before the current stream ...
+            if self.cuda:
+                self.torch.cuda.current_stream().synchronize()  # ... which the host then drains: buffers free
+            self.pending[b] = None
+
+    def begin_step(self):
+        """-> (buffer index, pose tensor the update of this step must fill)."""
+        b = self.steps & 1
+        self.steps += 1
+        if self.enabled:
+            self._finish(b)
+        return b, self.poses[b]
+
+    def gather_newest(self):
+        """Enqueue the gather of the newest finished step (call after launching the next update)."""
+        import torch.distributed as dist
+
+        b = self.ungathered
+        if self.enabled and b is not None:
+            self.pending[b] = dist.all_gather_into_tensor(self.gathered[b], self.poses[b], group=self.group, async_op=True)
+            self.ungathered = None
+
+    def end_step(self, b):
+        """The update that fills buffer b has completed."""
+        self.ungathered = b
+
+    def drain(self):
+        self.gather_newest()
+        if self.enabled:
+            self._finish(0), self._finish(1)
+
+    def records(self):
+        """The last step's records of ALL ranks in scan order (after drain()); checks order."""
+        b = (self.steps - 1) & 1
+        if not self.enabled:
+            host = self.poses[b].cpu().numpy()
+            return np.frombuffer(host[: (self.hi - self.lo) * RECORD_BYTES].tobytes(), dtype=POSE_DTYPE)
+        host = self.gathered[b].cpu().numpy()
+        stride = max(self.max_n, 1) * RECORD_BYTES
+        parts = [np.frombuffer(host[r * stride: r * stride + (hi - lo) * RECORD_BYTES].tobytes(), dtype=POSE_DTYPE)
+                 for r, (lo, hi) in enumerate(self.spans)]
+        rec = np.concatenate(parts)
+        if not np.array_equal(rec["scan_id"], np.arange(self.n_total)):
+            raise AssertionError("pose gather out of order")
+        return rec

@@ -17,10 +17,10 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def _built():
-    """Build the in-tree libraries once (no-op when they are already there)."""
+    """Build the in-tree libraries once per session (make: incremental, a no-op when up to date)."""
     import __graft_entry__ as g
 
-    g.build(only_missing=True)
+    g.build()
 
 
 @pytest.fixture(scope="session")
