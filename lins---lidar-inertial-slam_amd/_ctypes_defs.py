@@ -164,6 +164,7 @@ class Result:
         self.diverged = rc.diverged
         self.m_surf = rc.m_surf
         self.m_corner = rc.m_corner
+        self.reserved = tuple(rc.reserved[:])  # debug counters of the kernels (certificate / exhaustive-search statistics)
 
     def __repr__(self):
         return (

@@ -49,6 +49,8 @@
 #include "ieskf_binned.h"
 #include "ieskf_device.h"
 #include "icp_math.h"
+#include "ieskf_rowsum.h"
+#include "ieskf_split.h"
 
 namespace lins {
 namespace LINS_LDS_NS {
@@ -637,76 +639,6 @@ __device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, 
 }
 
 // ---------------------------------------------------------------------------
-// 6x6 pivoted elimination, every lane of the wave redundantly in registers (the wave is
-// one instruction stream anyway): no shuffles, no LDS traffic, no barriers.  Fully
-// unrolled; row exchanges are value selects so nothing is dynamically indexed.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void reg_solve6(double (&a)[6][7], double (&x)[6]) {
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    int p = k;
-    double best = fabs(a[k][k]);
-#pragma unroll
-    for (int i = k + 1; i < 6; ++i) {
-      double v = fabs(a[i][k]);
-      if (v > best) best = v, p = i;
-    }
-#pragma unroll
-    for (int i = k + 1; i < 6; ++i) {
-      const bool sw = (p == i);
-#pragma unroll
-      for (int j = k; j < 7; ++j) {
-        double u = a[k][j], w = a[i][j];
-        a[k][j] = sw ? w : u;
-        a[i][j] = sw ? u : w;
-      }
-    }
-    const double inv = 1.0 / a[k][k];
-#pragma unroll
-    for (int i = k + 1; i < 6; ++i) {
-      const double f = a[i][k] * inv;
-#pragma unroll
-      for (int j = k + 1; j < 7; ++j) a[i][j] -= f * a[k][j];
-    }
-  }
-#pragma unroll
-  for (int i = 5; i >= 0; --i) {
-    double sacc = a[i][6];
-#pragma unroll
-    for (int k = i + 1; k < 6; ++k) sacc -= a[i][k] * x[k];
-    x[i] = sacc / a[i][i];
-  }
-}
-
-// Rinvleft(-phi)^T and phi from a unit quaternion without libm sin/cos: with
-// h = |phi|/2 the half angle, cos h = |w| / |q| and sin h = |v| / |q| exactly, so
-// s = h cot h needs only the atan2 that Quat2axis performs anyway (math_utils.h:75-88,
-// 304-321; differs from the sin/cos route in the last ulp only).
-__device__ __forceinline__ void phi_and_Gt(const Q4& q, V3& phi, M3& Gt) {
-  const double mag = sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
-  phi = V3{q.x, q.y, q.z};
-  Gt = M3{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
-  if (!(mag >= 1e-10)) return;  // Quat2axis leaves v unscaled; |phi| < 1e-10 => Rinvleft = I
-  const double ang = wrap_pi(2.0 * atan2(mag, q.w));
-  const V3 u = V3{q.x, q.y, q.z} / mag;
-  phi = ang * u;
-  const double theta = norm(phi);
-  if (theta < 1e-10) return;
-  const double h = theta / 2.0;
-  const double n = sqrt(q.w * q.w + mag * mag);
-  const double s = h * ((fabs(q.w) / n) / (mag / n));
-  const V3 a = V3{-phi.x, -phi.y, -phi.z} / theta;  // axis of -phi
-  const M3 k = skew(a);
-  const double av[3] = {a.x, a.y, a.z};
-  // Rinvleft(-phi) = s I + (1 - s) a a^T - h [a]x ; store the transpose
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int jj = 0; jj < 3; ++jj)
-      Gt.m[jj * 3 + i] = (s * (i == jj ? 1.0 : 0.0) + (1.0 - s) * av[i] * av[jj]) - h * k.m[i * 3 + jj];
-}
-
-// ---------------------------------------------------------------------------
 // The serial tail of one iteration, kept out of line: its register needs (a 6x7 system in
 // registers, the 19-state) are allocated on their own instead of inflating — and spilling —
 // the search loop it would otherwise be fused with.  Called by every thread (barriers inside).
@@ -870,73 +802,126 @@ __device__ __noinline__ void icp_solve_and_update(int tid, int iter) {
 }
 
 // ---------------------------------------------------------------------------
-// rows -> 28 sums inside a wave without LDS: every lane forms the 28 products of its own row
-// (21 of H^T H, 6 of H^T r, r^T r; all zero for an unused lane), then five halving butterflies
-// (xor 32, 16, 8, 4, 2) in which a lane pair splits the sums it still carries — one keeps the lower
-// half, the other the upper half, each adding the partner's copy — and a final xor-1 add.  29
-// shuffles instead of 28 x 6; the tree is fixed, so the sums are bit-reproducible from run to run.
-// Afterwards lane l holds sum number reduce_sum_index(l) of the whole wave.
+// split path (ieskf_split.h): the candidate list of one query, gathered around its de-skewed position at the
+// state the list kernel starts from, with the exact selection (p1, p2, p3: grid positions, -1 = none) of the
+// search that has just run at that position.  Claims: everything within r_nn (all rings, all indices);
+// on the rings of the second / third point's class everything the index walk can reach within r2 / r3.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
-  const int lo = __shfl_xor(__double2loint(v), mask), hi = __shfl_xor(__double2hiint(v), mask);
-  return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ int reduce_sum_index(int lane) {
-  const int local = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
-  return (local < 7 && !(lane & 1)) ? ((lane >> 5) & 1) * 14 + ((lane >> 4) & 1) * 7 + local : -1;
-}
-__device__ __forceinline__ double wave_reduce_rows(const double (&row)[7], int lane) {
-  constexpr int A[28] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6};
-  constexpr int B[28] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6};
-  double v[28];
+// Out of line on purpose: inlined into the iteration loop its register needs slow every iteration down (measured:
+// +15 % on the three iterations before the hand-off); a call keeps them on the hand-off path.
+struct GatherArgs {
+  int is_surf, nq, n_corner_t, n_surf_t, n_lds, p1, p2, p3, rho0, stride, pad;
+  float thr, margin, ax, ay, az;
+};
+__device__ __noinline__ void split_gather(const GatherArgs ga, const float4* gs, SplitQ* out, float4* cb) {
+  const LdsStore& L = g_lds;
+  const bool is_surf = ga.is_surf != 0;
+  const LCloud c = is_surf ? LCloud{L.cell_end + kCellsCorner, L.ring_start[0], &L.el_ang[0][0], kAzSurf, 1, ga.n_corner_t, ga.n_surf_t, gs, ga.n_lds}
+                           : LCloud{L.cell_end, L.ring_start[1], &L.el_ang[1][0], kAzCorner, kAzSurf / kAzCorner, 0, ga.n_corner_t, gs, ga.n_lds};
+  const int nq = ga.nq, p1 = ga.p1, p2 = ga.p2, p3 = ga.p3, rho0 = ga.rho0, stride = ga.stride;
+  const float ax = ga.ax, ay = ga.ay, az = ga.az;
+  QueryPolar qp;
+  qp.rho = sqrtf(ax * ax + ay * ay);
+  qp.qn3 = sqrtf(qp.rho * qp.rho + az * az);
+  qp.el = atan2f(az, qp.rho);
+  qp.inv_unused = 0.f;
+  qp.a0_surf_or_corner = az_bin(ax, ay, c.naz);
+  SplitQ rec{ax, ay, az, 0.f, ax, ay, az, 0.f, 0.f, 0, -1, -1};
+  if (p1 >= 0 && !(ga.pad & 128)) {  // (pad & 128: timing aid, no lists)
+    const float thr = ga.thr, M = ga.margin;
+    const int j1 = pt_idx(L, c, p1);
+    const int fend = nq < c.n ? nq : c.n;
+    const WalkCtx w = make_walk_ctx(c, nq, j1, rho0);
+    // indices the walk reaches at all, by class (the cloud is ring-sorted): same ring / other rings
+    const int rs = c.ring_start[rho0], re = c.ring_start[rho0 + 1];
+    const bool any_same = j1 > (w.b_lo > rs ? w.b_lo : rs) || (j1 + 1 < (w.f_hi < re ? w.f_hi : re));
+    const bool any_other = rs > w.b_lo || w.f_hi > re;
+    const float r_none = sqrtf(thr) * (1.f + 2e-6f) + M;  // "nobody within the search radius", with the margin
+    auto radius = [&](int pos) { return sqrtf(pt_sqdist(L, c, pos, ax, ay, az)) * (1.f + 2e-6f) + M; };
+    const float r_nn = radius(p1);
+    const bool any2 = is_surf ? any_same : any_other, any3 = is_surf && any_other;
+    // A class without a winner would need everything the walk reaches within the whole search radius (+ margin)
+    // to certify "still none": wide windows for one lane.  (pad & 512, experiment: leave it to the list kernel, whose
+    // first encounter sweeps the walk's index range with the whole workgroup and re-establishes the claim —
+    // measured: no faster here, slower there.)
+    const bool lazy_none = (ga.pad & 512) != 0;
+    const float r_none_here = lazy_none ? r_nn : r_none;
+    const float r2 = !any2 ? r_nn : (p2 >= 0 ? fmaxf(radius(p2), r_nn) : r_none_here);
+    const float r3 = !any3 ? (is_surf ? r_nn : 0.f) : (p3 >= 0 ? fmaxf(radius(p3), r_nn) : r_none_here);
+    const int flags = lazy_none ? 0 : (((any2 && p2 < 0) ? (int)SPLITQ_NONE2 : 0) | ((any3 && p3 < 0) ? (int)SPLITQ_NONE3 : 0));
+    const float t_nn = r_nn * r_nn * (1.f + 4e-6f);
+    const int a0 = qp.a0_surf_or_corner;
+    // window bounds of the three radii, once: [0] r_nn, [1] r2, [2] r3
+    float delta[3];
+    int reachK[3];
 #pragma unroll
-  for (int k = 0; k < 28; ++k) v[k] = row[A[k]] * row[B[k]];
-  {
-    const bool up = (lane & 32) != 0;
+    for (int k = 0; k < 3; ++k) {
+      const float rb = (k == 0 ? r_nn : (k == 1 ? r2 : r3)) * (1.f + 2e-6f) + 1e-6f;
+      delta[k] = reach_elev(qp.qn3, rb), reachK[k] = reach(c, qp.rho, rb);
+    }
+    int count = 0;
+    // Rings in a wave-friendly order: the five rings around rho0 first (every lane has work there, the class
+    // claims live there), then whatever else the all-points radius reaches — found with one cheap wedge test per
+    // ring, normally nothing.
+    unsigned far = 0;
 #pragma unroll
-    for (int i = 0; i < 14; ++i) {
-      const double lo = v[i], hi = v[i + 14];
-      v[i] = (up ? hi : lo) + shfl_xor_f64(up ? lo : hi, 32);
+    for (int r = 0; r < kRingsBinned; ++r) {
+      const int dr = r - rho0;
+      if ((dr < -2 || dr > 2) && ring_nonempty(c, r) && ring_in_reach(c, r, qp.el, delta[0])) far |= 1u << r;
+    }
+#pragma unroll 1
+    for (int k = 0; k < 5 || far; ++k) {
+      int r;
+      if (k < 5) {
+        r = rho0 + (k == 0 ? 0 : (k == 1 ? -1 : (k == 2 ? 1 : (k == 3 ? -2 : 2))));
+        if (r < 0 || r >= kRingsBinned) continue;
+      } else {
+        r = __ffs(far) - 1;
+        far &= far - 1;
+      }
+      const int dr = r - rho0, adr = dr < 0 ? -dr : dr;
+      const int cls = is_surf ? (dr == 0 ? 2 : (adr <= 2 ? 3 : 0)) : ((adr >= 1 && adr <= 2) ? 2 : 0);
+      // beyond r_nn a ring is only worth visiting for indices the walk can reach: every index of a lower ring
+      // and of the nearest neighbour's own ring, the indices below the forward end on the rings above
+      const bool reachable = cls != 0 && (dr <= 0 || c.ring_start[r] < fend);
+      const int which = !reachable ? 0 : (cls == 2 ? 1 : 2);
+      if (!ring_nonempty(c, r) || !ring_in_reach(c, r, qp.el, which == 0 ? delta[0] : (which == 1 ? delta[1] : delta[2]))) continue;
+      const float rad = which == 0 ? r_nn : (which == 1 ? r2 : r3);
+      const bool none = reachable && (cls == 2 ? (flags & SPLITQ_NONE2) != 0 : (flags & SPLITQ_NONE3) != 0);
+      const int K = which == 0 ? reachK[0] : (which == 1 ? reachK[1] : reachK[2]);
+      const float t_r = rad * rad * (1.f + 4e-6f);
+      scan_cols(L, c, r, a0 - K, a0 + K, [&](float x, float y, float z, int j, int p, bool ok) {
+        const float d = sqdist3(x, y, z, ax, ay, az);
+        bool take = ok && d <= t_r;
+        if (take && d > t_nn) {  // beyond the all-points radius: only what the walk claims cover
+          int rk;
+          if (none)
+            take = walk_rank(w, j, rk);
+          else if (dr > 0)
+            take = j < fend;
+        }
+        if (take) {
+          if (count < kSplitK) cb[(size_t)count * stride] = split_pack(x, y, z, j, r);
+          ++count;
+        }
+      });
+    }
+    rec.j1 = j1;
+    if (count <= kSplitK) {  // (an overflowing list claims nothing: the list kernel searches exhaustively)
+      rec.r_nn = r_nn, rec.r2 = r2, rec.r3 = r3;
+      rec.meta = count | (rho0 << 8) | (flags << 16);
+    } else {
+      rec.meta = rho0 << 8;
     }
   }
-  {
-    const bool up = (lane & 16) != 0;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-      const double lo = v[i], hi = v[i + 7];
-      v[i] = (up ? hi : lo) + shfl_xor_f64(up ? lo : hi, 16);
-    }
-  }
-  v[7] = 0.0;
-  {
-    const bool up = (lane & 8) != 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const double lo = v[i], hi = v[i + 4];
-      v[i] = (up ? hi : lo) + shfl_xor_f64(up ? lo : hi, 8);
-    }
-  }
-  {
-    const bool up = (lane & 4) != 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const double lo = v[i], hi = v[i + 2];
-      v[i] = (up ? hi : lo) + shfl_xor_f64(up ? lo : hi, 4);
-    }
-  }
-  {
-    const bool up = (lane & 2) != 0;
-    const double lo = v[0], hi = v[1];
-    v[0] = (up ? hi : lo) + shfl_xor_f64(up ? lo : hi, 2);
-  }
-  return v[0] + shfl_xor_f64(v[0], 1);
+  *out = rec;
 }
 
 // ---------------------------------------------------------------------------
 // the kernel.  PASS_ONLY: one correspondence pass at a caller-supplied linearisation
 // state (lins_correspondences / lins_reduce_pass), dumping records / sums.
 // ---------------------------------------------------------------------------
-template <int BLOCK, int LANES, bool PASS_ONLY, bool PROF, bool ICP = false>
+template <int BLOCK, int LANES, bool PASS_ONLY, bool PROF, bool ICP = false, bool SPLIT = false>
 #if LINS_LDS_MINW > 1
 __global__ __launch_bounds__(BLOCK, LINS_LDS_MINW) void ieskf_lds_kernel(
 #else
@@ -947,7 +932,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     int iter_arg, double* __restrict__ state_out, double* __restrict__ a6_out, OutRec* __restrict__ out,
     int4* __restrict__ idx_store, lins_pose_record* __restrict__ poses, int scan_id_base,
     lins_corr* __restrict__ dump, double* __restrict__ sums_out, int* __restrict__ counts_out,
-    long long* __restrict__ prof_buf) {
+    long long* __restrict__ prof_buf, SplitScan* __restrict__ hand = nullptr, SplitQ* __restrict__ hq = nullptr,
+    float4* __restrict__ hcand = nullptr) {
+  static_assert(!SPLIT || (LANES == 1 && !PASS_ONLY && !ICP), "the split hand-off exists for the one-owner-lane update kernel");
   constexpr bool prof = PROF;  // phase profile compiled in only for the debug variant
   constexpr int kLBlock = BLOCK, kQPerWave = 64 / LANES, kQPerRound = (BLOCK / 64) * kQPerWave;
   static_assert((kRegReduce || kQPerRound <= kSlotCap) && BLOCK >= 256 && BLOCK / 64 <= kMaxLWaves, "block shape");
@@ -1550,6 +1537,70 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       icp_solve_and_update(tid, iter);
     else
       solve_and_update(prm, tid, iter, prof, t3);
+    if constexpr (SPLIT) {
+      // split path (ieskf_split.h): after the update of iteration split_iters - 1 the remaining iterations go to the
+      // list kernel.  Every query leaves its candidate list, gathered around its position de-skewed with the NEW
+      // state (the "anchor") with radii from this iteration's winners — still candidates, so their distances to the
+      // anchor bound the new winners'.  (A search pass at the new state before gathering gives exact radii and
+      // fewer exhaustive searches in the list kernel, but costs more than it saves: measured.)
+      if (iter + 1 >= prm.split_iters && iter + 1 < prm.num_iter && !L.conv && !L.div) {
+        constexpr int kW = BLOCK / 64, kSS = (kW * 5 + 4) / 8;
+        int sw = (sd.n_surf_q + kQPerWave - 1) / kQPerWave;
+        const bool al = sw * kQPerWave + sd.n_corner_q <= kQPerRound;
+        int sp_s = 0, sp_c = 0;
+        {
+          const int ws = kSS, wc = kW - ws;
+          const int ps = (sd.n_surf_q + ws - 1) / ws, pc = wc > 0 ? (sd.n_corner_q + wc - 1) / wc : 65;
+          if (ws < kW && ps <= 64 && pc <= 64) sp_s = ps, sp_c = pc, sw = ws;
+        }
+        const bool spr = (sp_s | sp_c) != 0;
+        const int spn = spr ? kQPerRound : (al ? sw * kQPerWave + sd.n_corner_q : total);
+        const int vs = wave * kQPerWave + q_in_wave;
+        int slot = vs;
+        bool active = lane_used && vs < spn;
+        if (spr) {
+          if (wave < sw)
+            slot = wave * sp_s + lane, active = lane < sp_s && slot < sd.n_surf_q;
+          else
+            slot = sd.n_surf_q + (wave - sw) * sp_c + lane, active = lane < sp_c && slot < total;
+        } else if (al) {
+          if (wave < sw)
+            active = active && vs < sd.n_surf_q;
+          else
+            slot = vs - sw * kQPerWave + sd.n_surf_q;
+        }
+        active = active && slot < total;
+        if (active) {
+          const bool is_surf = slot < sd.n_surf_q;
+          const int qi = is_surf ? slot : slot - sd.n_surf_q;
+          const LCloud& c = is_surf ? cs : cc;
+          const float4 q = arena[(is_surf ? sd.off_surf_q : sd.off_corner_q) + qi];
+          const V3 phi = L.ic.phi, t{L.ic.lin[0], L.ic.lin[1], L.ic.lin[2]};
+          float ax, ay, az;
+          transform_to_start(prm, phi, t, q, ax, ay, az);
+          // (a tracked candidate beyond the search radius is no winner)
+          const float thr = prm.nearest_f;
+          const int w1 = (a1 >= 0 && pt_sqdist(L, c, a1, ax, ay, az) < thr) ? a1 : -1;
+          const int w2 = (a2 >= 0 && pt_sqdist(L, c, a2, ax, ay, az) < thr) ? a2 : -1;
+          const int w3 = (a3 >= 0 && pt_sqdist(L, c, a3, ax, ay, az) < thr) ? a3 : -1;
+          split_gather(GatherArgs{is_surf, is_surf ? sd.n_surf_q : sd.n_corner_q, sd.n_corner_t, sd.n_surf_t, n_lds, w1, w2, w3, ra1,
+                                  total, prm.pad, prm.nearest_f, prm.split_margin, ax, ay, az},
+                       gs, hq + sd.slot_base + slot, hcand + (size_t)kSplitK * sd.slot_base + slot);
+        }
+        SplitScan* hs = hand + scan;
+        if (tid < 19) hs->lin[tid] = L.ic.lin[tid];
+        if (tid >= 32 && tid < 32 + 2 * (kRingsBinned + 1)) {
+          const int k = tid - 32, cl = k / (kRingsBinned + 1), r = k % (kRingsBinned + 1);
+          hs->ring_start[cl][r] = L.ring_start[cl][r];
+        }
+        if (tid == 0) {
+          hs->res_prev = L.res_prev, hs->res_last = L.res_last, hs->upd_norm = L.upd_norm;
+          hs->iter = iter + 1, hs->status = SPLIT_CONTINUE;
+          hs->dbg[0] = L.dbg[0], hs->dbg[1] = L.dbg[1], hs->dbg[2] = L.dbg[2], hs->dbg[3] = 0;
+        }
+        return;
+      }
+    }
     if (prof) {
       long long t4 = clock64();
       if (tid == 0) {
@@ -1568,6 +1619,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     for (int k = 0; k < 16; ++k) prof_out[(size_t)scan * 16 + k] = L.prof_acc[k];
   }
 
+  if (SPLIT && tid == 0) hand[scan].status = SPLIT_DONE;  // finished here (converged / diverged / out of iterations)
   // ---- hand-off to the Joseph kernel / the caller (SE:585-598) ---------------
   const int div = L.div;
   if (ICP) {  // filterState with rn_, qbn_ replaced (SE:590-592); the covariance is the caller's, un-updated

@@ -49,6 +49,17 @@ void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDe
     LINS_LAUNCH(lds_mr, 512, 1, false);
 }
 
+// split path (ieskf_split.h): the first prm.split_iters iterations + the candidate lists for the list kernel
+void launch_lds_mr_split(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
+                         float4* sorted, const double* state_in, const double* cov_in, double* state_out, double* a6,
+                         void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, void* hand, void* hq,
+                         float4* hcand) {
+  hipLaunchKernelGGL((lds_mr::ieskf_lds_kernel<512, 1, false, false, false, true>), dim3(n), dim3(512), 0, stream, prm, descs,
+                     arena, sorted, state_in, cov_in, (const double*)nullptr, 0, state_out, a6, (lds_mr::OutRec*)out, idx_store,
+                     poses, scan_id_base, (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, (long long*)nullptr,
+                     (SplitScan*)hand, (SplitQ*)hq, hcand);
+}
+
 // ICP / Gauss-Newton fallback (estimateTransform, SE:1163-1320) on the same grid and searches:
 // state_in = the pose to start from (the filter's), state_out = that state with rn_, qbn_ replaced
 void launch_lds_mr_icp(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,

@@ -1,0 +1,145 @@
+// ieskf_rowsum.h — register-level building blocks shared by the persistent LDS kernel (ieskf_lds_impl.h) and
+// the list kernel of the split path (ieskf_k1.hip): the 6x6 solve, the next iteration's constants and the
+// wave-level reduction of the H rows to the 28 sums.  Pure functions of their arguments (no LDS, no globals).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "ieskf_device.h"
+
+namespace lins {
+
+// ---------------------------------------------------------------------------
+// 6x6 pivoted elimination, every lane of the wave redundantly in registers (the wave is
+// one instruction stream anyway): no shuffles, no LDS traffic, no barriers.  Fully
+// unrolled; row exchanges are value selects so nothing is dynamically indexed.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void reg_solve6(double (&a)[6][7], double (&x)[6]) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int p = k;
+    double best = fabs(a[k][k]);
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      double v = fabs(a[i][k]);
+      if (v > best) best = v, p = i;
+    }
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      const bool sw = (p == i);
+#pragma unroll
+      for (int j = k; j < 7; ++j) {
+        double u = a[k][j], w = a[i][j];
+        a[k][j] = sw ? w : u;
+        a[i][j] = sw ? u : w;
+      }
+    }
+    const double inv = 1.0 / a[k][k];
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) {
+      const double f = a[i][k] * inv;
+#pragma unroll
+      for (int j = k + 1; j < 7; ++j) a[i][j] -= f * a[k][j];
+    }
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double sacc = a[i][6];
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) sacc -= a[i][k] * x[k];
+    x[i] = sacc / a[i][i];
+  }
+}
+
+// Rinvleft(-phi)^T and phi from a unit quaternion without libm sin/cos: with
+// h = |phi|/2 the half angle, cos h = |w| / |q| and sin h = |v| / |q| exactly, so
+// s = h cot h needs only the atan2 that Quat2axis performs anyway (math_utils.h:75-88,
+// 304-321; differs from the sin/cos route in the last ulp only).
+__device__ __forceinline__ void phi_and_Gt(const Q4& q, V3& phi, M3& Gt) {
+  const double mag = sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
+  phi = V3{q.x, q.y, q.z};
+  Gt = M3{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
+  if (!(mag >= 1e-10)) return;  // Quat2axis leaves v unscaled; |phi| < 1e-10 => Rinvleft = I
+  const double ang = wrap_pi(2.0 * atan2(mag, q.w));
+  const V3 u = V3{q.x, q.y, q.z} / mag;
+  phi = ang * u;
+  const double theta = norm(phi);
+  if (theta < 1e-10) return;
+  const double h = theta / 2.0;
+  const double n = sqrt(q.w * q.w + mag * mag);
+  const double s = h * ((fabs(q.w) / n) / (mag / n));
+  const V3 a = V3{-phi.x, -phi.y, -phi.z} / theta;  // axis of -phi
+  const M3 k = skew(a);
+  const double av[3] = {a.x, a.y, a.z};
+  // Rinvleft(-phi) = s I + (1 - s) a a^T - h [a]x ; store the transpose
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj)
+      Gt.m[jj * 3 + i] = (s * (i == jj ? 1.0 : 0.0) + (1.0 - s) * av[i] * av[jj]) - h * k.m[i * 3 + jj];
+}
+
+// ---------------------------------------------------------------------------
+// rows -> 28 sums inside a wave without LDS: every lane forms the 28 products of its own row
+// (21 of H^T H, 6 of H^T r, r^T r; all zero for an unused lane), then five halving butterflies
+// (xor 32, 16, 8, 4, 2) in which a lane pair splits the sums it still carries — one keeps the lower
+// half, the other the upper half, each adding the partner's copy — and a final xor-1 add.  29
+// shuffles instead of 28 x 6; the tree is fixed, so the sums are bit-reproducible from run to run.
+// Afterwards lane l holds sum number reduce_sum_index(l) of the whole wave.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+  const int lo = __shfl_xor(__double2loint(v), mask), hi = __shfl_xor(__double2hiint(v), mask);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int reduce_sum_index(int lane) {
+  const int local = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+  return (local < 7 && !(lane & 1)) ? ((lane >> 5) & 1) * 14 + ((lane >> 4) & 1) * 7 + local : -1;
+}
+__device__ __forceinline__ double wave_reduce_rows(const double (&row)[7], int lane) {
+  constexpr int A[28] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6};
+  constexpr int B[28] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6};
+  double v[28];
+#pragma unroll
+  for (int k = 0; k < 28; ++k) v[k] = row[A[k]] * row[B[k]];
+  {
+    const bool up = (lane & 32) != 0;
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+      const double lo = v[i], hi = v[i + 14];
+      v[i] = (up ? hi : lo) + shfl_xor_f64(up ? lo : hi, 32);
+    }
+  }
+  {
+    const bool up = (lane & 16) != 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const double lo = v[i], hi = v[i + 7];
+      v[i] = (up ? hi : lo) + shfl_xor_f64(up ? lo : hi, 16);
+    }
+  }
+  v[7] = 0.0;
+  {
+    const bool up = (lane & 8) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double lo = v[i], hi = v[i + 4];
+      v[i] = (up ? hi : lo) + shfl_xor_f64(up ? lo : hi, 8);
+    }
+  }
+  {
+    const bool up = (lane & 4) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const double lo = v[i], hi = v[i + 2];
+      v[i] = (up ? hi : lo) + shfl_xor_f64(up ? lo : hi, 4);
+    }
+  }
+  {
+    const bool up = (lane & 2) != 0;
+    const double lo = v[0], hi = v[1];
+    v[0] = (up ? hi : lo) + shfl_xor_f64(up ? lo : hi, 2);
+  }
+  return v[0] + shfl_xor_f64(v[0], 1);
+}
+
+}  // namespace lins

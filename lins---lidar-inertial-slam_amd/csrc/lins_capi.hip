@@ -38,6 +38,13 @@ void launch_lds_mr(hipStream_t, int, const DevParams&, const ScanDesc*, const fl
 void launch_lds_mr_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, float4*, const double*,
                         const double*, int, int4*, lins_corr*, double*, int*);
 int lds_mr_np_cap();
+void launch_lds_mr_split(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, float4*, const double*,
+                         const double*, double*, double*, void*, int4*, lins_pose_record*, int, void*, void*, float4*);
+void launch_k1(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const void*, const void*, const float4*,
+               const double*, const double*, double*, double*, void*, lins_pose_record*, int, lins_corr*, int, long long*);
+size_t split_scan_size();
+size_t split_q_size();
+size_t split_cand_slots();
 void launch_lds_mr_icp(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, float4*, const double*, double*,
                        void*, int4*);
 void launch_transform_to_end(hipStream_t, int, int, const void*, const float4*, float4*, float4*);
@@ -87,6 +94,16 @@ struct lins_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;  // IESKF kernel start / end, Joseph kernel end
+  hipEvent_t ev_k0 = nullptr;  // split path: end of the grid kernel (ev0 .. ev_k0 = grid kernel, ev_k0 .. ev1 = list kernel)
+  // split path (ieskf_split.h): hand-off buffers, allocated on first use for the uploaded query slots
+  void *d_split_hand = nullptr, *d_split_q = nullptr;
+  float4* d_split_c = nullptr;
+  size_t split_slots = 0;       // slots the hand-off buffers hold
+  size_t slots_uploaded = 0;    // query slots of the uploaded batch
+  bool split_ok = false;        // every uploaded scan can take the split path
+  bool last_split = false;      // the last batch ran the split path
+  lins_corr* d_split_dump = nullptr;  // debug: the list kernel's correspondences of one iteration (lins_debug_split_dump)
+  int split_dump_iter = -1;
   lins_params prm{};
   DevParams dprm{};
   int max_batch = 0, max_targets = 0;
@@ -223,9 +240,19 @@ void make_dev_params(const lins_params& p, int search, DevParams& d) {
   d.pad = 0;
   d.margin_cold = 0.10f;
   d.margin_warm = 0.04f;
-  if (const char* e = std::getenv("LINS_MARGIN_COLD")) d.margin_cold = (float)std::atof(e);
-  if (const char* e = std::getenv("LINS_MARGIN_WARM")) d.margin_warm = (float)std::atof(e);
-  if (const char* e = std::getenv("LINS_DEBUG_SKIP")) d.pad = std::atoi(e);  // profiling aid: 1 = skip walks, 2 = skip search
+  d.split_iters = 3;
+  d.split_margin = 0.10f;
+  // Tuning / profiling knobs, honoured only when LINS_ENABLE_DEBUG_KNOBS=1 is set as well: a stray variable in a
+  // production environment changes nothing.  The margins only trade search work for certificate hits (any value
+  // >= 0 gives the same results); LINS_DEBUG_SKIP deliberately breaks the searches (profiling aid).
+  const char* gate = std::getenv("LINS_ENABLE_DEBUG_KNOBS");
+  if (gate && gate[0] == '1') {
+    if (const char* e = std::getenv("LINS_MARGIN_COLD")) d.margin_cold = std::max(0.f, (float)std::atof(e));
+    if (const char* e = std::getenv("LINS_MARGIN_WARM")) d.margin_warm = std::max(0.f, (float)std::atof(e));
+    if (const char* e = std::getenv("LINS_SPLIT_ITERS")) d.split_iters = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("LINS_SPLIT_MARGIN")) d.split_margin = std::max(0.f, (float)std::atof(e));
+    if (const char* e = std::getenv("LINS_DEBUG_SKIP")) d.pad = std::atoi(e);  // 1 = skip walks, 2 = skip search, 8 = verify
+  }
 }
 
 // "auto": one workgroup per CU is all a small batch can use — the 1024-thread kernel gives each
@@ -234,6 +261,7 @@ void make_dev_params(const lins_params& p, int search, DevParams& d) {
 // front-end can emit) take the 1-lane shapes, whose several-rounds path is the tested one.
 int effective_search(const lins_ctx* ctx, int n) {
   int s = ctx->dprm.search;
+  if (s == SEARCH_SPLIT) s = SEARCH_MR;  // (the split path exists for lins_batch_run; its grid half IS the mr kernel)
   if (s == SEARCH_AUTO) s = n > ctx->n_cu ? (int)SEARCH_MR : (int)SEARCH_LDS3;
   if (s == SEARCH_LDS3 && !ctx->lds3_ok) s = SEARCH_LDS;
   return s;
@@ -335,10 +363,13 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
     return 0;
   });
   if (rc) return rc;
-  bool lds_ok = true, mr_ok = true, lds3_ok = true;
+  bool lds_ok = true, mr_ok = true, lds3_ok = true, split_ok = true;
   for (int s = 0; s < n; ++s) {
     const ScanDesc& d = ctx->h_desc[s];
     const bool grid = d.surf_sorted && d.corner_sorted;
+    // split path: one round of the 512-lane grid kernel (its lane <-> query layout spreads <= 5 x 64 plane and
+    // <= 3 x 64 line queries over the eight waves), 16-bit candidate indices
+    if (d.n_surf_q > 320 || d.n_corner_q > 192 || d.n_surf_t > 65535 || d.n_corner_t > 65535) split_ok = false;
     if (!grid || d.n_surf_t + d.n_corner_t > lds_np_cap()) lds_ok = false;
     if (!grid || d.n_surf_t + d.n_corner_t > lds_mr_np_cap()) mr_ok = false;
     if (d.n_surf_q + d.n_corner_q > 336) lds3_ok = false;  // (16 waves x 21 query slots = the VLP-16 caps, 144 flat + 192 sharp)
@@ -352,6 +383,8 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
   ctx->lds_ok = lds_ok;
   ctx->mr_ok = mr_ok;
   ctx->lds3_ok = lds3_ok;
+  ctx->split_ok = split_ok && mr_ok;
+  ctx->slots_uploaded = slots;
   ctx->ran = false;
   ctx->bytes_per_iter = bytes;
   return LINS_OK;
@@ -392,6 +425,10 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   ctx->max_targets = max_targets;
   ctx->arena_cap = (size_t)max_batch * (2 * align4(max_targets) + 2 * LINS_MAX_QUERY);
   ctx->slot_cap = (size_t)max_batch * LINS_MAX_QUERY;
+  if (ctx->arena_cap >= (size_t)1 << 31 || ctx->slot_cap >= (size_t)1 << 31) {  // ScanDesc offsets are 32-bit
+    delete ctx;
+    return LINS_E_CAPACITY;
+  }
 #define CREATE_TRY(expr)                             \
   do {                                               \
     hipError_t e__ = (expr);                         \
@@ -410,6 +447,7 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   CREATE_TRY(hipEventCreate(&ctx->ev0));
   CREATE_TRY(hipEventCreate(&ctx->ev1));
   CREATE_TRY(hipEventCreate(&ctx->ev2));
+  CREATE_TRY(hipEventCreate(&ctx->ev_k0));
   const size_t nb = (size_t)max_batch;
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_arena, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_desc, nb * sizeof(ScanDesc)));
@@ -468,6 +506,8 @@ void lins_destroy(lins_ctx* ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+  if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
+  (void)hipFree(ctx->d_split_hand), (void)hipFree(ctx->d_split_q), (void)hipFree(ctx->d_split_c), (void)hipFree(ctx->d_split_dump);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -484,6 +524,8 @@ int lins_set_search(lins_ctx* ctx, const char* mode) {
     ctx->dprm.search = SEARCH_LDS;
   else if (!std::strcmp(mode, "mr"))  // multi-resident: part of the grid in LDS, 2 scans per CU
     ctx->dprm.search = SEARCH_MR;
+  else if (!std::strcmp(mode, "split"))  // grid kernel for the first iterations, list kernel for the rest (ieskf_split.h)
+    ctx->dprm.search = SEARCH_SPLIT;
   else if (!std::strcmp(mode, "auto"))  // "mr" for batches larger than the CU count, "lds" otherwise
     ctx->dprm.search = SEARCH_AUTO;
   else
@@ -497,12 +539,36 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   if (!ctx) return LINS_E_ARG;
   if (ctx->n_uploaded <= 0) return LINS_E_STATE;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // split path: asked for by name; needs the reference's shipped ICP_FREQ = 1 (a search every iteration) and
+  // something left for the list kernel to do
+  const bool use_split = ctx->dprm.search == SEARCH_SPLIT && ctx->split_ok && ctx->dprm.icp_freq == 1 &&
+                         ctx->dprm.num_iter > ctx->dprm.split_iters;
+  if (use_split && ctx->split_slots < ctx->slots_uploaded) {  // (grow-only hand-off buffers)
+    (void)hipFree(ctx->d_split_hand), (void)hipFree(ctx->d_split_q), (void)hipFree(ctx->d_split_c);
+    ctx->d_split_hand = ctx->d_split_q = nullptr, ctx->d_split_c = nullptr, ctx->split_slots = 0;
+    const size_t slots = ctx->slots_uploaded;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_split_hand, (size_t)ctx->max_batch * split_scan_size()));
+    HIP_TRY(ctx, hipMalloc(&ctx->d_split_q, slots * split_q_size()));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_split_c, slots * split_cand_slots() * sizeof(float4)));
+    ctx->split_slots = slots;
+  }
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const int search = effective_search(ctx, ctx->n_uploaded);
   const bool want_lds = search >= SEARCH_LDS, want_mr = search == SEARCH_MR;
   const bool use_mr = want_mr && ctx->mr_ok, use_lds = want_lds && !want_mr && ctx->lds_ok;
-  ctx->last_search = use_mr ? SEARCH_MR : (use_lds ? search : (want_lds ? (int)SEARCH_BINNED : search));
-  if (use_mr || use_lds) {
+  ctx->last_search = use_split ? (int)SEARCH_SPLIT : (use_mr ? (int)SEARCH_MR : (use_lds ? search : (want_lds ? (int)SEARCH_BINNED : search)));
+  ctx->last_split = use_split;
+  if (use_split) {
+    launch_lds_mr_split(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_binned, ctx->d_state_in,
+                        ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx, (lins_pose_record*)d_poses,
+                        scan_id_base, ctx->d_split_hand, ctx->d_split_q, ctx->d_split_c);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+    launch_k1(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_split_hand, ctx->d_split_q,
+              ctx->d_split_c, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_out,
+              (lins_pose_record*)d_poses, scan_id_base, ctx->d_split_dump, ctx->split_dump_iter, ctx->d_prof);
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    launch_joseph(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_cov_in, ctx->d_a6, ctx->d_out, ctx->d_cov_out);
+  } else if (use_mr || use_lds) {
     if (use_mr)
       launch_lds_mr(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_binned, ctx->d_state_in,
                     ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx, (lins_pose_record*)d_poses,
@@ -521,9 +587,41 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
                       (lins_pose_record*)d_poses, scan_id_base, ctx->d_binned, ctx->d_prof);
   }
   HIP_TRY(ctx, hipGetLastError());
-  if (!(use_mr || use_lds)) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  if (!(use_split || use_mr || use_lds)) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
   ctx->ran = true;
+  return LINS_OK;
+}
+
+/* Split path: durations of the two kernels of the last lins_batch_run (ms, HIP events on the context's stream). */
+int lins_last_split_ms(lins_ctx* ctx, float* grid_ms, float* list_ms) {
+  if (!ctx || !grid_ms || !list_ms) return LINS_E_ARG;
+  if (!ctx->ran || !ctx->last_split) return LINS_E_STATE;
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+  HIP_TRY(ctx, hipEventElapsedTime(grid_ms, ctx->ev0, ctx->ev_k0));
+  HIP_TRY(ctx, hipEventElapsedTime(list_ms, ctx->ev_k0, ctx->ev1));
+  return LINS_OK;
+}
+
+/* Debug aid (split path): have the list kernel record the correspondences it decided in iteration `iter` of the
+ * NEXT lins_batch_run (iter < 0: off); after that run, `out` (one lins_corr per uploaded query slot: per scan the
+ * plane queries, then the line queries) receives them.  Iterations the grid kernel ran are not recorded. */
+int lins_debug_split_dump(lins_ctx* ctx, int iter, lins_corr* out, int n_slots) {
+  if (!ctx) return LINS_E_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (out) {
+    if (!ctx->d_split_dump || n_slots < 0 || (size_t)n_slots > ctx->slots_uploaded) return LINS_E_STATE;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, ctx->d_split_dump, (size_t)n_slots * sizeof(lins_corr), hipMemcpyDeviceToHost));
+    return LINS_OK;
+  }
+  (void)hipFree(ctx->d_split_dump);
+  ctx->d_split_dump = nullptr;
+  ctx->split_dump_iter = iter;
+  if (iter >= 0) {
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_split_dump, std::max<size_t>(ctx->slots_uploaded, 1) * sizeof(lins_corr)));
+    HIP_TRY(ctx, hipMemset(ctx->d_split_dump, 0xFF, std::max<size_t>(ctx->slots_uploaded, 1) * sizeof(lins_corr)));
+  }
   return LINS_OK;
 }
 

@@ -23,7 +23,7 @@ EXPORTS = [
     "lins_last_reproject_stats", "lins_icp_update_batch", "lins_extract_features_batch", "lins_last_frontend_stats",
     "lins_streams_init", "lins_streams_step", "lins_streams_stats", "lins_streams_peek", "lins_segment_batch",
     "lins_last_segment_ms", "lins_streams_step_raw", "lins_map_correspondences", "lins_scan2map_batch",
-    "lins_last_map_stats",
+    "lins_last_map_stats", "lins_last_split_ms",
 ]
 
 
@@ -37,7 +37,8 @@ class ReprojectJob(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "liblins_ieskf.so")
+    # (LINS_IESKF_LIB: A/B timing of two builds of the library in one GPU call, tools/ab_timing.py)
+    return os.environ.get("LINS_IESKF_LIB") or os.path.join(_HERE, "liblins_ieskf.so")
 
 
 def lib():
@@ -76,6 +77,8 @@ def lib():
         L.lins_last_reproject_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
         for name in EXPORTS:
             if name not in ("lins_destroy", "lins_strerror", "lins_last_hip_error"):
+                if os.environ.get("LINS_IESKF_LIB") and not hasattr(L, name):
+                    continue  # (an older build under A/B timing)
                 getattr(L, name).restype = C.c_int
         _LIB = L
     return _LIB
@@ -337,6 +340,28 @@ class IeskfContext:
         ms = C.c_float(0)
         self._check(lib().lins_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def last_split_ms(self):
+        """(grid kernel ms, list kernel ms) of the last run in "split" mode."""
+        a, b = C.c_float(0), C.c_float(0)
+        self._check(lib().lins_last_split_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def split_dump_arm(self, it):
+        """Debug: record the list kernel's correspondences of iteration `it` during the next run (it < 0: off)."""
+        L = lib()
+        L.lins_debug_split_dump.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.lins_debug_split_dump.restype = C.c_int
+        self._check(L.lins_debug_split_dump(self._h, it, None, 0))
+
+    def split_dump_read(self, n_slots):
+        import numpy as np
+
+        from ._ctypes_defs import CORR_DTYPE
+
+        out = np.zeros(n_slots, dtype=CORR_DTYPE)
+        self._check(lib().lins_debug_split_dump(self._h, 0, out.ctypes.data, n_slots))
+        return out
 
     def bytes_per_iter(self):
         b = C.c_uint64(0)

@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""A/B kernel timing of two builds of liblins_ieskf.so in ONE GPU call (boxes differ by several per cent, so two
+calls cannot be compared): alternates the libraries, several rounds, prints the medians.
+usage: tools/ab_timing.py libA.so libB.so [mode ...]   (modes default: mr split)"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import importlib, os, sys
+import numpy as np
+from concurrent.futures import ThreadPoolExecutor
+sys.path.insert(0, %r)
+PKG = "lins---lidar-inertial-slam_amd"
+pkg = importlib.import_module(PKG); host = importlib.import_module(PKG + ".host"); ieskf = importlib.import_module(PKG + ".ieskf")
+batch, mode = int(sys.argv[1]), sys.argv[2]
+with ThreadPoolExecutor(16) as ex:
+    pairs = list(ex.map(host.synth_pair, range(batch)))
+prm = pkg.default_params(num_iter=10, fixed_iters=1)
+with ieskf.IeskfContext(prm, max_batch=batch, max_targets=16384, search=mode) as ctx:
+    ctx.upload(pairs)
+    for _ in range(3):
+        ctx.run(); ctx.sync()
+    ks = []
+    for _ in range(15):
+        ctx.run(); ctx.sync(); ks.append(ctx.last_kernel_ms())
+    extra = ""
+    try:
+        a, b = ctx.last_split_ms(); extra = " %%.4f %%.4f" %% (a, b)
+    except Exception:
+        pass
+    print("RESULT %%.4f%%s" %% (float(np.median(ks)), extra))
+''' % ROOT
+
+
+def run(lib, mode, batch=1024):
+    e = dict(os.environ, LINS_IESKF_LIB=os.path.abspath(lib))
+    p = subprocess.run([sys.executable, "-c", CHILD, str(batch), mode], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    for line in p.stdout.decode().splitlines():
+        if line.startswith("RESULT"):
+            return [float(x) for x in line.split()[1:]]
+    return [float("nan"), p.stderr.decode()[-200:]]
+
+
+libs = [a for a in sys.argv[1:] if a.endswith('.so')]
+modes = [a for a in sys.argv[1:] if not a.endswith('.so')] or ["mr", "split"]
+res = {(l, m): [] for l in libs for m in modes}
+for rnd in range(3):
+    for m in modes:
+        for l in libs:
+            res[(l, m)].append(run(l, m))
+for m in modes:
+    for l in libs:
+        r = np.array([x[:3] if len(x) >= 3 and isinstance(x[1], float) else [x[0], np.nan, np.nan] for x in res[(l, m)]], dtype=float)
+        med = np.nanmedian(r, axis=0)
+        print(f"{m:6s} {os.path.basename(l):28s} kernel {med[0]:.4f} ms" + (f" (grid {med[1]:.4f} + list {med[2]:.4f})" if not np.isnan(med[1]) else ""))
