@@ -182,33 +182,31 @@ def test_icp_freq_reuses_indices(pkg, ieskf, oracle, pairs):
             assert np.abs(got.cov - want.cov).max() <= 1e-9 * np.abs(want.cov).max()
 
 
-def test_divergence_reports_and_icp_fallback(pkg, ieskf, oracle, pairs):
-    """A wildly wrong prior with a tight covariance makes the residual blow up (SE:566-570):
-    the C ABI reports diverged + the un-updated filter state; lins_host_perform_ieskf then
-    runs the ICP fallback (SE:585-592) with GPU correspondences."""
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1", "mr", "split", "auto"])
+def test_residual_blow_up_diverges_like_the_reference(pkg, ieskf, oracle, search):
+    """SE:566-570 (diverged == 1): tests/diverging.py builds a pair whose second iteration's residual norm exceeds
+    ten times the first's — one 1 mm row, then twenty 10 cm rows after the update jumped 10 m along the only free
+    direction.  The C ABI reports diverged = 1, the iteration count of the reference's loop and the UN-updated
+    filter state and covariance (SE:585-592 keeps Pk_)."""
+    from diverging import make_diverging_pair
+
+    pair = make_diverging_pair(pkg)
     prm = pkg.default_params(num_iter=30)
-    found = 0
-    with ieskf.IeskfContext(prm, max_batch=1, max_targets=16384, search="lds") as c:
-        for k, base in enumerate(pairs):
-            st = base.state.copy()
-            st[0:3] += [1.5, -1.0, 0.3]
-            cov = base.cov * 50.0
-            pair = pkg.ScanPair(base.surf_flat, base.corner_sharp, base.surf_last, base.corner_last, st, cov)
-            want = oracle.ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_BRUTE)
-            got = c.update(pair)
-            assert (got.iters, got.converged, got.diverged) == (want.iters, want.converged, want.diverged)
-            if want.diverged:
-                found += 1
-                assert np.array_equal(got.state, pair.state) and np.array_equal(got.cov, pair.cov)
-                full, used = c.perform_ieskf(pair)
-                assert used
-                wfull = oracle.perform_ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_BRUTE)
-                assert np.abs(full.state[:3] - wfull.state[:3]).max() <= 1e-6
-                assert np.abs(full.state[6:10] - wfull.state[6:10]).max() <= 1e-7
-                assert np.array_equal(full.cov, pair.cov)
-    # the fallback must be exercised directly too, even if no prior above diverged
-    if not found:
-        pytest.skip("no synthetic prior diverged; fallback path covered by test_icp_matches_oracle")
+    want = oracle.ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_BRUTE)
+    assert (want.iters, want.converged, want.diverged, want.m_surf, want.m_corner) == (2, 0, 1, 20, 0)
+    with ieskf.IeskfContext(prm, max_batch=1, max_targets=16384, search=search) as c:
+        got = c.update(pair)
+        assert (got.iters, got.converged, got.diverged) == (want.iters, want.converged, want.diverged)
+        assert (got.m_surf, got.m_corner) == (want.m_surf, want.m_corner)
+        assert abs(got.residual_norm - want.residual_norm) <= 1e-9
+        assert np.array_equal(got.state, pair.state) and np.array_equal(got.cov, pair.cov)
+        # performIESKF as the node sees it: the ICP fallback runs (SE:585-592) and the covariance stays the prior's
+        full, used = c.perform_ieskf(pair)
+        assert used
+        wfull = oracle.perform_ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_BRUTE)
+        assert np.abs(full.state[:3] - wfull.state[:3]).max() <= 1e-6
+        assert np.abs(full.state[6:10] - wfull.state[6:10]).max() <= 1e-7
+        assert np.array_equal(full.cov, pair.cov)
 
 
 def test_icp_matches_oracle(pkg, ieskf, oracle, pairs):

@@ -74,3 +74,15 @@ def test_numpy_restatement_identities():
     s[18] = -9.81
     dx = rng.normal(size=18) * 0.1
     assert np.allclose(o.box_minus(o.box_plus(s, dx), s), dx, atol=1e-12)
+
+
+def test_diverging_pair_on_both_cpu_restatements(pkg, oracle):
+    """(CPU) the C++ oracle and the independent numpy restatement agree that the pair takes SE:566-570."""
+    from diverging import make_diverging_pair
+    from oracle import np_oracle
+
+    pair = make_diverging_pair(pkg)
+    prm = pkg.default_params(num_iter=30)
+    a = oracle.ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_BRUTE)
+    b = np_oracle.perform_ieskf(prm, pair)
+    assert (a.iters, a.converged, a.diverged, a.m_surf) == (b["iters"], b["converged"], b["diverged"], b["m_surf"]) == (2, 0, 1, 20)
