@@ -1,0 +1,63 @@
+// debug_kernels.hip — direct device evaluation of the small-math building blocks of the update path, for unit
+// tests against the CPU oracle (lins_debug_math; not part of the drop-in surface).  One thread per item.
+//   op 0  Quat2axis(q)                      MU:75-88        in 4 (w x y z)   out 3
+//   op 1  axis2Quat(v)                      MU:61-73        in 3             out 4
+//   op 2  Rinvleft(v)                       MU:304-321      in 3             out 9 (row-major)
+//   op 3  GlobalState::boxPlus(x, dx)       KF:71-81        in 19 + 18       out 19
+//   op 4  GlobalState::boxMinus(a, b)=a(-)b KF:84-94        in 19 + 19       out 18
+//   op 5  the kernels' own per-iteration constants from a linearisation state (ieskf_rowsum.h phi_and_Gt, the
+//         sin/cos-free route the persistent kernels take): in 4 (q)          out 3 (phi) + 9 (Rinvleft(-phi)^T)
+//   op 6  transformToStart                  SE:1066-1080    in 19 (linState_) + 4 (point x y z intensity) + 1 (scan period)
+//                                                           out 3 (the f32 results, widened)
+#include <hip/hip_runtime.h>
+
+#include "ieskf_device.h"
+#include "ieskf_rowsum.h"
+
+namespace lins {
+
+__global__ void debug_math_kernel(int op, int n, int n_in, int n_out, const double* __restrict__ in, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double* a = in + (size_t)i * n_in;
+  double* o = out + (size_t)i * n_out;
+  if (op == 0) {
+    const V3 v = quat2axis(Q4{a[0], a[1], a[2], a[3]});
+    o[0] = v.x, o[1] = v.y, o[2] = v.z;
+  } else if (op == 1) {
+    const Q4 q = axis2quat(V3{a[0], a[1], a[2]});
+    o[0] = q.w, o[1] = q.x, o[2] = q.y, o[3] = q.z;
+  } else if (op == 2) {
+    const M3 m = rinvleft(V3{a[0], a[1], a[2]});
+    for (int k = 0; k < 9; ++k) o[k] = m.m[k];
+  } else if (op == 3) {
+    double s[19];
+    for (int k = 0; k < 19; ++k) s[k] = a[k];
+    box_plus_inplace(s, a + 19);
+    for (int k = 0; k < 19; ++k) o[k] = s[k];
+  } else if (op == 4) {
+    IterConst ic;
+    for (int k = 0; k < 19; ++k) ic.lin[k] = a[19 + k];  // d = filter (-) lin
+    make_iter_const(a, ic);
+    for (int k = 0; k < 18; ++k) o[k] = ic.d[k];
+  } else if (op == 5) {
+    V3 phi;
+    M3 gt;
+    phi_and_Gt(Q4{a[0], a[1], a[2], a[3]}, phi, gt);
+    o[0] = phi.x, o[1] = phi.y, o[2] = phi.z;
+    for (int k = 0; k < 9; ++k) o[3 + k] = gt.m[k];
+  } else if (op == 6) {
+    DevParams prm{};
+    prm.inv_period = (double)(1.f / (float)a[23]);
+    const V3 phi = quat2axis(Q4{a[6], a[7], a[8], a[9]});
+    float x, y, z;
+    transform_to_start(prm, phi, V3{a[0], a[1], a[2]}, make_float4((float)a[19], (float)a[20], (float)a[21], (float)a[22]), x, y, z);
+    o[0] = x, o[1] = y, o[2] = z;
+  }
+}
+
+void launch_debug_math(hipStream_t stream, int op, int n, int n_in, int n_out, const double* in, double* out) {
+  hipLaunchKernelGGL(debug_math_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, op, n, n_in, n_out, in, out);
+}
+
+}  // namespace lins

@@ -42,6 +42,7 @@ void launch_lds_mr_split(hipStream_t, int, const DevParams&, const ScanDesc*, co
                          const double*, double*, double*, void*, int4*, lins_pose_record*, int, void*, void*, float4*);
 void launch_k1(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const void*, const void*, const float4*,
                const double*, const double*, double*, double*, void*, lins_pose_record*, int, lins_corr*, int, long long*);
+void launch_debug_math(hipStream_t, int, int, int, int, const double*, double*);
 size_t split_scan_size();
 size_t split_q_size();
 size_t split_cand_slots();
@@ -590,6 +591,28 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   if (!(use_split || use_mr || use_lds)) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
   ctx->ran = true;
+  return LINS_OK;
+}
+
+/* Debug aid (unit tests of the device math against the oracle; see debug_kernels.hip for the op codes):
+ * evaluates op on n items of n_in doubles each, n_out doubles out per item. */
+int lins_debug_math(lins_ctx* ctx, int op, int n, const double* in, int n_in, double* out, int n_out) {
+  static const int kIn[7] = {4, 3, 3, 37, 38, 4, 24}, kOut[7] = {3, 4, 9, 19, 18, 12, 3};
+  if (!ctx || !in || !out || op < 0 || op > 6 || n < 0 || n_in != kIn[op] || n_out != kOut[op]) return LINS_E_ARG;
+  if (n == 0) return LINS_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  double *d_in = nullptr, *d_out = nullptr;
+  HIP_TRY(ctx, hipMalloc((void**)&d_in, (size_t)n * n_in * 8));
+  hipError_t e = hipMalloc((void**)&d_out, (size_t)n * n_out * 8);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, (size_t)n * n_in * 8, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    launch_debug_math(ctx->stream, op, n, n_in, n_out, d_in, d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n * n_out * 8, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_in), (void)hipFree(d_out);
+  if (e != hipSuccess) return fail_hip(ctx, e, "lins_debug_math");
   return LINS_OK;
 }
 

@@ -1,0 +1,118 @@
+"""Direct device tests of the small-math building blocks through lins_debug_math, against
+the CPU oracle's own helpers: Quat2axis / axis2Quat / Rinvleft (MU:61-88, 304-321), GlobalState boxPlus / boxMinus
+(KF:71-94), the kernels' sin/cos-free route to phi and Rinvleft(-phi)^T, and transformToStart (SE:1066-1080) —
+including the branches the end-to-end tests never reach: |theta| < 1e-10, w < 0 (angle beyond pi, wrap_pi),
+rotations close to pi."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg, ieskf):
+    c = ieskf.IeskfContext(pkg.default_params(), max_batch=1, max_targets=1024)
+    yield c
+    c.close()
+
+
+def dev(ieskf, ctx, op, x, n_out):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros((len(x), n_out))
+    L = ieskf.lib()
+    L.lins_debug_math.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    L.lins_debug_math.restype = C.c_int
+    assert L.lins_debug_math(ctx._h, op, len(x), x.ctypes.data, x.shape[1], out.ctypes.data, n_out) == 0
+    return out
+
+
+def quats(rng, n):
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    # special cases: identity, tiny vector parts around the 1e-10 branch, w < 0, w = 0, rotation by ~pi
+    extra = [[1, 0, 0, 0], [1, 3e-11, 0, 0], [1, 0, 2e-10, 0], [1, 9.99e-11, 0, 0], [-1, 1e-11, 0, 0], [-0.6, 0.8, 0, 0],
+             [0, 1, 0, 0], [1e-9, 0.6, 0.8, 0], [-1e-9, 0, 0.6, 0.8], [0.5, -0.5, 0.5, -0.5]]
+    return np.concatenate([np.array(extra, dtype=np.float64), q])
+
+
+def vecs(rng, n):
+    v = rng.normal(size=(n, 3)) * rng.choice([1e-12, 1e-6, 1e-2, 0.5, 2.0], size=(n, 1))
+    extra = [[0, 0, 0], [5e-11, 0, 0], [0, 1.0001e-10, 0], [0, 0, 9.999e-11], [3.0, 0, 0], [0, 3.14159, 0], [0, 0, -3.2]]
+    return np.concatenate([np.array(extra, dtype=np.float64), v])
+
+
+def test_quat2axis_axis2quat_rinvleft(ieskf, oracle, ctx):
+    rng = np.random.default_rng(11)
+    q = quats(rng, 200)
+    got = dev(ieskf, ctx, 0, q, 3)
+    want = np.array([oracle.quat2axis(x) for x in q])
+    assert np.abs(got - want).max() <= 1e-14  # (device atan2 vs glibc: last ulp of an angle <= 2 pi)
+    v = vecs(rng, 200)
+    got = dev(ieskf, ctx, 1, v, 4)
+    want = np.array([oracle.axis2quat(x) for x in v])
+    assert np.abs(got - want).max() <= 1e-15
+    assert np.array_equal(got[0], [1, 0, 0, 0]) and np.array_equal(got[1], [1, 0, 0, 0]) and np.array_equal(got[3], [1, 0, 0, 0])
+    assert got[2, 0] != 1.0 or got[2, 2] != 0.0  # |v| = 1.0001e-10 is past the branch: a real rotation
+    got = dev(ieskf, ctx, 2, v, 9)
+    want = np.array([oracle.rinvleft(x) for x in v]).reshape(-1, 9)
+    scale = np.maximum(1.0, np.abs(want).max(axis=1, keepdims=True))
+    assert (np.abs(got - want) / scale).max() <= 1e-13  # (cot(theta/2) near theta = 2 pi is large: relative)
+    assert np.array_equal(got[0].reshape(3, 3), np.eye(3)) and np.array_equal(got[1].reshape(3, 3), np.eye(3))
+
+
+def test_box_plus_box_minus(ieskf, oracle, ctx):
+    rng = np.random.default_rng(12)
+    n = 200
+    q = quats(rng, n - 10)
+    s = rng.normal(size=(n, 19))
+    s[:, 6:10] = q
+    dx = rng.normal(size=(n, 18)) * rng.choice([1e-12, 1e-4, 0.1, 1.5], size=(n, 1))
+    dx[:3, 6:9] = [[0, 0, 0], [5e-11, 0, 0], [0, 0, 2e-10]]
+    got = dev(ieskf, ctx, 3, np.concatenate([s, dx], axis=1), 19)
+    want = np.array([oracle.box_plus(a, b) for a, b in zip(s, dx)])
+    assert np.abs(got - want).max() <= 1e-14
+    assert np.abs(np.linalg.norm(got[:, 6:10], axis=1) - 1).max() <= 1e-15  # boxPlus normalises (KF:78)
+    b = rng.normal(size=(n, 19))
+    b[:, 6:10] = quats(rng, n - 10)
+    b[:5, 6:10] = s[:5, 6:10]  # equal attitudes: Quat2axis of the identity (the < 1e-10 branch)
+    got = dev(ieskf, ctx, 4, np.concatenate([s, b], axis=1), 18)
+    want = np.array([oracle.box_minus(x, y) for x, y in zip(s, b)])
+    assert np.abs(got - want).max() <= 1e-13
+    # (x [+] d) [-] x = d on the device alone, for increments below pi
+    d_small = rng.normal(size=(n, 18)) * 0.3
+    plus = dev(ieskf, ctx, 3, np.concatenate([s, d_small], axis=1), 19)
+    back = dev(ieskf, ctx, 4, np.concatenate([plus, s], axis=1), 18)
+    assert np.abs(back - d_small).max() <= 1e-12
+
+
+def test_kernel_iteration_constants_route(ieskf, oracle, ctx):
+    """phi_and_Gt (what the persistent kernels really run between iterations: h cot h from the quaternion's own
+    half-angle, no sin / cos) against the reference's formulas Quat2axis + Rinvleft(-phi)."""
+    rng = np.random.default_rng(13)
+    q = quats(rng, 300)
+    got = dev(ieskf, ctx, 5, q, 12)
+    phi = np.array([oracle.quat2axis(x) for x in q])
+    assert np.abs(got[:, :3] - phi).max() <= 1e-14
+    gt = np.array([oracle.rinvleft(-p).T for p in phi]).reshape(-1, 9)
+    scale = np.maximum(1.0, np.abs(gt).max(axis=1, keepdims=True))
+    assert (np.abs(got[:, 3:] - gt) / scale).max() <= 1e-12
+
+
+def test_transform_to_start(pkg, ieskf, oracle, ctx):
+    rng = np.random.default_rng(14)
+    n = 400
+    prm = pkg.default_params()
+    lin = rng.normal(size=(n, 19))
+    lin[:, 6:10] = quats(rng, n - 10)
+    lin[:10, 6:10] = [1, 0, 0, 0]  # no rotation at all: the theta < 1e-10 branch of axis2Quat(s * phi)
+    pts = np.zeros((n, 4), dtype=np.float32)
+    pts[:, :3] = rng.normal(size=(n, 3)) * 20
+    pts[:, 3] = rng.integers(0, 16, size=n) + rng.uniform(-0.02, 0.12, size=n)  # ring + 0.1 * relTime (SE:649-650)
+    pts[:5, 3] = [0.0, 3.0, -0.01, 15.1, 7.05]
+    x = np.concatenate([lin, pts.astype(np.float64), np.full((n, 1), prm.scan_period)], axis=1)
+    got = dev(ieskf, ctx, 6, x, 3).astype(np.float32)
+    want = np.array([oracle.transform_to_start(prm, l, p)[0, :3] for l, p in zip(lin, pts)], dtype=np.float32)
+    ulp = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1 and (ulp > 0).mean() <= 1e-3  # (f64 sin / cos of ocml vs glibc under an f32 rounding)

@@ -78,7 +78,7 @@ def test_reduction_and_host_solve(pkg, ieskf, oracle, ctx, pairs, search):
         assert np.abs(dx - tr["dx"][k]).max() <= 1e-8 * max(1.0, np.abs(tr["dx"][k]).max())
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1", "mr", "auto"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1", "mr", "split", "auto"])
 def test_full_ieskf_matches_oracle(pkg, oracle, ctx, pairs, search):
     """configs[2]: on-device reduction + solve + full loop, reference stop rule."""
     ctx.set_search(search)
@@ -115,6 +115,7 @@ def test_warm_started_search_returns_the_same_triplets(pkg, ieskf, oracle, pairs
     """Iterations >= 1 start the search from the previous iteration's triplet (bounds only).
     Debug flag 4 makes the single-pass kernel run the pass twice, the second time warm: the
     dumped records must still be the oracle's, bit for bit."""
+    monkeypatch.setenv("LINS_ENABLE_DEBUG_KNOBS", "1")
     monkeypatch.setenv("LINS_DEBUG_SKIP", "4")
     prm = pkg.default_params(num_iter=30)
     with ieskf.IeskfContext(prm, max_batch=1, max_targets=16384, search=search) as c:
@@ -133,6 +134,7 @@ def test_search_certificates_never_disagree_with_a_real_search(pkg, ieskf, oracl
     prm = pkg.default_params(num_iter=10, fixed_iters=1)
     batch = host.synth_batch(24, start=100)
     want = [oracle.ieskf(prm, p, oracle.FORM_DENSE, oracle.NN_KDTREE) for p in batch]
+    monkeypatch.setenv("LINS_ENABLE_DEBUG_KNOBS", "1")
     monkeypatch.setenv("LINS_DEBUG_SKIP", "8")
     lib = ieskf.lib()
     import ctypes as C
