@@ -29,21 +29,78 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
 def traffic_from_profiles(search):
-    """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE x2 on gfx950 +
-    WRITE_SIZE, MI355X_MICROARCH.md).  PMC collection needs rocprofv3 around the process, so it is
-    measured in a separate run of this same command (tools/pmc_run.sh) and read back from the latest
-    profiles/rNN_pmc_traffic.json; null when there is no such file for this search mode."""
+    """HBM-side bytes per launch of the dominant kernel from the PMC counters.  PMC collection needs rocprofv3 around
+    the process, so it happens in a separate run of this same command (tools/pmc_traffic.py on the GPU box, which
+    also calibrates FETCH_SIZE / WRITE_SIZE on a streaming copy of known size) and is read back from the newest
+    profiles/rNN_pmc_traffic.json — but only when that record was taken from exactly these sources (content digest
+    of csrc/ + include/, the stamp build() uses): a record of another build is reported as stale, not as a number.
+    -> (traffic dict | None, note)"""
     import glob
 
-    if search not in ("auto", "mr"):
-        return None
+    import __graft_entry__ as g
+
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
-        return None
+        return None, "no PMC record"
     try:
-        return float(json.load(open(files[-1]))["traffic_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
-        return None
+        rec = json.load(open(files[-1]))
+    except (OSError, ValueError):
+        return None, "unreadable PMC record"
+    if rec.get("search") not in (search, "auto" if search == "mr" else search):
+        return None, f"PMC record is for search={rec.get('search')}"
+    if rec.get("source_digest") != g._source_digest():
+        return None, "stale: PMC record taken from other sources (" + os.path.basename(files[-1]) + ")"
+    keep = ("bytes_lo", "bytes_hi", "fetch_size_bytes", "write_size_bytes", "calibration", "kernel", "meaning")
+    return {k: rec[k] for k in keep if k in rec}, os.path.basename(files[-1])
+
+
+def reference_stop_rule_rate(pkg, ieskf, pairs, args, max_targets):
+    """The same scans under the reference's own loop control (SE:475, 575-578: NUM_ITER = 30, stop at |dx| <= 1e-2):
+    what the path delivers when it is used as performIESKF is — scans/s, and the iterations they really needed."""
+    import numpy as np
+
+    prm = pkg.default_params(num_iter=30, fixed_iters=0)
+    with ieskf.IeskfContext(prm, max_batch=len(pairs), max_targets=max(max_targets, 1024), search=args.search) as c:
+        c.upload(pairs)
+        for _ in range(2):
+            c.run()
+            c.sync()
+        t0 = time.perf_counter()
+        n = 10
+        for _ in range(n):
+            c.run()
+            c.sync()
+        dt = (time.perf_counter() - t0) / n
+        its = c.total_iters()
+        res = c.download()
+    return {"scans_per_s": len(pairs) / dt, "iterations_per_s": its / dt, "ms_per_step": dt * 1e3,
+            "mean_iterations_per_scan": its / len(pairs), "converged": int(sum(r.converged for r in res)),
+            "diverged": int(sum(r.diverged for r in res)), "num_iter": 30, "stop_rule": "|dx| <= 1e-2 (SE:575-578)"}
+
+
+def single_scan_latency(pkg, ieskf, pair):
+    """BASELINE.json configs[2]: ONE scan pair, full on-device loop (the live lins_fusion_node case): kernel time
+    of the single-scan kernel and the end-to-end latency of lins_ieskf_update (upload + kernels + download)."""
+    import numpy as np
+
+    prm = pkg.default_params(num_iter=30, fixed_iters=0)
+    with ieskf.IeskfContext(prm, max_batch=1, max_targets=16384, search="auto") as c:
+        c.upload([pair])
+        ks, e2e = [], []
+        for k in range(25):
+            c.run()
+            c.sync()
+            if k >= 5:
+                ks.append(c.last_kernel_ms())
+        its = c.total_iters()
+        for k in range(25):
+            t0 = time.perf_counter()
+            c.update(pair)
+            if k >= 5:
+                e2e.append((time.perf_counter() - t0) * 1e3)
+    return {"kernel": "lds_full::ieskf_lds_kernel<1024,3>", "kernel_ms": float(np.median(ks)), "iterations": int(its),
+            "us_per_iteration": float(np.median(ks)) * 1e3 / max(int(its), 1), "update_call_ms_incl_pcie": float(np.median(e2e)),
+            "stop_rule": "|dx| <= 1e-2 (SE:575-578), NUM_ITER 30"}
 
 
 def self_launch(args):
@@ -113,6 +170,7 @@ def main():
     ap.add_argument("--search", default=os.environ.get("LINS_SEARCH", "auto"))
     ap.add_argument("--cpu-sample", type=int, default=192, help="scans timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the reference-stop-rule and single-scan blocks")
     ap.add_argument("--dry-run", action="store_true", help="launcher + pose gather only, gloo, no GPU (test aid)")
     args = ap.parse_args()
 
@@ -226,6 +284,7 @@ def main():
         # algorithmic bytes per launch = sum_scans B_iter(scan) * iterations(scan); with the
         # fixed-iteration mode every non-diverged scan runs args.iters iterations
         alg_bytes = bytes_iter_local / len(pairs) * iters_local
+        traffic = traffic_from_profiles(args.search)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "ESKF iterations/sec (16x1800 VLP-16, ~2k feat)",
@@ -262,7 +321,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic_from_profiles(args.search),
+                "traffic": traffic[0]["bytes_hi"] if traffic[0] else None,  # fabric-side upper bound, see traffic_detail
+                "traffic_detail": traffic[0],
+                "traffic_source": traffic[1],
                 "copy_ceiling_GBs": copy_gbs,  # measured stream-copy rate (read + write) on this box
                 "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
                 "alg_bytes_per_launch": alg_bytes,
@@ -288,6 +349,9 @@ def main():
                 "all_cores": {"value": itn / secn, "cores": ncpu},
                 "reduced_6x6_form_1core": {"value": itr / secr, "cores": 1},
             }
+        if world == 1 and not args.no_extras:
+            out["reference_stop_rule"] = reference_stop_rule_rate(pkg, ieskf, pairs, args, max_targets)
+            out["single_scan"] = single_scan_latency(pkg, ieskf, pairs[0])
     else:
         out = None
     ctx.close()

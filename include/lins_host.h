@@ -124,7 +124,12 @@ int lins_last_frontend_stats(lins_ctx* ctx, float* kernel_ms, uint64_t* bytes);
  * A stream's first scan has nothing to match against: no update is run (out[k].iters = 0, state / covariance
  * returned as given) and its clouds are re-projected with the pose in prior_state[k] (the caller's bootstrap
  * guess, SE:331-425 uses the IMU-integrated one).  prior_state: n x 19, prior_cov: n x 324, feature_counts
- * (optional): n x 4 = sharp, less sharp, flat, less flat.                                                   */
+ * (optional): n x 4 = sharp, less sharp, flat, less flat.
+ * A step completes for EVERY stream or not at all: a diverged stream whose clouds cannot take the device ICP
+ * fallback (ICP_FREQ != 1, or clouds beyond the grid kernels' limits) keeps its un-updated filter — out[k].diverged
+ * set and out[k].reserved[0] = LINS_E_UNSUPPORTED — while the other streams advance normally; a rejected input
+ * (LINS_E_INPUT / _ARG / _CAPACITY) advances nothing; a HIP error (LINS_E_HIP) leaves the resident clouds in an
+ * unknown state, every later step then returns LINS_E_STATE until lins_streams_init is called again.       */
 int lins_streams_init(lins_ctx* ctx, int n_streams);   /* n_streams <= the context's max_batch */
 int lins_streams_step(lins_ctx* ctx, const lins_segmented_scan* scans, const double* prior_state,
                       const double* prior_cov, double scan_period, lins_result* out, int32_t* feature_counts);

@@ -56,6 +56,55 @@ __global__ void debug_math_kernel(int op, int n, int n_in, int n_out, const doub
   }
 }
 
+// op 100..: cycle counts of the building blocks (microbenchmark): out[0] = shader cycles per call, one 256-thread
+// workgroup per launch block, `n` blocks (to load the CU with several), 64 dependent repetitions
+__global__ __launch_bounds__(256) void debug_cycles_kernel(int op, const double* __restrict__ in, double* __restrict__ out) {
+  const int tid = threadIdx.x;
+  DevParams prm{};
+  prm.inv_period = 10.0, prm.icp_freq = 1, prm.lidar_scale = 1.0;
+  V3 phi{in[0], in[1], in[2]}, t{in[3], in[4], in[5]};
+  float4 q = make_float4((float)in[6] + tid * 0.01f, (float)in[7], (float)in[8], 3.05f);
+  float acc = 0.f;
+  double dacc = 0.0;
+  const long long t0 = clock64();
+#pragma unroll 1
+  for (int r = 0; r < 64; ++r) {
+    if (op == 100) {  // transformToStart
+      float x, y, z;
+      transform_to_start(prm, phi, t, q, x, y, z);
+      q.x = x * 0.999f + acc * 1e-9f, acc += y + z;
+    } else if (op == 101) {  // plane row
+      QueryOut o;
+      o.accepted = 0;
+      o.c[0] = o.c[1] = o.c[2] = o.c[3] = 0.f;
+      surf_row(prm, 1, q.x, q.y, q.z, make_float4(1.f + acc, 2.f, 3.f, 0.f), make_float4(1.5f, 2.2f, 3.f, 0.f), make_float4(1.f, 2.6f, 3.1f, 0.f), o);
+      acc += o.c[0] * 1e-3f + o.c[3];
+    } else if (op == 102) {  // 28 sums of a wave
+      double row[7] = {dacc + 1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0 + tid};
+      dacc += wave_reduce_rows(row, tid & 63) * 1e-9;
+    } else if (op == 103) {  // 6x6 solve in one lane
+      if ((tid & 63) == 0) {
+        double a[6][7], x6[6];
+        for (int i = 0; i < 6; ++i)
+          for (int j = 0; j < 7; ++j) a[i][j] = (i == j ? 10.0 : 0.1 * (i + j)) + dacc;
+        reg_solve6(a, x6);
+        dacc += x6[0] * 1e-9;
+      }
+    } else if (op == 104) {  // next iteration's constants
+      V3 p2;
+      M3 gt;
+      phi_and_Gt(Q4{1.0 - dacc, 0.01, 0.02, 0.03 + dacc}, p2, gt);
+      dacc += (p2.x + gt.m[1]) * 1e-9;
+    }
+  }
+  const long long t1 = clock64();
+  if (tid == 0) out[blockIdx.x * 2] = (double)(t1 - t0) / 64.0, out[blockIdx.x * 2 + 1] = (double)acc + dacc;
+}
+
+void launch_debug_cycles(hipStream_t stream, int op, int blocks, const double* in, double* out) {
+  hipLaunchKernelGGL(debug_cycles_kernel, dim3(blocks), dim3(256), 0, stream, op, in, out);
+}
+
 void launch_debug_math(hipStream_t stream, int op, int n, int n_in, int n_out, const double* in, double* out) {
   hipLaunchKernelGGL(debug_math_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, op, n, n_in, n_out, in, out);
 }

@@ -44,6 +44,7 @@ struct Lds {
   int ring_start[2][kRingsBinned + 1];
   int m_surf, m_corner, iter, conv, div;
   int nbrute, brute_total, gcount;
+  long long prof[8];  // phase clocks of the PROF variant
   unsigned short brute_q[kBruteCap];
 };
 __shared__ Lds g;
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
   if (tid == 0) {
     L.res_prev = hs->res_prev, L.res_last = hs->res_last, L.upd_norm = hs->upd_norm;
     L.iter = hs->iter, L.conv = 0, L.div = 0, L.m_surf = 0, L.m_corner = 0, L.brute_total = 0;
+    for (int k = 0; k < 8; ++k) L.prof[k] = 0;
   }
   __syncthreads();
   if (tid < 64) {  // wave 0, lane-redundant: constants of the first iteration
@@ -355,6 +357,7 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
     if (tid == 0) L.m_surf = 0, L.m_corner = 0;
     double acc = 0;
     int ms = 0, mc = 0;
+    long long pt[6] = {PROF ? clock64() : 0, 0, 0, 0, 0, 0};  // phase clocks of the PROF variant (lane 0 of wave 0 reports)
     for (int base = 0; base < total; base += kBlock) {
       const int slot = base + tid;
       const bool active = slot < total;
@@ -380,6 +383,7 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
         q = arena[(is_surf ? sd.off_surf_q : sd.off_corner_q) + qi];
         const V3 t{L.ic.lin[0], L.ic.lin[1], L.ic.lin[2]};
         transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2]);
+        if (PROF) pt[1] = clock64();
         const float sx = o.sel[0], sy = o.sel[1], sz = o.sel[2];
         SplitQ mq;
         {
@@ -476,6 +480,7 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
           was_brute = true;
         }
       }
+      if (PROF) pt[2] = clock64();
       __syncthreads();
       const int nb = L.nbrute;  // (uniform)
       for (int b = 0; b < nb; ++b) {
@@ -509,6 +514,7 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
         __syncthreads();
       }
       if (nb && tid == 0) L.brute_total += nb;
+      if (PROF) pt[3] = clock64();
       double row[7] = {0, 0, 0, 0, 0, 0, 0};
       if (active) {
         if (is_surf) {
@@ -536,7 +542,9 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
           dump[sd.slot_base + slot] = r;
         }
       }
+      if (PROF) pt[4] = clock64();
       acc += wave_reduce_rows(row, lane);
+      if (PROF) pt[5] = clock64();
     }
     {
       const int sidx28 = reduce_sum_index(lane);
@@ -552,7 +560,16 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
       L.sums[tid] = sacc;
     }
     __syncthreads();
+    const long long ts0 = PROF ? clock64() : 0;
     solve_and_update(prm, tid, iter);
+    if (PROF && tid == 0) {
+      // [0] de-skew [1] meta + list pass + certificates [2] wait + exhaustive searches [3] rows [4] wave reduction
+      // [5] barriers + fold of the partials [6] solve + update   (thread 0's view, summed over the iterations)
+      long long* pp = L.prof;  // (LDS: a global accumulator would put its own memory latency into the next phase)
+      const long long te = clock64();
+      pp[0] += pt[1] - pt[0], pp[1] += pt[2] - pt[1], pp[2] += pt[3] - pt[2], pp[3] += pt[4] - pt[3], pp[4] += pt[5] - pt[4];
+      pp[5] += ts0 - pt[5], pp[6] += te - ts0, pp[7] += 1;
+    }
   }
 
   // ---- hand-off to the Joseph kernel / the caller (SE:585-598), as the persistent kernel does ----
@@ -566,7 +583,10 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
     r.m_surf = L.m_surf, r.m_corner = L.m_corner;
     r.pad[0] = hs->dbg[0], r.pad[1] = hs->dbg[1], r.pad[2] = L.brute_total;
     out[scan] = r;
-    if (PROF) prof_buf[(size_t)scan * 16 + 12] = clock64() - t_begin;
+    if (PROF) {
+      for (int k = 0; k < 8; ++k) prof_buf[(size_t)scan * 16 + k] = L.prof[k];
+      prof_buf[(size_t)scan * 16 + 12] = clock64() - t_begin;
+    }
   }
   if (poses && tid < 32) {
     lins_pose_record* pr = poses + scan;

@@ -1080,7 +1080,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         }
         if (prof) {
           s1 = clock64();
+#ifndef LINS_PROF_WAVES
           if (tid == 0) L.prof_acc[6] += s1 - s0;
+#endif
         }
         auto dist_to = [&](int pos) { return pt_sqdist(L, c, pos, o.sel[0], o.sel[1], o.sel[2]); };
         auto drift_from = [&](const float* cp) {
@@ -1163,7 +1165,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           if (active) sel1 = p1;
           if (prof) {
             s2 = clock64();
+#ifndef LINS_PROF_WAVES
             if (tid == 0) L.prof_acc[7] += s2 - s1;
+#endif
           }
           // --- second / third point: certificate (owner) --------------------------------------------------
           bool need_walk = false, flip2 = false, flip3 = false, said23 = false;
@@ -1243,7 +1247,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
               atomicAdd(&L.dbg[2], 1);
             }
           }
+#ifndef LINS_PROF_WAVES
           if (prof && tid == 0) L.prof_acc[8] += clock64() - s2;
+#endif
           if (active && prm.icp_freq > 1) {
             // ICP mode: estimateTransform searches the corners only after >= 10 plane rows were accepted
             // (SE:1175-1178) — a corner triplet is committed after the reduction, once that count is known
@@ -1294,7 +1300,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
             dump[sd.slot_base + slot] = r;
           }
         }
+#ifndef LINS_PROF_WAVES
         if (prof && tid == 0) L.prof_acc[9] += clock64() - s3;
+#endif
       } else if (active) {
         const bool is_surf = slot < sd.n_surf_q;
         const int qi = is_surf ? slot : slot - sd.n_surf_q;
@@ -1307,7 +1315,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2]);
         if (prof) {
           s1 = clock64();
+#ifndef LINS_PROF_WAVES
           if (tid == 0) L.prof_acc[6] += s1 - s0;
+#endif
         }
         o.accepted = 0;
         o.c[0] = o.c[1] = o.c[2] = o.c[3] = 0.f;
@@ -1370,7 +1380,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           sel1 = p1;
           if (prof) {
             s2 = clock64();
+#ifndef LINS_PROF_WAVES
             if (tid == 0) L.prof_acc[7] += s2 - s1;
+#endif
           }
           // --- second / third point ------------------------------------------------------------------
           if (p1 >= 0) {
@@ -1422,7 +1434,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
             }
           }
           have_cert = single_round;
+#ifndef LINS_PROF_WAVES
           if (prof && tid == 0) L.prof_acc[8] += clock64() - s2;
+#endif
           if (prm.icp_freq > 1 && role == 0) {
             // ICP mode: estimateTransform searches the corners only after >= 10 plane rows were accepted
             // (SE:1175-1178) — a corner triplet is committed after the reduction, once that count is known
@@ -1473,10 +1487,15 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
             dump[sd.slot_base + slot] = r;
           }
         }
+#ifndef LINS_PROF_WAVES
         if (prof && tid == 0) L.prof_acc[9] += clock64() - s3;
+#endif
       }
       if (kRegReduce) {
         if (prof) t1 = clock64();
+#ifdef LINS_PROF_WAVES  // (experiment: per-wave correspondence time of the late iterations in slots 6..13)
+        if (prof && lane == 0 && iter >= LINS_PROF_WAVES) L.prof_acc[6 + wave] += t1 - t0;
+#endif
         acc += wave_reduce_rows(row, lane);  // no LDS, no barrier: the rows never leave registers
       } else {
         if (lane_used && role == 0) {
@@ -1605,7 +1624,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       long long t4 = clock64();
       if (tid == 0) {
         L.prof_acc[1] += t1 - t0, L.prof_acc[2] += t2 - t1, L.prof_acc[3] += t3 - t2, L.prof_acc[4] += t4 - t3;
+#ifndef LINS_PROF_WAVES
         if (iter < 3) L.prof_acc[10 + iter] = t4 - t0;
+#endif
       }
     }
   }
@@ -1613,8 +1634,10 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     long long* prof_out = prof_buf;
     L.prof_acc[5] = clock64() - t_begin;
     // residency probe: [13] = HW_ID | XCC_ID << 32, [14] / [15] = start / end on the 100 MHz wall clock
+#ifndef LINS_PROF_WAVES
     L.prof_acc[13] = (long long)(unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |
                      ((long long)(unsigned)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);
+#endif
     L.prof_acc[14] = t_wall_begin, L.prof_acc[15] = wall_clock64();
     for (int k = 0; k < 16; ++k) prof_out[(size_t)scan * 16 + k] = L.prof_acc[k];
   }

@@ -43,6 +43,7 @@ void launch_lds_mr_split(hipStream_t, int, const DevParams&, const ScanDesc*, co
 void launch_k1(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const void*, const void*, const float4*,
                const double*, const double*, double*, double*, void*, lins_pose_record*, int, lins_corr*, int, long long*);
 void launch_debug_math(hipStream_t, int, int, int, int, const double*, double*);
+void launch_debug_cycles(hipStream_t, int, int, const double*, double*);
 size_t split_scan_size();
 size_t split_q_size();
 size_t split_cand_slots();
@@ -159,6 +160,7 @@ struct lins_ctx {
     ScanDesc* d_desc = nullptr;
     void* d_jobs = nullptr;
     std::vector<int> last_counts;  // per stream: less sharp, less flat of the resident last scan (-1: none yet)
+    bool failed = false;           // a step stopped half way (HIP error): the resident clouds are not trustworthy any more
     float update_ms = 0.f, frontend_ms = 0.f, reproject_ms = 0.f;
   } st;
   void* map_state = nullptr;  // scan-to-map row (lins_map_capi.hip), freed through map_state_free
@@ -560,6 +562,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   ctx->last_search = use_split ? (int)SEARCH_SPLIT : (use_mr ? (int)SEARCH_MR : (use_lds ? search : (want_lds ? (int)SEARCH_BINNED : search)));
   ctx->last_split = use_split;
   if (use_split) {
+    if (ctx->d_prof) HIP_TRY(ctx, hipMemsetAsync(ctx->d_prof, 0, (size_t)ctx->max_batch * 16 * sizeof(long long), ctx->stream));
     launch_lds_mr_split(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_binned, ctx->d_state_in,
                         ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx, (lins_pose_record*)d_poses,
                         scan_id_base, ctx->d_split_hand, ctx->d_split_q, ctx->d_split_c);
@@ -597,6 +600,18 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
 /* Debug aid (unit tests of the device math against the oracle; see debug_kernels.hip for the op codes):
  * evaluates op on n items of n_in doubles each, n_out doubles out per item. */
 int lins_debug_math(lins_ctx* ctx, int op, int n, const double* in, int n_in, double* out, int n_out) {
+  if (ctx && in && out && op >= 100 && op <= 104 && n >= 1 && n_in >= 9 && n_out == 2) {  // cycle microbenchmarks, n blocks
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_in, 9 * 8));
+    HIP_TRY(ctx, hipMalloc((void**)&d_out, (size_t)n * 2 * 8));
+    HIP_TRY(ctx, hipMemcpy(d_in, in, 9 * 8, hipMemcpyHostToDevice));
+    launch_debug_cycles(ctx->stream, op, n, d_in, d_out);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, d_out, (size_t)n * 2 * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(d_in), (void)hipFree(d_out);
+    return LINS_OK;
+  }
   static const int kIn[7] = {4, 3, 3, 37, 38, 4, 24}, kOut[7] = {3, 4, 9, 19, 18, 12, 3};
   if (!ctx || !in || !out || op < 0 || op > 6 || n < 0 || n_in != kIn[op] || n_out != kOut[op]) return LINS_E_ARG;
   if (n == 0) return LINS_OK;
@@ -992,8 +1007,17 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
                              lins_result* out, int32_t* feature_counts) {
   if (!ctx || !prior_state || !prior_cov || !out) return LINS_E_ARG;
   auto& t = ctx->st;
-  if (t.n <= 0) return LINS_E_STATE;
+  if (t.n <= 0 || t.failed) return LINS_E_STATE;  // (after a failed step: lins_streams_init again)
   if (stream_cloud_size() != sizeof(StreamCloudHost)) return LINS_E_STATE;
+  // A step either completes for every stream — slots flipped, resident clouds re-projected — or marks the streams
+  // context failed: no half-advanced state survives an early return.
+  struct Guard {
+    bool& failed;
+    bool done = false;
+    ~Guard() {
+      if (!done) failed = true;
+    }
+  } guard{t.failed};
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int n = t.n, cur = t.cur, last = cur ^ 1;
   ctx->n_uploaded = 0, ctx->ran = false;  // the batch buffers are reused below
@@ -1010,12 +1034,18 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
     rc = fe_run(ctx, n, scans, scan_period, t.d_arena, reinterpret_cast<const long long(*)[4]>(offs.data()), counts);
   } else {  // raw clouds: the image_projection stage on the device feeds the front-end where its output lies
     rc = sg_run(ctx, n, raw, n_raw, reinterpret_cast<const long long(*)[4]>(offs.data()));
-    if (rc) return rc;
+    if (rc) {
+      guard.done = rc != LINS_E_HIP;  // (a rejected input has advanced nothing: only this scan's own slots were touched)
+      return rc;
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipEventElapsedTime(&ctx->fe.sg_ms, ctx->ev0, ctx->ev2));
     rc = fe_launch(ctx, n, scan_period, t.d_arena, counts, 0);
   }
-  if (rc) return rc;
+  if (rc) {
+    guard.done = rc != LINS_E_HIP;
+    return rc;
+  }
   t.frontend_ms = ctx->fe.ms;
   // 2. IESKF update of every stream against its resident last scan (a stream's first scan: an update
   //    with no rows, which leaves the given state — the bootstrap pose — untouched)
@@ -1089,7 +1119,12 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
   // 2b. diverged filters: the ICP fallback (SE:585-592) on the same resident clouds, pose into the state row
   for (int k = 0; k < n; ++k) {
     if (!out[k].diverged) continue;
-    if (!mr_ok || ctx->prm.icp_freq != 1) return LINS_E_UNSUPPORTED;
+    if (!mr_ok || ctx->prm.icp_freq != 1) {
+      // this stream's clouds cannot take the device fallback: it keeps the un-updated filter (what performIESKF
+      // holds before SE:585), flagged per stream — the other streams' step is not thrown away
+      out[k].reserved[0] = LINS_E_UNSUPPORTED;
+      continue;
+    }
     launch_lds_mr_icp(ctx->stream, 1, ctx->dprm, t.d_desc + k, t.d_arena, t.d_sorted, ctx->d_state_in + (size_t)k * 19,
                       ctx->d_state_out + (size_t)k * 19, (char*)ctx->d_out + (size_t)k * sizeof(OutRecHost), ctx->d_idx);
     HIP_TRY(ctx, hipGetLastError());
@@ -1119,6 +1154,7 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipEventElapsedTime(&t.reproject_ms, ctx->ev0, ctx->ev2));
   t.cur = last;
+  guard.done = true;
   return LINS_OK;
 }
 

@@ -507,3 +507,32 @@ def test_segmentation_of_a_cloud_with_more_points_than_cells(pkg, ieskf, host):
     assert list(g.c.start_ring) == list(want.c.start_ring) and list(g.c.end_ring) == list(want.c.end_ring)
     assert np.array_equal(g.cloud[:n], want.cloud[:n]) and np.array_equal(g.range[:n], want.range[:n])
     assert np.array_equal(g.col[:n], want.col[:n]) and np.array_equal(g.ground[:n], want.ground[:n])
+
+
+def test_streams_step_keeps_the_healthy_streams_when_one_cannot_take_the_fallback(pkg, ieskf, host):
+    """ICP_FREQ = 2: the device ICP fallback is not available, so a diverged stream (NaN prior covariance ->
+    diverged = 2, SE:552-563) keeps its un-updated filter and is flagged in ITS result — the step still completes for
+    every stream (slots flipped, clouds re-projected) and the next step runs."""
+    n = 3
+    seg0 = [host.frontend_segment(host.synth_raw_scan(60 + i, 0)) for i in range(n)]
+    seg1 = [host.frontend_segment(host.synth_raw_scan(60 + i, 1)) for i in range(n)]
+    pairs = host.synth_batch(n, start=60)
+    boot = np.zeros((n, 19))
+    for i, p in enumerate(pairs):
+        boot[i, 0:3], boot[i, 6:10] = p.meta["true_t"], p.meta["true_q"]
+    cov = np.stack([p.cov for p in pairs])
+    prm = pkg.default_params(num_iter=12, icp_freq=2)
+    with ieskf.IeskfContext(prm, max_batch=n, max_targets=16384) as c:
+        c.streams_init(n)
+        c.streams_step(seg0, boot, cov)
+        bad_cov = cov.copy()
+        bad_cov[1] = np.nan
+        prior = np.stack([p.state for p in pairs])
+        r1, _ = c.streams_step(seg1, prior, bad_cov)
+        assert r1[1].diverged == 2 and r1[1].reserved[0] == -7  # LINS_E_UNSUPPORTED, this stream only
+        assert np.array_equal(r1[1].state, prior[1])
+        for k in (0, 2):
+            assert r1[k].diverged == 0 and r1[k].reserved[0] == 0 and r1[k].iters > 0
+            assert np.abs(r1[k].state[:3] - pairs[k].meta["true_t"]).max() < 0.1
+        r2, _ = c.streams_step(seg0, prior, cov)  # the context is still consistent: slots swapped back, everybody steps
+        assert all(np.isfinite(r.state).all() and r.iters > 0 for r in r2)

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 run() { # name counters...
   name=$1; shift
   rm -rf $root/gpurun_out/${tag}_$name
-  rocprofv3 --kernel-trace --pmc "$@" -d $root/gpurun_out/${tag}_$name -- python $root/bench.py --steps 2 --warmup 1 --no-cpu $BENCH_ARGS > $root/gpurun_out/${tag}_$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" -d $root/gpurun_out/${tag}_$name -- python $root/bench.py --steps 2 --warmup 1 --no-cpu --no-extras $BENCH_ARGS > $root/gpurun_out/${tag}_$name.log 2>&1
   python $root/tools/rocpd_summary.py $(find $root/gpurun_out/${tag}_$name -name "*.db") | grep -E "ieskf|^kernel" | sed 's/void lins:://; s/([^)]*)//' > $root/gpurun_out/${tag}.$name.txt
   rm -rf $root/gpurun_out/${tag}_$name
 }

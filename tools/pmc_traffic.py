@@ -1,0 +1,95 @@
+#!/usr/bin/env python
+"""HBM-side traffic of the bench's dominant kernel from the PMC counters, with its own calibration (GPU box).
+
+Runs, each in its own rocprofv3 pass (PMC only with --kernel-trace, as gpurun requires):
+  1. bench.py under --pmc FETCH_SIZE, then under --pmc WRITE_SIZE           -> counters per launch of every kernel
+  2. a streaming float4 copy of KNOWN size (lins_debug_stream_copy) under the same two counters
+     -> calibration factors  known bytes / counter bytes  for 16-B-per-lane coalesced reads and writes
+and writes profiles/<tag>_pmc_traffic.json, stamped with the content digest of the sources the library was built
+from (bench.py only reports a record whose stamp matches the sources it runs).
+
+What the numbers mean (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE count the L2's fabric-side
+requests, Infinity-Cache hits included — an UPPER bound of HBM traffic; on gfx950 FETCH_SIZE tallies wide
+coalesced reads at half their bytes.  bytes_lo takes the counters as they are, bytes_hi applies the factors
+calibrated on the copy (reads x ~2); the kernel's dword scratch traffic is not the calibrated pattern, so the
+truth lies in [lo, hi].
+usage: tools/pmc_traffic.py <tag> [bench args...]"""
+import glob
+import json
+import os
+import sqlite3
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "gpurun_out")
+
+
+def counters(cmd, counter, tag):
+    d = os.path.join(OUT, f"_pmc_{tag}_{counter}")
+    subprocess.run(["rm", "-rf", d])
+    env = dict(os.environ, TMPDIR="/tmp")
+    p = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "--"] + cmd, cwd="/tmp", env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+    res = {}
+    if dbs:
+        cur = sqlite3.connect(dbs[0]).cursor()
+        for name, val, n in cur.execute(
+                "select k.name, sum(p.counter_value), count(distinct k.dispatch_id) from pmc_events p join kernels k"
+                " on p.dispatch_id = k.dispatch_id where p.counter_name = ? group by k.name", (counter,)):
+            res[name] = (val, n)
+    subprocess.run(["rm", "-rf", d])
+    return res, p.stdout.decode()[-400:]
+
+
+def main():
+    tag = sys.argv[1]
+    bench_args = sys.argv[2:]
+    import __graft_entry__ as g
+
+    bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras"] + bench_args
+    copy = [sys.executable, "-c",
+            "import sys, ctypes as C, importlib; sys.path.insert(0, %r);"
+            "pkg = importlib.import_module('lins---lidar-inertial-slam_amd'); ieskf = importlib.import_module('lins---lidar-inertial-slam_amd.ieskf');"
+            "c = ieskf.IeskfContext(pkg.default_params(), max_batch=1024, max_targets=8192); L = ieskf.lib();"
+            "L.lins_debug_stream_copy.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_double)]; g = C.c_double(0);"
+            "assert L.lins_debug_stream_copy(c._h, 1 << 28, 3, C.byref(g)) == 0; print('copy GB/s', g.value)" % ROOT]
+    rec = {"tag": tag, "source_digest": g._source_digest(), "command": " ".join(bench[1:]), "kernels": {}}
+    search = "auto"
+    if "--search" in bench_args:
+        search = bench_args[bench_args.index("--search") + 1]
+    rec["search"] = search
+    cal = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        res, tail = counters(bench, counter, tag)
+        if not res:
+            print("no counters from", counter, tail)
+        for name, (val, n) in res.items():
+            rec["kernels"].setdefault(name, {})[counter + "_KB_per_launch"] = val / n
+        cres, ctail = counters(copy, counter, tag + "cal")
+        for name, (val, n) in cres.items():
+            if "copy" in name:
+                cal[counter] = {"kernel": name, "counter_KB_per_launch": val / n, "known_KB_per_launch": (1 << 28) / 1024.0,
+                                "factor": ((1 << 28) / 1024.0) / (val / n) if val else None}
+    rec["calibration"] = cal
+    # the dominant kernel = the one with the most traffic among the IESKF kernels
+    iesk = {k: v for k, v in rec["kernels"].items() if "ieskf" in k and "joseph" not in k}
+    if iesk:
+        dom = max(iesk, key=lambda k: sum(iesk[k].values()))
+        f = iesk[dom].get("FETCH_SIZE_KB_per_launch", 0.0) * 1024
+        w = iesk[dom].get("WRITE_SIZE_KB_per_launch", 0.0) * 1024
+        ff = (cal.get("FETCH_SIZE") or {}).get("factor") or 2.0
+        wf = (cal.get("WRITE_SIZE") or {}).get("factor") or 1.0
+        rec.update(kernel=dom, fetch_size_bytes=f, write_size_bytes=w, bytes_lo=f + w, bytes_hi=ff * f + max(wf, 1.0) * w,
+                   meaning="per launch; fabric-side (L2 <-> Infinity Fabric) bytes, Infinity-Cache hits included: an upper bound "
+                           "of HBM traffic; lo = counters as reported, hi = with the factors calibrated on a streaming copy")
+    path = os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_traffic.json")
+    with open(path, "w") as fh:
+        json.dump(rec, fh, indent=1)
+    print(json.dumps(rec, indent=1))
+
+
+if __name__ == "__main__":
+    main()
