@@ -18,6 +18,7 @@
 
 #include "../../../include/lins_host.h"
 #include "../icp_math.h"
+#include "../lins_ctx_priv.h"
 #include "../lins_math.h"
 
 using namespace lins;
@@ -52,6 +53,9 @@ bool gauss_newton_step(const lins_params& prm, double* t, Q4& q, const lins_scan
 extern "C" int lins_host_perform_ieskf(lins_ctx* ctx, const lins_params* prm, const lins_scan_pair* in,
                                         lins_result* out, int32_t* used_icp_fallback) {
   if (!ctx || !prm || !in || !out) return LINS_E_ARG;
+  // the device loop runs with the parameters the context was created with; the host half of the fallback must not
+  // run with others (the argument exists for callers that keep their own copy: it has to be the same values)
+  if (std::memcmp(prm, lins::ctx_params(ctx), sizeof(lins_params)) != 0) return LINS_E_ARG;
   if (used_icp_fallback) *used_icp_fallback = 0;
   int rc = lins_ieskf_update(ctx, in, out);
   if (rc != LINS_OK || !out->diverged) return rc;

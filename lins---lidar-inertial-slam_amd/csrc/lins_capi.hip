@@ -196,6 +196,7 @@ void** ctx_map_slot(lins_ctx* ctx, void (*free_fn)(void*)) {
   return &ctx->map_state;
 }
 void ctx_events(lins_ctx* ctx, hipEvent_t* a, hipEvent_t* b) { *a = ctx->ev0, *b = ctx->ev2; }
+const lins_params* ctx_params(const lins_ctx* ctx) { return &ctx->prm; }
 }  // namespace lins
 
 namespace {

@@ -13,4 +13,5 @@ int ctx_fail_hip(lins_ctx* ctx, hipError_t e, const char* what);  // records the
 void** ctx_map_slot(lins_ctx* ctx, void (*free_fn)(void*));       // attachment slot (free_fn is remembered)
 // the context's event pair for kernel timing
 void ctx_events(lins_ctx* ctx, hipEvent_t* a, hipEvent_t* b);
+const lins_params* ctx_params(const lins_ctx* ctx);  // the parameters the context was created with
 }  // namespace lins
