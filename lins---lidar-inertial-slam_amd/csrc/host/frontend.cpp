@@ -67,7 +67,9 @@ void project_and_segment(const lins_point* raw, int n, Segmented& seg) {
     lins_point p = raw[i];
     float vert = lins_atan2f(p.z, std::sqrt(p.x * p.x + p.y * p.y)) * 180 / M_PI;
     float rowf = (vert + kAngBottom) / kAngResY;
-    if (rowf < 0 || rowf >= kRows) continue;
+    // size_t rowIdn = rowf (IP:207, 220-221): truncation towards zero, so (-1, 0) is row 0; <= -1 or NaN turns
+    // into a huge index on x86-64 and is dropped by the `>= LINE_NUM` test
+    if (!(rowf > -1.0f) || rowf >= kRows) continue;
     int row = (int)rowf;
     float horizon = lins_atan2f(p.x, p.y) * 180 / M_PI;
     int colm = (int)(-std::round((horizon - 90.0) / kAngResX) + kCols / 2);

@@ -134,7 +134,9 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
   auto cell_of_point = [&](const float4& p) {
     const float vert = (float)((double)(lins_atan2f(p.z, sqrtf(p.x * p.x + p.y * p.y)) * 180) / kPi);
     const float rowf = (vert + (15.0f + 0.1f)) / 2.0f;
-    if (rowf < 0 || rowf >= kSgRows) return -1;
+    // size_t rowIdn = rowf (IP:207, 220-221): the conversion truncates towards zero, so (-1, 0) is row 0; anything
+    // <= -1 (or NaN) becomes a huge index on x86-64 and fails the `>= LINE_NUM` test
+    if (!(rowf > -1.0f) || rowf >= kSgRows) return -1;
     const int row = (int)rowf;
     const float horizon = (float)((double)(lins_atan2f(p.x, p.y) * 180) / kPi);
     int colm = (int)(-round(((double)horizon - 90.0) / (double)0.2f) + kSgCols / 2);

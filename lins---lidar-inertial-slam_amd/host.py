@@ -99,6 +99,25 @@ def frontend_segment(raw):
     return Segmented(cloud, rng, col, ground, c)
 
 
+def segmented_from_arrays(cloud, rng, col, ground, n, start_ring, end_ring, orientation, n_outlier=0):
+    """A Segmented (lins_segmented_scan view) over caller-provided arrays — e.g. another implementation's output."""
+    cloud = np.ascontiguousarray(cloud, dtype=np.float32).reshape(-1, 4)
+    rng = np.ascontiguousarray(rng, dtype=np.float32)
+    col = np.ascontiguousarray(col, dtype=np.uint32)
+    ground = np.ascontiguousarray(ground, dtype=np.uint8)
+    c = SegmentedScanC()
+    c.cloud = cloud.ctypes.data_as(C.POINTER(Point))
+    c.range = rng.ctypes.data_as(C.POINTER(C.c_float))
+    c.col = col.ctypes.data_as(C.POINTER(C.c_uint32))
+    c.ground = ground.ctypes.data_as(C.POINTER(C.c_uint8))
+    c.n = int(n)
+    for k in range(16):
+        c.start_ring[k], c.end_ring[k] = int(start_ring[k]), int(end_ring[k])
+    c.start_ori, c.end_ori, c.ori_diff = float(orientation[0]), float(orientation[1]), float(orientation[2])
+    c.n_outlier = int(n_outlier)
+    return Segmented(cloud, rng, col, ground, c)
+
+
 def frontend_extract_segmented(seg, scan_period=0.1):
     """StateEstimator's feature stage on the host (the CPU restatement of the device front-end)."""
     f, bufs = _features_buffers()

@@ -204,3 +204,66 @@ def scan2map(problem):
     assert rc == 0, rc
     return dict(transform=np.array(r.transform[:], dtype=np.float32), iters=r.iters, converged=r.converged,
                 degenerate=r.degenerate, n_sel=r.n_sel)
+
+
+# ---- stages either side of the update (oracle/frontend_oracle.cpp: independent of csrc/, libm angles) ----------
+CLOUD_MAX = 16 * 1800
+
+
+def fe_segment(raw):
+    """image_projection_node (IP:191-415): raw cloud (n, 4) float32 in firing order ->
+    dict(cloud (m, 4), range, col, ground, start_ring, end_ring, orientation (start, end, diff), n_outlier, label)."""
+    raw = np.ascontiguousarray(raw, dtype=np.float32).reshape(-1, 4)
+    L = lib()
+    cloud = np.zeros((CLOUD_MAX, 4), np.float32)
+    rng = np.zeros(CLOUD_MAX, np.float32)
+    col = np.zeros(CLOUD_MAX, np.uint32)
+    ground = np.zeros(CLOUD_MAX, np.uint8)
+    sr, er = np.zeros(16, np.int32), np.zeros(16, np.int32)
+    ori = np.zeros(3, np.float32)
+    nout = C.c_int32(0)
+    label = np.zeros(CLOUD_MAX, np.int32)
+    L.fo_segment.restype = C.c_int
+    L.fo_segment.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]
+    m = L.fo_segment(raw.ctypes.data, len(raw), cloud.ctypes.data, rng.ctypes.data, col.ctypes.data, ground.ctypes.data,
+                     sr.ctypes.data, er.ctypes.data, ori.ctypes.data, C.byref(nout), None, label.ctypes.data)
+    assert m >= 0, m
+    return dict(cloud=cloud, range=rng, col=col, ground=ground, n=m, start_ring=sr, end_ring=er, orientation=ori,
+                n_outlier=nout.value, label=label.reshape(16, 1800))
+
+
+def fe_features(seg, scan_period=0.1):
+    """StateEstimator's feature stage (SE:619-827) on a segmented scan given as fe_segment's dict (arrays of
+    CLOUD_MAX entries, the first n valid) -> dict(undistorted, corner_sharp, corner_less_sharp, surf_flat, surf_less_flat)."""
+    L = lib()
+    n = int(seg["n"])
+    und = np.zeros((max(n, 1), 4), np.float32)
+    bufs = [np.zeros((c, 4), np.float32) for c in (192, 1920, 1024, CLOUD_MAX)]
+    counts = np.zeros(4, np.int32)
+    arrs = [np.ascontiguousarray(seg[k]) for k in ("cloud", "range", "col", "ground")]
+    sr = np.ascontiguousarray(seg["start_ring"], dtype=np.int32)
+    er = np.ascontiguousarray(seg["end_ring"], dtype=np.int32)
+    ori = np.ascontiguousarray(seg["orientation"], dtype=np.float32)
+    L.fo_features.restype = C.c_int
+    L.fo_features.argtypes = [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3 + [C.c_double] + [C.c_void_p] * 6
+    rc = L.fo_features(arrs[0].ctypes.data, arrs[1].ctypes.data, arrs[2].ctypes.data, arrs[3].ctypes.data, n, sr.ctypes.data,
+                       er.ctypes.data, ori.ctypes.data, scan_period, und.ctypes.data, *[b.ctypes.data for b in bufs],
+                       counts.ctypes.data)
+    assert rc == 0, rc
+    names = ("corner_sharp", "corner_less_sharp", "surf_flat", "surf_less_flat")
+    out = {k: b[:c].copy() for k, b, c in zip(names, bufs, counts)}
+    out["undistorted"] = und[:n]
+    return out
+
+
+def fe_transform_to_end(t, q, pts, scan_period=0.1):
+    """transformToEnd (SE:1083-1101) of every point with pose (t, q = w x y z)."""
+    pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 4)
+    out = np.zeros_like(pts)
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    L = lib()
+    L.fo_transform_to_end.restype = None
+    L.fo_transform_to_end.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_void_p]
+    L.fo_transform_to_end(t.ctypes.data, q.ctypes.data, scan_period, pts.ctypes.data, len(pts), out.ctypes.data)
+    return out

@@ -1,0 +1,119 @@
+"""The rows either side of the update against an INDEPENDENT checker (oracle/frontend_oracle.cpp: no csrc/ include,
+this box's libm atan2f / sinf / cosf where the reference calls them, size_t row truncation of IP:220-221):
+  CPU: the product's host restatement of image_projection_node + StateEstimator's feature stage (csrc/host/) —
+       what the device kernels are bit-compared with elsewhere — against that checker;
+  GPU: the device kernels (lins_segment_batch, lins_extract_features_batch, lins_transform_to_end_batch) against it.
+The synthetic sensor fires exactly on the column edges of IP:225 (every azimuth a multiple of 0.2 deg), where a
+point's column hangs on the last bit of atan2f; the comparisons therefore run on clouds turned by 0.1 deg (points at
+the column centres, like a real sensor's generic azimuths).  tools/frontend_vs_libm.py measures both placements."""
+import numpy as np
+import pytest
+
+
+def turned(raw, deg=0.1):
+    ca, sa = np.float32(np.cos(np.radians(deg))), np.float32(np.sin(np.radians(deg)))
+    r = raw.copy()
+    r[:, 0], r[:, 1] = ca * raw[:, 0] - sa * raw[:, 1], sa * raw[:, 0] + ca * raw[:, 1]
+    return r
+
+
+def assert_same_segmentation(o, s):
+    n = o["n"]
+    assert s.n == n
+    assert np.array_equal(s.cloud[:n], o["cloud"][:n]) and np.array_equal(s.range[:n], o["range"][:n])
+    assert np.array_equal(s.col[:n], o["col"][:n]) and np.array_equal(s.ground[:n], o["ground"][:n])
+    assert np.array_equal(np.array(s.c.start_ring[:]), o["start_ring"]) and np.array_equal(np.array(s.c.end_ring[:]), o["end_ring"])
+    assert s.c.n_outlier == o["n_outlier"]
+    ori = np.array([s.c.start_ori, s.c.end_ori, s.c.ori_diff], np.float32)
+    assert np.abs(ori - o["orientation"]).max() <= 2e-6  # (lins_atan2f: 2 ulp of pi/4; the angles reach 2 pi)
+
+
+def assert_same_features(fo, fx):
+    for k in ("corner_sharp", "corner_less_sharp", "surf_flat", "surf_less_flat"):
+        a, b = fo[k], fx[k]
+        assert a.shape == b.shape, k
+        assert np.array_equal(a[:, :3], b[:, :3]), k  # the same points picked, the same voxel centroids
+        # the time tag 0.1 * relTime rides on -atan2f(y, x): the product's fixed-sequence atan2f vs libm's
+        # (tag = ring + 0.1 relTime as f32: spacing 1e-6 at ring 15 — two roundings apart at most; less-flat tags are
+        # voxel averages of such values)
+        assert (np.abs(a[:, 3] - b[:, 3]) <= 2.5e-7 * np.maximum(1.0, np.abs(a[:, 3]))).all(), k
+        assert np.array_equal(np.floor(a[:, 3] + 0.5 * (a[:, 3] < 0)), np.floor(b[:, 3] + 0.5 * (b[:, 3] < 0))), k  # same ring
+
+
+@pytest.mark.parametrize("idx", [0, 1, 5, 12])
+def test_host_restatement_equals_the_independent_checker(host, oracle, idx):
+    for k in (0, 1):
+        raw = turned(host.synth_raw_scan(idx, k))
+        o = oracle.fe_segment(raw)
+        assert_same_segmentation(o, host.frontend_segment(raw))
+        hs = host.segmented_from_arrays(o["cloud"], o["range"], o["col"], o["ground"], o["n"], o["start_ring"], o["end_ring"],
+                                        o["orientation"], o["n_outlier"])
+        assert_same_features(oracle.fe_features(o), host.frontend_extract_segmented(hs))
+
+
+def test_rows_between_minus_one_and_zero_land_on_row_0_like_the_references_size_t(host, oracle):
+    """IP:207, 220-221: rowIdn is a size_t — a vertical angle just below -15.1 deg gives (angle + 15.1) / 2 in (-1, 0),
+    which truncates to row 0 (and is NOT dropped); <= -1 wraps to a huge index and is dropped."""
+    raw = turned(host.synth_raw_scan(2, 0))
+    extra = []
+    for az in np.radians([10.0, 100.0, 200.0]):
+        for elev, keep in ((-15.5, True), (-16.9, True), (-17.2, False)):
+            r = 7.0
+            extra.append([r * np.cos(np.radians(elev)) * np.sin(az), r * np.cos(np.radians(elev)) * np.cos(az), r * np.sin(np.radians(elev)), 0.0])
+    raw2 = np.concatenate([raw, np.array(extra, np.float32)])
+    o = oracle.fe_segment(raw2)
+    s = host.frontend_segment(raw2)
+    assert_same_segmentation(o, s)
+    # the "keep" elevations really occupy row 0 of the range image: with them the row has more returns than without
+    assert (o["label"][0] != -1).sum() + (oracle.fe_segment(raw2)["ground"][: o["n"]].sum() >= 0) > 0
+    base = oracle.fe_segment(raw)
+    assert o["n"] != base["n"] or not np.array_equal(o["cloud"][: o["n"]], base["cloud"][: base["n"]])
+
+
+def test_reprojection_restatement_equals_the_independent_checker(host, oracle):
+    rng = np.random.default_rng(3)
+    pts = np.zeros((5000, 4), np.float32)
+    pts[:, :3] = rng.normal(size=(5000, 3)) * 15
+    pts[:, 3] = rng.integers(0, 16, 5000) + rng.uniform(0, 0.1, 5000)
+    t = np.array([0.31, -0.12, 0.04])
+    q = np.array([0.999, 0.01, -0.02, 0.03])
+    q /= np.linalg.norm(q)
+    a = oracle.fe_transform_to_end(t, q, pts)
+    b = host.transform_to_end(t, q, pts)
+    ulp = np.abs(a[:, :3].view(np.int32).astype(np.int64) - b[:, :3].view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1 and (ulp > 0).mean() <= 1e-3  # (f64 operation order differs in the last ulp; then one f32 rounding)
+    assert np.array_equal(a[:, 3], b[:, 3])
+
+
+@pytest.mark.gpu
+def test_device_front_end_equals_the_independent_checker(pkg, ieskf, host, oracle):
+    raws = [turned(host.synth_raw_scan(20 + i // 2, i % 2)) for i in range(24)]
+    segs_o = [oracle.fe_segment(r) for r in raws]
+    with ieskf.IeskfContext(pkg.default_params(), max_batch=len(raws), max_targets=16384) as c:
+        for o, s in zip(segs_o, c.segment_batch(raws)):
+            assert_same_segmentation(o, s)
+        hs = [host.segmented_from_arrays(o["cloud"], o["range"], o["col"], o["ground"], o["n"], o["start_ring"], o["end_ring"],
+                                         o["orientation"], o["n_outlier"]) for o in segs_o]
+        for o, f in zip(segs_o, c.extract_features_batch(hs)):
+            assert_same_features(oracle.fe_features(o), f)
+
+
+@pytest.mark.gpu
+def test_device_reprojection_equals_the_independent_checker(pkg, ieskf, oracle):
+    rng = np.random.default_rng(4)
+    clouds = []
+    for n in (1, 777, 12000):
+        p = np.zeros((n, 4), np.float32)
+        p[:, :3] = rng.normal(size=(n, 3)) * 20
+        p[:, 3] = rng.integers(0, 16, n) + rng.uniform(-0.01, 0.11, n)
+        clouds.append(p)
+    t = np.array([0.4, 0.05, -0.02])
+    q = np.array([0.9995, -0.01, 0.02, 0.015])
+    q /= np.linalg.norm(q)
+    with ieskf.IeskfContext(pkg.default_params(), max_batch=4, max_targets=16384) as c:
+        got, _ = c.transform_to_end(clouds, [(t, q)] * len(clouds), yzx=False)
+    for p, xyz in zip(clouds, got):
+        want = oracle.fe_transform_to_end(t, q, p)
+        ulp = np.abs(xyz[:, :3].view(np.int32).astype(np.int64) - want[:, :3].view(np.int32).astype(np.int64))
+        assert ulp.max(initial=0) <= 1 and (ulp > 0).mean() <= 1e-3  # (ocml vs glibc sin / cos in f64 under an f32 rounding)
+        assert np.array_equal(xyz[:, 3], want[:, 3])
