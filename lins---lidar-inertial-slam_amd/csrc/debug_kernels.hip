@@ -46,6 +46,12 @@ __global__ void debug_math_kernel(int op, int n, int n_in, int n_out, const doub
     phi_and_Gt(Q4{a[0], a[1], a[2], a[3]}, phi, gt);
     o[0] = phi.x, o[1] = phi.y, o[2] = phi.z;
     for (int k = 0; k < 9; ++k) o[3 + k] = gt.m[k];
+  } else if (op == 7) {  // one lane's reg_solve6 and (below, whole wave) wave_solve6 on the same 6 x 7 system
+    double m[6][7], x6[6];
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 7; ++c) m[r][c] = a[r * 7 + c];
+    reg_solve6(m, x6);
+    for (int k = 0; k < 6; ++k) o[k] = x6[k];
   } else if (op == 6) {
     DevParams prm{};
     prm.inv_period = (double)(1.f / (float)a[23]);
@@ -90,6 +96,11 @@ __global__ __launch_bounds__(256) void debug_cycles_kernel(int op, const double*
         reg_solve6(a, x6);
         dacc += x6[0] * 1e-9;
       }
+    } else if (op == 105) {  // 6x6 solve spread over the wave
+      const int l = tid & 63, i = l / 7, j = l % 7;
+      double x6[6];
+      wave_solve6(l < 42 ? (i == j ? 10.0 : 0.1 * (i + j)) + dacc : 0.0, l, x6);
+      dacc += x6[0] * 1e-9;
     } else if (op == 104) {  // next iteration's constants
       V3 p2;
       M3 gt;
@@ -99,6 +110,17 @@ __global__ __launch_bounds__(256) void debug_cycles_kernel(int op, const double*
   }
   const long long t1 = clock64();
   if (tid == 0) out[blockIdx.x * 2] = (double)(t1 - t0) / 64.0, out[blockIdx.x * 2 + 1] = (double)acc + dacc;
+}
+
+// op 8: wave_solve6, one system per WAVE (64 threads per item): out 6
+__global__ void debug_wave_solve_kernel(int n, const double* __restrict__ in, double* __restrict__ out) {
+  const int item = blockIdx.x, l = threadIdx.x;
+  double x6[6];
+  wave_solve6(l < 42 ? in[(size_t)item * 42 + l] : 0.0, l, x6);
+  if (l < 6) out[(size_t)item * 6 + l] = x6[l];
+}
+void launch_debug_wave_solve(hipStream_t stream, int n, const double* in, double* out) {
+  hipLaunchKernelGGL(debug_wave_solve_kernel, dim3(n), dim3(64), 0, stream, n, in, out);
 }
 
 void launch_debug_cycles(hipStream_t stream, int op, int blocks, const double* in, double* out) {

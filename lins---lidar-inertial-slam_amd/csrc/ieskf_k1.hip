@@ -26,6 +26,9 @@ namespace k1 {
 constexpr int kBlock = 256, kWaves = kBlock / 64;
 constexpr int kBackRank = 0x40000000;
 constexpr int kBruteCap = kBlock;  // (one entry per lane and round)
+constexpr int kPool = 1792;      // candidates of the scan kept in LDS (28 KB: four workgroups still fit a CU)
+constexpr int kMaxQ = 512;       // queries of a split scan (lins_capi.hip: <= 320 plane + 192 line)
+constexpr unsigned short kNotInLds = 0xFFFF;
 
 struct OutRec {  // (layout of the persistent kernels' record, lins_capi.hip reads it)
   double residual_norm, update_norm;
@@ -39,12 +42,20 @@ struct Lds {
   double sums[28];
   double partial[kWaves * 28];
   double aug[3][42];
+  double stage[22];  // the update's results on their way to the other waves: linState_ (19), |r|, |r| kept, |dx|
+  int stage_flags[2];  // diverged, converged
   double res_prev, res_last, upd_norm;
   unsigned long long red[kWaves][3];
   int ring_start[2][kRingsBinned + 1];
   int m_surf, m_corner, iter, conv, div;
   int nbrute, brute_total, gcount;
   long long prof[8];  // phase clocks of the PROF variant
+  // The scan's candidate lists, copied ONCE from the hand-off buffer (L2) and read by every iteration from here:
+  // query q's list is pool[qoff[q] .. + count).  qoff = kNotInLds: that list did not fit, or the list kernel has
+  // re-gathered it since — it is read from global memory.
+  float4 pool[kPool];
+  unsigned short qoff[kMaxQ];
+  int scan_tmp[8];
   unsigned short brute_q[kBruteCap];
 };
 __shared__ Lds g;
@@ -98,13 +109,12 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
 __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int iter) {
   Lds& L = g;
   const int lane = tid & 63, wave = tid >> 6;
-  double lin[19];
-  double rn = 0, un = 0, res_prev = 0;
-  int div = 0, conv = 0;
-  if (wave < 3) {
+  // ---- wave 0: the 6 x 7 system, its solution (spread over the wave), dx, the stop tests and boxPlus; the new
+  // linearisation state is STAGED in LDS (the old one may still be read by the other waves until the barrier)
+  if (wave == 0) {
+    double v = 0.0;
     if (lane < 42) {
       const int i = lane / 7, j = lane % 7;
-      double v;
       if (j < 6) {
         v = (i == j ? prm.r2 : 0.0);
 #pragma unroll
@@ -114,27 +124,9 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
 #pragma unroll
         for (int k = 0; k < 6; ++k) v += sym6(L.sums, i, k) * L.ic.d[sidx(k)];
       }
-      L.aug[wave][lane] = v;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane == 0) {
-      double a[6][7], x6[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 7; ++j) a[i][j] = L.aug[wave][i * 7 + j];
-      reg_solve6(a, x6);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) L.aug[wave][k] = x6[k];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double wsol[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) wsol[k] = L.aug[wave][k];
+    wave_solve6(v, lane, wsol);
     double dxi = 0;
     if (lane < 18) {
       double sacc = 0;
@@ -142,14 +134,15 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
       for (int k = 0; k < 6; ++k) sacc += L.P[lane * 18 + sidx(k)] * wsol[k];
       dxi = L.ic.d[lane] - sacc;
     }
+    double lin[19];
 #pragma unroll
     for (int k = 0; k < 19; ++k) lin[k] = L.ic.lin[k];
     double dth[3] = {0, 0, 0};
     bool has_nan = false;
-    un = 0;
+    double un = 0;
 #pragma unroll
     for (int k = 0; k < 18; ++k) {
-      const double vk = __shfl(dxi, k);
+      const double vk = readlane_f64(dxi, k);
       has_nan = has_nan || isnan(vk);
       un += vk * vk;
       if (k >= 6 && k < 9)
@@ -158,8 +151,9 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
         lin[k < 6 ? k : k + 1] += vk;
     }
     un = sqrt(un);
-    rn = sqrt(L.sums[27]);
-    res_prev = L.res_prev;
+    const double rn = sqrt(L.sums[27]);
+    double res_prev = L.res_prev;
+    int div = 0, conv = 0;
     if (has_nan) {
       div = 2, un = L.upd_norm;
     } else if (rn > res_prev * 10) {
@@ -170,15 +164,23 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
       if (un <= 1e-2 && !prm.fixed_iters) conv = 1;
       res_prev = rn;
     }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 19; ++k) L.stage[k] = lin[k];
+      L.stage[19] = rn, L.stage[20] = res_prev, L.stage[21] = un;
+      L.stage_flags[0] = div, L.stage_flags[1] = conv;
+    }
   }
-  __syncthreads();  // every reader of the old linearisation state is done
-  if (wave < 3 && !div) {
-    const Q4 q{lin[6], lin[7], lin[8], lin[9]};
+  __syncthreads();  // every reader of the old linearisation state is done; the staged one is visible
+  const int div = L.stage_flags[0];
+  if (wave < 3 && !div && !(prm.pad & 8192)) {
+    // the constants of the next iteration, one wave each: linState_ + R^T | phi, Rinvleft(-phi)^T | x_filter (-) x_lin
+    const Q4 q{L.stage[6], L.stage[7], L.stage[8], L.stage[9]};
     if (wave == 0) {
       const M3 Rt = mtrans(qmat(q));
       if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 19; ++k) L.ic.lin[k] = lin[k];
+        for (int k = 0; k < 19; ++k) L.ic.lin[k] = L.stage[k];
         L.ic.Rt = Rt;
       }
     } else if (wave == 1) {
@@ -192,19 +194,19 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
       if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          L.ic.d[0 + k] = L.filt[0 + k] - lin[0 + k];
-          L.ic.d[3 + k] = L.filt[3 + k] - lin[3 + k];
-          L.ic.d[9 + k] = L.filt[10 + k] - lin[10 + k];
-          L.ic.d[12 + k] = L.filt[13 + k] - lin[13 + k];
-          L.ic.d[15 + k] = L.filt[16 + k] - lin[16 + k];
+          L.ic.d[0 + k] = L.filt[0 + k] - L.stage[0 + k];
+          L.ic.d[3 + k] = L.filt[3 + k] - L.stage[3 + k];
+          L.ic.d[9 + k] = L.filt[10 + k] - L.stage[10 + k];
+          L.ic.d[12 + k] = L.filt[13 + k] - L.stage[13 + k];
+          L.ic.d[15 + k] = L.filt[16 + k] - L.stage[16 + k];
         }
         L.ic.d[6] = da.x, L.ic.d[7] = da.y, L.ic.d[8] = da.z;
       }
     }
   }
   if (tid == 0) {
-    L.res_last = rn, L.res_prev = res_prev, L.upd_norm = un;
-    L.conv = conv, L.div = div;
+    L.res_last = L.stage[19], L.res_prev = L.stage[20], L.upd_norm = L.stage[21];
+    L.conv = L.stage_flags[1], L.div = div;
     L.iter = iter + 1;
   }
   __syncthreads();
@@ -336,6 +338,27 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
     for (int k = 0; k < 8; ++k) L.prof[k] = 0;
   }
   __syncthreads();
+  {  // candidate lists -> LDS (coalesced: lane = query, one list slot per trip)
+    int run = 0;
+    for (int base = 0; base < total; base += kBlock) {
+      const int slot = base + tid;
+      int cnt = 0;
+      if (slot < total) cnt = __float_as_int(ld_fresh(reinterpret_cast<const float4*>(hq + sd.slot_base + slot) + 2).y) & 0xFF;
+      const int off = run + block_exclusive_scan(cnt, tid, L.scan_tmp);
+      if (tid == kBlock - 1) L.scan_tmp[6] = off + cnt;
+      if (slot < total) {
+        const bool fits = off + cnt <= kPool;
+        L.qoff[slot] = fits ? (unsigned short)off : kNotInLds;
+        if (fits) {
+          const float4* cb = hcand + (size_t)kSplitK * sd.slot_base + slot;
+          for (int k = 0; k < cnt; ++k) L.pool[off + k] = ld_fresh(cb + (size_t)k * total);
+        }
+      }
+      __syncthreads();
+      run = L.scan_tmp[6];
+      __syncthreads();
+    }
+  }
   if (tid < 64) {  // wave 0, lane-redundant: constants of the first iteration
     IterConst ic;
     double filt[19];
@@ -382,7 +405,10 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
       if (active) {
         q = arena[(is_surf ? sd.off_surf_q : sd.off_corner_q) + qi];
         const V3 t{L.ic.lin[0], L.ic.lin[1], L.ic.lin[2]};
-        transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2]);
+        if (prm.pad & 1024)
+          o.sel[0] = q.x, o.sel[1] = q.y, o.sel[2] = q.z;  // (timing experiments: pad bits 1024..16384 drop one phase each)
+        else
+          transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2]);
         if (PROF) pt[1] = clock64();
         const float sx = o.sel[0], sy = o.sel[1], sz = o.sel[2];
         SplitQ mq;
@@ -393,8 +419,12 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
           mq.bx = m1.x, mq.by = m1.y, mq.bz = m1.z, mq.r2 = m1.w;
           mq.r3 = m2.x, mq.meta = __float_as_int(m2.y), mq.j1 = __float_as_int(m2.z), mq.jc = __float_as_int(m2.w);
         }
+        if (prm.pad & 16384) mq.meta = 0;
         const int count = mq.meta & 0xFF, rho0 = (mq.meta >> 8) & 0xFF, flags = mq.meta >> 16;
         const float4* cb = hcand + (size_t)kSplitK * sd.slot_base + slot;
+        const int loff = L.qoff[slot];
+        const bool in_lds = loff != kNotInLds;
+        auto cand = [&](int k) { return in_lds ? L.pool[loff + k] : ld_fresh(cb + (size_t)k * total); };
         my_count = count;
         auto dist_from = [&](float x, float y, float z) {
           const float ex = sx - x, ey = sy - y, ez = sz - z;
@@ -415,7 +445,7 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
           for (int k0 = 0; k0 < count; k0 += 4) {
             float4 cv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) cv[u] = ld_fresh(cb + (size_t)(k0 + u < count ? k0 + u : count - 1) * total);
+            for (int u = 0; u < 4; ++u) cv[u] = cand(k0 + u < count ? k0 + u : count - 1);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               if (k0 + u >= count) break;
@@ -442,7 +472,7 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
         bool ok = c1 >= 0 && certified(__uint_as_float((unsigned)(k1 >> 32)), mq.r_nn, drift);
         if (!ok) why = c1 < 0 ? 1 : 2;
         if (ok) {
-          t1 = ld_fresh(cb + (size_t)c1 * total);
+          t1 = cand(c1);
           j1 = __float_as_int(t1.w) & 0xFFFF;
           rho = (__float_as_int(t1.w) >> 16) & 0xFF;
           ok = mq.jc >= 0 || rho == rho0;  // (the grid kernel's ring claims are stated relative to rho0)
@@ -468,8 +498,8 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
           } else {
             if (ok && !judge(c2, k2, mq.r2, (flags & SPLITQ_NONE2) != 0, any_other)) ok = false, why = 4;
           }
-          if (c2 >= 0) t2 = ld_fresh(cb + (size_t)c2 * total), j2 = __float_as_int(t2.w) & 0xFFFF;
-          if (c3 >= 0) t3 = ld_fresh(cb + (size_t)c3 * total), j3 = __float_as_int(t3.w) & 0xFFFF;
+          if (c2 >= 0) t2 = cand(c2), j2 = __float_as_int(t2.w) & 0xFFFF;
+          if (c3 >= 0) t3 = cand(c3), j3 = __float_as_int(t3.w) & 0xFFFF;
         }
         if (!ok && (prm.pad & 64)) ok = true, j1 = j2 = j3 = -1;  // (timing aid: no exhaustive searches — wrong results)
         if (!ok) {  // not certified: exhaustive search below (of the walk only when the nearest neighbour is certified)
@@ -509,6 +539,7 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
             mq->bx = o.sel[0], mq->by = o.sel[1], mq->bz = o.sel[2], mq->r2 = br.r2, mq->r3 = br.r3;
             mq->meta = (mq->meta & ~0xFF) | br.new_count;
             mq->jc = br.j1;
+            L.qoff[oslot] = kNotInLds;  // (the list grew in the hand-off buffer: read it from there from now on)
           }
         }
         __syncthreads();
@@ -543,7 +574,7 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
         }
       }
       if (PROF) pt[4] = clock64();
-      acc += wave_reduce_rows(row, lane);
+      if (!(prm.pad & 2048)) acc += wave_reduce_rows(row, lane);
       if (PROF) pt[5] = clock64();
     }
     {

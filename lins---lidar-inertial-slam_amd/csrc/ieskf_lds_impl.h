@@ -646,18 +646,19 @@ __device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, 
 __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int iter, bool prof, long long& t3) {
   LdsStore& L = g_lds;
   const int lane = tid & 63, wave = tid >> 6;
-  // ---- solve + state update: waves 0-2, each redundantly, in registers ----------------------
-  // (sigma^2 I + A P_SS) w = g + A d_S  (push-through form of SE:542-549), dx = d - P[:,S] w,
-  // NaN / divergence / convergence tests and boxPlus (SE:552-580); after one barrier the three
-  // waves split the constants of the next iteration: wave 0 -> linState_, flags, R^T;
-  // wave 1 -> phi, Rinvleft(-phi)^T;  wave 2 -> x_filter (-) x_lin.
-  double lin[19];
-  double rn = 0, un = 0, res_prev = 0;
-  int div = 0, conv = 0;
-  if (wave < 3) {
+  // ---- wave 0: (sigma^2 I + A P_SS) w = g + A d_S  (push-through form of SE:542-549) solved across the wave
+  // (wave_solve6: the one-lane elimination's operations, element by element), dx = d - P[:,S] w, NaN / divergence /
+  // convergence tests and boxPlus (SE:552-580).  The new linearisation state is STAGED in LDS — the old one may
+  // still be read by the other waves until the barrier — and after it three waves split the constants of the next
+  // iteration: wave 0 -> linState_, R^T;  wave 1 -> phi, Rinvleft(-phi)^T;  wave 2 -> x_filter (-) x_lin.
+  // (Until round 2 the first three waves each ran the whole solve redundantly to save the staging: 2 x ~2.5 k
+  // issued instructions per iteration for nothing.)
+  double* const stage = &L.aug[0][0];  // 22 doubles: linState_ (19), |r|, |r| kept, |dx|
+  int* const stage_flags = reinterpret_cast<int*>(&L.aug[1][0]);  // diverged, converged
+  if (wave == 0) {
+    double v = 0.0;
     if (lane < 42) {
       const int i = lane / 7, j = lane % 7;
-      double v;
       if (j < 6) {
         v = (i == j ? prm.r2 : 0.0);
 #pragma unroll
@@ -667,29 +668,9 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
 #pragma unroll
         for (int k = 0; k < 6; ++k) v += sym6(L.sums, i, k) * L.ic.d[sidx(k)];
       }
-      L.aug[wave][lane] = v;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // one lane per wave eliminates (registers, unrolled); a single active lane keeps whatever the
-    // register allocator spills for the 6x7 system to 1/64 of the scratch traffic
-    if (lane == 0) {
-      double a[6][7], x6[6];
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 7; ++j) a[i][j] = L.aug[wave][i * 7 + j];
-      reg_solve6(a, x6);
-#pragma unroll
-      for (int k = 0; k < 6; ++k) L.aug[wave][k] = x6[k];  // the system is consumed: reuse its first row
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double wsol[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) wsol[k] = L.aug[wave][k];
+    wave_solve6(v, lane, wsol);
     double dxi = 0;
     if (lane < 18) {
       double sacc = 0;
@@ -698,17 +679,15 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
       dxi = L.ic.d[lane] - sacc;
     }
     if (prof) t3 = clock64();
-    // broadcast dx lane by lane and fold it straight into the state (no dx[18] array: this
-    // section runs under the search loop's 128-VGPR budget): additive blocks now, the
-    // attitude increment through the quaternion below (boxPlus, KF:71-81)
+    double lin[19];
 #pragma unroll
     for (int k = 0; k < 19; ++k) lin[k] = L.ic.lin[k];
     double dth[3] = {0, 0, 0};
     bool has_nan = false;
-    un = 0;
+    double un = 0;
 #pragma unroll
     for (int k = 0; k < 18; ++k) {
-      const double vk = __shfl(dxi, k);
+      const double vk = readlane_f64(dxi, k);
       has_nan = has_nan || isnan(vk);
       un += vk * vk;
       if (k >= 6 && k < 9)
@@ -717,8 +696,9 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
         lin[k < 6 ? k : k + 1] += vk;  // p,v at 0..5; ba,bw,g at 10..18 (q occupies 6..9)
     }
     un = sqrt(un);
-    rn = sqrt(L.sums[27]);
-    res_prev = L.res_prev;
+    const double rn = sqrt(L.sums[27]);
+    double res_prev = L.res_prev;
+    int div = 0, conv = 0;
     if (has_nan) {
       div = 2, un = L.upd_norm;
     } else if (rn > res_prev * 10) {
@@ -729,16 +709,23 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
       if (un <= 1e-2 && !prm.fixed_iters) conv = 1;
       res_prev = rn;
     }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 19; ++k) stage[k] = lin[k];
+      stage[19] = rn, stage[20] = res_prev, stage[21] = un;
+      stage_flags[0] = div, stage_flags[1] = conv;
+    }
   }
-  __syncthreads();  // every reader of the old linearisation state is done
+  __syncthreads();  // every reader of the old linearisation state is done; the staged one is visible
+  const int div = stage_flags[0];
   if (wave < 3 && !div) {
-    const Q4 q{lin[6], lin[7], lin[8], lin[9]};
+    const Q4 q{stage[6], stage[7], stage[8], stage[9]};
     // (static indices only: a lane-indexed register array would be spilled to scratch)
     if (wave == 0) {
       const M3 Rt = mtrans(qmat(q));
       if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k < 19; ++k) L.ic.lin[k] = lin[k];
+        for (int k = 0; k < 19; ++k) L.ic.lin[k] = stage[k];
         L.ic.Rt = Rt;
       }
     } else if (wave == 1) {
@@ -753,19 +740,19 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
       if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          L.ic.d[0 + k] = L.filt[0 + k] - lin[0 + k];
-          L.ic.d[3 + k] = L.filt[3 + k] - lin[3 + k];
-          L.ic.d[9 + k] = L.filt[10 + k] - lin[10 + k];
-          L.ic.d[12 + k] = L.filt[13 + k] - lin[13 + k];
-          L.ic.d[15 + k] = L.filt[16 + k] - lin[16 + k];
+          L.ic.d[0 + k] = L.filt[0 + k] - stage[0 + k];
+          L.ic.d[3 + k] = L.filt[3 + k] - stage[3 + k];
+          L.ic.d[9 + k] = L.filt[10 + k] - stage[10 + k];
+          L.ic.d[12 + k] = L.filt[13 + k] - stage[13 + k];
+          L.ic.d[15 + k] = L.filt[16 + k] - stage[16 + k];
         }
         L.ic.d[6] = da.x, L.ic.d[7] = da.y, L.ic.d[8] = da.z;
       }
     }
   }
   if (tid == 0) {
-    L.res_last = rn, L.res_prev = res_prev, L.upd_norm = un;
-    L.conv = conv, L.div = div;
+    L.res_last = stage[19], L.res_prev = stage[20], L.upd_norm = stage[21];
+    L.conv = stage_flags[1], L.div = div;
     L.iter = iter + 1;
   }
   __syncthreads();

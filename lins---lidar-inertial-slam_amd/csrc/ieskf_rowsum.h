@@ -51,6 +51,52 @@ __device__ __forceinline__ void reg_solve6(double (&a)[6][7], double (&x)[6]) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// The same elimination spread over the lanes of ONE wave: lane l < 42 holds element (l / 7, l % 7) of the 6 x 7
+// system [N | z].  Every element goes through exactly the operations reg_solve6 applies to it, in the same order
+// (first-maximum pivot, row exchange, f = a_ik * (1 / a_kk), a_ij -= f * a_kj as a multiply and a subtract), so
+// the solution is bit-identical — in ~1/3 of the instructions and a fraction of the dependent latency of the
+// one-lane version (which runs 6 x 7 doubles through a single lane's registers).  Call with all 64 lanes active;
+// returns x[0..5] in every lane.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double shfl_f64(double v, int src) {
+  const int lo = __shfl(__double2loint(v), src), hi = __shfl(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+// (a wave-uniform source lane: v_readlane, no LDS crossbar round trip)
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void wave_solve6(double a, int lane, double (&x)[6]) {
+  const int i = lane < 42 ? lane / 7 : 7, j = lane < 42 ? lane % 7 : 0;  // (lanes >= 42 take part in no update)
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int p = k;
+    double best = fabs(readlane_f64(a, k * 7 + k));
+#pragma unroll
+    for (int r = k + 1; r < 6; ++r) {
+      const double v = fabs(readlane_f64(a, r * 7 + k));
+      if (v > best) best = v, p = r;
+    }
+    if (p != k) {  // (wave-uniform) exchange rows k and p
+      const int src = i == k ? p * 7 + j : (i == p ? k * 7 + j : lane);
+      a = shfl_f64(a, src);
+    }
+    const double inv = 1.0 / readlane_f64(a, k * 7 + k);
+    const double aik = shfl_f64(a, (i < 6 ? i : 0) * 7 + k), akj = shfl_f64(a, k * 7 + j);
+    const double f = aik * inv;
+    if (i > k && i < 6 && j > k) a -= f * akj;
+  }
+#pragma unroll
+  for (int r = 5; r >= 0; --r) {
+    double sacc = readlane_f64(a, r * 7 + 6);
+#pragma unroll
+    for (int k = r + 1; k < 6; ++k) sacc -= readlane_f64(a, r * 7 + k) * x[k];
+    x[r] = sacc / readlane_f64(a, r * 7 + r);
+  }
+}
+
 // Rinvleft(-phi)^T and phi from a unit quaternion without libm sin/cos: with
 // h = |phi|/2 the half angle, cos h = |w| / |q| and sin h = |v| / |q| exactly, so
 // s = h cot h needs only the atan2 that Quat2axis performs anyway (math_utils.h:75-88,

@@ -116,3 +116,22 @@ def test_transform_to_start(pkg, ieskf, oracle, ctx):
     want = np.array([oracle.transform_to_start(prm, l, p)[0, :3] for l, p in zip(lin, pts)], dtype=np.float32)
     ulp = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
     assert ulp.max() <= 1 and (ulp > 0).mean() <= 1e-3  # (f64 sin / cos of ocml vs glibc under an f32 rounding)
+
+
+def test_wave_solve6_is_bit_identical_to_the_one_lane_elimination(ieskf, ctx):
+    """The 6 x 6 pivoted elimination spread over a wave (ieskf_rowsum.h wave_solve6) performs, element by element,
+    the operations of the one-lane reg_solve6: same pivots, same roundings, the same bits — also on systems that
+    force row exchanges, and with a NaN in the system (the divergence test of SE:552-563 must see the same NaNs)."""
+    rng = np.random.default_rng(21)
+    sys_ = rng.normal(size=(300, 6, 7))
+    sys_[:100, np.arange(6), np.arange(6)] += 8.0        # diagonally dominant: no exchanges
+    sys_[100:150, 0, 0] = 1e-12                            # forces pivoting at the first step
+    sys_[150:160, 2, :] = sys_[150:160, 1, :]              # singular: inf / nan results, still the same ones
+    sys_[160, 3, 4] = np.nan
+    x = sys_.reshape(300, 42)
+    a = dev(ieskf, ctx, 7, x, 6)
+    b = dev(ieskf, ctx, 8, x, 6)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.uint64), b[~np.isnan(b)].view(np.uint64))
+    ok = np.isfinite(a).all(axis=1)
+    res = np.einsum("nij,nj->ni", sys_[ok][:, :, :6], a[ok]) - sys_[ok][:, :, 6]
+    assert np.abs(res[:100]).max() <= 1e-12
