@@ -241,10 +241,16 @@ __device__ __noinline__ BruteOut brute_query(const float4* __restrict__ tg, int 
     r.j1 = known_j1;
   } else {
     unsigned long long k1 = sentinel;
-    for (int j = tid; j < n; j += kBlock) {
-      const float4 t = tg[j];
-      const unsigned long long k = pack_key(sqdist3(t.x, t.y, t.z, sx, sy, sz), j);
-      k1 = k < k1 ? k : k1;
+    for (int j0 = tid; j0 < n; j0 += 4 * kBlock) {  // (four loads in flight per trip)
+      float4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = tg[j0 + u * kBlock < n ? j0 + u * kBlock : n - 1];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (j0 + u * kBlock >= n) break;
+        const unsigned long long k = pack_key(sqdist3(t[u].x, t[u].y, t[u].z, sx, sy, sz), j0 + u * kBlock);
+        k1 = k < k1 ? k : k1;
+      }
     }
     k1 = wave_min_u64(k1);
     if (lane == 0) L.red[wave][0] = k1;
@@ -258,17 +264,32 @@ __device__ __noinline__ BruteOut brute_query(const float4* __restrict__ tg, int 
   const Walk w = make_walk(L.ring_start[is_surf ? 0 : 1], n, nq, j1, rho);
   unsigned long long k2 = sentinel, k3 = sentinel;
   const int w_hi = w.f_hi > j1 ? w.f_hi : j1;  // (the forward part may be empty: its end is bounded by the QUERY count)
-  for (int j = w.b_lo + tid; j < w_hi; j += kBlock) {
+  // One sweep of the walk's index range, kBruteHold points per thread kept in registers (their loads all in flight
+  // together: a dependent load per point would cost a memory round trip each) — the re-gather below reuses them;
+  // a range beyond kBlock * kBruteHold points (more than ~3 full rings) sweeps the rest from memory again.
+  constexpr int kBruteHold = 8;
+  float4 held[kBruteHold];
+#pragma unroll
+  for (int u = 0; u < kBruteHold; ++u) {
+    const int j = w.b_lo + tid + u * kBlock;
+    held[u] = j < w_hi ? tg[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  auto visit = [&](int j, const float4& t) {
     int rank;
-    if (!walk_rank(w, j, rank)) continue;  // (j1 itself)
-    const float4 t = tg[j];
+    if (!walk_rank(w, j, rank)) return;  // (j1 itself)
     const bool on_rho = ring_of(t.w) == rho;
     const unsigned long long k = pack_key(sqdist3(t.x, t.y, t.z, sx, sy, sz), rank);
     if (is_surf ? on_rho : !on_rho)
       k2 = k < k2 ? k : k2;
     else if (is_surf)
       k3 = k < k3 ? k : k3;
+  };
+#pragma unroll
+  for (int u = 0; u < kBruteHold; ++u) {
+    const int j = w.b_lo + tid + u * kBlock;
+    if (j < w_hi) visit(j, held[u]);
   }
+  for (int j = w.b_lo + tid + kBruteHold * kBlock; j < w_hi; j += kBlock) visit(j, tg[j]);
   k2 = wave_min_u64(k2), k3 = wave_min_u64(k3);
   if (lane == 0) L.red[wave][1] = k2, L.red[wave][2] = k3;
   __syncthreads();
@@ -287,19 +308,23 @@ __device__ __noinline__ BruteOut brute_query(const float4* __restrict__ tg, int 
   auto radius = [&](unsigned long long k) { return sqrtf(k < sentinel ? __uint_as_float((unsigned)(k >> 32)) : thr) * (1.f + 2e-6f) + margin; };
   r.r2 = radius(k2), r.r3 = is_surf ? radius(k3) : 0.f;
   const float t2 = r.r2 * r.r2 * (1.f + 4e-6f), t3 = r.r3 * r.r3 * (1.f + 4e-6f);
-  for (int j = w.b_lo + tid; j < w_hi; j += kBlock) {
+  auto regather = [&](int j, const float4& t) {
     int rank;
-    if (!walk_rank(w, j, rank)) continue;
-    const float4 t = tg[j];
+    if (!walk_rank(w, j, rank)) return;
     const int ring = ring_of(t.w);
-    const bool on_rho = ring == rho;
-    const bool cls2 = is_surf ? on_rho : !on_rho;
-    if (!cls2 && !is_surf) continue;
+    const bool cls2 = is_surf ? ring == rho : ring != rho;
+    if (!cls2 && !is_surf) return;
     if (sqdist3(t.x, t.y, t.z, sx, sy, sz) <= (cls2 ? t2 : t3)) {
       const int k = atomicAdd(&L.gcount, 1);
       if (k < kSplitK) cb[(size_t)k * stride] = split_pack(t.x, t.y, t.z, j, ring);
     }
+  };
+#pragma unroll
+  for (int u = 0; u < kBruteHold; ++u) {
+    const int j = w.b_lo + tid + u * kBlock;
+    if (j < w_hi) regather(j, held[u]);
   }
+  for (int j = w.b_lo + tid + kBruteHold * kBlock; j < w_hi; j += kBlock) regather(j, tg[j]);
   __syncthreads();
   r.new_count = L.gcount;
   return r;
@@ -470,8 +495,12 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
         };
         pass(true);
         bool ok = c1 >= 0 && certified(__uint_as_float((unsigned)(k1 >> 32)), mq.r_nn, drift);
-        if (!ok) why = c1 < 0 ? 1 : 2;
-        if (ok) {
+        // nobody listed inside the search radius, and everybody unlisted provably outside it: still no neighbour
+        // (SE:851 drops the feature) — j1 = j2 = j3 = -1 stand
+        const bool still_none = c1 < 0 && certified(thr, mq.r_nn, drift);
+        if (!ok && !still_none) why = c1 < 0 ? 1 : 2;
+        if (still_none) ok = true;
+        if (ok && c1 >= 0) {
           t1 = cand(c1);
           j1 = __float_as_int(t1.w) & 0xFFFF;
           rho = (__float_as_int(t1.w) >> 16) & 0xFF;

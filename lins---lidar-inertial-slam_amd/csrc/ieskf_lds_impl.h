@@ -900,6 +900,26 @@ __device__ __noinline__ void split_gather(const GatherArgs ga, const float4* gs,
     } else {
       rec.meta = rho0 << 8;
     }
+  } else if (!(ga.pad & 128)) {
+    // No target inside the search radius (SE:851 leaves such a feature out).  To keep saying so without searching,
+    // the list kernel needs to know that nothing comes close: everything within the search radius + margin of the
+    // anchor is listed (normally nothing at all) — "still none" then holds while the query drifts less than the margin.
+    const float r_nn = sqrtf(ga.thr) * (1.f + 2e-6f) + ga.margin;
+    const float rb = r_nn * (1.f + 2e-6f) + 1e-6f, t_nn = r_nn * r_nn * (1.f + 4e-6f);
+    const float delta = reach_elev(qp.qn3, rb);
+    const int K = reach(c, qp.rho, rb), a0 = qp.a0_surf_or_corner;
+    int count = 0;
+#pragma unroll 1
+    for (int r = 0; r < kRingsBinned; ++r) {
+      if (!ring_nonempty(c, r) || !ring_in_reach(c, r, qp.el, delta)) continue;
+      scan_cols(L, c, r, a0 - K, a0 + K, [&](float x, float y, float z, int j, int p, bool ok) {
+        if (ok && sqdist3(x, y, z, ax, ay, az) <= t_nn) {
+          if (count < kSplitK) cb[(size_t)count * stride] = split_pack(x, y, z, j, r);
+          ++count;
+        }
+      });
+    }
+    if (count <= kSplitK) rec.r_nn = r_nn, rec.meta = count | (0xFF << 8);  // (rho0 = 255: no class claims)
   }
   *out = rec;
 }
