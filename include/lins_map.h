@@ -29,8 +29,14 @@ typedef struct lins_map_problem {
   const lins_point* scan_surf;   /* laserCloudSurfTotalLastDS */
   int32_t n_map_corner, n_map_surf, n_scan_corner, n_scan_surf;
   float transform[6]; /* transformTobeMapped: rx, ry, rz, tx, ty, tz */
-  int32_t reserved[2];
+  int32_t reserved[2]; /* [0]: flags (LINS_MAP_REUSE), [1]: 0 */
 } lins_map_problem;
+
+/* reserved[0] flag: the two map clouds of this problem are the ones of the previous call at the same batch index
+ * (the mapping node's local map only changes with its key frames): when EVERY problem of a batch says so and the
+ * sizes match, the maps already resident on the device — uploaded and bucketed into 1 m cells by the last call —
+ * are used as they are; map_corner / map_surf are not read.                                                     */
+#define LINS_MAP_REUSE 1
 
 /* one query of cornerOptimization / surfOptimization */
 typedef struct lins_map_corr {
@@ -51,12 +57,13 @@ typedef struct lins_map_result {
 
 /* one correspondence pass at in->transform: n_scan_corner + n_scan_surf records */
 int lins_map_correspondences(lins_ctx* ctx, const lins_map_problem* in, lins_map_corr* corner, lins_map_corr* surf);
-/* scan2MapOptimization for n independent problems (maps are gridded once per problem, then up to 10 rounds of
- * {correspondence + row + reduction kernels, host Gauss-Newton step}); the precondition of LM:1636
+/* scan2MapOptimization for n independent problems, entirely on the device: the maps are bucketed into 1 m cells by
+ * a counting-sort kernel (or reused, LINS_MAP_REUSE), then the up to 10 rounds of {correspondence + row + reduction
+ * kernel, 6x6 Gauss-Newton step kernel with the degeneracy projection} run back to back; the precondition of LM:1636
  * (> 10 corner and > 100 surf map points) not met => transform returned unchanged with iters = 0 */
 int lins_scan2map_batch(lins_ctx* ctx, int n, const lins_map_problem* in, lins_map_result* out);
-/* HIP-event time (ms) of the correspondence kernels of the last call, summed over its rounds, and the number of
- * query evaluations they did */
+/* HIP-event time (ms) of the device sequence of the last call (the rounds' kernels; lins_map_correspondences: its
+ * one pass) and the number of query evaluations it did */
 int lins_last_map_stats(lins_ctx* ctx, float* kernel_ms, uint64_t* queries);
 
 #ifdef __cplusplus

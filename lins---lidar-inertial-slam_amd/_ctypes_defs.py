@@ -197,9 +197,11 @@ class MapProblem:
         f = lambda a: np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 4)
         self.map_corner, self.map_surf, self.scan_corner, self.scan_surf = f(map_corner), f(map_surf), f(scan_corner), f(scan_surf)
         self.transform = np.asarray(transform, dtype=np.float32).copy()
+        self.reuse_resident_map = False  # LINS_MAP_REUSE: the maps are the previous call's (lins_map.h)
 
     def as_c(self):
         c = MapProblemC()
+        c.reserved[0] = 1 if self.reuse_resident_map else 0
         pp = lambda a: a.ctypes.data_as(C.POINTER(Point))
         c.map_corner, c.map_surf, c.scan_corner, c.scan_surf = pp(self.map_corner), pp(self.map_surf), pp(self.scan_corner), pp(self.scan_surf)
         c.n_map_corner, c.n_map_surf = len(self.map_corner), len(self.map_surf)

@@ -11,6 +11,7 @@
 // of A^T A, A^T b (f64, fixed-shape tree per block; the host adds the per-block partials in order).
 #include <hip/hip_runtime.h>
 
+#include "lm_math.h"
 #include "map_math.h"
 
 namespace lins {
@@ -172,6 +173,112 @@ __global__ __launch_bounds__(kMapBlock) void map_corr_kernel(const MapDev* __res
     out[tid] = s;
   }
 }
+
+// ---------------------------------------------------------------------------
+// The local map's 1 m gridding on the device (what the reference's kdtree->setInputCloud stands for, LM:1637-1638):
+// one 1024-thread workgroup per cloud counting-sorts the raw points into the cells of the integer lattice — zero
+// the cursors, histogram (L2 atomics), exclusive scan, scatter.  The order inside a cell is whatever the atomics
+// give: the 5-NN is decided on (distance, index) keys, so it does not matter.
+// ---------------------------------------------------------------------------
+struct MapGridJob {
+  long long off_raw;   // raw points of this cloud in the staging arena
+  long long off_pts;   // sorted points
+  long long off_cells; // ncell + 1 starts (relative to off_pts), followed by ncell + 1 scratch cursors
+  int n, ncell;
+  int cmin[3], cdim[3];
+};
+constexpr int kGridBlock = 1024;
+
+__global__ __launch_bounds__(kGridBlock) void map_grid_kernel(const MapGridJob* __restrict__ jobs, const float4* __restrict__ raw,
+                                                              float4* __restrict__ pts, int* __restrict__ cells) {
+  const MapGridJob jb = jobs[blockIdx.x];
+  const int tid = threadIdx.x;
+  int* const starts = cells + jb.off_cells;
+  int* const cursor = starts + jb.ncell + 1;
+  const float4* const src = raw + jb.off_raw;
+  for (int c = tid; c <= jb.ncell; c += kGridBlock) cursor[c] = 0;
+  __syncthreads();
+  auto cell_of = [&](const float4& q) {
+    const int cx = (int)floorf(q.x) - jb.cmin[0], cy = (int)floorf(q.y) - jb.cmin[1], cz = (int)floorf(q.z) - jb.cmin[2];
+    return (cz * jb.cdim[1] + cy) * jb.cdim[0] + cx;
+  };
+  for (int i = tid; i < jb.n; i += kGridBlock) atomicAdd(&cursor[cell_of(src[i])], 1);
+  __syncthreads();
+  // exclusive scan: every thread owns a contiguous run of cells
+  __shared__ int chunk_sum[kGridBlock];
+  const int per = (jb.ncell + kGridBlock - 1) / kGridBlock;
+  const int c_lo = tid * per < jb.ncell ? tid * per : jb.ncell, c_hi = c_lo + per < jb.ncell ? c_lo + per : jb.ncell;
+  int local = 0;
+  for (int c = c_lo; c < c_hi; ++c) local += cursor[c];
+  chunk_sum[tid] = local;
+  __syncthreads();
+  for (int o = 1; o < kGridBlock; o <<= 1) {  // Hillis-Steele inclusive scan of the chunk sums
+    const int v = tid >= o ? chunk_sum[tid - o] : 0;
+    __syncthreads();
+    chunk_sum[tid] += v;
+    __syncthreads();
+  }
+  int run = chunk_sum[tid] - local;
+  for (int c = c_lo; c < c_hi; ++c) {
+    const int cnt = cursor[c];
+    starts[c] = run, cursor[c] = run;
+    run += cnt;
+  }
+  if (tid == 0) starts[jb.ncell] = jb.n;
+  __syncthreads();
+  float4* const dst = pts + jb.off_pts;
+  for (int i = tid; i < jb.n; i += kGridBlock) {
+    const float4 p = src[i];
+    const int pos = atomicAdd(&cursor[cell_of(p)], 1);
+    dst[pos] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// LMOptimization's step between two correspondence rounds (LM:1583-1632), one thread per problem: the per-block
+// partials are added in block order, the 6x6 step of lm_math.h moves the transform, and the next round's rotation
+// terms / the problem's "still running" flag are written where the correspondence kernel reads them — the ten
+// rounds of scan2MapOptimization run back to back without the host.
+// ---------------------------------------------------------------------------
+__global__ void map_lm_kernel(int n, int iter, int blocks_per_problem, MapDev* __restrict__ probs, MapRound* __restrict__ rounds,
+                              const double* __restrict__ partials, lins_map_result* __restrict__ results, LmCarry* __restrict__ carry) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  lins_map_result r = results[k];
+  if (iter < 0) {  // initialisation: rotation terms of the given transform, counters
+    r.iters = 0, r.converged = 0, r.degenerate = 0, r.n_sel = 0;
+    results[k] = r;
+    carry[k].degenerate = 0;
+  } else {
+    if (!probs[k].active) return;
+    double sums[28];
+    for (int t = 0; t < 28; ++t) sums[t] = 0.0;
+    for (int b = 0; b < blocks_per_problem; ++b)
+      for (int t = 0; t < 28; ++t) sums[t] += partials[((size_t)k * blocks_per_problem + b) * 28 + t];
+    r.n_sel = (int)sums[27];
+    r.iters = iter + 1;
+    LmCarry c = carry[k];
+    if (lm_step_from_sums(sums, iter, r.transform, c)) r.converged = 1, probs[k].active = 0;
+    r.degenerate = c.degenerate;
+    carry[k] = c;
+    results[k] = r;
+  }
+  const MapRoundParams p = lm_make_round(r.transform);
+  MapRound rd;
+  rd.as = p.as, rd.tg = p.tg, rd.pad = 0.f;
+  rounds[k] = rd;
+}
+
+void launch_map_grid(hipStream_t stream, int n_jobs, const void* jobs, const float4* raw, float4* pts, int* cells) {
+  hipLaunchKernelGGL(map_grid_kernel, dim3(n_jobs), dim3(kGridBlock), 0, stream, (const MapGridJob*)jobs, raw, pts, cells);
+}
+void launch_map_lm(hipStream_t stream, int n, int iter, int blocks_per_problem, void* probs, void* rounds, const double* partials,
+                   lins_map_result* results, void* carry) {
+  hipLaunchKernelGGL(map_lm_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, n, iter, blocks_per_problem, (MapDev*)probs,
+                     (MapRound*)rounds, partials, results, (LmCarry*)carry);
+}
+size_t map_grid_job_size() { return sizeof(MapGridJob); }
+size_t map_carry_size() { return sizeof(LmCarry); }
 
 void launch_map_corr(hipStream_t stream, int n_problems, int blocks_per_problem, const void* probs, const void* rounds,
                      const float4* pts, const int* cells, const float4* queries, lins_map_corr* recs, double* partials) {

@@ -112,3 +112,22 @@ def test_scan2map_edge_cases(pkg, ieskf, oracle, ctx):
         ctx.scan2map_batch([defs.MapProblem(prob.map_corner, bad, prob.scan_corner, prob.scan_surf, prob.transform)])
     # the context is still usable afterwards
     assert ctx.scan2map_batch([prob])[0]["iters"] > 0
+
+
+def test_resident_maps_are_reused_when_every_problem_says_so(ctx):
+    """LINS_MAP_REUSE: a second call with the flag on every problem runs on the maps the first call left on the device
+    (bucketed by the gridding kernel) — same answers; a changed map size silently falls back to a fresh upload."""
+    probs = [make_problem(defs, 70 + k)[0] for k in range(3)]
+    first = ctx.scan2map_batch(probs)
+    for p in probs:
+        p.reuse_resident_map = True
+        p.map_surf_backup, p.map_surf = p.map_surf, np.full_like(p.map_surf, np.nan)  # must not be read at all
+    again = ctx.scan2map_batch(probs)
+    for a, b in zip(first, again):
+        assert (a["iters"], a["converged"], a["n_sel"]) == (b["iters"], b["converged"], b["n_sel"]) and np.array_equal(a["transform"], b["transform"])
+    for p in probs:
+        p.map_surf = p.map_surf_backup
+    probs[1] = make_problem(defs, 99, n_map_surf=5000)[0]
+    probs[1].reuse_resident_map = True  # size differs from the resident one: uploaded afresh, flag or not
+    third = ctx.scan2map_batch(probs)
+    assert third[1]["iters"] > 0 and np.array_equal(third[0]["transform"], first[0]["transform"])
