@@ -536,3 +536,47 @@ def test_streams_step_keeps_the_healthy_streams_when_one_cannot_take_the_fallbac
             assert np.abs(r1[k].state[:3] - pairs[k].meta["true_t"]).max() < 0.1
         r2, _ = c.streams_step(seg0, prior, cov)  # the context is still consistent: slots swapped back, everybody steps
         assert all(np.isfinite(r.state).all() and r.iters > 0 for r in r2)
+
+
+def test_pipelined_batch_call_equals_the_staged_path(pkg, oracle, ieskf):
+    """lins_ieskf_update_batch pipelines large batches in chunks (pack || H2D || kernels): same bits as
+    upload / run / download of the whole batch; a chunk with an oversized scan takes the global-memory grid
+    on its own and still matches the oracle; a contract violation in a later chunk fails the whole call."""
+    rng = np.random.default_rng(77)
+    base = [make_pair(pkg, rng, 40 + 7 * k, 50 + 5 * k, 600 + 90 * k, 200 + 30 * k, "offgrid") for k in range(7)]
+    base.append(make_pair(pkg, rng, 0, 0, 500, 100, "offgrid"))  # (no queries)
+    n = 1100 + 37
+    pairs = [base[(k * 5 + k // 8) % len(base)] for k in range(n)]
+    c = ieskf.IeskfContext(pkg.default_params(num_iter=30), device=0, max_batch=n, max_targets=13000)
+    try:
+        for search in ("auto", "mr", "lds"):
+            c.set_search(search)
+            got = c.update_batch(pairs)
+            c.upload(pairs)
+            c.run()
+            want = c.download()
+            for k, (g, w) in enumerate(zip(got, want)):
+                assert (g.iters, g.converged, g.diverged, g.m_surf, g.m_corner) == (w.iters, w.converged, w.diverged, w.m_surf, w.m_corner), (search, k)
+                assert np.array_equal(g.state.view(np.int64), w.state.view(np.int64)), (search, k)
+                assert np.array_equal(g.cov.view(np.int64), w.cov.view(np.int64)), (search, k)
+        c.set_search("auto")
+        mixed = list(pairs)
+        mixed[900] = make_pair(pkg, rng, 40, 50, 12000, 900, "offgrid")  # does not fit LDS: its chunk falls back
+        got = c.update_batch(mixed)
+        for k in (0, 511, 512, 899, 900, 901, n - 1):
+            want = oracle.ieskf(pkg.default_params(num_iter=30), mixed[k], oracle.FORM_DENSE, oracle.NN_BRUTE)
+            g = got[k]
+            assert (g.iters, g.converged, g.diverged, g.m_surf, g.m_corner) == (want.iters, want.converged, want.diverged, want.m_surf, want.m_corner), k
+            if not want.diverged:
+                assert np.abs(g.state - want.state).max() <= 1e-6 * max(1.0, np.abs(want.state).max()), k
+        bad = list(pairs)
+        p = bad[1000]
+        sf = p.surf_flat.copy()
+        sf[3, 0] = np.nan
+        bad[1000] = pkg.ScanPair(sf, p.corner_sharp, p.surf_last, p.corner_last, p.state, p.cov)
+        with pytest.raises(Exception):
+            c.update_batch(bad)
+        again = c.update_batch(pairs)  # the context is usable after the failed call
+        assert all(np.isfinite(r.state).all() for r in again[:16])
+    finally:
+        c.close()
