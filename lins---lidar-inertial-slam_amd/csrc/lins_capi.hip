@@ -316,6 +316,56 @@ int parallel_scans(int n, F fn) {
   return 0;
 }
 
+// The pipelined form: a pool of host threads runs fn(k) for k = 0, 1, 2 ... ; as soon as every item of a chunk
+// [lo, hi) is done, the CALLING thread runs ready(lo, hi) (queue the chunk's copy, its kernels) while the pool is
+// already packing the next chunks.  Chunks are `chunk` items, the last one takes the remainder (< 2 chunks).  Returns
+// the first non-zero result of fn (smallest index of the chunk that saw it) or of ready; later chunks are abandoned.
+template <class F, class R>
+int pack_pipelined(int n, int chunk, F fn, R ready) {
+  if (n <= 0) return 0;
+  const int n_chunks = std::max(1, n / chunk);
+  auto chunk_of = [&](int k) { return std::min(k / chunk, n_chunks - 1); };
+  std::vector<int> rcs(n, 0);
+  std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[n_chunks]);
+  for (int c = 0; c < n_chunks; ++c) done[c].store(0);
+  std::atomic<int> next{0};
+  std::atomic<bool> stop{false};
+  const unsigned hw = std::thread::hardware_concurrency();
+  const int T = std::max(1, std::min({16, (int)(hw ? hw : 1) - 1, n}));
+  std::vector<std::thread> pool;
+  for (int t = 0; t < T; ++t)
+    pool.emplace_back([&] {
+      for (int k; !stop.load(std::memory_order_relaxed) && (k = next.fetch_add(1)) < n;) {
+        rcs[k] = fn(k);
+        done[chunk_of(k)].fetch_add(1, std::memory_order_release);
+      }
+    });
+  int rc = 0;
+  for (int c = 0; c < n_chunks && !rc; ++c) {
+    const int lo = c * chunk, hi = c + 1 == n_chunks ? n : lo + chunk;
+    while (done[c].load(std::memory_order_acquire) < hi - lo) std::this_thread::yield();
+    for (int k = lo; k < hi && !rc; ++k) rc = rcs[k];
+    if (!rc) rc = ready(lo, hi);
+  }
+  stop.store(true);
+  for (auto& th : pool) th.join();
+  return rc;
+}
+
+// stage times of a call on stderr (LINS_ENABLE_DEBUG_KNOBS=1 and LINS_BATCH_TRACE set)
+struct CallTrace {
+  bool on = false;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  CallTrace() {
+    const char* g = std::getenv("LINS_ENABLE_DEBUG_KNOBS");
+    on = g && g[0] == '1' && std::getenv("LINS_BATCH_TRACE");
+  }
+  double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+  void mark(const char* what) const {
+    if (on) std::fprintf(stderr, "  [trace] %-28s %.3f ms\n", what, ms());
+  }
+};
+
 struct RangeFlags {  // which kernel families the scans of a range can take
   bool lds_ok = true, mr_ok = true, lds3_ok = true, split_ok = true;
 };
@@ -845,30 +895,39 @@ static int fe_run(lins_ctx* ctx, int n, const lins_segmented_scan* in, double sc
     HIP_TRY(ctx, hipHostMalloc((void**)&f.h_ground, total));
     f.h_cap = total;
   }
-  // pass 2 (threaded): input contract + packing into the pinned staging
-  const int rcv = parallel_scans(n, [&](int k) -> int {
-    const lins_segmented_scan& s = in[k];
-    const size_t o = (size_t)hs[k].off;
-    for (int i = 0; i < s.n; ++i) {
-      const lins_point& p = s.cloud[i];
-      if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z) || !std::isfinite(p.intensity) ||
-          !std::isfinite(s.range[i]) || s.col[i] >= (uint32_t)LINS_SCAN_NUM)
-        return LINS_E_INPUT;
-    }
-    if (s.n) {
-      std::memcpy(f.h_cloud + o, s.cloud, s.n * sizeof(float4));
-      std::memcpy(f.h_range + o, s.range, s.n * sizeof(float));
-      std::memcpy(f.h_col + o, s.col, s.n * sizeof(unsigned));
-      std::memcpy(f.h_ground + o, s.ground, s.n);
-    }
-    return 0;
-  });
-  if (rcv) return rcv;
-  if (total) {
-    HIP_TRY(ctx, hipMemcpyAsync(f.d_cloud, f.h_cloud, total * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(f.d_range, f.h_range, total * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(f.d_col, f.h_col, total * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(f.d_ground, f.h_ground, total, hipMemcpyHostToDevice, ctx->stream));
+  // pass 2 (host pool): input contract + packing into the pinned staging; every complete chunk of scans is sent
+  // while the next ones are being packed
+  const int rcv = pack_pipelined(
+      n, 64,
+      [&](int k) -> int {
+        const lins_segmented_scan& s = in[k];
+        const size_t o = (size_t)hs[k].off;
+        for (int i = 0; i < s.n; ++i) {
+          const lins_point& p = s.cloud[i];
+          if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z) || !std::isfinite(p.intensity) ||
+              !std::isfinite(s.range[i]) || s.col[i] >= (uint32_t)LINS_SCAN_NUM)
+            return LINS_E_INPUT;
+        }
+        if (s.n) {
+          std::memcpy(f.h_cloud + o, s.cloud, s.n * sizeof(float4));
+          std::memcpy(f.h_range + o, s.range, s.n * sizeof(float));
+          std::memcpy(f.h_col + o, s.col, s.n * sizeof(unsigned));
+          std::memcpy(f.h_ground + o, s.ground, s.n);
+        }
+        return 0;
+      },
+      [&](int lo, int hi) -> int {
+        const size_t a = (size_t)hs[lo].off, cnt = (hi < n ? (size_t)hs[hi].off : total) - a;
+        if (!cnt) return 0;
+        HIP_TRY(ctx, hipMemcpyAsync(f.d_cloud + a, f.h_cloud + a, cnt * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(f.d_range + a, f.h_range + a, cnt * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(f.d_col + a, f.h_col + a, cnt * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(f.d_ground + a, f.h_ground + a, cnt, hipMemcpyHostToDevice, ctx->stream));
+        return 0;
+      });
+  if (rcv) {
+    (void)hipStreamSynchronize(ctx->stream);  // (copies of earlier chunks may still read the staging)
+    return rcv;
   }
   HIP_TRY(ctx, hipMemcpyAsync(f.d_scans, hs.data(), (size_t)n * sizeof(FeScanHost), hipMemcpyHostToDevice, ctx->stream));
   return fe_launch(ctx, n, scan_period, out_base, counts, bytes);
@@ -935,21 +994,30 @@ static int sg_run(lins_ctx* ctx, int n, const lins_point* const* raw, const int3
     HIP_TRY(ctx, hipHostMalloc((void**)&f.h_raw, total * sizeof(float4)));
     f.h_raw_cap = total;
   }
-  const int rcv = parallel_scans(n, [&](int k) -> int {
-    const lins_point* p = raw[k];
-    for (int i = 0; i < n_raw[k]; ++i)  // (no-return points may be NaN in a real driver's cloud: they never project)
-      if (std::isinf(p[i].x) || std::isinf(p[i].y) || std::isinf(p[i].z)) return LINS_E_INPUT;
-    std::memcpy(f.h_raw + hr[k].off, p, (size_t)n_raw[k] * sizeof(float4));
-    return 0;
-  });
-  if (rcv) return rcv;
+  const int rcv = pack_pipelined(
+      n, 64,
+      [&](int k) -> int {
+        const lins_point* p = raw[k];
+        for (int i = 0; i < n_raw[k]; ++i)  // (no-return points may be NaN in a real driver's cloud: they never project)
+          if (std::isinf(p[i].x) || std::isinf(p[i].y) || std::isinf(p[i].z)) return LINS_E_INPUT;
+        std::memcpy(f.h_raw + hr[k].off, p, (size_t)n_raw[k] * sizeof(float4));
+        return 0;
+      },
+      [&](int lo, int hi) -> int {  // a complete chunk of clouds travels while the next ones are packed
+        const size_t a = (size_t)hr[lo].off, cnt = (hi < n ? (size_t)hr[hi].off : total) - a;
+        HIP_TRY(ctx, hipMemcpyAsync(f.d_raw + a, f.h_raw + a, cnt * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+        return 0;
+      });
+  if (rcv) {
+    (void)hipStreamSynchronize(ctx->stream);
+    return rcv;
+  }
   std::vector<FeScanHost> hs(n);
   for (int k = 0; k < n; ++k) {
     std::memset(&hs[k], 0, sizeof hs[k]);
     hs[k].off = (long long)((size_t)k * N);
     hs[k].o_sharp = offs[k][0], hs[k].o_less_sharp = offs[k][1], hs[k].o_flat = offs[k][2], hs[k].o_less_flat = offs[k][3];
   }
-  HIP_TRY(ctx, hipMemcpyAsync(f.d_raw, f.h_raw, total * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(f.d_raws, hr.data(), (size_t)n * sizeof(SgRawHost), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(f.d_scans, hs.data(), (size_t)n * sizeof(FeScanHost), hipMemcpyHostToDevice, ctx->stream));
   // segmentAlphaX / Y and segmentTheta as the host restatement forms them (parameters.h:88-92)
@@ -1094,6 +1162,7 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
       if (!done) failed = true;
     }
   } guard{t.failed};
+  const CallTrace trace;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const int n = t.n, cur = t.cur, last = cur ^ 1;
   ctx->n_uploaded = 0, ctx->ran = false;  // the batch buffers are reused below
@@ -1123,6 +1192,7 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
     return rc;
   }
   t.frontend_ms = ctx->fe.ms;
+  trace.mark("front-end done (synced)");
   // 2. IESKF update of every stream against its resident last scan (a stream's first scan: an update
   //    with no rows, which leaves the given state — the bootstrap pose — untouched)
   bool lds_ok = true, mr_ok = true, lds3_ok = true;
@@ -1175,6 +1245,7 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)n * sizeof(OutRecHost), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipEventElapsedTime(&t.update_ms, ctx->ev0, ctx->ev1));
+  trace.mark("update done (synced)");
   for (int k = 0; k < n; ++k) {
     lins_result& r = out[k];
     std::memset(&r, 0, sizeof r);
@@ -1229,6 +1300,7 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
   HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipEventElapsedTime(&t.reproject_ms, ctx->ev0, ctx->ev2));
+  trace.mark("re-projection done (synced)");
   t.cur = last;
   guard.done = true;
   return LINS_OK;
@@ -1416,48 +1488,28 @@ int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins
   }
   ctx->n_uploaded = 0, ctx->ran = false;
 
-  const int n_chunks = n / kChunk;  // (the last chunk takes the remainder: no tiny launch)
-  auto chunk_of = [&](int s) { return std::min(s / kChunk, n_chunks - 1); };
-  std::vector<int> rcs(n, 0);
-  std::unique_ptr<std::atomic<int>[]> done(new std::atomic<int>[n_chunks]);
-  for (int c = 0; c < n_chunks; ++c) done[c].store(0);
-  std::atomic<int> next{0};
-  std::atomic<bool> stop{false};
-  const unsigned hw = std::thread::hardware_concurrency();
-  const int T = std::max(1, std::min(16, (int)(hw ? hw : 1) - 1));
-  std::vector<std::thread> pool;
-  for (int t = 0; t < T; ++t)
-    pool.emplace_back([&] {
-      for (int s; !stop.load(std::memory_order_relaxed) && (s = next.fetch_add(1)) < n;) {
-        rcs[s] = pack_one(ctx, in, s);
-        done[chunk_of(s)].fetch_add(1, std::memory_order_release);
-      }
-    });
-  auto finish = [&](int r) {
-    stop.store(true);
-    for (auto& th : pool) th.join();
-    if (r) (void)hipStreamSynchronize(ctx->copy_stream), (void)hipStreamSynchronize(ctx->stream);
-    return r;
-  };
   RangeFlags all;
-  for (int c = 0; c < n_chunks; ++c) {
-    const int lo = c * kChunk, hi = c + 1 == n_chunks ? n : lo + kChunk;
-    while (done[c].load(std::memory_order_acquire) < hi - lo) std::this_thread::yield();
-    if (trace) std::fprintf(stderr, "chunk %d packed at %.3f ms\n", c, now_ms());
-    for (int s = lo; s < hi; ++s)
-      if (rcs[s]) return finish(rcs[s]);
-    const RangeFlags fl = range_flags(ctx, lo, hi);
-    const size_t arena_end = hi < n ? (size_t)ctx->h_desc[hi].off_surf_q : arena_used;
-    if ((rc = h2d_range(ctx, lo, hi, arena_end, ctx->copy_stream))) return finish(rc);
-    hipError_t e = hipEventRecord(ctx->ev_copy, ctx->copy_stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_copy, 0);
-    if (e == hipSuccess && c == 0) e = hipEventRecord(ctx->ev0, ctx->stream);
-    if (e != hipSuccess) return finish(fail_hip(ctx, e, "chunk hand-over (event record / stream wait)"));
-    if ((rc = run_range(ctx, lo, hi - lo, n, fl, nullptr, 0))) return finish(rc);
-    all.lds_ok = all.lds_ok && fl.lds_ok, all.mr_ok = all.mr_ok && fl.mr_ok, all.lds3_ok = all.lds3_ok && fl.lds3_ok;
-    all.split_ok = all.split_ok && fl.split_ok;
+  rc = pack_pipelined(
+      n, kChunk, [&](int s) { return pack_one(ctx, in, s); },
+      [&](int lo, int hi) -> int {
+        if (trace) std::fprintf(stderr, "scans %d..%d packed at %.3f ms\n", lo, hi, now_ms());
+        const RangeFlags fl = range_flags(ctx, lo, hi);
+        const size_t arena_end = hi < n ? (size_t)ctx->h_desc[hi].off_surf_q : arena_used;
+        int r = h2d_range(ctx, lo, hi, arena_end, ctx->copy_stream);
+        if (r) return r;
+        hipError_t e = hipEventRecord(ctx->ev_copy, ctx->copy_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_copy, 0);
+        if (e == hipSuccess && lo == 0) e = hipEventRecord(ctx->ev0, ctx->stream);
+        if (e != hipSuccess) return fail_hip(ctx, e, "chunk hand-over (event record / stream wait)");
+        if ((r = run_range(ctx, lo, hi - lo, n, fl, nullptr, 0))) return r;
+        all.lds_ok = all.lds_ok && fl.lds_ok, all.mr_ok = all.mr_ok && fl.mr_ok, all.lds3_ok = all.lds3_ok && fl.lds3_ok;
+        all.split_ok = all.split_ok && fl.split_ok;
+        return 0;
+      });
+  if (rc) {
+    (void)hipStreamSynchronize(ctx->copy_stream), (void)hipStreamSynchronize(ctx->stream);
+    return rc;
   }
-  finish(0);
   if (trace) {
     std::fprintf(stderr, "all issued at %.3f ms (arena %.1f MB)\n", now_ms(), arena_used * 16e-6);
     (void)hipStreamSynchronize(ctx->copy_stream);
