@@ -653,6 +653,11 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
   // iteration: wave 0 -> linState_, R^T;  wave 1 -> phi, Rinvleft(-phi)^T;  wave 2 -> x_filter (-) x_lin.
   // (Until round 2 the first three waves each ran the whole solve redundantly to save the staging: 2 x ~2.5 k
   // issued instructions per iteration for nothing.)
+  if (prm.pad & 0x10000) {  // counting aid (LINS_DEBUG_SKIP bit 0x10000): no solve, no update — the state stands still
+    if (tid == 0) L.iter = iter + 1;
+    __syncthreads();
+    return;
+  }
   double* const stage = &L.aug[0][0];  // 22 doubles: linState_ (19), |r|, |r| kept, |dx|
   int* const stage_flags = reinterpret_cast<int*>(&L.aug[1][0]);  // diverged, converged
   if (wave == 0) {
@@ -930,7 +935,9 @@ __device__ __noinline__ void split_gather(const GatherArgs ga, const float4* gs,
 // ---------------------------------------------------------------------------
 template <int BLOCK, int LANES, bool PASS_ONLY, bool PROF, bool ICP = false, bool SPLIT = false>
 #if LINS_LDS_MINW > 1
-__global__ __launch_bounds__(BLOCK, LINS_LDS_MINW) void ieskf_lds_kernel(
+// (second argument: waves per SIMD the register allocation must allow.  A 256-thread workgroup — LINS_LDS_CARRY2 —
+// has half the waves, so two resident workgroups leave each wave twice the registers.)
+__global__ __launch_bounds__(BLOCK, BLOCK >= 512 ? LINS_LDS_MINW : LINS_LDS_MINW / 2) void ieskf_lds_kernel(
 #else
 __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #endif
@@ -1004,6 +1011,18 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   float lb1 = 0.f, lb2 = 0.f, lb3 = 0.f, certA[3] = {0.f, 0.f, 0.f}, certB[3] = {0.f, 0.f, 0.f};
   bool have_cert = false;
   bool searched = false;  // a search iteration has run: certificates and warm candidates exist (uniform)
+#ifdef LINS_LDS_CARRY2
+  // A scan with more queries than lanes (up to twice as many) takes TWO rounds per iteration, and every lane keeps
+  // the tracked candidates and certificates of BOTH its queries: the set of the round that is not running waits in
+  // the shadow registers below, the two sets are exchanged after each round (2 x 19 register moves — the round body
+  // exists once).  This is what lets the batch kernel run as 256-thread workgroups: half the waves, twice the
+  // registers per wave, no scratch.
+  int sh_i[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
+  float sh_f[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  constexpr bool kCarry2 = LANES == 1;
+#else
+  constexpr bool kCarry2 = false;
+#endif
 
   for (;;) {
     const int iter = L.iter;
@@ -1032,6 +1051,8 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     }
     const bool spread = LANES == 1 && (spread_s | spread_c) != 0;
     const int span = spread ? kQPerRound : (aligned ? surf_waves * kQPerWave + sd.n_corner_q : total);  // row slots in use
+    const bool two_rounds = kCarry2 && span > kQPerRound && span <= 2 * kQPerRound;  // both rounds' state is carried
+    const int per_wave2 = (total + BLOCK / 64 - 1) / (BLOCK / 64);  // two rounds: queries per wave, 64 in the first round
     int4 held = make_int4(0, 0, 0, -1);  // (ICP, ICP_FREQ > 1, single round) a corner triplet waiting for the plane-row count
     for (int base = 0; base < span; base += kQPerRound) {
       const int vslot = base + wave * kQPerWave + q_in_wave;  // position in the (padded) layout
@@ -1048,8 +1069,12 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         else
           slot = vslot - surf_waves * kQPerWave + sd.n_surf_q;
       }
+      if (two_rounds) {  // wave w serves queries [w * per, (w + 1) * per): its first 64 in round 0, the rest in round 1
+        const int k = (base ? 64 : 0) + lane;
+        slot = wave * per_wave2 + k, active = k < per_wave2 && slot < total;
+      }
       double row[7] = {0, 0, 0, 0, 0, 0, 0};
-      if (span > kQPerRound) {  // several rounds: the lane <-> query mapping changes, nothing carries over
+      if (span > kQPerRound && !two_rounds) {  // several rounds: the lane <-> query mapping changes, nothing carries over
         a1 = b1c = ra1 = rb1 = a2 = b2c = a3 = b3c = sel1 = -1, have_cert = false;
         lb1 = lb2 = lb3 = 0.f;
       }
@@ -1063,7 +1088,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         const int qi = is_surf ? slot : slot - sd.n_surf_q;
         const LCloud& c = is_surf ? cs : cc;
         const float thr = prm.nearest_f;
-        const bool single_round = span <= kQPerRound;
+        const bool single_round = span <= kQPerRound || two_rounds;  // (the lane <-> query mapping is fixed)
         const bool warm_iter = single_round && searched;  // certificates / warm candidates exist (uniform)
         const float margin = warm_iter ? prm.margin_warm : prm.margin_cold;
         const bool verify = (prm.pad & 8) != 0;  // test aid: search anyway and count disagreements
@@ -1081,9 +1106,15 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         int p1 = -1, p2 = -1, p3 = -1;
         long long s0 = prof ? clock64() : 0, s1 = s0, s2 = s0;
         if (active) {
-          q = arena[(is_surf ? sd.off_surf_q : sd.off_corner_q) + qi];
+          if (prm.pad & 0x400000)  // (counting aid: no query load)
+            q = make_float4(1.f + lane, 2.f, 0.5f, 3.25f);
+          else
+            q = arena[(is_surf ? sd.off_surf_q : sd.off_corner_q) + qi];
           V3 t{L.ic.lin[0], L.ic.lin[1], L.ic.lin[2]};
-          transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2]);
+          if (prm.pad & 0x100000)  // (counting aid: no de-skew)
+            o.sel[0] = q.x, o.sel[1] = q.y, o.sel[2] = q.z;
+          else
+            transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2]);
         }
         if (prof) {
           s1 = clock64();
@@ -1106,11 +1137,15 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           // (distance, key) order as the search); otherwise the search runs again, warm-started from A.
           bool need_nn = false, said = false, flip = false;
           int pred = -1;
-          if (active) {
-            qp.rho = sqrtf(o.sel[0] * o.sel[0] + o.sel[1] * o.sel[1]);
-            qp.qn3 = sqrtf(qp.rho * qp.rho + o.sel[2] * o.sel[2]);
-            qp.el = atan2f(o.sel[2], qp.rho);
-            qp.a0_surf_or_corner = az_bin(o.sel[0], o.sel[1], c.naz);
+          if (active && (prm.pad & 0x80000) && warm_iter) {  // (counting aid: every certificate holds, unchecked)
+            pred = a1, said = true;
+          } else if (active) {
+            if (!(prm.pad & 0x200000)) {
+              qp.rho = sqrtf(o.sel[0] * o.sel[0] + o.sel[1] * o.sel[1]);
+              qp.qn3 = sqrtf(qp.rho * qp.rho + o.sel[2] * o.sel[2]);
+              qp.el = atan2f(o.sel[2], qp.rho);
+              qp.a0_surf_or_corner = az_bin(o.sel[0], o.sel[1], c.naz);
+            }
             const float da = a1 >= 0 ? dist_to(a1) : INFINITY, db = b1c >= 0 ? dist_to(b1c) : INFINITY;
             bool ok = warm_iter && !(prm.pad & 16) && certified(fminf(fminf(da, db), thr), lb1, drift_from(certA));
             const unsigned long long ka = da < thr ? pack_key(da, pt_idx(L, c, a1)) : kNone;
@@ -1182,7 +1217,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           if (active && p1 >= 0) {
             j1 = pt_idx(L, c, p1);  // (p1 >= 0 => p1 is candidate A, on ring ra1)
             need_walk = nn_changed || !warm_iter;
-            if (!need_walk) {
+            if (!need_walk && (prm.pad & 0x80000)) {
+              pred2 = a2, pred3 = a3, said23 = true;
+            } else if (!need_walk) {
               const WalkCtx w = make_walk_ctx(c, is_surf ? sd.n_surf_q : sd.n_corner_q, j1, ra1);
               const float dB = drift_from(certB);
               auto judge = [&](int pa, int pb, float lb, int& pd, bool& fl) {
@@ -1270,7 +1307,12 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           p1 = s.x, p2 = s.y, p3 = s.z;
         }
         long long s3 = prof ? clock64() : 0;
-        if (active) {
+        // The iteration constants the rows need (R^T, G^T: 36 registers' worth, the same for every lane) are read from
+        // LDS HERE.  Without the fence the compiler hoists those reads to the top of the iteration, finds no
+        // registers for them across the search code, and moves them through scratch: ~12 scratch stores and as many
+        // waited-for scratch loads per wave and iteration — the bulk of a late iteration's time.
+        asm volatile("" ::: "memory");
+        if (active && !(prm.pad & 0x20000)) {  // (counting aid: LINS_DEBUG_SKIP bit 0x20000 drops the rows)
           auto pt4 = [&](int pos) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             pt_xyz(L, c, pos, v.x, v.y, v.z);
@@ -1498,12 +1540,23 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         if (prof && tid == 0) L.prof_acc[9] += clock64() - s3;
 #endif
       }
+#ifdef LINS_LDS_CARRY2
+      if (two_rounds) {  // the other round's set becomes current
+        auto xi = [](int& a, int& b) { const int t = a; a = b, b = t; };
+        auto xf = [](float& a, float& b) { const float t = a; a = b, b = t; };
+        xi(a1, sh_i[0]), xi(b1c, sh_i[1]), xi(ra1, sh_i[2]), xi(rb1, sh_i[3]), xi(a2, sh_i[4]), xi(b2c, sh_i[5]);
+        xi(a3, sh_i[6]), xi(b3c, sh_i[7]), xi(sel1, sh_i[8]);
+        xf(lb1, sh_f[0]), xf(lb2, sh_f[1]), xf(lb3, sh_f[2]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xf(certA[k], sh_f[3 + k]), xf(certB[k], sh_f[6 + k]);
+      }
+#endif
       if (kRegReduce) {
         if (prof) t1 = clock64();
 #ifdef LINS_PROF_WAVES  // (experiment: per-wave correspondence time of the late iterations in slots 6..13)
         if (prof && lane == 0 && iter >= LINS_PROF_WAVES) L.prof_acc[6 + wave] += t1 - t0;
 #endif
-        acc += wave_reduce_rows(row, lane);  // no LDS, no barrier: the rows never leave registers
+        if (!(prm.pad & 0x40000)) acc += wave_reduce_rows(row, lane);  // no LDS, no barrier: the rows never leave registers
       } else {
         if (lane_used && role == 0) {
           const int local = wave * kQPerWave + q_in_wave;

@@ -23,6 +23,12 @@
 #define LINS_LDS_REGREDUCE 1
 #define LINS_LDS_WAVES 8
 #define LINS_LDS_MINW 4
+#ifndef LINS_MR_BLOCK
+#define LINS_MR_BLOCK 512
+#endif
+#if LINS_MR_BLOCK == 256
+#define LINS_LDS_CARRY2 1
+#endif
 #define LINS_LDS_BYTES 80896
 #include "ieskf_lds_impl.h"
 
@@ -44,9 +50,9 @@ void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDe
                    float4* sorted, const double* state_in, const double* cov_in, double* state_out, double* a6,
                    void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof) {
   if (prof)
-    LINS_LAUNCH(lds_mr, 512, 1, true);
+    LINS_LAUNCH(lds_mr, LINS_MR_BLOCK, 1, true);
   else
-    LINS_LAUNCH(lds_mr, 512, 1, false);
+    LINS_LAUNCH(lds_mr, LINS_MR_BLOCK, 1, false);
 }
 
 // split path (ieskf_split.h): the first prm.split_iters iterations + the candidate lists for the list kernel
