@@ -643,7 +643,10 @@ __device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, 
 // registers, the 19-state) are allocated on their own instead of inflating — and spilling —
 // the search loop it would otherwise be fused with.  Called by every thread (barriers inside).
 // ---------------------------------------------------------------------------
-__device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int iter, bool prof, long long& t3) {
+// (Scalars by value, the profile stamp returned: a reference to the kernel's parameter struct or to a local would
+// force them into scratch for the whole kernel — every later read of a parameter a scratch load.)
+__device__ __noinline__ long long solve_and_update(double prm_r2, int prm_fixed_iters, int prm_pad, int tid, int iter, bool prof) {
+  long long t3 = 0;
   LdsStore& L = g_lds;
   const int lane = tid & 63, wave = tid >> 6;
   // ---- wave 0: (sigma^2 I + A P_SS) w = g + A d_S  (push-through form of SE:542-549) solved across the wave
@@ -653,10 +656,10 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
   // iteration: wave 0 -> linState_, R^T;  wave 1 -> phi, Rinvleft(-phi)^T;  wave 2 -> x_filter (-) x_lin.
   // (Until round 2 the first three waves each ran the whole solve redundantly to save the staging: 2 x ~2.5 k
   // issued instructions per iteration for nothing.)
-  if (prm.pad & 0x10000) {  // counting aid (LINS_DEBUG_SKIP bit 0x10000): no solve, no update — the state stands still
+  if (prm_pad & 0x10000) {  // counting aid (LINS_DEBUG_SKIP bit 0x10000): no solve, no update — the state stands still
     if (tid == 0) L.iter = iter + 1;
     __syncthreads();
-    return;
+    return t3;
   }
   double* const stage = &L.aug[0][0];  // 22 doubles: linState_ (19), |r|, |r| kept, |dx|
   int* const stage_flags = reinterpret_cast<int*>(&L.aug[1][0]);  // diverged, converged
@@ -665,7 +668,7 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
     if (lane < 42) {
       const int i = lane / 7, j = lane % 7;
       if (j < 6) {
-        v = (i == j ? prm.r2 : 0.0);
+        v = (i == j ? prm_r2 : 0.0);
 #pragma unroll
         for (int k = 0; k < 6; ++k) v += sym6(L.sums, i, k) * L.P[sidx(k) * 18 + sidx(j)];
       } else {
@@ -711,7 +714,7 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
     } else {
       const Q4 qn = qnormalized(qmul(Q4{lin[6], lin[7], lin[8], lin[9]}, axis2quat(V3{dth[0], dth[1], dth[2]})));
       lin[6] = qn.w, lin[7] = qn.x, lin[8] = qn.y, lin[9] = qn.z;
-      if (un <= 1e-2 && !prm.fixed_iters) conv = 1;
+      if (un <= 1e-2 && !prm_fixed_iters) conv = 1;
       res_prev = rn;
     }
     if (lane == 0) {
@@ -761,6 +764,7 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
     L.iter = iter + 1;
   }
   __syncthreads();
+  return t3;
 }
 
 // ---------------------------------------------------------------------------
@@ -1615,7 +1619,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     if (ICP)
       icp_solve_and_update(tid, iter);
     else
-      solve_and_update(prm, tid, iter, prof, t3);
+      t3 = solve_and_update(prm.r2, prm.fixed_iters, prm.pad, tid, iter, prof);
     if constexpr (SPLIT) {
       // split path (ieskf_split.h): after the update of iteration split_iters - 1 the remaining iterations go to the
       // list kernel.  Every query leaves its candidate list, gathered around its position de-skewed with the NEW
