@@ -119,6 +119,37 @@ __global__ void debug_wave_solve_kernel(int n, const double* __restrict__ in, do
   wave_solve6(l < 42 ? in[(size_t)item * 42 + l] : 0.0, l, x6);
   if (l < 6) out[(size_t)item * 6 + l] = x6[l];
 }
+// op 9: wave_reduce_rows (one wave per item, 64 rows of 7 in, the 28 sums out); op 10: the same tree with plain
+// __shfl_xor exchanges — the two must agree bit for bit (the cross-lane paths of xor_lane_i32 are then right)
+__device__ __forceinline__ double reduce_rows_ref(const double (&row)[7], int lane) {
+  constexpr int A[28] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6};
+  constexpr int B[28] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6};
+  double v[28];
+  for (int k = 0; k < 28; ++k) v[k] = row[A[k]] * row[B[k]];
+  int cnt = 14;
+  for (int m = 32; m >= 2; m >>= 1) {
+    const bool up = (lane & m) != 0;
+    if (m == 8) v[7] = 0.0;
+    for (int i = 0; i < cnt; ++i) {
+      const double lo = v[i], hi = v[i + cnt];
+      v[i] = (up ? hi : lo) + shfl_xor_f64(up ? lo : hi, m);
+    }
+    cnt = m == 16 ? 4 : cnt / 2;
+  }
+  return v[0] + shfl_xor_f64(v[0], 1);
+}
+__global__ void debug_reduce_rows_kernel(int op, const double* __restrict__ in, double* __restrict__ out) {
+  const int item = blockIdx.x, l = threadIdx.x;
+  double row[7];
+  for (int k = 0; k < 7; ++k) row[k] = in[((size_t)item * 64 + l) * 7 + k];
+  const double acc = op == 9 ? wave_reduce_rows(row, l) : reduce_rows_ref(row, l);
+  const int idx = reduce_sum_index(l);
+  if (idx >= 0) out[(size_t)item * 28 + idx] = acc;
+}
+void launch_debug_reduce_rows(hipStream_t stream, int op, int n, const double* in, double* out) {
+  hipLaunchKernelGGL(debug_reduce_rows_kernel, dim3(n), dim3(64), 0, stream, op, in, out);
+}
+
 void launch_debug_wave_solve(hipStream_t stream, int n, const double* in, double* out) {
   hipLaunchKernelGGL(debug_wave_solve_kernel, dim3(n), dim3(64), 0, stream, n, in, out);
 }

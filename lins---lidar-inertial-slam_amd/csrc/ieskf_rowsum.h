@@ -137,6 +137,34 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
   const int lo = __shfl_xor(__double2loint(v), mask), hi = __shfl_xor(__double2hiint(v), mask);
   return __hiloint2double(hi, lo);
 }
+// The same exchange (lane <-> lane ^ MASK, MASK a power of two, every lane of the wave active) on the VALU's own
+// cross-lane paths instead of the LDS crossbar (ds_bpermute: an address register and ~100 clocks per dword):
+// quad permutes for 1 and 2, two bank-masked row shifts for 4, a row rotation for 8, the gfx950 lane-swap
+// instructions for 16 and 32.
+template <int MASK>
+__device__ __forceinline__ int xor_lane_i32(int v, int lane) {
+  if constexpr (MASK == 1) {
+    return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
+  } else if constexpr (MASK == 2) {
+    return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);  // quad_perm [2, 3, 0, 1]
+  } else if constexpr (MASK == 4) {
+    const int r = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);  // row_shl:4 into lanes 0-3, 8-11 of a row
+    return __builtin_amdgcn_update_dpp(r, v, 0x114, 0xF, 0xA, false);         // row_shr:4 into lanes 4-7, 12-15
+  } else if constexpr (MASK == 8) {
+    return __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true);  // row_ror:8
+  } else if constexpr (MASK == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((lane & 16) ? r[0] : r[1]);
+  } else {
+    static_assert(MASK == 32, "power of two below the wave size");
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((lane & 32) ? r[0] : r[1]);
+  }
+}
+template <int MASK>
+__device__ __forceinline__ double xor_lane_f64(double v, int lane) {
+  return __hiloint2double(xor_lane_i32<MASK>(__double2hiint(v), lane), xor_lane_i32<MASK>(__double2loint(v), lane));
+}
 __device__ __forceinline__ int reduce_sum_index(int lane) {
   const int local = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
   return (local < 7 && !(lane & 1)) ? ((lane >> 5) & 1) * 14 + ((lane >> 4) & 1) * 7 + local : -1;
@@ -152,7 +180,7 @@ __device__ __forceinline__ double wave_reduce_rows(const double (&row)[7], int l
 #pragma unroll
     for (int i = 0; i < 14; ++i) {
       const double lo = v[i], hi = v[i + 14];
-      v[i] = (up ? hi : lo) + shfl_xor_f64(up ? lo : hi, 32);
+      v[i] = (up ? hi : lo) + xor_lane_f64<32>(up ? lo : hi, lane);
     }
   }
   {
@@ -160,7 +188,7 @@ __device__ __forceinline__ double wave_reduce_rows(const double (&row)[7], int l
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       const double lo = v[i], hi = v[i + 7];
-      v[i] = (up ? hi : lo) + shfl_xor_f64(up ? lo : hi, 16);
+      v[i] = (up ? hi : lo) + xor_lane_f64<16>(up ? lo : hi, lane);
     }
   }
   v[7] = 0.0;
@@ -169,7 +197,7 @@ __device__ __forceinline__ double wave_reduce_rows(const double (&row)[7], int l
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const double lo = v[i], hi = v[i + 4];
-      v[i] = (up ? hi : lo) + shfl_xor_f64(up ? lo : hi, 8);
+      v[i] = (up ? hi : lo) + xor_lane_f64<8>(up ? lo : hi, lane);
     }
   }
   {
@@ -177,15 +205,15 @@ __device__ __forceinline__ double wave_reduce_rows(const double (&row)[7], int l
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const double lo = v[i], hi = v[i + 2];
-      v[i] = (up ? hi : lo) + shfl_xor_f64(up ? lo : hi, 4);
+      v[i] = (up ? hi : lo) + xor_lane_f64<4>(up ? lo : hi, lane);
     }
   }
   {
     const bool up = (lane & 2) != 0;
     const double lo = v[0], hi = v[1];
-    v[0] = (up ? hi : lo) + shfl_xor_f64(up ? lo : hi, 2);
+    v[0] = (up ? hi : lo) + xor_lane_f64<2>(up ? lo : hi, lane);
   }
-  return v[0] + shfl_xor_f64(v[0], 1);
+  return v[0] + xor_lane_f64<1>(v[0], lane);
 }
 
 }  // namespace lins

@@ -47,6 +47,7 @@ void launch_k1(hipStream_t, int, const DevParams&, const ScanDesc*, const float4
 void launch_debug_math(hipStream_t, int, int, int, int, const double*, double*);
 void launch_debug_cycles(hipStream_t, int, int, const double*, double*);
 void launch_debug_wave_solve(hipStream_t, int, const double*, double*);
+void launch_debug_reduce_rows(hipStream_t, int, int, const double*, double*);
 size_t split_scan_size();
 size_t split_q_size();
 size_t split_cand_slots();
@@ -735,8 +736,8 @@ int lins_debug_math(lins_ctx* ctx, int op, int n, const double* in, int n_in, do
     (void)hipFree(d_in), (void)hipFree(d_out);
     return LINS_OK;
   }
-  static const int kIn[9] = {4, 3, 3, 37, 38, 4, 24, 42, 42}, kOut[9] = {3, 4, 9, 19, 18, 12, 3, 6, 6};
-  if (!ctx || !in || !out || op < 0 || op > 8 || n < 0 || n_in != kIn[op] || n_out != kOut[op]) return LINS_E_ARG;
+  static const int kIn[11] = {4, 3, 3, 37, 38, 4, 24, 42, 42, 448, 448}, kOut[11] = {3, 4, 9, 19, 18, 12, 3, 6, 6, 28, 28};
+  if (!ctx || !in || !out || op < 0 || op > 10 || n < 0 || n_in != kIn[op] || n_out != kOut[op]) return LINS_E_ARG;
   if (n == 0) return LINS_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   double *d_in = nullptr, *d_out = nullptr;
@@ -744,7 +745,9 @@ int lins_debug_math(lins_ctx* ctx, int op, int n, const double* in, int n_in, do
   hipError_t e = hipMalloc((void**)&d_out, (size_t)n * n_out * 8);
   if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, (size_t)n * n_in * 8, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
-    if (op == 8)
+    if (op >= 9)
+      launch_debug_reduce_rows(ctx->stream, op, n, d_in, d_out);
+    else if (op == 8)
       launch_debug_wave_solve(ctx->stream, n, d_in, d_out);
     else
       launch_debug_math(ctx->stream, op, n, n_in, n_out, d_in, d_out);

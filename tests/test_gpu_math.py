@@ -135,3 +135,19 @@ def test_wave_solve6_is_bit_identical_to_the_one_lane_elimination(ieskf, ctx):
     ok = np.isfinite(a).all(axis=1)
     res = np.einsum("nij,nj->ni", sys_[ok][:, :, :6], a[ok]) - sys_[ok][:, :, 6]
     assert np.abs(res[:100]).max() <= 1e-12
+
+
+def test_row_reduction_on_the_valu_lane_paths_matches_the_shuffle_tree(ieskf, ctx):
+    """wave_reduce_rows exchanges lanes with DPP / lane-swap instructions (ieskf_rowsum.h xor_lane_i32); the same
+    tree written with __shfl_xor must give the same bits, and both the 28 sums of the 64 rows."""
+    rng = np.random.default_rng(5)
+    rows = rng.normal(size=(50, 64, 7)) * 10.0 ** rng.integers(-3, 4, size=(50, 64, 1))
+    x = rows.reshape(50, 448)
+    a = dev(ieskf, ctx, 9, x, 28)
+    b = dev(ieskf, ctx, 10, x, 28)
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    A = [0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6]
+    B = [0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4, 5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6]
+    want = np.stack([(rows[:, :, i] * rows[:, :, j]).sum(axis=1) for i, j in zip(A, B)], axis=1)
+    scale = np.stack([np.abs(rows[:, :, i] * rows[:, :, j]).sum(axis=1) for i, j in zip(A, B)], axis=1)
+    assert (np.abs(a - want) <= 1e-13 * scale).all()

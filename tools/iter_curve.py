@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""Kernel time of the batch workload as a function of the (fixed) iteration count: the differences are the cost of
+iteration k, the intercept is the set-up (grid build).  usage: tools/iter_curve.py [search] [max_iter]"""
+import importlib, os, sys
+from concurrent.futures import ThreadPoolExecutor
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PKG = "lins---lidar-inertial-slam_amd"
+pkg = importlib.import_module(PKG); host = importlib.import_module(PKG + ".host"); ieskf = importlib.import_module(PKG + ".ieskf")
+search = sys.argv[1] if len(sys.argv) > 1 else "mr"
+kmax = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+n = 1024
+with ThreadPoolExecutor(16) as ex:
+    pairs = list(ex.map(host.synth_pair, range(n)))
+ctxs = []
+for it in range(1, kmax + 1):
+    c = ieskf.IeskfContext(pkg.default_params(num_iter=it, fixed_iters=1), max_batch=n, max_targets=16384, search=search)
+    c.upload(pairs)
+    for _ in range(2):
+        c.run(); c.sync()
+    ctxs.append(c)
+ts = np.zeros((11, kmax))
+for rep in range(11):
+    for k, c in enumerate(ctxs):
+        c.run(); c.sync(); ts[rep, k] = c.last_kernel_ms()
+med = np.median(ts, axis=0)
+prev = 0.0
+for k in range(kmax):
+    print(f"{k + 1:2d} iterations: {med[k]:.4f} ms   (+{(med[k] - prev) * 1e3:6.1f} us)")
+    prev = med[k]
