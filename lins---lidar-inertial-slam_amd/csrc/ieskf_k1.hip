@@ -106,7 +106,8 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
 // kernel's LDS block — (sigma^2 I + A P_SS) w = g + A d_S, dx = d - P[:,S] w, NaN / divergence /
 // convergence tests, boxPlus (SE:542-580), then the constants of the next iteration.
 // ---------------------------------------------------------------------------
-__device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int iter) {
+// (scalars by value: a reference to the kernel's parameter struct would keep the whole struct in scratch)
+__device__ __noinline__ void solve_and_update(double prm_r2, int prm_fixed_iters, int prm_pad, int tid, int iter) {
   Lds& L = g;
   const int lane = tid & 63, wave = tid >> 6;
   // ---- wave 0: the 6 x 7 system, its solution (spread over the wave), dx, the stop tests and boxPlus; the new
@@ -116,7 +117,7 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
     if (lane < 42) {
       const int i = lane / 7, j = lane % 7;
       if (j < 6) {
-        v = (i == j ? prm.r2 : 0.0);
+        v = (i == j ? prm_r2 : 0.0);
 #pragma unroll
         for (int k = 0; k < 6; ++k) v += sym6(L.sums, i, k) * L.P[sidx(k) * 18 + sidx(j)];
       } else {
@@ -161,7 +162,7 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
     } else {
       const Q4 qn = qnormalized(qmul(Q4{lin[6], lin[7], lin[8], lin[9]}, axis2quat(V3{dth[0], dth[1], dth[2]})));
       lin[6] = qn.w, lin[7] = qn.x, lin[8] = qn.y, lin[9] = qn.z;
-      if (un <= 1e-2 && !prm.fixed_iters) conv = 1;
+      if (un <= 1e-2 && !prm_fixed_iters) conv = 1;
       res_prev = rn;
     }
     if (lane == 0) {
@@ -173,7 +174,7 @@ __device__ __noinline__ void solve_and_update(const DevParams& prm, int tid, int
   }
   __syncthreads();  // every reader of the old linearisation state is done; the staged one is visible
   const int div = L.stage_flags[0];
-  if (wave < 3 && !div && !(prm.pad & 8192)) {
+  if (wave < 3 && !div && !(prm_pad & 8192)) {
     // the constants of the next iteration, one wave each: linState_ + R^T | phi, Rinvleft(-phi)^T | x_filter (-) x_lin
     const Q4 q{L.stage[6], L.stage[7], L.stage[8], L.stage[9]};
     if (wave == 0) {
@@ -576,6 +577,7 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
       if (nb && tid == 0) L.brute_total += nb;
       if (PROF) pt[3] = clock64();
       double row[7] = {0, 0, 0, 0, 0, 0, 0};
+      asm volatile("" ::: "memory");  // (R^T, G^T are read from LDS here instead of hoisted over the list pass and spilled)
       if (active) {
         if (is_surf) {
           if (j1 >= 0 && j2 >= 0 && j3 >= 0) surf_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], t1, t2, t3, o);
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
     }
     __syncthreads();
     const long long ts0 = PROF ? clock64() : 0;
-    solve_and_update(prm, tid, iter);
+    solve_and_update(prm.r2, prm.fixed_iters, prm.pad, tid, iter);
     if (PROF && tid == 0) {
       // [0] de-skew [1] meta + list pass + certificates [2] wait + exhaustive searches [3] rows [4] wave reduction
       // [5] barriers + fold of the partials [6] solve + update   (thread 0's view, summed over the iterations)

@@ -1503,6 +1503,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           p1 = s.x, p2 = s.y, p3 = s.z;
         }
         long long s3 = prof ? clock64() : 0;
+        asm volatile("" ::: "memory");  // (R^T, G^T are read from LDS here, not hoisted and spilled: see the one-lane path)
         if (role == 0) {
           auto pt4 = [&](int pos) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
