@@ -1,16 +1,39 @@
 #!/bin/bash
-# Regenerates the line-of-record artifacts for round $1 (default r01) on the GPU box into gpurun_out/.
-tag=${1:-r01}
+# Regenerates the line-of-record artifacts for round $1 (default r02) on the GPU box into gpurun_out/; copy what is
+# to be judged into profiles/ afterwards (tools/README.md).  PMC passes are separate rocprofv3 runs with
+# --kernel-trace only (never combined with other trace domains).
+tag=${1:-r02}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out
 cd $root
+python -m pytest tests -q -m gpu > $out/${tag}_pytest_gpu.log 2>&1; tail -2 $out/${tag}_pytest_gpu.log
+python tools/pmc_traffic.py $tag > $out/${tag}_pmc_traffic.log 2>&1; tail -3 $out/${tag}_pmc_traffic.log
+cp $out/${tag}_pmc_traffic.json profiles/ 2>/dev/null   # (bench.py reads the record from profiles/, stamp-checked)
 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
-tail -1 $out/${tag}_bench.json
-python tools/e2e_rate.py > $out/${tag}_e2e.txt 2>&1; cat $out/${tag}_e2e.txt
-python tools/reproject_rate.py > $out/${tag}_reproject.txt 2>&1; cat $out/${tag}_reproject.txt
-( cd /tmp && export TMPDIR=/tmp && rm -rf $out/${tag}_kt && rocprofv3 --kernel-trace --stats -d $out/${tag}_kt -- python $root/bench.py --no-cpu --no-extras > $out/${tag}_kt.log 2>&1
+tail -1 $out/${tag}_bench.json | cut -c1-300
+( cd /tmp && export TMPDIR=/tmp && rm -rf $out/${tag}_kt && rocprofv3 --kernel-trace --stats -d $out/${tag}_kt -- python $root/bench.py --no-cpu > $out/${tag}_kt.log 2>&1
   python $root/tools/rocpd_summary.py $(find $out/${tag}_kt -name "*.db") > $out/${tag}_kernel_stats.csv; rm -rf $out/${tag}_kt )
 cat $out/${tag}_kernel_stats.csv
+{
+  python tools/e2e_rate.py 2>&1 | tail -2
+  python tools/streams_rate.py 1024 2>&1 | tail -2
+  python tools/map_rate.py 2>&1 | tail -4
+  python tools/reproject_rate.py 2>&1 | tail -1
+  python tools/frontend_rate.py 2>&1 | tail -2
+} > $out/${tag}_aux_rates.txt 2>&1
+cat $out/${tag}_aux_rates.txt
+{
+  echo "== tools/late_iter_time.py mr  (one late iteration of the batch kernel, by phase)"
+  python tools/late_iter_time.py mr 2>&1 | tail -8
+  echo "== tools/iter_curve.py mr 10"
+  python tools/iter_curve.py mr 10 2>&1 | tail -10
+  echo "== tools/wg_cost_model.py 1024 mr  (tail of the launch)"
+  python tools/wg_cost_model.py 1024 mr 2>&1 | tail -3
+  echo "== tools/split_timing.py"
+  python tools/split_timing.py 2>&1 | tail -6
+} > $out/${tag}_kernel_anatomy.txt 2>&1
+cat $out/${tag}_kernel_anatomy.txt
+bash tools/late_iter_pmc.sh mr > /dev/null 2>&1; tail -6 $out/late_iter_pmc.txt; cp $out/late_iter_pmc.txt $out/${tag}_late_iter_pmc.txt
 bash tools/pmc_run.sh ${tag}pmc --batch 1024 --search auto > $out/${tag}_pmc_all.txt 2>&1
-cat $out/${tag}_pmc_all.txt
+tail -40 $out/${tag}_pmc_all.txt
