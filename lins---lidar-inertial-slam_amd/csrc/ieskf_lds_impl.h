@@ -580,6 +580,7 @@ __device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, 
   for (int k = 0; k < kPerThread; ++k) {
     const int j = tid + k * kLBlock;
     cell_of[k] = -1;
+    int eb = 0, ek = -1;  // elevation bits, (cloud, ring) key of this lane's point
     if (j < n_all) {
       const bool is_s = j < sd.n_surf_t;
       float4 p = is_s ? ts[j] : tc[j - sd.n_surf_t];
@@ -587,9 +588,32 @@ __device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, 
       int cell = is_s ? kCellsCorner + r * kAzSurf + az_bin(p.x, p.y, kAzSurf) : r * kAzCorner + az_bin(p.x, p.y, kAzCorner);
       cell_of[k] = cell;
       atomicAdd(&cnt32[cell >> 1], 1u << ((cell & 1) * 16));
-      int eb = ordered_int(atan2f(p.z, sqrtf(p.x * p.x + p.y * p.y)));
-      atomicMin(&L.el_bits[is_s ? 0 : 1][r][0], eb);
-      atomicMax(&L.el_bits[is_s ? 0 : 1][r][1], eb);
+      eb = ordered_int(atan2f(p.z, sqrtf(p.x * p.x + p.y * p.y)));
+      ek = (is_s ? 0 : kRingsBinned) + r;
+    }
+    // elevation wedge of the ring: the 64 consecutive points of a wave nearly always lie on one ring of one cloud —
+    // then the wave folds its min / max in registers and ONE lane updates LDS (64 atomics on the same address are
+    // processed one after the other and hold up the LDS pipeline for the co-resident workgroup as well)
+    const int ek0 = __builtin_amdgcn_readfirstlane(ek);
+    if (__all(ek == ek0 || ek < 0)) {
+      if (ek0 >= 0 || __any(ek >= 0)) {
+        int lo = ek >= 0 ? eb : 0x7FFFFFFF, hi = ek >= 0 ? eb : (int)0x80000000;
+        const int lane = tid & 63;
+        lo = min(lo, xor_lane_i32<1>(lo, lane)), hi = max(hi, xor_lane_i32<1>(hi, lane));
+        lo = min(lo, xor_lane_i32<2>(lo, lane)), hi = max(hi, xor_lane_i32<2>(hi, lane));
+        lo = min(lo, xor_lane_i32<4>(lo, lane)), hi = max(hi, xor_lane_i32<4>(hi, lane));
+        lo = min(lo, xor_lane_i32<8>(lo, lane)), hi = max(hi, xor_lane_i32<8>(hi, lane));
+        lo = min(lo, xor_lane_i32<16>(lo, lane)), hi = max(hi, xor_lane_i32<16>(hi, lane));
+        lo = min(lo, xor_lane_i32<32>(lo, lane)), hi = max(hi, xor_lane_i32<32>(hi, lane));
+        const unsigned long long m = __ballot(ek >= 0);
+        if (m && lane == __ffsll(m) - 1) {
+          atomicMin(&L.el_bits[ek / kRingsBinned][ek % kRingsBinned][0], lo);
+          atomicMax(&L.el_bits[ek / kRingsBinned][ek % kRingsBinned][1], hi);
+        }
+      }
+    } else if (ek >= 0) {
+      atomicMin(&L.el_bits[ek / kRingsBinned][ek % kRingsBinned][0], eb);
+      atomicMax(&L.el_bits[ek / kRingsBinned][ek % kRingsBinned][1], eb);
     }
   }
   __syncthreads();
