@@ -28,6 +28,8 @@ cat $out/${tag}_aux_rates.txt
   python tools/late_iter_time.py mr 2>&1 | tail -8
   echo "== tools/iter_curve.py mr 10"
   python tools/iter_curve.py mr 10 2>&1 | tail -10
+  echo "== tools/cold_iter_time.py  (set-up and the cold iteration)"
+  python tools/cold_iter_time.py 2>&1 | tail -7
   echo "== tools/wg_cost_model.py 1024 mr  (tail of the launch)"
   python tools/wg_cost_model.py 1024 mr 2>&1 | tail -3
   echo "== tools/split_timing.py"
