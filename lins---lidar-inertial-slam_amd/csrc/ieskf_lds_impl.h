@@ -76,8 +76,12 @@ __constant__ unsigned char kLPairB[28] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3,
                                           5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6};
 
 struct LdsStore {
+#ifdef LINS_LDS_AOS
+  float4 pt[kNpCap];  // grid-sorted targets, one 16-byte record (x, y, z, original index bits) per position
+#else
   float px[kNpCap], py[kNpCap], pz[kNpCap];  // grid-sorted targets: corner cells, then surf cells
   unsigned short pidx[kNpCap];               // original index inside its cloud
+#endif
   double slots[kRegReduce ? 1 : kSlotCap * 7];  // H rows (slot reduction only)
   // exclusive end (absolute position) per cell, corner cells first; during the build the same
   // words are the histogram / scatter counters (two u16 counters per 32-bit LDS atomic).  A union,
@@ -121,14 +125,23 @@ struct LCloud {  // one target cloud's grid (all pointers into LDS)
 // the others are read from the sorted global copy (L2): rare — the searches end in the low rings.
 __device__ __forceinline__ void pt_xyz(const LdsStore& L, const LCloud& c, int p, float& x, float& y, float& z) {
   if (!kHybrid || p < c.n_lds) {
+#ifdef LINS_LDS_AOS
+    const float4 v = L.pt[p];
+    x = v.x, y = v.y, z = v.z;
+#else
     x = L.px[p], y = L.py[p], z = L.pz[p];
+#endif
   } else {
     const float4 g = c.gs[p];
     x = g.x, y = g.y, z = g.z;
   }
 }
 __device__ __forceinline__ int pt_idx(const LdsStore& L, const LCloud& c, int p) {
+#ifdef LINS_LDS_AOS
+  if (!kHybrid || p < c.n_lds) return __float_as_int(L.pt[p].w);
+#else
   if (!kHybrid || p < c.n_lds) return (int)L.pidx[p];
+#endif
   return __float_as_int(c.gs[p].w);
 }
 __device__ __forceinline__ float pt_sqdist(const LdsStore& L, const LCloud& c, int p, float sx, float sy, float sz) {
@@ -268,7 +281,12 @@ __device__ __forceinline__ void scan_cols(const LdsStore& L, const LCloud& c, in
 #pragma unroll
       for (int u = 0; u < kScanBatch; ++u) {
         const int pu = p + u < el ? p + u : el - 1;
+#ifdef LINS_LDS_AOS
+        const float4 v = L.pt[pu];
+        x[u] = v.x, y[u] = v.y, z[u] = v.z, j[u] = __float_as_int(v.w);
+#else
         x[u] = L.px[pu], y[u] = L.py[pu], z[u] = L.pz[pu], j[u] = (int)L.pidx[pu];
+#endif
       }
 #pragma unroll
       for (int u = 0; u < kScanBatch; ++u) f(x[u], y[u], z[u], j[u], p + u, p + u < el);
@@ -641,8 +659,12 @@ __device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, 
       // order inside a cell is irrelevant (keyed ties)
       const int pos = (int)((atomicAdd(&cnt32[cell >> 1], 1u << sh) >> sh) & 0xFFFFu);
       if (!kHybrid || pos < kNpCap) {
+#ifdef LINS_LDS_AOS
+        L.pt[pos] = make_float4(p.x, p.y, p.z, __int_as_float(jj));
+#else
         L.px[pos] = p.x, L.py[pos] = p.y, L.pz[pos] = p.z;
         L.pidx[pos] = (unsigned short)jj;
+#endif
       } else {
         gsorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(jj));
       }

@@ -2,7 +2,7 @@
 // batch-throughput path.  512-thread workgroups (8 waves: two per SIMD, so the placement of a
 // workgroup's waves is balanced whatever SIMD the dispatcher starts on), one owner lane per query (the
 // searches of the warm iterations are served by several lanes, see ieskf_lds_impl.h), whose
-// LDS holds only the first 4736 grid positions of the scan — the corner cloud and the low surf
+// LDS holds only the first 4224 grid positions of the scan — the corner cloud and the low surf
 // rings, where nearly every search ends; the rest of the grid is a sorted copy in global memory
 // that the same loops fall through to.  At < 80 KB of LDS and 128 VGPRs two independent scans are
 // resident per CU and fill each other's barriers and serial tails (measured with the HW_ID /
@@ -15,7 +15,12 @@
 // <= 128 / 80 VGPRs even when LDS would allow it); three workgroups per CU at 96 VGPRs (588 B of
 // scratch per lane: no faster than two).
 #define LINS_LDS_NS lds_mr
-#define LINS_LDS_CAP 4736
+// 16-byte point records (x, y, z, original index bits): a candidate is ONE ds_read_b128 instead of three b32 reads and a
+// u16 read at four different addresses; 4224 instead of 4736 positions fit (measured: -2.9 % kernel time; LDS
+// instructions and bank conflicts in DESIGN.md section 7).  The full-residency shapes keep the 14-byte SoA layout: their
+// point is to hold a whole scan.
+#define LINS_LDS_AOS 1
+#define LINS_LDS_CAP 4224
 #define LINS_LDS_NMAX 12288
 #ifndef LINS_LDS_SCANBATCH
 #define LINS_LDS_SCANBATCH 2  // (measured: 1 -> 7.9, 2 -> 8.1, 3 -> 8.0, 4 -> 7.75, 8 -> 7.1 M it/s at 128 VGPRs)
