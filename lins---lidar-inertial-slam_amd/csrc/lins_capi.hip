@@ -770,6 +770,17 @@ int lins_last_split_ms(lins_ctx* ctx, float* grid_ms, float* list_ms) {
   return LINS_OK;
 }
 
+/* Debug aid (split path): the linearisation state the grid kernel handed over for scan `scan` in the last run. */
+int lins_debug_split_hand(lins_ctx* ctx, int scan, double* lin19, int* iter_status2) {
+  if (!ctx || !lin19 || !iter_status2 || !ctx->d_split_hand || scan < 0 || scan >= ctx->max_batch) return LINS_E_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const char* base = (const char*)ctx->d_split_hand + (size_t)scan * split_scan_size();
+  HIP_TRY(ctx, hipMemcpy(lin19, base, 19 * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(iter_status2, base + 22 * 8, 2 * 4, hipMemcpyDeviceToHost));
+  return LINS_OK;
+}
+
 /* Debug aid (split path): have the list kernel record the correspondences it decided in iteration `iter` of the
  * NEXT lins_batch_run (iter < 0: off); after that run, `out` (one lins_corr per uploaded query slot: per scan the
  * plane queries, then the line queries) receives them.  Iterations the grid kernel ran are not recorded. */

@@ -81,3 +81,24 @@ def test_split_needs_icp_freq_1_else_runs_the_persistent_kernel(pkg, ieskf, orac
         w = oracle.ieskf(prm, p, oracle.FORM_DENSE, oracle.NN_BRUTE)
         assert (g.iters, g.converged, g.diverged) == (w.iters, w.converged, w.diverged)
         assert np.abs(g.state[:3] - w.state[:3]).max() <= 1e-6
+
+
+def test_handed_over_state_is_the_persistent_kernels(pkg, ieskf, host):
+    """The grid kernel hands the list kernel the linearisation state after `split_iters` iterations: bit for bit the
+    state the persistent kernel has at that point (lins_debug_split_hand)."""
+    import ctypes as C
+
+    pair = host.synth_pair(5)
+    with ieskf.IeskfContext(pkg.default_params(num_iter=3, fixed_iters=1), max_batch=1, max_targets=16384, search="mr") as c:
+        x3 = c.update(pair).state
+    with ieskf.IeskfContext(pkg.default_params(num_iter=6, fixed_iters=1), max_batch=1, max_targets=16384, search="split") as c:
+        c.upload([pair])
+        c.run()
+        c.sync()
+        L = ieskf.lib()
+        L.lins_debug_split_hand.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        lin = np.zeros(19)
+        st = np.zeros(2, np.int32)
+        assert L.lins_debug_split_hand(c._h, 0, lin.ctypes.data, st.ctypes.data) == 0
+    assert tuple(st) == (3, 1)  # next iteration 3, status "continue"
+    assert np.array_equal(lin.view(np.int64), x3.view(np.int64))
