@@ -144,7 +144,14 @@ int lins_streams_stats(lins_ctx* ctx, float* frontend_ms, float* update_ms, floa
 int lins_streams_peek(lins_ctx* ctx, int stream, int which, lins_point* out, int cap);
 
 /* the front-end's atan2 (csrc/lins_math.h: a fixed f32 operation sequence shared bit for bit by the host
- * restatement and the device kernels; within 2 ulp(pi/4) of the true value)                        */
+ * restatement and the device kernels; within 2 ulp(pi/4) of the true value).
+ * KNOWN DEVIATION from the reference, which calls libm's atan2 where points are BINNED by angle (image row / column
+ * IP:217-225, ground angle IP:262, segmentation angle IP:381, relative time SE:630): a point whose angle lies within
+ * the last bit of a bin edge may fall into the neighbouring bin.  Measured against an independent glibc-based checker
+ * (oracle/frontend_oracle.cpp, tools/frontend_vs_libm.py, profiles/r02_frontend_vs_libm.txt): on clouds with generic
+ * azimuths 0 of 18.4 M cells, 0 picks and 0 coordinates differ, 0.8 % of the relative-time tags differ by at most two
+ * f32 roundings; on clouds whose every firing sits exactly ON a column edge (the stock synthetic sensor), 22 % of the
+ * cells differ — between any two atan2f implementations.                                               */
 float lins_host_atan2f(float y, float x);
 
 /* transformToEnd for every point, with the scan's final relative pose

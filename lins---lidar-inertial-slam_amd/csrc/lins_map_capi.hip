@@ -19,6 +19,7 @@
 #include "map_math.h"
 
 namespace lins {
+void launch_map_selfcheck(hipStream_t, float*);
 void launch_map_corr(hipStream_t, int, int, const void*, const void*, const float4*, const int*, const float4*,
                      lins_map_corr*, double*);
 void launch_map_grid(hipStream_t, int, const void*, const float4*, float4*, int*);
@@ -65,6 +66,7 @@ struct MapState {
   std::vector<MapDevHost> resident_dev;
   float ms = 0.f;
   uint64_t queries = 0;
+  bool selfcheck_done = false;
 };
 
 void map_state_free(void* p) {
@@ -233,6 +235,24 @@ MapState* state_of(lins_ctx* ctx) {
   return (MapState*)*slot;
 }
 
+// once per context: the device plane fit on a known wall (see map_selfcheck_kernel)
+int map_selfcheck(lins_ctx* ctx, MapState* m) {
+  if (m->selfcheck_done) return LINS_OK;
+  float* d = nullptr;
+  float h[5] = {0, 0, 0, 0, 0};
+  MAP_TRY(ctx, hipMalloc((void**)&d, sizeof h));
+  launch_map_selfcheck(ctx_stream(ctx), d);
+  hipError_t e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, ctx_stream(ctx));
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx_stream(ctx));
+  (void)hipFree(d);
+  if (e != hipSuccess) return ctx_fail_hip(ctx, e, "map self-check");
+  // normal (0, -1, 0) scaled by the weight s ~ 0.97, signed distance -0.05 scaled likewise, accepted
+  const bool ok = h[4] == 1.f && std::fabs(h[0]) < 1e-3f && std::fabs(h[2]) < 1e-3f && h[1] < -0.9f && std::fabs(h[3] + 0.0485f) < 2e-3f;
+  if (!ok) return ctx_fail_hip(ctx, hipErrorUnknown, "scan-to-map plane fit self-check failed: the 5x3 QR is miscompiled (toolchain / flags changed?)");
+  m->selfcheck_done = true;
+  return LINS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -246,9 +266,11 @@ int lins_scan2map_batch(lins_ctx* ctx, int n, const lins_map_problem* in, lins_m
     return LINS_E_STATE;
   MAP_TRY(ctx, hipSetDevice(ctx_device(ctx)));
   MapState* m = state_of(ctx);
+  int rc = map_selfcheck(ctx, m);
+  if (rc) return rc;
   std::vector<MapDevHost> dev;
   int max_q = 0;
-  int rc = map_upload(ctx, m, n, in, dev, &max_q);
+  rc = map_upload(ctx, m, n, in, dev, &max_q);
   if (rc) {
     m->resident_dev.clear(), m->resident_sizes.clear();
     return rc;
@@ -287,9 +309,11 @@ int lins_map_correspondences(lins_ctx* ctx, const lins_map_problem* in, lins_map
   if (map_dev_size() != sizeof(MapDevHost) || map_round_size() != sizeof(MapRoundParams)) return LINS_E_STATE;
   MAP_TRY(ctx, hipSetDevice(ctx_device(ctx)));
   MapState* m = state_of(ctx);
+  int rc = map_selfcheck(ctx, m);
+  if (rc) return rc;
   std::vector<MapDevHost> dev;
   int max_q = 0;
-  int rc = map_upload(ctx, m, 1, in, dev, &max_q);
+  rc = map_upload(ctx, m, 1, in, dev, &max_q);
   if (rc) {
     m->resident_dev.clear(), m->resident_sizes.clear();
     return rc;

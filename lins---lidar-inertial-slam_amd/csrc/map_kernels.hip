@@ -285,6 +285,16 @@ void launch_map_corr(hipStream_t stream, int n_problems, int blocks_per_problem,
   hipLaunchKernelGGL(map_corr_kernel, dim3(blocks_per_problem, n_problems), dim3(kMapBlock), 0, stream, (const MapDev*)probs,
                      (const MapRound*)rounds, pts, cells, queries, recs, partials, blocks_per_problem);
 }
+// Start-up self-check of the plane fit: five points of the wall y = 2 and a query 5 cm in front of it must give a
+// normal along y.  (ROCm 7.2's SLP vectoriser loses the y column of the unrolled 5 x 3 QR at -O2 and above — this file
+// is built with -fno-slp-vectorize; the check catches a toolchain or flag change that brings the miscompile back.)
+__global__ void map_selfcheck_kernel(float* __restrict__ out) {
+  const float px[5] = {0.3f, -0.4f, 0.1f, 0.5f, -0.2f}, py[5] = {2.f, 2.f, 2.f, 2.f, 2.f}, pz[5] = {0.2f, 0.1f, -0.3f, -0.1f, 0.4f};
+  float c[4];
+  const int acc = map_surf_fit(px, py, pz, 0.05f, 2.05f, 0.02f, c);
+  out[0] = c[0], out[1] = c[1], out[2] = c[2], out[3] = c[3], out[4] = (float)acc;
+}
+void launch_map_selfcheck(hipStream_t stream, float* out) { hipLaunchKernelGGL(map_selfcheck_kernel, dim3(1), dim3(1), 0, stream, out); }
 size_t map_dev_size() { return sizeof(MapDev); }
 size_t map_round_size() { return sizeof(MapRound); }
 int map_block() { return kMapQPerBlock; }  // queries per block
