@@ -606,7 +606,10 @@ __device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, 
       int cell = is_s ? kCellsCorner + r * kAzSurf + az_bin(p.x, p.y, kAzSurf) : r * kAzCorner + az_bin(p.x, p.y, kAzCorner);
       cell_of[k] = cell;
       atomicAdd(&cnt32[cell >> 1], 1u << ((cell & 1) * 16));
-      eb = ordered_int(atan2f(p.z, sqrtf(p.x * p.x + p.y * p.y)));
+      // elevation of the point as the ratio z / rho: atan is monotone, so the ring's wedge is the atan of the extreme
+      // ratios — two atanf per ring at the end instead of an atan2f per point (rho = 0: +-inf / 0, atan gives +-pi/2 / 0)
+      const float rho_p = sqrtf(p.x * p.x + p.y * p.y);
+      eb = ordered_int(rho_p > 0.f ? p.z / rho_p : (p.z > 0.f ? INFINITY : (p.z < 0.f ? -INFINITY : 0.f)));
       ek = (is_s ? 0 : kRingsBinned) + r;
     }
     // elevation wedge of the ring: the 64 consecutive points of a wave nearly always lie on one ring of one cloud —
@@ -677,7 +680,8 @@ __device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, 
   }
   if (tid < 2 * kRingsBinned) {
     int cl = tid / kRingsBinned, r = tid % kRingsBinned;
-    float lo = ordered_float(L.el_bits[cl][r][0]) - kSlack, hi = ordered_float(L.el_bits[cl][r][1]) + kSlack;
+    // (atanf of the ratio vs the queries' atan2f(z, rho): a few ulp of an angle below 0.3 rad, ~1e-7 — inside kSlack)
+    float lo = atanf(ordered_float(L.el_bits[cl][r][0])) - kSlack, hi = atanf(ordered_float(L.el_bits[cl][r][1])) + kSlack;
     const bool empty = L.el_bits[cl][r][0] == 0x7FFFFFFF;  // no point touched the ring's min/max
     L.el_ang[cl][r] = empty ? make_float2(INFINITY, -INFINITY) : make_float2(lo, hi);
   }
