@@ -9,6 +9,10 @@
 //         sin/cos-free route the persistent kernels take): in 4 (q)          out 3 (phi) + 9 (Rinvleft(-phi)^T)
 //   op 6  transformToStart                  SE:1066-1080    in 19 (linState_) + 4 (point x y z intensity) + 1 (scan period)
 //                                                           out 3 (the f32 results, widened)
+//   op 7 / 8    reg_solve6 in one lane / wave_solve6 over a wave (round 1's elimination + back-substitution)
+//   op 11 / 12  gj_solve6 in one lane (lins_solve6.h, the definition) / wave_gj_solve6 over a wave (what the kernels run)
+//   op 13 / 14  axis2quat_fast / quat2axis_fast (lins_math.h): the short-series forms of op 1 / op 0 the serial tail uses
+//   op 15       phi_and_Gt_general: op 5 with the small-rotation shortcut disabled
 #include <hip/hip_runtime.h>
 
 #include "ieskf_device.h"
@@ -52,6 +56,24 @@ __global__ void debug_math_kernel(int op, int n, int n_in, int n_out, const doub
       for (int c = 0; c < 7; ++c) m[r][c] = a[r * 7 + c];
     reg_solve6(m, x6);
     for (int k = 0; k < 6; ++k) o[k] = x6[k];
+  } else if (op == 11) {
+    double m[6][7], x6[6];
+    for (int r = 0; r < 6; ++r)
+      for (int c = 0; c < 7; ++c) m[r][c] = a[r * 7 + c];
+    gj_solve6(m, x6);
+    for (int k = 0; k < 6; ++k) o[k] = x6[k];
+  } else if (op == 13) {
+    const Q4 q = axis2quat_fast(V3{a[0], a[1], a[2]});
+    o[0] = q.w, o[1] = q.x, o[2] = q.y, o[3] = q.z;
+  } else if (op == 14) {
+    const V3 v = quat2axis_fast(Q4{a[0], a[1], a[2], a[3]});
+    o[0] = v.x, o[1] = v.y, o[2] = v.z;
+  } else if (op == 15) {
+    V3 phi;
+    M3 gt;
+    phi_and_Gt_general(Q4{a[0], a[1], a[2], a[3]}, phi, gt);
+    o[0] = phi.x, o[1] = phi.y, o[2] = phi.z;
+    for (int k = 0; k < 9; ++k) o[3 + k] = gt.m[k];
   } else if (op == 6) {
     DevParams prm{};
     prm.inv_period = (double)(1.f / (float)a[23]);
@@ -101,6 +123,28 @@ __global__ __launch_bounds__(256) void debug_cycles_kernel(int op, const double*
       double x6[6];
       wave_solve6(l < 42 ? (i == j ? 10.0 : 0.1 * (i + j)) + dacc : 0.0, l, x6);
       dacc += x6[0] * 1e-9;
+    } else if (op == 106) {  // the Gauss-Jordan solve spread over the wave (what the kernels run)
+      const int l = tid & 63, i = l / 7, j = l % 7;
+      double x6[6];
+      wave_gj_solve6(l < 42 ? (i == j ? 10.0 : 0.1 * (i + j)) + dacc : 0.0, l, x6);
+      dacc += x6[0] * 1e-9;
+    } else if (op == 107) {  // next iteration's constants by the general (atan2) route
+      V3 p2;
+      M3 gt;
+      phi_and_Gt_general(Q4{1.0 - dacc, 0.01, 0.02, 0.03 + dacc}, p2, gt);
+      dacc += (p2.x + gt.m[1]) * 1e-9;
+    } else if (op == 108) {  // boxPlus' quaternion step, libm route / short series
+      const Q4 r = axis2quat(V3{0.001 + dacc, 0.002, 0.003});
+      dacc += (r.x + r.w) * 1e-9;
+    } else if (op == 109) {
+      const Q4 r = axis2quat_fast(V3{0.001 + dacc, 0.002, 0.003});
+      dacc += (r.x + r.w) * 1e-9;
+    } else if (op == 110) {  // boxMinus' rotation part, libm route / short series
+      const V3 r = quat2axis(Q4{1.0 - dacc, 0.001, 0.002, 0.003});
+      dacc += r.x * 1e-9;
+    } else if (op == 111) {
+      const V3 r = quat2axis_fast(Q4{1.0 - dacc, 0.001, 0.002, 0.003});
+      dacc += r.x * 1e-9;
     } else if (op == 104) {  // next iteration's constants
       V3 p2;
       M3 gt;
@@ -112,11 +156,14 @@ __global__ __launch_bounds__(256) void debug_cycles_kernel(int op, const double*
   if (tid == 0) out[blockIdx.x * 2] = (double)(t1 - t0) / 64.0, out[blockIdx.x * 2 + 1] = (double)acc + dacc;
 }
 
-// op 8: wave_solve6, one system per WAVE (64 threads per item): out 6
-__global__ void debug_wave_solve_kernel(int n, const double* __restrict__ in, double* __restrict__ out) {
+// op 8 / 12: wave_solve6 / wave_gj_solve6, one system per WAVE (64 threads per item): out 6
+__global__ void debug_wave_solve_kernel(int n, int gj, const double* __restrict__ in, double* __restrict__ out) {
   const int item = blockIdx.x, l = threadIdx.x;
   double x6[6];
-  wave_solve6(l < 42 ? in[(size_t)item * 42 + l] : 0.0, l, x6);
+  if (gj)
+    wave_gj_solve6(l < 42 ? in[(size_t)item * 42 + l] : 0.0, l, x6);
+  else
+    wave_solve6(l < 42 ? in[(size_t)item * 42 + l] : 0.0, l, x6);
   if (l < 6) out[(size_t)item * 6 + l] = x6[l];
 }
 // op 9: wave_reduce_rows (one wave per item, 64 rows of 7 in, the 28 sums out); op 10: the same tree with plain
@@ -150,8 +197,8 @@ void launch_debug_reduce_rows(hipStream_t stream, int op, int n, const double* i
   hipLaunchKernelGGL(debug_reduce_rows_kernel, dim3(n), dim3(64), 0, stream, op, in, out);
 }
 
-void launch_debug_wave_solve(hipStream_t stream, int n, const double* in, double* out) {
-  hipLaunchKernelGGL(debug_wave_solve_kernel, dim3(n), dim3(64), 0, stream, n, in, out);
+void launch_debug_wave_solve(hipStream_t stream, int n, int gj, const double* in, double* out) {
+  hipLaunchKernelGGL(debug_wave_solve_kernel, dim3(n), dim3(64), 0, stream, n, gj, in, out);
 }
 
 void launch_debug_cycles(hipStream_t stream, int op, int blocks, const double* in, double* out) {

@@ -126,14 +126,21 @@ __device__ __noinline__ void solve_and_update(double prm_r2, int prm_fixed_iters
         for (int k = 0; k < 6; ++k) v += sym6(L.sums, i, k) * L.ic.d[sidx(k)];
       }
     }
+    // (what dx needs from LDS besides the solution is read BEFORE the solve: the reads then wait behind nothing)
+    double pls[6] = {0, 0, 0, 0, 0, 0}, dl = 0;
+    if (lane < 18) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pls[k] = L.P[lane * 18 + sidx(k)];
+      dl = L.ic.d[lane];
+    }
     double wsol[6];
-    wave_solve6(v, lane, wsol);
+    wave_gj_solve6(v, lane, wsol);
     double dxi = 0;
     if (lane < 18) {
       double sacc = 0;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) sacc += L.P[lane * 18 + sidx(k)] * wsol[k];
-      dxi = L.ic.d[lane] - sacc;
+      for (int k = 0; k < 6; ++k) sacc += pls[k] * wsol[k];
+      dxi = dl - sacc;
     }
     double lin[19];
 #pragma unroll
@@ -160,7 +167,7 @@ __device__ __noinline__ void solve_and_update(double prm_r2, int prm_fixed_iters
     } else if (rn > res_prev * 10) {
       div = 1, un = L.upd_norm;
     } else {
-      const Q4 qn = qnormalized(qmul(Q4{lin[6], lin[7], lin[8], lin[9]}, axis2quat(V3{dth[0], dth[1], dth[2]})));
+      const Q4 qn = qnormalized(qmul(Q4{lin[6], lin[7], lin[8], lin[9]}, axis2quat_fast(V3{dth[0], dth[1], dth[2]})));
       lin[6] = qn.w, lin[7] = qn.x, lin[8] = qn.y, lin[9] = qn.z;
       if (un <= 1e-2 && !prm_fixed_iters) conv = 1;
       res_prev = rn;
@@ -191,7 +198,7 @@ __device__ __noinline__ void solve_and_update(double prm_r2, int prm_fixed_iters
       if (lane == 0) L.ic.phi = phi, L.ic.Gt = Gt;
     } else {
       const Q4 qf{L.filt[6], L.filt[7], L.filt[8], L.filt[9]};
-      const V3 da = quat2axis(qmul(qinverse(q), qf));
+      const V3 da = quat2axis_fast(qmul(qinverse(q), qf));
       if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
     IterConst ic;
     double filt[19];
     for (int k = 0; k < 19; ++k) ic.lin[k] = L.ic.lin[k], filt[k] = L.filt[k];
-    make_iter_const(filt, ic);
+    make_iter_const_tail(filt, ic);
     if (tid == 0) {
       L.ic.phi = ic.phi, L.ic.Rt = ic.Rt, L.ic.Gt = ic.Gt;
       for (int k = 0; k < 18; ++k) L.ic.d[k] = ic.d[k];

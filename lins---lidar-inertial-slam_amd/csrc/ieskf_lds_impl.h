@@ -590,53 +590,80 @@ __device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, 
   const float4* ts = arena + sd.off_surf_t;
   const float4* tc = arena + sd.off_corner_t;
   const int n_all = sd.n_surf_t + sd.n_corner_t;
-  // each thread owns the points tid, tid + BLOCK, ...; the cell of each is kept in a register
-  // between the histogram pass and the scatter pass (no second atan2f, no second classification)
+  // Ownership: wave w owns the points [w * 64 P, (w + 1) * 64 P), P = ceil(n_all / BLOCK), lane l of it the points
+  // w * 64 P + 64 k + l — a wave's loads are as coalesced as with the strided ownership (tid + k * BLOCK) of round 1,
+  // but its consecutive steps are consecutive 64-point runs of the ring-sorted cloud, so the (cloud, ring) key of a
+  // step changes every ~7 steps instead of every step: see the elevation wedge below.  The cell of each point is
+  // kept in a register between the histogram pass and the scatter pass (no second atan2f, no second classification).
   constexpr int kPerThread = (kNpMax + BLOCK - 1) / BLOCK;
+  const int per_lane = (n_all + kLBlock - 1) / kLBlock;
+  const int lane = tid & 63, j_first = (tid >> 6) * 64 * per_lane + lane;
   int cell_of[kPerThread];
+  // Elevation wedge of a ring (min / max of z / rho over its points; atan is monotone, so the wedge is the atan of the
+  // extreme ratios — two atanf per ring at the end instead of an atan2f per point).  The 64 points of a wave's step
+  // nearly always lie on one ring of one cloud, and so do the steps before and after: every lane folds its points of
+  // the current RUN of equal keys into two registers, and only when the key changes (or at the end) does the wave
+  // fold the 64 partial results (six cross-lane steps) and ONE lane update LDS.  Round 1 issued 64 same-address
+  // atomics per step (processed one after the other, holding up the LDS pipeline for the co-resident workgroup as
+  // well); the first round-2 version folded the wave at every step: ~70 instructions per point for two numbers per ring.
+  int run_key = -1, run_lo = 0x7FFFFFFF, run_hi = (int)0x80000000;
+  auto flush_run = [&]() {
+    if (run_key >= 0) {  // (wave-uniform)
+      int lo = run_lo, hi = run_hi;
+      lo = min(lo, xor_lane_i32<1>(lo, lane)), hi = max(hi, xor_lane_i32<1>(hi, lane));
+      lo = min(lo, xor_lane_i32<2>(lo, lane)), hi = max(hi, xor_lane_i32<2>(hi, lane));
+      lo = min(lo, xor_lane_i32<4>(lo, lane)), hi = max(hi, xor_lane_i32<4>(hi, lane));
+      lo = min(lo, xor_lane_i32<8>(lo, lane)), hi = max(hi, xor_lane_i32<8>(hi, lane));
+      lo = min(lo, xor_lane_i32<16>(lo, lane)), hi = max(hi, xor_lane_i32<16>(hi, lane));
+      lo = min(lo, xor_lane_i32<32>(lo, lane)), hi = max(hi, xor_lane_i32<32>(hi, lane));
+      if (lane == 0) {
+        atomicMin(&L.el_bits[run_key / kRingsBinned][run_key % kRingsBinned][0], lo);
+        atomicMax(&L.el_bits[run_key / kRingsBinned][run_key % kRingsBinned][1], hi);
+      }
+    }
+    run_lo = 0x7FFFFFFF, run_hi = (int)0x80000000;
+  };
 #pragma unroll
   for (int k = 0; k < kPerThread; ++k) {
-    const int j = tid + k * kLBlock;
+    const int j = j_first + k * 64;
     cell_of[k] = -1;
-    int eb = 0, ek = -1;  // elevation bits, (cloud, ring) key of this lane's point
-    if (j < n_all) {
-      const bool is_s = j < sd.n_surf_t;
-      float4 p = is_s ? ts[j] : tc[j - sd.n_surf_t];
-      int r = ring_of(p.w);
-      int cell = is_s ? kCellsCorner + r * kAzSurf + az_bin(p.x, p.y, kAzSurf) : r * kAzCorner + az_bin(p.x, p.y, kAzCorner);
-      cell_of[k] = cell;
-      atomicAdd(&cnt32[cell >> 1], 1u << ((cell & 1) * 16));
-      // elevation of the point as the ratio z / rho: atan is monotone, so the ring's wedge is the atan of the extreme
-      // ratios — two atanf per ring at the end instead of an atan2f per point (rho = 0: +-inf / 0, atan gives +-pi/2 / 0)
-      const float rho_p = sqrtf(p.x * p.x + p.y * p.y);
-      eb = ordered_int(rho_p > 0.f ? p.z / rho_p : (p.z > 0.f ? INFINITY : (p.z < 0.f ? -INFINITY : 0.f)));
-      ek = (is_s ? 0 : kRingsBinned) + r;
-    }
-    // elevation wedge of the ring: the 64 consecutive points of a wave nearly always lie on one ring of one cloud —
-    // then the wave folds its min / max in registers and ONE lane updates LDS (64 atomics on the same address are
-    // processed one after the other and hold up the LDS pipeline for the co-resident workgroup as well)
-    const int ek0 = __builtin_amdgcn_readfirstlane(ek);
-    if (__all(ek == ek0 || ek < 0)) {
-      if (ek0 >= 0 || __any(ek >= 0)) {
-        int lo = ek >= 0 ? eb : 0x7FFFFFFF, hi = ek >= 0 ? eb : (int)0x80000000;
-        const int lane = tid & 63;
-        lo = min(lo, xor_lane_i32<1>(lo, lane)), hi = max(hi, xor_lane_i32<1>(hi, lane));
-        lo = min(lo, xor_lane_i32<2>(lo, lane)), hi = max(hi, xor_lane_i32<2>(hi, lane));
-        lo = min(lo, xor_lane_i32<4>(lo, lane)), hi = max(hi, xor_lane_i32<4>(hi, lane));
-        lo = min(lo, xor_lane_i32<8>(lo, lane)), hi = max(hi, xor_lane_i32<8>(hi, lane));
-        lo = min(lo, xor_lane_i32<16>(lo, lane)), hi = max(hi, xor_lane_i32<16>(hi, lane));
-        lo = min(lo, xor_lane_i32<32>(lo, lane)), hi = max(hi, xor_lane_i32<32>(hi, lane));
-        const unsigned long long m = __ballot(ek >= 0);
-        if (m && lane == __ffsll(m) - 1) {
-          atomicMin(&L.el_bits[ek / kRingsBinned][ek % kRingsBinned][0], lo);
-          atomicMax(&L.el_bits[ek / kRingsBinned][ek % kRingsBinned][1], hi);
+    if (k < per_lane) {  // (wave-uniform)
+      int eb = 0, ek = -1;  // elevation bits, (cloud, ring) key of this lane's point
+      if (j < n_all) {
+        const bool is_s = j < sd.n_surf_t;
+        const float4 p = is_s ? ts[j] : tc[j - sd.n_surf_t];
+        const int r = ring_of(p.w), naz = is_s ? kAzSurf : kAzCorner;
+        const int cell = (is_s ? kCellsCorner : 0) + r * naz + az_bin(p.x, p.y, naz);
+        cell_of[k] = cell;
+        atomicAdd(&cnt32[cell >> 1], 1u << ((cell & 1) * 16));
+        // z / rho through the hardware's reciprocal square root (1 ulp): the ratio is off by < 2^-22 relative, the
+        // elevation by < 1.2e-7 rad — two orders below kSlack.  rho = 0: +-inf / 0 (atanf gives +-pi/2 / 0); a
+        // ratio that overflows to +-inf widens the wedge, never narrows it.
+        const float rho2 = p.x * p.x + p.y * p.y;
+        eb = ordered_int(rho2 > 0.f ? p.z * __frsqrt_rn(rho2) : (p.z > 0.f ? INFINITY : (p.z < 0.f ? -INFINITY : 0.f)));
+        ek = (is_s ? 0 : kRingsBinned) + r;
+      }
+      const unsigned long long have = __ballot(ek >= 0);
+      if (have) {  // (wave-uniform)
+        const int ek0 = __builtin_amdgcn_readlane(ek, __ffsll((long long)have) - 1);
+        if (__all(ek == ek0 || ek < 0)) {
+          if (ek0 != run_key) {
+            flush_run();
+            run_key = ek0;
+          }
+          if (ek >= 0) run_lo = min(run_lo, eb), run_hi = max(run_hi, eb);
+        } else {  // a step that straddles rings: its lanes update LDS themselves
+          flush_run();
+          run_key = -1;
+          if (ek >= 0) {
+            atomicMin(&L.el_bits[ek / kRingsBinned][ek % kRingsBinned][0], eb);
+            atomicMax(&L.el_bits[ek / kRingsBinned][ek % kRingsBinned][1], eb);
+          }
         }
       }
-    } else if (ek >= 0) {
-      atomicMin(&L.el_bits[ek / kRingsBinned][ek % kRingsBinned][0], eb);
-      atomicMax(&L.el_bits[ek / kRingsBinned][ek % kRingsBinned][1], eb);
     }
   }
+  flush_run();
   __syncthreads();
   // exclusive scan over all cells: corner cells first, so surf positions start at n_corner_t
   constexpr int per = (ncell + kLBlock - 1) / kLBlock;
@@ -653,7 +680,7 @@ __device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, 
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < kPerThread; ++k) {
-    const int j = tid + k * kLBlock;
+    const int j = j_first + k * 64;
     if (cell_of[k] >= 0) {
       const bool is_s = j < sd.n_surf_t;
       const int jj = is_s ? j : j - sd.n_surf_t;
@@ -727,14 +754,21 @@ __device__ __noinline__ long long solve_and_update(double prm_r2, int prm_fixed_
         for (int k = 0; k < 6; ++k) v += sym6(L.sums, i, k) * L.ic.d[sidx(k)];
       }
     }
+    // (what dx needs from LDS besides the solution is read BEFORE the solve: the reads then wait behind nothing)
+    double pls[6] = {0, 0, 0, 0, 0, 0}, dl = 0;
+    if (lane < 18) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) pls[k] = L.P[lane * 18 + sidx(k)];
+      dl = L.ic.d[lane];
+    }
     double wsol[6];
-    wave_solve6(v, lane, wsol);
+    wave_gj_solve6(v, lane, wsol);
     double dxi = 0;
     if (lane < 18) {
       double sacc = 0;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) sacc += L.P[lane * 18 + sidx(k)] * wsol[k];
-      dxi = L.ic.d[lane] - sacc;
+      for (int k = 0; k < 6; ++k) sacc += pls[k] * wsol[k];
+      dxi = dl - sacc;
     }
     if (prof) t3 = clock64();
     double lin[19];
@@ -762,7 +796,7 @@ __device__ __noinline__ long long solve_and_update(double prm_r2, int prm_fixed_
     } else if (rn > res_prev * 10) {
       div = 1, un = L.upd_norm;
     } else {
-      const Q4 qn = qnormalized(qmul(Q4{lin[6], lin[7], lin[8], lin[9]}, axis2quat(V3{dth[0], dth[1], dth[2]})));
+      const Q4 qn = qnormalized(qmul(Q4{lin[6], lin[7], lin[8], lin[9]}, axis2quat_fast(V3{dth[0], dth[1], dth[2]})));
       lin[6] = qn.w, lin[7] = qn.x, lin[8] = qn.y, lin[9] = qn.z;
       if (un <= 1e-2 && !prm_fixed_iters) conv = 1;
       res_prev = rn;
@@ -794,7 +828,7 @@ __device__ __noinline__ long long solve_and_update(double prm_r2, int prm_fixed_
     } else {
       // boxMinus(filter, lin), KF:84-94
       const Q4 qf{L.filt[6], L.filt[7], L.filt[8], L.filt[9]};
-      const V3 da = quat2axis(qmul(qinverse(q), qf));
+      const V3 da = quat2axis_fast(qmul(qinverse(q), qf));
       if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -1040,7 +1074,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     IterConst ic;
     double filt[19];
     for (int k = 0; k < 19; ++k) ic.lin[k] = L.ic.lin[k], filt[k] = L.filt[k];
-    make_iter_const(filt, ic);
+    make_iter_const_tail(filt, ic);
     if (tid == 0) {
       L.ic.phi = ic.phi, L.ic.Rt = ic.Rt, L.ic.Gt = ic.Gt;
       for (int k = 0; k < 18; ++k) L.ic.d[k] = ic.d[k];

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ieskf_device.h"
+#include "lins_solve6.h"
 
 namespace lins {
 
@@ -97,11 +98,43 @@ __device__ __forceinline__ void wave_solve6(double a, int lane, double (&x)[6]) 
   }
 }
 
-// Rinvleft(-phi)^T and phi from a unit quaternion without libm sin/cos: with
-// h = |phi|/2 the half angle, cos h = |w| / |q| and sin h = |v| / |q| exactly, so
-// s = h cot h needs only the atan2 that Quat2axis performs anyway (math_utils.h:75-88,
+// ---------------------------------------------------------------------------
+// The solve the kernels run since round 2: Gauss-Jordan (lins_solve6.h gj_solve6 — the definition, with the why)
+// spread over the wave like wave_solve6 above.  Per column: the pivot by scalar integer compares on the high words,
+// ONE division, two lane gathers, and every row — above and below the pivot — cleared in the same step; the solution
+// is the last column, no back-substitution.  About a quarter of wave_solve6's dependent chain (which stays, with
+// reg_solve6, as the reference the device test compares against within rounding).  Bit-identical to gj_solve6.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void wave_gj_solve6(double a, int lane, double (&x)[6]) {
+  const int i = lane < 42 ? lane / 7 : 7, j = lane < 42 ? lane % 7 : 0;  // (lanes >= 42 take part in no update)
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int p = k;
+    unsigned best = (unsigned)__builtin_amdgcn_readlane(__double2hiint(a), k * 7 + k) & 0x7FFFFFFFu;
+#pragma unroll
+    for (int r = k + 1; r < 6; ++r) {
+      const unsigned h = (unsigned)__builtin_amdgcn_readlane(__double2hiint(a), r * 7 + k) & 0x7FFFFFFFu;
+      if (h > best) best = h, p = r;
+    }
+    if (p != k) {  // (wave-uniform) exchange rows k and p
+      const int src = i == k ? p * 7 + j : (i == p ? k * 7 + j : lane);
+      a = shfl_f64(a, src);
+    }
+    const double inv = 1.0 / readlane_f64(a, k * 7 + k);
+    const double aik = shfl_f64(a, (i < 6 ? i : 0) * 7 + k), akj = shfl_f64(a, k * 7 + j);
+    const double nkj = akj * inv;  // the normalised pivot row
+    if (i < 6 && j > k) a = i == k ? nkj : a - aik * nkj;
+  }
+#pragma unroll
+  for (int r = 0; r < 6; ++r) x[r] = readlane_f64(a, r * 7 + 6);
+}
+
+// Rinvleft(-phi)^T and phi from a unit quaternion without libm sin/cos.  Small rotations (w > 0, tan(|phi|/2) <= 1/8:
+// every scan-to-scan motion a lidar sees) take the short-series form phi_and_gt_small of lins_math.h — no square
+// root, one division, two fma chains.  Otherwise: with h = |phi|/2 the half angle, cos h = |w| / |q| and
+// sin h = |v| / |q| exactly, so s = h cot h needs only the atan2 that Quat2axis performs anyway (math_utils.h:75-88,
 // 304-321; differs from the sin/cos route in the last ulp only).
-__device__ __forceinline__ void phi_and_Gt(const Q4& q, V3& phi, M3& Gt) {
+__device__ __forceinline__ void phi_and_Gt_general(const Q4& q, V3& phi, M3& Gt) {
   const double mag = sqrt(q.x * q.x + q.y * q.y + q.z * q.z);
   phi = V3{q.x, q.y, q.z};
   Gt = M3{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
@@ -123,6 +156,29 @@ __device__ __forceinline__ void phi_and_Gt(const Q4& q, V3& phi, M3& Gt) {
 #pragma unroll
     for (int jj = 0; jj < 3; ++jj)
       Gt.m[jj * 3 + i] = (s * (i == jj ? 1.0 : 0.0) + (1.0 - s) * av[i] * av[jj]) - h * k.m[i * 3 + jj];
+}
+__device__ __forceinline__ void phi_and_Gt(const Q4& q, V3& phi, M3& Gt) {
+  if (!phi_and_gt_small(q, phi, Gt)) phi_and_Gt_general(q, phi, Gt);
+}
+
+// The constants of an iteration from its linearisation state, by the routes the serial tail between two iterations
+// takes (phi_and_Gt, quat2axis_fast) — so that an update's first iteration, the list kernel's first iteration after
+// the hand-over and every later iteration compute them alike.  (make_iter_const of ieskf_device.h, the libm route,
+// stays with the any-size kernels.)
+__device__ __forceinline__ void make_iter_const_tail(const double* filt, IterConst& ic) {
+  const Q4 q{ic.lin[6], ic.lin[7], ic.lin[8], ic.lin[9]};
+  ic.Rt = mtrans(qmat(q));
+  phi_and_Gt(q, ic.phi, ic.Gt);
+  const Q4 qf{filt[6], filt[7], filt[8], filt[9]};
+  const V3 da = quat2axis_fast(qmul(qinverse(q), qf));  // boxMinus(filter, lin), KF:84-94
+  for (int k = 0; k < 3; ++k) {
+    ic.d[0 + k] = filt[0 + k] - ic.lin[0 + k];
+    ic.d[3 + k] = filt[3 + k] - ic.lin[3 + k];
+    ic.d[9 + k] = filt[10 + k] - ic.lin[10 + k];
+    ic.d[12 + k] = filt[13 + k] - ic.lin[13 + k];
+    ic.d[15 + k] = filt[16 + k] - ic.lin[16 + k];
+  }
+  ic.d[6] = da.x, ic.d[7] = da.y, ic.d[8] = da.z;
 }
 
 // ---------------------------------------------------------------------------

@@ -46,7 +46,7 @@ void launch_k1(hipStream_t, int, const DevParams&, const ScanDesc*, const float4
                const double*, const double*, double*, double*, void*, lins_pose_record*, int, lins_corr*, int, long long*);
 void launch_debug_math(hipStream_t, int, int, int, int, const double*, double*);
 void launch_debug_cycles(hipStream_t, int, int, const double*, double*);
-void launch_debug_wave_solve(hipStream_t, int, const double*, double*);
+void launch_debug_wave_solve(hipStream_t, int, int, const double*, double*);
 void launch_debug_reduce_rows(hipStream_t, int, int, const double*, double*);
 size_t split_scan_size();
 size_t split_q_size();
@@ -724,7 +724,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
 /* Debug aid (unit tests of the device math against the oracle; see debug_kernels.hip for the op codes):
  * evaluates op on n items of n_in doubles each, n_out doubles out per item. */
 int lins_debug_math(lins_ctx* ctx, int op, int n, const double* in, int n_in, double* out, int n_out) {
-  if (ctx && in && out && op >= 100 && op <= 105 && n >= 1 && n_in >= 9 && n_out == 2) {  // cycle microbenchmarks, n blocks
+  if (ctx && in && out && op >= 100 && op <= 111 && n >= 1 && n_in >= 9 && n_out == 2) {  // cycle microbenchmarks, n blocks
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     double *d_in = nullptr, *d_out = nullptr;
     HIP_TRY(ctx, hipMalloc((void**)&d_in, 9 * 8));
@@ -736,8 +736,9 @@ int lins_debug_math(lins_ctx* ctx, int op, int n, const double* in, int n_in, do
     (void)hipFree(d_in), (void)hipFree(d_out);
     return LINS_OK;
   }
-  static const int kIn[11] = {4, 3, 3, 37, 38, 4, 24, 42, 42, 448, 448}, kOut[11] = {3, 4, 9, 19, 18, 12, 3, 6, 6, 28, 28};
-  if (!ctx || !in || !out || op < 0 || op > 10 || n < 0 || n_in != kIn[op] || n_out != kOut[op]) return LINS_E_ARG;
+  static const int kIn[16] = {4, 3, 3, 37, 38, 4, 24, 42, 42, 448, 448, 42, 42, 3, 4, 4};
+  static const int kOut[16] = {3, 4, 9, 19, 18, 12, 3, 6, 6, 28, 28, 6, 6, 4, 3, 12};
+  if (!ctx || !in || !out || op < 0 || op > 15 || n < 0 || n_in != kIn[op] || n_out != kOut[op]) return LINS_E_ARG;
   if (n == 0) return LINS_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   double *d_in = nullptr, *d_out = nullptr;
@@ -745,10 +746,10 @@ int lins_debug_math(lins_ctx* ctx, int op, int n, const double* in, int n_in, do
   hipError_t e = hipMalloc((void**)&d_out, (size_t)n * n_out * 8);
   if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, (size_t)n * n_in * 8, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
-    if (op >= 9)
+    if (op == 9 || op == 10)
       launch_debug_reduce_rows(ctx->stream, op, n, d_in, d_out);
-    else if (op == 8)
-      launch_debug_wave_solve(ctx->stream, n, d_in, d_out);
+    else if (op == 8 || op == 12)
+      launch_debug_wave_solve(ctx->stream, n, op == 12, d_in, d_out);
     else
       launch_debug_math(ctx->stream, op, n, n_in, n_out, d_in, d_out);
     e = hipGetLastError();

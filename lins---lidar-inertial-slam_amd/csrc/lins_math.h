@@ -144,6 +144,92 @@ LINS_HD V3 quat2axis(Q4 q) {
   }
   return v;
 }
+// ---------------------------------------------------------------------------
+// Short-series forms of the same maps for SMALL rotations (device: the serial tail between two IESKF iterations,
+// where one wave walks through these formulas while the rest of the workgroup waits — every dependent instruction
+// of that chain is paid in full).  libm's sin / cos / atan2 are general-range routines of 60-100 dependent
+// instructions each; for the angles that occur here (an update step, the rotation over one scan) the Taylor series
+// in z = (half angle)^2 or tan^2 is exact to the last ulp or two after a dozen fused multiply-adds, and the
+// square root, the unit axis and most divisions of the textbook route cancel algebraically:
+//   axis2Quat(v):  (cos h, (v / |v|) sin h),  h = |v| / 2      =  (C(z), v * S(z) / 2),  z = |v|^2 / 4
+//   Quat2axis(q):  2 atan2(|qv|, w) qv / |qv|,  w > 0          =  qv * 2 A(z) / w,       z = |qv|^2 / w^2
+// with S(z) = sin(sqrt z) / sqrt z, C(z) = cos(sqrt z), A(z) = atan(sqrt z) / sqrt z.  Outside the stated ranges the
+// callers take the libm route; the 1e-10 branches of MU:61-88 are kept (on the squared norm).  fma() is correctly
+// rounded on host and device, so the host build reproduces the device bits (tests/test_fastmath.py measures the
+// distance to libm in long double: <= 2 ulp).
+// ---------------------------------------------------------------------------
+LINS_HD double lins_fma(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_fma(a, b, c);
+#else
+  return fma(a, b, c);
+#endif
+}
+// sin(h) / h and cos(h), z = h^2 <= 0.25 (|h| <= 0.5): remainders below 1e-19 relative
+LINS_HD void lins_sinc_cos_small(double z, double& sinc, double& c) {
+  double s = -1.0 / 121645100408832000.0;  // 1/19!
+  s = lins_fma(s, z, 1.0 / 355687428096000.0);   // 1/17!
+  s = lins_fma(s, z, -1.0 / 1307674368000.0);    // 1/15!
+  s = lins_fma(s, z, 1.0 / 6227020800.0);        // 1/13!
+  s = lins_fma(s, z, -1.0 / 39916800.0);         // 1/11!
+  s = lins_fma(s, z, 1.0 / 362880.0);            // 1/9!
+  s = lins_fma(s, z, -1.0 / 5040.0);             // 1/7!
+  s = lins_fma(s, z, 1.0 / 120.0);               // 1/5!
+  s = lins_fma(s, z, -1.0 / 6.0);                // 1/3!
+  sinc = lins_fma(s, z, 1.0);
+  double k = 1.0 / 6402373705728000.0;   // 1/18!
+  k = lins_fma(k, z, -1.0 / 20922789888000.0);   // 1/16!
+  k = lins_fma(k, z, 1.0 / 87178291200.0);       // 1/14!
+  k = lins_fma(k, z, -1.0 / 479001600.0);        // 1/12!
+  k = lins_fma(k, z, 1.0 / 3628800.0);           // 1/10!
+  k = lins_fma(k, z, -1.0 / 40320.0);            // 1/8!
+  k = lins_fma(k, z, 1.0 / 720.0);               // 1/6!
+  k = lins_fma(k, z, -1.0 / 24.0);               // 1/4!
+  k = lins_fma(k, z, 0.5);                       // 1/2!
+  c = lins_fma(-k, z, 1.0);
+}
+// A(z) = atan(t) / t and Q(z) = (1 - A(z)) / z for z = t^2 <= 1/64 (t <= 0.125): the alternating series
+// 1 - z/3 + z^2/5 - ..., cut after z^11 / 23 (next term < 1.6e-23)
+LINS_HD void lins_atanc_small(double z, double& A, double& Q) {
+  double q = 1.0 / 25.0;
+  q = lins_fma(-q, z, 1.0 / 23.0);
+  q = lins_fma(-q, z, 1.0 / 21.0);
+  q = lins_fma(-q, z, 1.0 / 19.0);
+  q = lins_fma(-q, z, 1.0 / 17.0);
+  q = lins_fma(-q, z, 1.0 / 15.0);
+  q = lins_fma(-q, z, 1.0 / 13.0);
+  q = lins_fma(-q, z, 1.0 / 11.0);
+  q = lins_fma(-q, z, 1.0 / 9.0);
+  q = lins_fma(-q, z, 1.0 / 7.0);
+  q = lins_fma(-q, z, 1.0 / 5.0);
+  q = lins_fma(-q, z, 1.0 / 3.0);
+  Q = q;
+  A = lins_fma(-q, z, 1.0);
+}
+constexpr double kFastHalfAngleSq = 0.25;     // axis2quat_fast: |v| <= 1 rad
+constexpr double kFastTanSq = 1.0 / 64.0;     // quat2axis_fast: tan(angle / 2) <= 1/8, i.e. angle <= 0.2487 rad
+
+LINS_HD Q4 axis2quat_fast(V3 v) {
+  const double n2 = dot(v, v);
+  if (n2 < 1e-20) return {1, 0, 0, 0};  // theta < 1e-10 (MU:63)
+  const double z = 0.25 * n2;
+  if (!(z <= kFastHalfAngleSq)) return axis2quat(v);
+  double sinc, c;
+  lins_sinc_cos_small(z, sinc, c);
+  const double k = 0.5 * sinc;
+  return {c, v.x * k, v.y * k, v.z * k};
+}
+LINS_HD V3 quat2axis_fast(Q4 q) {
+  const double m2 = q.x * q.x + q.y * q.y + q.z * q.z;
+  if (m2 < 1e-20) return {q.x, q.y, q.z};  // mag < 1e-10: the vector part as it is (MU:78-86)
+  if (!(q.w > 0.0 && m2 <= kFastTanSq * (q.w * q.w))) return quat2axis(q);
+  const double rw = 1.0 / q.w;
+  double A, Q;
+  lins_atanc_small((m2 * rw) * rw, A, Q);
+  const double k = (2.0 * A) * rw;
+  return {q.x * k, q.y * k, q.z * k};
+}
+
 LINS_HD M3 rinvleft(V3 axis) {
   double theta = norm(axis);
   M3 r{{1, 0, 0, 0, 1, 0, 0, 0, 1}};
@@ -158,6 +244,28 @@ LINS_HD M3 rinvleft(V3 axis) {
       r.m[i * 3 + j] = (s * (i == j ? 1.0 : 0.0) + (1.0 - s) * av[i] * av[j]) - h * k.m[i * 3 + j];
   return r;
 }
+// phi = Quat2axis(q) and Gt = Rinvleft(-phi)^T in one go for a small rotation (w > 0, tan(|phi| / 2) <= 1/8).
+// With h = |phi| / 2, t = tan h = |qv| / w, z = t^2 and the series A, Q above:
+//   phi = qv * 2 A / w,   h cot h = A,   (1 - h cot h) / |phi|^2 = Q / (4 A^2),   h / |phi| = 1/2, so
+//   Rinvleft(-phi) = s I + (1 - s) a a^T - h [a]x  with a = -phi / |phi|, s = h cot h      (MU:304-321)
+//                  = A I + (Q / w^2) qv qv^T + (A / w) [qv]x
+// — no square root, one division, two short fma chains.  Returns false (outputs untouched) outside that range.
+LINS_HD bool phi_and_gt_small(const Q4& q, V3& phi, M3& Gt) {
+  const double m2 = q.x * q.x + q.y * q.y + q.z * q.z;
+  if (!(q.w > 0.0 && m2 >= 1e-20 && m2 <= kFastTanSq * (q.w * q.w))) return false;
+  const double rw = 1.0 / q.w;
+  double A, Q;
+  lins_atanc_small((m2 * rw) * rw, A, Q);
+  const double k = (2.0 * A) * rw, c1 = (Q * rw) * rw, c2 = A * rw;
+  phi = V3{q.x * k, q.y * k, q.z * k};
+  const double v[3] = {q.x, q.y, q.z};
+  const M3 sk = skew(V3{q.x, q.y, q.z});
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      Gt.m[j * 3 + i] = ((i == j ? A : 0.0) + c1 * v[i] * v[j]) + c2 * sk.m[i * 3 + j];
+  return true;
+}
+
 LINS_HD Q4 rpy2quat(V3 rpy) {
   double hy = rpy.z * 0.5, hp = rpy.y * 0.5, hr = rpy.x * 0.5;
   double cy = cos(hy), sy = sin(hy), cp = cos(hp), sp = sin(hp), cr = cos(hr), sr = sin(hr);

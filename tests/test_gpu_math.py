@@ -137,6 +137,70 @@ def test_wave_solve6_is_bit_identical_to_the_one_lane_elimination(ieskf, ctx):
     assert np.abs(res[:100]).max() <= 1e-12
 
 
+def small_quats(rng, n):
+    """unit quaternions of SMALL rotations (w > 0, tan(angle / 2) <= 1/8: the short-series range) and of rotations
+    just outside it, plus the 1e-10 branch"""
+    ang = rng.uniform(0, 0.3, size=n) * rng.choice([1e-6, 1e-3, 0.1, 1.0], size=n)
+    ax = rng.normal(size=(n, 3))
+    ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    q = np.concatenate([np.cos(ang / 2)[:, None], ax * np.sin(ang / 2)[:, None]], axis=1)
+    extra = [[1, 0, 0, 0], [1, 3e-11, 0, 0], [1, 0, 1.0001e-10, 0], [1, 0.124, 0, 0], [1, 0.1251, 0, 0], [2.0, 0.02, -0.04, 0.06]]
+    return np.concatenate([np.array(extra, dtype=np.float64), q])
+
+
+def test_short_series_forms_of_the_serial_tail(ieskf, oracle, ctx):
+    """axis2quat_fast / quat2axis_fast / the small-rotation branch of phi_and_Gt (lins_math.h): what the wave that
+    walks from one iteration to the next really evaluates, against the oracle's libm formulas (MU:61-88, 304-321)
+    — inside the series' range, just outside it (the libm fallback), and across the 1e-10 branches."""
+    rng = np.random.default_rng(31)
+    v = np.concatenate([vecs(rng, 200), rng.normal(size=(200, 3)) * 0.2])
+    got = dev(ieskf, ctx, 13, v, 4)
+    want = np.array([oracle.axis2quat(x) for x in v])
+    assert np.abs(got - want).max() <= 1e-15
+    assert np.array_equal(got[0], [1, 0, 0, 0]) and np.array_equal(got[1], [1, 0, 0, 0]) and np.array_equal(got[3], [1, 0, 0, 0])
+    q = np.concatenate([quats(rng, 100), small_quats(rng, 400)])
+    got = dev(ieskf, ctx, 14, q, 3)
+    want = np.array([oracle.quat2axis(x) for x in q])
+    assert np.abs(got - want).max() <= 1e-14
+    got = dev(ieskf, ctx, 5, q, 12)
+    ref = dev(ieskf, ctx, 15, q, 12)  # the same constants by the general (atan2) route, on the device
+    assert np.abs(got[:, :3] - want).max() <= 1e-14
+    gt = np.array([oracle.rinvleft(-p).T for p in want]).reshape(-1, 9)
+    scale = np.maximum(1.0, np.abs(gt).max(axis=1, keepdims=True))
+    assert (np.abs(got[:, 3:] - gt) / scale).max() <= 1e-12
+    small = (q[:, 0] > 0) & ((q[:, 1:] ** 2).sum(axis=1) <= q[:, 0] ** 2 / 64) & ((q[:, 1:] ** 2).sum(axis=1) >= 1e-20)
+    assert small.sum() > 200 and (~small).sum() > 100
+    assert np.array_equal(got[~small], ref[~small])                # outside the range: the general route itself
+    assert np.abs(got[small] - ref[small]).max() <= 2e-15          # inside: the two routes agree to rounding
+
+
+def test_gauss_jordan_solve_of_the_kernels(ieskf, ctx):
+    """wave_gj_solve6 (ieskf_rowsum.h, what the kernels run) returns the bits of the scalar definition gj_solve6
+    (lins_solve6.h) — row exchanges, singular systems and a NaN included — and solves: against numpy, and against
+    round 1's elimination + back-substitution within the conditioning."""
+    rng = np.random.default_rng(22)
+    sys_ = rng.normal(size=(400, 6, 7))
+    sys_[:100, np.arange(6), np.arange(6)] += 8.0
+    sys_[100:150, 0, 0] = 1e-12
+    sys_[150:160, 2, :] = sys_[150:160, 1, :]
+    sys_[160, 3, 4] = np.nan
+    sys_[161:200] *= 10.0 ** rng.integers(-6, 7, size=(39, 1, 1))
+    sys_[200:230, 1, 1] = 0.0
+    x = sys_.reshape(400, 42)
+    a = dev(ieskf, ctx, 11, x, 6)
+    b = dev(ieskf, ctx, 12, x, 6)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)].view(np.uint64), b[~np.isnan(b)].view(np.uint64))
+    assert np.isnan(b[160]).any()  # a NaN in the system reaches the solution (SE:552-563 must see it)
+    old = dev(ieskf, ctx, 8, x, 6)
+    ok = np.isfinite(b).all(axis=1) & np.isfinite(old).all(axis=1)
+    ok[150:161] = False
+    want = np.stack([np.linalg.solve(m[:, :6], m[:, 6]) for m in sys_[ok]])
+    cond = np.array([np.linalg.cond(m[:, :6]) for m in sys_[ok]])
+    tol = 4e-15 * np.maximum(cond, 10.0) * np.abs(want).max(axis=1)
+    assert (np.abs(b[ok] - want).max(axis=1) <= tol).all()
+    assert (np.abs(b[ok] - old[ok]).max(axis=1) <= 2 * tol).all()
+
+
 def test_row_reduction_on_the_valu_lane_paths_matches_the_shuffle_tree(ieskf, ctx):
     """wave_reduce_rows exchanges lanes with DPP / lane-swap instructions (ieskf_rowsum.h xor_lane_i32); the same
     tree written with __shfl_xor must give the same bits, and both the 28 sums of the 64 rows."""
