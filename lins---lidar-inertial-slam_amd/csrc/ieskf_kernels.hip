@@ -29,6 +29,7 @@
 
 #include "ieskf_binned.h"
 #include "ieskf_device.h"
+#include "ieskf_joseph.h"
 
 namespace lins {
 
@@ -212,53 +213,6 @@ __device__ __forceinline__ void setup_bins(const ScanDesc& sd, const float4* __r
   __syncthreads();
 }
 
-// ---------------------------------------------------------------------------
-// 6 x 6 pivoted elimination in LDS, cooperative over the block.
-// aug = [N | B] row-major 6 x nc; sol (nrhs = nc - 6 columns, row-major 6 x nrhs) = N^-1 B.
-// Pivot rows are chosen per column among the not-yet-used rows (implicit row
-// exchange).  Every thread of the block must call this (it contains barriers).
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void block_solve6(double* aug, int nc, double* sol, int* piv, int* used, int tid) {
-  if (tid < 6) used[tid] = 0;
-  __syncthreads();
-  for (int k = 0; k < 6; ++k) {
-    if (tid == 0) {
-      int p = -1;
-      double best = -1.0;
-      for (int i = 0; i < 6; ++i)
-        if (!used[i]) {
-          double v = fabs(aug[i * nc + k]);
-          if (p < 0 || v > best) best = v, p = i;
-        }
-      piv[k] = p;
-      used[p] = 1;
-    }
-    __syncthreads();
-    const int p = piv[k];
-    const int i = tid / nc, j = tid - i * nc;
-    if (i < 6 && !used[i] && j > k) {
-      double f = aug[i * nc + k] / aug[p * nc + k];
-      aug[i * nc + j] -= f * aug[p * nc + j];
-    }
-    __syncthreads();
-  }
-  const int nrhs = nc - 6;
-  if (tid < nrhs) {
-    const int col = 6 + tid;
-    double x[6];
-#pragma unroll
-    for (int k = 5; k >= 0; --k) {
-      const int p = piv[k];
-      double s = aug[p * nc + col];
-#pragma unroll
-      for (int j = k + 1; j < 6; ++j) s -= aug[p * nc + j] * x[j];
-      x[k] = s / aug[p * nc + k];
-    }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) sol[k * nrhs + tid] = x[k];
-  }
-  __syncthreads();
-}
 
 // ---------------------------------------------------------------------------
 // LDS layout of the persistent kernel
@@ -474,79 +428,13 @@ __global__ __launch_bounds__(kJosephBlock) void ieskf_joseph_kernel(DevParams pr
                                                                     const double* __restrict__ a6_in,
                                                                     const OutRec* __restrict__ out,
                                                                     double* __restrict__ cov_out) {
-  __shared__ double P[324], IKH[324], T[324], O[324];
-  __shared__ double A[21], aug[72], Y[36], Zt[36], PSZ[108];
-  __shared__ int piv[6], used[6];
+  __shared__ double P[324], A[21];
+  __shared__ JosephScratch scratch;
   const int tid = threadIdx.x, scan = blockIdx.x;
   for (int k = tid; k < 324; k += kJosephBlock) P[k] = cov_in[(size_t)scan * 324 + k];
-  if (out[scan].diverged) {
-    __syncthreads();
-    for (int k = tid; k < 324; k += kJosephBlock) cov_out[(size_t)scan * 324 + k] = P[k];
-    return;
-  }
   if (tid < 21) A[tid] = a6_in[(size_t)scan * 21 + tid];
   __syncthreads();
-  if (tid < 36) {
-    int i = tid / 6, j = tid - i * 6;
-    double t = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) t += sym6(A, i, k) * P[sidx(k) * 18 + sidx(j)];
-    aug[i * 12 + j] = t + (i == j ? prm.r2 : 0.0);
-    aug[i * 12 + 6 + j] = sym6(A, i, j);
-  }
-  __syncthreads();
-  block_solve6(aug, 12, Y, piv, used, tid);  // Y = N^-1 A
-  if (tid < 36) {
-    int i = tid / 6, j = tid - i * 6;
-    double t = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) t += sym6(A, i, k) * P[sidx(k) * 18 + sidx(j)];
-    aug[i * 12 + j] = t + (i == j ? prm.r2 : 0.0);
-    aug[i * 12 + 6 + j] = Y[j * 6 + i];  // Y^T
-  }
-  __syncthreads();
-  block_solve6(aug, 12, Zt, piv, used, tid);  // Zt = N^-1 Y^T  => Z = Y N^-T
-  for (int e = tid; e < 324; e += kJosephBlock) {
-    int i = e / 18, j = e - i * 18;
-    double v = (i == j) ? 1.0 : 0.0;
-    int kj = (j < 3) ? j : ((j >= 6 && j < 9) ? j - 3 : -1);  // KH has non-zero columns only in S
-    if (kj >= 0) {
-      double s = 0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) s += P[i * 18 + sidx(k)] * Y[k * 6 + kj];
-      v -= s;
-    }
-    IKH[e] = v;
-  }
-  for (int e = tid; e < 108; e += kJosephBlock) {
-    int i = e / 6, j = e - i * 6;
-    double s = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) s += P[i * 18 + sidx(k)] * Zt[j * 6 + k];  // Z[k][j] = Zt[j][k]
-    PSZ[e] = s;
-  }
-  __syncthreads();
-  for (int e = tid; e < 324; e += kJosephBlock) {
-    int i = e / 18, j = e - i * 18;
-    double s = 0;
-    for (int k = 0; k < 18; ++k) s += IKH[i * 18 + k] * P[k * 18 + j];
-    T[e] = s;
-  }
-  __syncthreads();
-  for (int e = tid; e < 324; e += kJosephBlock) {
-    int i = e / 18, j = e - i * 18;
-    double s = 0;
-    for (int k = 0; k < 18; ++k) s += T[i * 18 + k] * IKH[j * 18 + k];
-    double kk = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) kk += PSZ[i * 6 + k] * P[j * 18 + sidx(k)];
-    O[e] = s + prm.r2 * kk;
-  }
-  __syncthreads();
-  for (int e = tid; e < 324; e += kJosephBlock) {
-    int i = e / 18, j = e - i * 18;
-    cov_out[(size_t)scan * 324 + e] = 0.5 * (O[i * 18 + j] + O[j * 18 + i]);
-  }
+  joseph_update<kJosephBlock>(prm.r2, out[scan].diverged != 0, P, A, scratch, cov_out + (size_t)scan * 324, tid);
 }
 
 // ---------------------------------------------------------------------------

@@ -52,6 +52,10 @@
 #include "ieskf_rowsum.h"
 #include "ieskf_split.h"
 
+#ifndef LINS_GRID_PF
+#define LINS_GRID_PF 4  // steps of the grid build whose point reads are in flight together (measured: 1 -> 4: -0.9 %, 8: as 4)
+#endif
+
 namespace lins {
 namespace LINS_LDS_NS {
 
@@ -245,6 +249,21 @@ __device__ __forceinline__ bool certified(float d_now, float lb, float drift) {
   return sqrtf(d_now) * (1.f + 4e-6f) + 2e-6f < (lb - drift * (1.f + 4e-6f)) * (1.f - 4e-6f);
 }
 
+// ---- azimuth column of a point on the LDS grid ---------------------------------------------
+// The grid only has to be CONSISTENT: a point within angular distance D of a query must sit within the query's
+// window of +-K columns, K = reach().  With columns of width w and a column function floor(g(theta) / w) whose angle
+// g is off by at most eps, |g(p) - g(q)| <= D + 2 eps, so the two columns differ by at most floor((D + 2 eps) / w) + 1
+// <= floor(D / w) + 2 as long as 2 eps < w — which is what reach() adds (its "+ 2": one column for the query's offset
+// inside its own column, one for rounding).  The finest columns are 2 pi / 128 = 0.049 rad wide, so an angle good to
+// 4e-3 rad is enough: lins_atan2_coarse (a dozen instructions, lins_math.h) instead of atan2f (~45) for the 7 700
+// points of the build and for every query of every iteration.  Results cannot change: every pruning decision stays a
+// superset decision, and ties are resolved on explicit keys.
+static_assert((kAzSurf & (kAzSurf - 1)) == 0 && (kAzCorner & (kAzCorner - 1)) == 0, "column counts are powers of two");
+__device__ __forceinline__ int az_bin_lds(float x, float y, int naz) {
+  int a = (int)((lins_atan2_coarse(y, x) + kPiF) * ((float)naz * (0.5f / kPiF)));
+  return a < 0 ? 0 : (a >= naz ? naz - 1 : a);
+}
+
 // ---- columns / windows on the LDS grid ----------------------------------------------------
 // All lanes of a wave run the SAME code on different (ring, column-range) data: every
 // scan goes through scan_cols(), whose point loop exists once per call site, so splitting
@@ -256,8 +275,7 @@ __device__ __forceinline__ void scan_cols(const LdsStore& L, const LCloud& c, in
     const int naz = c.naz, row = r * naz;
     int len = hi - lo;
     if (len >= naz - 1) lo = 0, len = naz - 1;  // at most naz columns
-    lo %= naz;
-    if (lo < 0) lo += naz;
+    lo &= naz - 1;  // (naz is a power of two: the non-negative remainder without an integer division, ~20 instructions)
     hi = lo + len;
     const int c0 = row + lo, c1 = row + (hi < naz ? hi : naz - 1);
     s0 = c0 ? (int)c.cell_end[c0 - 1] : c.base;
@@ -430,7 +448,7 @@ __device__ __forceinline__ CoopMap coop_map(bool need, int lane) {
 }
 // lanes per search when n searches share a wave: 64 / n rounded down to a power of two (1: everyone for himself)
 __device__ __forceinline__ int coop_lanes(int n, int cap) {
-  const int l = 1 << (31 - __clz(64 / n));
+  const int l = n <= 1 ? 64 : 64 >> (32 - __clz(n - 1));  // = 64 / n rounded down to a power of two, without the division
   return l > cap ? cap : l;
 }
 
@@ -623,41 +641,57 @@ __device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, 
     }
     run_lo = 0x7FFFFFFF, run_hi = (int)0x80000000;
   };
+  // The point reads of LINS_GRID_PF consecutive steps are issued together (clamped addresses, no branch in between):
+  // a wave pays the HBM latency once per chunk instead of once per step.
+  constexpr int kChunk = LINS_GRID_PF;
 #pragma unroll
-  for (int k = 0; k < kPerThread; ++k) {
-    const int j = j_first + k * 64;
-    cell_of[k] = -1;
-    if (k < per_lane) {  // (wave-uniform)
-      int eb = 0, ek = -1;  // elevation bits, (cloud, ring) key of this lane's point
-      if (j < n_all) {
-        const bool is_s = j < sd.n_surf_t;
-        const float4 p = is_s ? ts[j] : tc[j - sd.n_surf_t];
-        const int r = ring_of(p.w), naz = is_s ? kAzSurf : kAzCorner;
-        const int cell = (is_s ? kCellsCorner : 0) + r * naz + az_bin(p.x, p.y, naz);
-        cell_of[k] = cell;
-        atomicAdd(&cnt32[cell >> 1], 1u << ((cell & 1) * 16));
-        // z / rho through the hardware's reciprocal square root (1 ulp): the ratio is off by < 2^-22 relative, the
-        // elevation by < 1.2e-7 rad — two orders below kSlack.  rho = 0: +-inf / 0 (atanf gives +-pi/2 / 0); a
-        // ratio that overflows to +-inf widens the wedge, never narrows it.
-        const float rho2 = p.x * p.x + p.y * p.y;
-        eb = ordered_int(rho2 > 0.f ? p.z * __frsqrt_rn(rho2) : (p.z > 0.f ? INFINITY : (p.z < 0.f ? -INFINITY : 0.f)));
-        ek = (is_s ? 0 : kRingsBinned) + r;
+  for (int k0 = 0; k0 < kPerThread; k0 += kChunk) {
+    float4 pbuf[kChunk];
+    if (k0 < per_lane) {  // (wave-uniform)
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) {
+        const int j = j_first + (k0 + u) * 64, jc = j < n_all ? j : n_all - 1;
+        pbuf[u] = jc < sd.n_surf_t ? ts[jc] : tc[jc - sd.n_surf_t];
       }
-      const unsigned long long have = __ballot(ek >= 0);
-      if (have) {  // (wave-uniform)
-        const int ek0 = __builtin_amdgcn_readlane(ek, __ffsll((long long)have) - 1);
-        if (__all(ek == ek0 || ek < 0)) {
-          if (ek0 != run_key) {
+    }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      const int k = k0 + u;
+      if (k >= kPerThread) break;
+      const int j = j_first + k * 64;
+      cell_of[k] = -1;
+      if (k < per_lane) {  // (wave-uniform)
+        int eb = 0, ek = -1;  // elevation bits, (cloud, ring) key of this lane's point
+        if (j < n_all) {
+          const bool is_s = j < sd.n_surf_t;
+          const float4 p = pbuf[u];
+          const int r = ring_of(p.w), naz = is_s ? kAzSurf : kAzCorner;
+          const int cell = (is_s ? kCellsCorner : 0) + r * naz + az_bin_lds(p.x, p.y, naz);
+          cell_of[k] = cell;
+          atomicAdd(&cnt32[cell >> 1], 1u << ((cell & 1) * 16));
+          // z / rho through the hardware's reciprocal square root (1 ulp): the ratio is off by < 2^-22 relative, the
+          // elevation by < 1.2e-7 rad — two orders below kSlack.  rho = 0: +-inf / 0 (atanf gives +-pi/2 / 0); a
+          // ratio that overflows to +-inf widens the wedge, never narrows it.
+          const float rho2 = p.x * p.x + p.y * p.y;
+          eb = ordered_int(rho2 > 0.f ? p.z * __frsqrt_rn(rho2) : (p.z > 0.f ? INFINITY : (p.z < 0.f ? -INFINITY : 0.f)));
+          ek = (is_s ? 0 : kRingsBinned) + r;
+        }
+        const unsigned long long have = __ballot(ek >= 0);
+        if (have) {  // (wave-uniform)
+          const int ek0 = __builtin_amdgcn_readlane(ek, __ffsll((long long)have) - 1);
+          if (__all(ek == ek0 || ek < 0)) {
+            if (ek0 != run_key) {
+              flush_run();
+              run_key = ek0;
+            }
+            if (ek >= 0) run_lo = min(run_lo, eb), run_hi = max(run_hi, eb);
+          } else {  // a step that straddles rings: its lanes update LDS themselves
             flush_run();
-            run_key = ek0;
-          }
-          if (ek >= 0) run_lo = min(run_lo, eb), run_hi = max(run_hi, eb);
-        } else {  // a step that straddles rings: its lanes update LDS themselves
-          flush_run();
-          run_key = -1;
-          if (ek >= 0) {
-            atomicMin(&L.el_bits[ek / kRingsBinned][ek % kRingsBinned][0], eb);
-            atomicMax(&L.el_bits[ek / kRingsBinned][ek % kRingsBinned][1], eb);
+            run_key = -1;
+            if (ek >= 0) {
+              atomicMin(&L.el_bits[ek / kRingsBinned][ek % kRingsBinned][0], eb);
+              atomicMax(&L.el_bits[ek / kRingsBinned][ek % kRingsBinned][1], eb);
+            }
           }
         }
       }
@@ -905,7 +939,7 @@ __device__ __noinline__ void split_gather(const GatherArgs ga, const float4* gs,
   qp.qn3 = sqrtf(qp.rho * qp.rho + az * az);
   qp.el = atan2f(az, qp.rho);
   qp.inv_unused = 0.f;
-  qp.a0_surf_or_corner = az_bin(ax, ay, c.naz);
+  qp.a0_surf_or_corner = az_bin_lds(ax, ay, c.naz);
   SplitQ rec{ax, ay, az, 0.f, ax, ay, az, 0.f, 0.f, 0, -1, -1};
   if (p1 >= 0 && !(ga.pad & 128)) {  // (pad & 128: timing aid, no lists)
     const float thr = ga.thr, M = ga.margin;
@@ -1232,7 +1266,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
               qp.rho = sqrtf(o.sel[0] * o.sel[0] + o.sel[1] * o.sel[1]);
               qp.qn3 = sqrtf(qp.rho * qp.rho + o.sel[2] * o.sel[2]);
               qp.el = atan2f(o.sel[2], qp.rho);
-              qp.a0_surf_or_corner = az_bin(o.sel[0], o.sel[1], c.naz);
+              qp.a0_surf_or_corner = az_bin_lds(o.sel[0], o.sel[1], c.naz);
             }
             const float da = a1 >= 0 ? dist_to(a1) : INFINITY, db = b1c >= 0 ? dist_to(b1c) : INFINITY;
             bool ok = warm_iter && !(prm.pad & 16) && certified(fminf(fminf(da, db), thr), lb1, drift_from(certA));
@@ -1467,7 +1501,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           qp.qn3 = sqrtf(qp.rho * qp.rho + o.sel[2] * o.sel[2]);
           qp.el = atan2f(o.sel[2], qp.rho);
           qp.inv_unused = 0.f;
-          qp.a0_surf_or_corner = az_bin(o.sel[0], o.sel[1], c.naz);
+          qp.a0_surf_or_corner = az_bin_lds(o.sel[0], o.sel[1], c.naz);
           const float thr = prm.nearest_f;
           const float margin = have_cert ? prm.margin_warm : prm.margin_cold;
           auto dist_to = [&](int pos) { return pt_sqdist(L, c, pos, o.sel[0], o.sel[1], o.sel[2]); };

@@ -122,6 +122,23 @@ LINS_HD float lins_atan2f(float y, float x) {
   return y < 0.f ? -r : ((y == 0.f && 1.f / y < 0.f) ? -r : r);
 }
 
+// atan2 to within 4e-3 rad in a dozen instructions: a (pi/4 + 0.273 (1 - a)) on the first octant (a = min / max of
+// |x|, |y|; maximum error 3.8e-3 rad) and the usual reflections.  For BINNING only (the azimuth columns of the LDS
+// grid, ieskf_lds_impl.h az_bin_lds, where the search windows carry a whole column of slack): never for geometry.
+LINS_HD float lins_atan2_coarse(float y, float x) {
+  const float ax = x < 0.f ? -x : x, ay = y < 0.f ? -y : y;
+  const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float a = mn * __frcp_rn(mx);  // (0 * inf = NaN at the origin: the caller's integer conversion maps it to column 0)
+#else
+  const float a = mn / mx;
+#endif
+  float r = a * (0.78539816f + 0.273f * (1.f - a));
+  if (ay > ax) r = 1.57079633f - r;
+  if (x < 0.f) r = 3.14159265f - r;
+  return y < 0.f ? -r : r;
+}
+
 LINS_HD double wrap_pi(double x) {
   const double pi = 3.14159265358979323846;
   while (x >= pi) x -= 2.0 * pi;

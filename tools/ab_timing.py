@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""A/B kernel timing of two builds of liblins_ieskf.so in ONE GPU call (boxes differ by several per cent, so two
+"""A/B kernel (and whole-step wall) timing of two builds of liblins_ieskf.so in ONE GPU call (boxes differ by several per cent, so two
 calls cannot be compared): alternates the libraries, several rounds, prints the medians.
 usage: tools/ab_timing.py libA.so libB.so [mode ...]   (modes default: mr split)"""
 import os
@@ -28,9 +28,11 @@ with ieskf.IeskfContext(prm, max_batch=batch, max_targets=16384, search=mode) as
     ctx.upload(pairs)
     for _ in range(3):
         ctx.run(); ctx.sync()
-    ks = []
+    import time
+    ks, ws = [], []
     for _ in range(15):
-        ctx.run(); ctx.sync(); ks.append(ctx.last_kernel_ms())
+        t0 = time.perf_counter(); ctx.run(); ctx.sync(); ws.append((time.perf_counter() - t0) * 1e3); ks.append(ctx.last_kernel_ms())
+    print("WALL %%.4f" %% float(np.median(ws)))
     extra = ""
     try:
         a, b = ctx.last_split_ms(); extra = " %%.4f %%.4f" %% (a, b)
@@ -40,11 +42,18 @@ with ieskf.IeskfContext(prm, max_batch=batch, max_targets=16384, search=mode) as
 ''' % ROOT
 
 
+WALL = {}
+
+
 def run(lib, mode, batch=1024):
     e = dict(os.environ, LINS_IESKF_LIB=os.path.abspath(lib))
     p = subprocess.run([sys.executable, "-c", CHILD, str(batch), mode], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    wall = float("nan")
     for line in p.stdout.decode().splitlines():
+        if line.startswith("WALL"):
+            wall = float(line.split()[1])
         if line.startswith("RESULT"):
+            WALL.setdefault((lib, mode), []).append(wall)
             return [float(x) for x in line.split()[1:]]
     return [float("nan"), p.stderr.decode()[-200:]]
 
@@ -60,4 +69,5 @@ for m in modes:
     for l in libs:
         r = np.array([x[:3] if len(x) >= 3 and isinstance(x[1], float) else [x[0], np.nan, np.nan] for x in res[(l, m)]], dtype=float)
         med = np.nanmedian(r, axis=0)
-        print(f"{m:6s} {os.path.basename(l):28s} kernel {med[0]:.4f} ms" + (f" (grid {med[1]:.4f} + list {med[2]:.4f})" if not np.isnan(med[1]) else ""))
+        print(f"{m:6s} {os.path.basename(l):28s} kernel {med[0]:.4f} ms" + (f" (grid {med[1]:.4f} + list {med[2]:.4f})" if not np.isnan(med[1]) else "")
+              + f"   step (run + sync, wall) {np.nanmedian(WALL.get((l, m), [np.nan])):.4f} ms")
