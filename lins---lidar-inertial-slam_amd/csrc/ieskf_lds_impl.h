@@ -52,6 +52,13 @@
 #include "ieskf_rowsum.h"
 #include "ieskf_split.h"
 
+#ifndef LINS_SPREAD_S
+// waves the plane / line queries of a 512-thread workgroup are spread over.  Measured on the batch workload (91 plane
+// + 164 line queries on average), one GPU call: 5 / 3 (round 1's choice) 0.692 ms, 4 / 4 0.685, 4 / 3 0.705, 3 / 3 0.711,
+// 3 / 5 0.712, 2 / 3 0.760 — using fewer than all eight waves never pays.
+#define LINS_SPREAD_S 4
+#define LINS_SPREAD_C 4
+#endif
 #ifndef LINS_GRID_PF
 #define LINS_GRID_PF 4  // steps of the grid build whose point reads are in flight together (measured: 1 -> 4: -0.9 %, 8: as 4)
 #endif
@@ -1164,10 +1171,10 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     // the number of active lanes — spread the queries over ALL waves instead of filling them one by
     // one: plane queries (the costlier kind: two walks over five rings) evenly over the first
     // kSpreadSurf waves, line queries evenly over the rest.
-    constexpr int kWaves = BLOCK / 64, kSpreadSurf = (kWaves * 5 + 4) / 8;
+    constexpr int kWaves = BLOCK / 64, kSpreadSurf = LINS_SPREAD_S > 0 && BLOCK == 512 ? LINS_SPREAD_S : (kWaves * 5 + 4) / 8;
     int spread_s = 0, spread_c = 0;  // queries per wave of either kind (0 = not spread)
     if (LANES == 1) {
-      const int ws = kSpreadSurf, wc = kWaves - ws;  // (measured: 4 or 5 of 8 waves for the plane queries, no difference)
+      const int ws = kSpreadSurf, wc = LINS_SPREAD_C > 0 && BLOCK == 512 ? LINS_SPREAD_C : kWaves - ws;
       const int ps = (sd.n_surf_q + ws - 1) / ws, pc = wc > 0 ? (sd.n_corner_q + wc - 1) / wc : 65;
       if (ws < kWaves && ps <= 64 && pc <= 64) spread_s = ps, spread_c = pc, surf_waves = ws;
     }
@@ -1746,12 +1753,12 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       // anchor bound the new winners'.  (A search pass at the new state before gathering gives exact radii and
       // fewer exhaustive searches in the list kernel, but costs more than it saves: measured.)
       if (iter + 1 >= prm.split_iters && iter + 1 < prm.num_iter && !L.conv && !L.div) {
-        constexpr int kW = BLOCK / 64, kSS = (kW * 5 + 4) / 8;
+        constexpr int kW = BLOCK / 64, kSS = LINS_SPREAD_S > 0 && BLOCK == 512 ? LINS_SPREAD_S : (kW * 5 + 4) / 8;
         int sw = (sd.n_surf_q + kQPerWave - 1) / kQPerWave;
         const bool al = sw * kQPerWave + sd.n_corner_q <= kQPerRound;
         int sp_s = 0, sp_c = 0;
         {
-          const int ws = kSS, wc = kW - ws;
+          const int ws = kSS, wc = LINS_SPREAD_C > 0 && BLOCK == 512 ? LINS_SPREAD_C : kW - ws;
           const int ps = (sd.n_surf_q + ws - 1) / ws, pc = wc > 0 ? (sd.n_corner_q + wc - 1) / wc : 65;
           if (ws < kW && ps <= 64 && pc <= 64) sp_s = ps, sp_c = pc, sw = ws;
         }
