@@ -37,7 +37,7 @@
 //                       three lanes and merged with wave shuffles on (distance, key)
 //     1 lane / query    plane / line residual + Jacobian (f64 -> f32) -> H row in LDS
 //     224 lanes         28 f64 sums, fixed-shape tree (8 strided groups -> ordered fold)
-//     <=42 lanes        6x6 pivoted elimination in LDS, dx
+//     42 lanes of wave 0  6x6 Gauss-Jordan, one element per lane (ieskf_rowsum.h wave_gj_solve6), dx
 //     wave 0            NaN / divergence / convergence, boxPlus, next constants
 //   16 waves x 21 queries = 336 queries per round = the VLP-16 caps (144 flat + 192 sharp).
 //
@@ -768,8 +768,13 @@ __device__ __noinline__ long long solve_and_update(double prm_r2, int prm_fixed_
   LdsStore& L = g_lds;
   const int lane = tid & 63, wave = tid >> 6;
   // ---- wave 0: (sigma^2 I + A P_SS) w = g + A d_S  (push-through form of SE:542-549) solved across the wave
-  // (wave_solve6: the one-lane elimination's operations, element by element), dx = d - P[:,S] w, NaN / divergence /
-  // convergence tests and boxPlus (SE:552-580).  The new linearisation state is STAGED in LDS — the old one may
+  // (wave_gj_solve6: Gauss-Jordan, one element per lane, no back-substitution), dx = d - P[:,S] w, NaN / divergence /
+  // convergence tests and boxPlus (SE:552-580).  This wave walks a chain of dependent f64 operations while the other
+  // seven wait at the barrier, so the chain is kept short: the rotation maps take their short-series forms
+  // (lins_math.h axis2quat_fast, quat2axis_fast, phi_and_gt_small — no libm call, no square root, one division for
+  // the rotations an update sees) and fall back to libm outside their range.  Round 2, measured in isolation
+  // (tools/tail_cycles.py): solve 3418 -> 2487 cycles, boxPlus' axis2quat 1487 -> 582, phi + Rinvleft 2087 -> 863;
+  // in the kernel the tail's share of a late iteration fell from 12.8 to 5.4 us per launch.  The new linearisation state is STAGED in LDS — the old one may
   // still be read by the other waves until the barrier — and after it three waves split the constants of the next
   // iteration: wave 0 -> linState_, R^T;  wave 1 -> phi, Rinvleft(-phi)^T;  wave 2 -> x_filter (-) x_lin.
   // (Until round 2 the first three waves each ran the whole solve redundantly to save the staging: 2 x ~2.5 k

@@ -11,9 +11,20 @@ pkg = importlib.import_module(PKG); host = importlib.import_module(PKG + ".host"
 from oracle import oracle
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 start = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
+# third argument: a prior that MATTERS.  The shipped filter starts from init_pos_std = init_att_std = 0, so P_SS is tiny
+# and the posterior state hardly depends on the 28 sums; "wide" adds a seeded, fully correlated SPD block (5 cm / 0.5 deg
+# / 0.1 m/s and matching bias scales) to every prior covariance, so that gain, solve and Joseph update carry weight.
+wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
 prm = pkg.default_params(num_iter=30)
 with ThreadPoolExecutor(32) as ex:
     pairs = list(ex.map(host.synth_pair, range(start, start + n)))
+if wide:
+    scale = np.array([0.05] * 3 + [0.1] * 3 + [0.009] * 3 + [0.02] * 3 + [0.002] * 3 + [0.01] * 3)
+    for k, p in enumerate(pairs):
+        m = np.random.default_rng(900000 + start + k).normal(size=(18, 18)) / np.sqrt(18.0)
+        p.cov = np.ascontiguousarray(p.cov + (scale[:, None] * (m @ m.T + 0.5 * np.eye(18)) * scale[None, :]))
+    print("# prior covariances widened (argument 'wide'): P += D (M M^T + I/2) D, D = diag(5 cm, 0.1 m/s, 0.5 deg, ...)")
+with ThreadPoolExecutor(32) as ex:
     t0 = time.time()
     want = list(ex.map(lambda p: oracle.ieskf(prm, p, oracle.FORM_REDUCED, oracle.NN_KDTREE), pairs))
 print(f"oracle: {n} scans in {time.time() - t0:.1f} s, iterations {sum(w.iters for w in want)}, diverged {sum(1 for w in want if w.diverged)}")
