@@ -12,9 +12,13 @@ python tools/pmc_traffic.py $tag > $out/${tag}_pmc_traffic.log 2>&1; tail -3 $ou
 cp $out/${tag}_pmc_traffic.json profiles/ 2>/dev/null   # (bench.py reads the record from profiles/, stamp-checked)
 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 tail -1 $out/${tag}_bench.json | cut -c1-300
-( cd /tmp && export TMPDIR=/tmp && rm -rf $out/${tag}_kt && rocprofv3 --kernel-trace --stats -d $out/${tag}_kt -- python $root/bench.py --no-cpu > $out/${tag}_kt.log 2>&1
-  python $root/tools/rocpd_summary.py $(find $out/${tag}_kt -name "*.db") > $out/${tag}_kernel_stats.csv; rm -rf $out/${tag}_kt )
-cat $out/${tag}_kernel_stats.csv
+# kernel trace of the bench command proper (warm-up + timed steps only: the batch kernel's average IS the step's kernel
+# time) and of the command with its extra blocks (30-iteration launches of the stop-rule block, the single-scan kernel)
+( cd /tmp && export TMPDIR=/tmp && rm -rf $out/${tag}_kt && rocprofv3 --kernel-trace --stats -d $out/${tag}_kt -- python $root/bench.py --no-cpu --no-extras > $out/${tag}_kt.log 2>&1
+  python $root/tools/rocpd_summary.py $(find $out/${tag}_kt -name "*.db") > $out/${tag}_kernel_stats.csv; rm -rf $out/${tag}_kt
+  rocprofv3 --kernel-trace --stats -d $out/${tag}_kt -- python $root/bench.py --no-cpu > $out/${tag}_kt_extras.log 2>&1
+  python $root/tools/rocpd_summary.py $(find $out/${tag}_kt -name "*.db") > $out/${tag}_kernel_stats_extras.csv; rm -rf $out/${tag}_kt )
+cat $out/${tag}_kernel_stats.csv $out/${tag}_kernel_stats_extras.csv
 {
   python tools/e2e_rate.py 2>&1 | tail -2
   python tools/streams_rate.py 1024 2>&1 | tail -2
