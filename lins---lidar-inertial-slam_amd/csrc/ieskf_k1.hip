@@ -37,6 +37,7 @@ struct OutRec {  // (layout of the persistent kernels' record, lins_capi.hip rea
 
 struct Lds {
   double P[324];
+  double trig[kSincCosTab];  // series coefficients of the de-skew (as in the grid kernel: the two must de-skew alike)
   IterConst ic;
   double filt[19];
   double sums[28];
@@ -392,6 +393,7 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
       __syncthreads();
     }
   }
+  if (tid == 64) lins_sinc_cos_table(L.trig);
   if (tid < 64) {  // wave 0, lane-redundant: constants of the first iteration
     IterConst ic;
     double filt[19];
@@ -441,7 +443,7 @@ __global__ __launch_bounds__(kBlock, 4) void ieskf_k1_kernel(
         if (prm.pad & 1024)
           o.sel[0] = q.x, o.sel[1] = q.y, o.sel[2] = q.z;  // (timing experiments: pad bits 1024..16384 drop one phase each)
         else
-          transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2]);
+          transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2], g.trig);
         if (PROF) pt[1] = clock64();
         const float sx = o.sel[0], sy = o.sel[1], sz = o.sel[2];
         SplitQ mq;

@@ -102,6 +102,10 @@ struct LdsStore {
     unsigned cell_word[(kCellsCorner + kCellsSurf) / 2];
   };
   double P[324];
+  // Series coefficients of the de-skew's axis2Quat (lins_math.h axis2quat_tab), read from here where they are used: as
+  // literals the compiler keeps all eighteen in registers across the search loop (6 -> 42 spilled registers, +7 %);
+  // from LDS the short series replaces libm's sin / cos + sqrt + three divisions per query and iteration: -2.2 %.
+  double trig[kSincCosTab];
   IterConst ic;
   double filt[19];
   double sums[28];
@@ -240,6 +244,16 @@ __device__ __forceinline__ void merge_query_lanes(Best& b, int lane_base, int ro
   }
 }
 
+// Square roots that only feed pruning windows and certificates — every one of them under a relative slack of 1e-6 or
+// more — may come straight from v_sqrt_f32 (1 ulp) instead of the correctly rounded sequence (~10 instructions).
+// (every use multiplies the result by (1 +- 1e-6) or more in the safe direction: cert_lb / certified, reach.)  With
+// bound_divf below: -2.4 % on the batch kernel.  The same treatment of the queries' rho / |q| / elevation (a
+// 16-instruction atan for |z| <= rho) measured +-0: not kept.
+__device__ __forceinline__ float bound_sqrtf(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+// ... and a quotient that only has to be an UPPER bound: the hardware reciprocal (1 ulp) times a factor that covers it.
+__device__ __forceinline__ float bound_divf(float x, float y) { return x * __frcp_rn(y) * (1.f + 3e-7f); }
+
 // ---- certificates: skipping a search that provably returns the same answer -----------------
 // After a search run with its pruning bound inflated by `margin` metres, every candidate other
 // than the winner is at least  lb = min(sqrt(omin), sqrt(d_best) + margin)  away from the query
@@ -250,10 +264,10 @@ __device__ __forceinline__ void merge_query_lanes(Best& b, int lane_base, int ro
 // skipped.  With no winner (nothing inside the search radius) the same test against the radius
 // certifies that there is still none.
 __device__ __forceinline__ float cert_lb(const Best& b, float thr, float margin) {
-  return fminf(sqrtf(b.omin), sqrtf(b.pos >= 0 ? b.d() : thr) + margin);
+  return fminf(bound_sqrtf(b.omin), bound_sqrtf(b.pos >= 0 ? b.d() : thr) + margin);
 }
 __device__ __forceinline__ bool certified(float d_now, float lb, float drift) {
-  return sqrtf(d_now) * (1.f + 4e-6f) + 2e-6f < (lb - drift * (1.f + 4e-6f)) * (1.f - 4e-6f);
+  return bound_sqrtf(d_now) * (1.f + 4e-6f) + 2e-6f < (lb - drift * (1.f + 4e-6f)) * (1.f - 4e-6f);
 }
 
 // ---- azimuth column of a point on the LDS grid ---------------------------------------------
@@ -277,7 +291,7 @@ __device__ __forceinline__ int az_bin_lds(float x, float y, int naz) {
 // a query's ring windows over three lanes is real parallelism, not serialised branches.
 template <class F>
 __device__ __forceinline__ void scan_cols(const LdsStore& L, const LCloud& c, int r, int lo, int hi, F f) {
-  int s0 = 0, e0 = 0, s1 = 0, e1 = 0;
+  int s0 = 0, e0 = 0, s1 = 0, e1 = 0, spans = 1;  // (a window that wraps past the last column has a second span)
   if (lo <= hi) {
     const int naz = c.naz, row = r * naz;
     int len = hi - lo;
@@ -288,12 +302,13 @@ __device__ __forceinline__ void scan_cols(const LdsStore& L, const LCloud& c, in
     s0 = c0 ? (int)c.cell_end[c0 - 1] : c.base;
     e0 = (int)c.cell_end[c1];
     if (hi >= naz) {  // wrapped tail: columns 0 .. hi-naz
+      spans = 2;
       s1 = row ? (int)c.cell_end[row - 1] : c.base;
       e1 = (int)c.cell_end[row + hi - naz];
     }
   }
 #pragma unroll 1
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < spans; ++k) {
     const int s = k ? s1 : s0, e = k ? e1 : e0;
     const int el = kHybrid ? (e < c.n_lds ? e : c.n_lds) : e;
     // kScanBatch points per trip, all their LDS reads issued before the first is consumed (the
@@ -337,7 +352,7 @@ __device__ __forceinline__ float asin_ub(float s) { return s + 0.5707964f * s * 
 
 __device__ __forceinline__ int reach(const LCloud& c, float rho, float sqrt_bound) {
   const int half = c.naz / 2;
-  float s = (sqrt_bound * (1.f + 1e-6f) + kSlack * rho + 1e-6f) / rho;  // rho == 0 -> inf/nan -> all columns
+  float s = bound_divf(sqrt_bound * (1.f + 1e-6f) + kSlack * rho + 1e-6f, rho);  // rho == 0 -> inf/nan -> all columns
   if (!(s < 1.f)) return half;
   int k = (int)(asin_ub(s) * (1.f + 1e-6f) * ((float)c.naz * (0.5f / kPiF))) + 2;
   return k < half ? k : half;
@@ -351,7 +366,7 @@ __device__ __forceinline__ bool ring_nonempty(const LCloud& c, int r) {
 // is within delta = asin(sqrt(bound)/|q|) of the ring's elevation wedge (a point at
 // elevation difference g < 90 deg is at least |q| sin g away, |q| beyond that)
 __device__ __forceinline__ float reach_elev(float qn3, float sqrt_bound) {
-  float s = (sqrt_bound * (1.f + 1e-6f) + kSlack * qn3 + 1e-6f) / qn3;
+  float s = bound_divf(sqrt_bound * (1.f + 1e-6f) + kSlack * qn3 + 1e-6f, qn3);
   return s < 1.f ? asin_ub(s) * (1.f + 1e-6f) + kSlack : 4.f;  // 4 rad > any elevation difference
 }
 __device__ __forceinline__ bool ring_in_reach(const LCloud& c, int r, float el_q, float delta) {
@@ -403,7 +418,7 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
   }
   const int cin = warm ? 0 : 2;  // first column either side that the seed has not covered
   const float B = b.d();  // fixed bound for everything below (conservative: >= the final best)
-  const float sqrtB = sqrtf(B) + margin;  // pruning bound inflated by the certificate margin
+  const float sqrtB = bound_sqrtf(B) + margin;  // pruning bound inflated by the certificate margin
   const int K = reach(c, rho, sqrtB);
   const float delta = reach_elev(qn3, sqrtB);
   // This lane's tasks as a bit mask (bit i <-> task t = role + LANES i): task 0 = own ring right
@@ -411,26 +426,36 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
   // tests are independent LDS reads, issued together; only surviving tasks enter the scan loop.
   constexpr int kTasks = 2 + 2 * (kRingsBinned - 1), kPerLane = LANES ? (kTasks + LANES - 1) / LANES : kTasks;
   unsigned todo = 0;
+  // One lane per query (the cold iteration): the thirty "other ring" tasks are simply the sixteen rings — bit 2 + r
+  // stands for ring r, tested with a compile-time index (half the tests, no task -> ring arithmetic).  The order the
+  // tasks are visited in does not matter: the bound is fixed, winner / runner-up / omin are order-free.
+  const bool by_ring = LANES == 0 && LN == 1;  // (wave-uniform)
+  if (by_ring) {
+    todo = (own && K >= cin) ? 3u : 0u;
 #pragma unroll
-  for (int i = 0; i < kPerLane; ++i) {
-    const int t = role + LN * i;
-    if (LANES == 0 && t >= kTasks) break;
-    const int k = t - 2, off = (k >> 1) + 1;
-    const int r = t < 2 ? rq : rq + ((k & 1) ? -off : off);
-    bool go;
-    if (t < 2)
-      go = own && K >= cin;
-    else
-      go = t < kTasks && r >= 0 && r < kRingsBinned && ring_in_reach(c, r < 0 ? 0 : (r >= kRingsBinned ? kRingsBinned - 1 : r), el_q, delta);
-    todo |= go ? (1u << i) : 0u;
+    for (int r = 0; r < kRingsBinned; ++r) todo |= (r != rq && ring_in_reach(c, r, el_q, delta)) ? (4u << r) : 0u;
+  } else {
+#pragma unroll
+    for (int i = 0; i < kPerLane; ++i) {
+      const int t = role + LN * i;
+      if (LANES == 0 && t >= kTasks) break;
+      const int k = t - 2, off = (k >> 1) + 1;
+      const int r = t < 2 ? rq : rq + ((k & 1) ? -off : off);
+      bool go;
+      if (t < 2)
+        go = own && K >= cin;
+      else
+        go = t < kTasks && r >= 0 && r < kRingsBinned && ring_in_reach(c, r < 0 ? 0 : (r >= kRingsBinned ? kRingsBinned - 1 : r), el_q, delta);
+      todo |= go ? (1u << i) : 0u;
+    }
   }
 #pragma unroll 1
   while (todo) {
     const int i = __ffs(todo) - 1;
     todo &= todo - 1;
-    const int t = role + LN * i;
+    const int t = by_ring ? (i < 2 ? i : 2) : role + LN * i;
     const int k = t - 2, off = (k >> 1) + 1;
-    const int r = t < 2 ? rq : rq + ((k & 1) ? -off : off);
+    const int r = by_ring ? (i < 2 ? rq : i - 2) : (t < 2 ? rq : rq + ((k & 1) ? -off : off));
     rcur = r;
     // own ring: right part (with the centre column when warm) / left part; other rings: whole window
     scan_cols(L, c, r, t == 0 ? a0 + cin : a0 - K, t == 1 ? a0 - (warm ? 1 : 2) : a0 + K, f);
@@ -499,7 +524,7 @@ __device__ __forceinline__ void walk_task(const LdsStore& L, const LCloud& c, co
                                           bool centre_done, int a0, float sx, float sy, float sz, float rho_q,
                                           float qn3, float el_q, float margin, Best& cur) {
   bool go = walk_ring_has_candidates(c, w, r);
-  if (go) go = ring_in_reach(c, r, el_q, reach_elev(qn3, sqrtf(cur.d()) + margin));
+  if (go) go = ring_in_reach(c, r, el_q, reach_elev(qn3, bound_sqrtf(cur.d()) + margin));
   auto f = [&](float x, float y, float z, int j, int p, bool ok) {
     int rank;
     const bool in_walk = walk_rank(w, j, rank);
@@ -515,7 +540,7 @@ __device__ __forceinline__ void walk_task(const LdsStore& L, const LCloud& c, co
   const int half = c.naz / 2;
 #pragma unroll 1
   for (int round = 0; round < 8 && go; ++round) {
-    const int K = reach(c, rho_q, sqrtf(cur.d()) + margin);
+    const int K = reach(c, rho_q, bound_sqrtf(cur.d()) + margin);
     if (K <= kk) break;
     const int nk = kk < 1 ? K : (K < 4 * kk ? K : 4 * kk);  // (a bound from a warm candidate: one shot)
     scan_cols(L, c, r, a0 + kk + 1, a0 + nk, f);
@@ -1110,6 +1135,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     L.ic.lin[tid] = PASS_ONLY ? lin_in[(size_t)scan * 19 + tid] : v;
   }
   if (tid < 28) L.sums[tid] = 0;
+  if (tid == 64) lins_sinc_cos_table(L.trig);
   if (tid == 0) {
     L.res_prev = 1e6, L.res_last = 0, L.upd_norm = 0;
     L.iter = PASS_ONLY ? iter_arg : 0, L.conv = 0, L.div = 0, L.m_surf = 0, L.m_corner = 0;
@@ -1248,7 +1274,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           if (prm.pad & 0x100000)  // (counting aid: no de-skew)
             o.sel[0] = q.x, o.sel[1] = q.y, o.sel[2] = q.z;
           else
-            transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2]);
+            transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2], g_lds.trig);
         }
         if (prof) {
           s1 = clock64();
@@ -1259,7 +1285,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         auto dist_to = [&](int pos) { return pt_sqdist(L, c, pos, o.sel[0], o.sel[1], o.sel[2]); };
         auto drift_from = [&](const float* cp) {
           float ex = o.sel[0] - cp[0], ey = o.sel[1] - cp[1], ez = o.sel[2] - cp[2];
-          return sqrtf(ex * ex + ey * ey + ez * ez);
+          return bound_sqrtf(ex * ex + ey * ey + ez * ez);
         };
         if (do_search) {
           if (!single_round) a1 = b1c = a2 = b2c = a3 = b3c = sel1 = -1;
@@ -1495,7 +1521,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         V3 t{L.ic.lin[0], L.ic.lin[1], L.ic.lin[2]};
         QueryOut o;
         long long s0 = prof ? clock64() : 0, s1 = s0, s2 = s0;
-        transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2]);
+        transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2], g_lds.trig);
         if (prof) {
           s1 = clock64();
 #ifndef LINS_PROF_WAVES
@@ -1519,7 +1545,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           auto dist_to = [&](int pos) { return pt_sqdist(L, c, pos, o.sel[0], o.sel[1], o.sel[2]); };
           auto drift_from = [&](const float* cp) {
             float ex = o.sel[0] - cp[0], ey = o.sel[1] - cp[1], ez = o.sel[2] - cp[2];
-            return sqrtf(ex * ex + ey * ey + ez * ez);
+            return bound_sqrtf(ex * ex + ey * ey + ez * ez);
           };
           // Per selection the last search left two tracked candidates — the winner A and the
           // runner-up B (grid positions, -1 = absent) — and a lower bound lb for the distance of every
@@ -1791,7 +1817,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           const float4 q = arena[(is_surf ? sd.off_surf_q : sd.off_corner_q) + qi];
           const V3 phi = L.ic.phi, t{L.ic.lin[0], L.ic.lin[1], L.ic.lin[2]};
           float ax, ay, az;
-          transform_to_start(prm, phi, t, q, ax, ay, az);
+          transform_to_start(prm, phi, t, q, ax, ay, az, g_lds.trig);
           // (a tracked candidate beyond the search radius is no winner)
           const float thr = prm.nearest_f;
           const int w1 = (a1 >= 0 && pt_sqdist(L, c, a1, ax, ay, az) < thr) ? a1 : -1;

@@ -129,9 +129,9 @@ LINS_HD float lins_atan2_coarse(float y, float x) {
   const float ax = x < 0.f ? -x : x, ay = y < 0.f ? -y : y;
   const float mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
 #if defined(__HIP_DEVICE_COMPILE__)
-  const float a = mn * __frcp_rn(mx);  // (0 * inf = NaN at the origin: the caller's integer conversion maps it to column 0)
+  const float a = mx > 0.f ? mn * __frcp_rn(mx) : 0.f;  // (the origin: angle 0)
 #else
-  const float a = mn / mx;
+  const float a = mx > 0.f ? mn / mx : 0.f;
 #endif
   float r = a * (0.78539816f + 0.273f * (1.f - a));
   if (ay > ax) r = 1.57079633f - r;
@@ -236,6 +236,30 @@ LINS_HD Q4 axis2quat_fast(V3 v) {
   const double k = 0.5 * sinc;
   return {c, v.x * k, v.y * k, v.z * k};
 }
+// The coefficients of lins_sinc_cos_small as a table (highest power first: 9 of sin(h)/h — the final 1 is implied —
+// then 9 of (1 - cos h)/h^2), for callers that want them read from memory where they are used instead of living in
+// registers: axis2quat_tab below is axis2quat_fast with the table (same operations, same bits).
+constexpr int kSincCosTab = 18;
+LINS_HD void lins_sinc_cos_table(double* t) {
+  t[0] = -1.0 / 121645100408832000.0, t[1] = 1.0 / 355687428096000.0, t[2] = -1.0 / 1307674368000.0;
+  t[3] = 1.0 / 6227020800.0, t[4] = -1.0 / 39916800.0, t[5] = 1.0 / 362880.0, t[6] = -1.0 / 5040.0;
+  t[7] = 1.0 / 120.0, t[8] = -1.0 / 6.0;
+  t[9] = 1.0 / 6402373705728000.0, t[10] = -1.0 / 20922789888000.0, t[11] = 1.0 / 87178291200.0;
+  t[12] = -1.0 / 479001600.0, t[13] = 1.0 / 3628800.0, t[14] = -1.0 / 40320.0, t[15] = 1.0 / 720.0;
+  t[16] = -1.0 / 24.0, t[17] = 0.5;
+}
+LINS_HD Q4 axis2quat_tab(V3 v, const double* t) {
+  const double n2 = dot(v, v);
+  if (n2 < 1e-20) return {1, 0, 0, 0};  // theta < 1e-10 (MU:63)
+  const double z = 0.25 * n2;
+  if (!(z <= kFastHalfAngleSq)) return axis2quat(v);
+  double s = t[0], k = t[9];
+  for (int i = 1; i < 9; ++i) s = lins_fma(s, z, t[i]), k = lins_fma(k, z, t[9 + i]);
+  const double sinc = lins_fma(s, z, 1.0), c = lins_fma(-k, z, 1.0);
+  const double h = 0.5 * sinc;
+  return {c, v.x * h, v.y * h, v.z * h};
+}
+
 LINS_HD V3 quat2axis_fast(Q4 q) {
   const double m2 = q.x * q.x + q.y * q.y + q.z * q.z;
   if (m2 < 1e-20) return {q.x, q.y, q.z};  // mag < 1e-10: the vector part as it is (MU:78-86)
