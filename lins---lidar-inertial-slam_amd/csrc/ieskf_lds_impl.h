@@ -465,7 +465,10 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
 }
 
 // ---- wave-cooperative searches: which lanes need one, and who serves whom ------------------------
-constexpr int kCoopMaxLanes = 8;  // (measured on the batch workload: 2 -> 8.4, 4 -> 8.9, 8 -> 8.9, 16 -> 8.85 M it/s)
+#ifndef LINS_COOP_LANES
+#define LINS_COOP_LANES 8  // (re-timed at the end of round 2: 4, 8, 16 within 0.2 %)
+#endif
+constexpr int kCoopMaxLanes = LINS_COOP_LANES;  // (measured on the batch workload: 2 -> 8.4, 4 -> 8.9, 8 -> 8.9, 16 -> 8.85 M it/s)
 struct CoopMap {
   int n;          // searches needed in this wave
   int rank;       // this lane's position in the permutation (needing lanes first, in lane order)

@@ -23,7 +23,8 @@
 #define LINS_LDS_CAP 4208  // (4224 until 16 positions made room for the de-skew's coefficient table)
 #define LINS_LDS_NMAX 12288
 #ifndef LINS_LDS_SCANBATCH
-#define LINS_LDS_SCANBATCH 2  // (measured: 1 -> 7.9, 2 -> 8.1, 3 -> 8.0, 4 -> 7.75, 8 -> 7.1 M it/s at 128 VGPRs)
+#define LINS_LDS_SCANBATCH 2  // (measured: 1 -> 7.9, 2 -> 8.1, 3 -> 8.0, 4 -> 7.75, 8 -> 7.1 M it/s at 128 VGPRs;
+                              // re-timed at the end of round 2: 3 -> -0.5 % (noise, 18 spilled registers), 4 -> +2 %)
 #endif
 #define LINS_LDS_REGREDUCE 1
 #define LINS_LDS_WAVES 8
