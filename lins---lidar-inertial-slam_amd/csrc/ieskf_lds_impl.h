@@ -16,10 +16,19 @@
 //                             (coop_map / coop_lanes below).
 //
 // One workgroup owns one scan pair for the whole iterated update.  Both target clouds of
-// the scan are counting-sorted ONCE into (ring x azimuth-column) grids kept as SoA
-// (x[], y[], z[] f32 + u16 original index): after that single coalesced pass over the
-// scan's ~125 KB in HBM, every iteration's correspondence search is LDS traffic (mr: plus
-// rare L2 reads) — the candidate windows are staged in LDS, not re-gathered from L2.
+// the scan are counting-sorted ONCE into (ring x azimuth-column) grids of 16-byte records
+// (x, y, z, original index bits — one ds_read_b128 per candidate; the SoA layout of round 1
+// stays behind LINS_LDS_AOS): after that single coalesced pass over the scan's ~125 KB in
+// HBM, every iteration's correspondence search is LDS traffic (mr: plus rare L2 reads) —
+// the candidate windows are staged in LDS, not re-gathered from L2.
+//
+// The kernel is bound by instruction issue and latency (~60 % VALU-busy
+// with 31 of 64 lanes at work), not by HBM, so what round 2 did to it is mostly about the
+// instructions a wave executes: arithmetic that only feeds pruning bounds or certificates
+// takes the hardware's 1-ulp sqrt / rcp (bound_sqrtf, bound_divf), azimuth columns a
+// 12-instruction atan2 (az_bin_lds), the rotation maps their short series (lins_math.h), the
+// 6x6 solve a Gauss-Jordan over one wave (ieskf_rowsum.h) — each with the argument why the
+// results cannot change, or the tolerance under which they may, next to the code.
 //
 // Parameters supplied by the including translation unit:
 //   LINS_LDS_NS         namespace of this instantiation
@@ -35,8 +44,9 @@
 //     3 lanes / query   de-skew (f64, redundantly per lane) -> exact NN + index walk on
 //                       the LDS grid, the ring windows of one query split over its
 //                       three lanes and merged with wave shuffles on (distance, key)
-//     1 lane / query    plane / line residual + Jacobian (f64 -> f32) -> H row in LDS
-//     224 lanes         28 f64 sums, fixed-shape tree (8 strided groups -> ordered fold)
+//     1 lane / query    plane / line residual + Jacobian (f64 -> f32) -> H row in registers
+//     every wave        28 f64 sums by a fixed-shape register butterfly (ieskf_rowsum.h
+//                       wave_reduce_rows), then an ordered fold over the wave partials
 //     42 lanes of wave 0  6x6 Gauss-Jordan, one element per lane (ieskf_rowsum.h wave_gj_solve6), dx
 //     wave 0            NaN / divergence / convergence, boxPlus, next constants
 //   16 waves x 21 queries = 336 queries per round = the VLP-16 caps (144 flat + 192 sharp).
