@@ -64,6 +64,18 @@ int main(int argc, char** argv) {
       ++n_general;
     }
   }
+  // 2b. the de-skew's table form (coefficients read from memory: LDS on the device) is the literal form, bit for bit
+  int tab_diff = 0;
+  {
+    double tab[kSincCosTab];
+    lins_sinc_cos_table(tab);
+    for (int k = 0; k < 200000; ++k) {
+      const double sc = k % 3 == 0 ? 2.5 : (k % 3 == 1 ? 0.05 : 1e-9);
+      const V3 v{sc * (rnd() - 0.5), sc * (rnd() - 0.5), sc * (rnd() - 0.5)};
+      const Q4 a = axis2quat_fast(v), b = axis2quat_tab(v, tab);
+      if (!(a.w == b.w && a.x == b.x && a.y == b.y && a.z == b.z)) ++tab_diff;
+    }
+  }
   // 3. Gauss-Jordan: residual of random systems (diagonally dominant, pivoting forced, mixed scales)
   double e_res = 0;
   for (int k = 0; k < 20000; ++k) {
@@ -85,8 +97,8 @@ int main(int argc, char** argv) {
     }
   }
   // 4. a dump of systems + solutions for numpy (stdout line 2..): 50 systems
-  printf("sinc_ulp %.3f cos_ulp %.3f atanc_ulp %.3f atanq_ulp %.3f a2q_ulp %.3f q2a_ulp %.3f phi_ulp %.3f gt_ulp %.3f n_small %d n_general %d gj_res %.3e\n",
-         e_sinc, e_cos, e_atanc, e_q, e_a2q, e_q2a, e_phi, e_gt, n_small, n_general, e_res);
+  printf("sinc_ulp %.3f cos_ulp %.3f atanc_ulp %.3f atanq_ulp %.3f a2q_ulp %.3f q2a_ulp %.3f phi_ulp %.3f gt_ulp %.3f n_small %d n_general %d tab_diff %d gj_res %.3e\n",
+         e_sinc, e_cos, e_atanc, e_q, e_a2q, e_q2a, e_phi, e_gt, n_small, n_general, tab_diff, e_res);
   for (int k = 0; k < 50; ++k) {
     double a[6][7], x[6];
     for (int i = 0; i < 6; ++i)

@@ -36,6 +36,8 @@ def test_fast_maps_agree_with_the_libm_routes(report):
     # componentwise distance to the libm route in ulps of the largest component (each route is itself ~2 ulp from
     # the true value: an atan2 or sin / cos, a square root, divisions)
     assert v["a2q_ulp"] <= 2.0 and v["q2a_ulp"] <= 4.0 and v["phi_ulp"] <= 4.0 and v["gt_ulp"] <= 4.0
+    # the de-skew's form with its coefficients in a table (axis2quat_tab: LDS on the device) returns axis2quat_fast's bits
+    assert v["tab_diff"] == 0
 
 
 def test_gauss_jordan_against_numpy(report):
