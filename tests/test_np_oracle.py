@@ -86,3 +86,30 @@ def test_diverging_pair_on_both_cpu_restatements(pkg, oracle):
     a = oracle.ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_BRUTE)
     b = np_oracle.perform_ieskf(prm, pair)
     assert (a.iters, a.converged, a.diverged, a.m_surf) == (b["iters"], b["converged"], b["diverged"], b["m_surf"]) == (2, 0, 1, 20)
+
+
+@pytest.mark.parametrize("seed", [3, 11])
+def test_both_restatements_with_a_prior_that_matters(pkg, host, oracle, seed):
+    """The shipped filter starts from init_pos_std = init_att_std = 0: P_SS is tiny and the posterior hardly depends on
+    the 28 sums, so agreement on the goldens says little about the gain / solve / Joseph algebra.  Here every prior gets
+    a seeded, fully correlated 18 x 18 block (5 cm / 0.5 deg / 0.1 m/s, as `tools/parity_sweep.py ... wide` on the GPU):
+    the posterior moves by centimetres, and the two independently written restatements must still agree — with each
+    other, and the C++ oracle's dense M x M form with its reduced 6 x 6 form."""
+    from oracle import np_oracle
+
+    pair = host.synth_pair(700 + seed)
+    scale = np.array([0.05] * 3 + [0.1] * 3 + [0.009] * 3 + [0.02] * 3 + [0.002] * 3 + [0.01] * 3)
+    m = np.random.default_rng(seed).normal(size=(18, 18)) / np.sqrt(18.0)
+    pair.cov = np.ascontiguousarray(pair.cov + scale[:, None] * (m @ m.T + 0.5 * np.eye(18)) * scale[None, :])
+    prm = pkg.default_params(num_iter=30)
+    dense = oracle.ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_BRUTE)
+    red = oracle.ieskf(prm, pair, oracle.FORM_REDUCED, oracle.NN_KDTREE)
+    got = np_oracle.perform_ieskf(prm, pair)
+    for r in (red,):
+        assert (r.iters, r.converged, r.diverged, r.m_surf, r.m_corner) == (dense.iters, dense.converged, dense.diverged, dense.m_surf, dense.m_corner)
+        assert np.abs(r.state - dense.state).max() <= 1e-10 and np.abs(r.cov - dense.cov).max() <= 1e-12 * np.abs(dense.cov).max()
+    assert (got["iters"], got["converged"], got["diverged"], got["m_surf"], got["m_corner"]) == \
+        (dense.iters, dense.converged, dense.diverged, dense.m_surf, dense.m_corner)
+    assert np.abs(got["state"] - dense.state).max() <= 1e-9
+    assert np.abs(got["cov"] - dense.cov).max() <= 1e-9 * np.abs(dense.cov).max()
+    assert np.abs(dense.state[:3] - pair.state[:3]).max() > 1e-3  # the prior does matter: the position moved by millimetres at least
