@@ -1,0 +1,256 @@
+"""ctypes binding of oracle/_ref/liblins_ref.so — the REFERENCE'S OWN SOURCES (StateEstimator.hpp, KalmanFilter.hpp,
+math_utils.h ...), compiled verbatim from /root/reference against the stand-in headers of oracle/ref_shim/
+(oracle/Makefile, target _ref; driver: oracle/ref_driver.cpp).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by the
+product package.  /root/reference does not exist on the GPU box: the library is built where it does (this
+container) and travels with the repository snapshot; available() says whether it is there.
+"""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_ref", "liblins_ref.so")
+REFERENCE_INCLUDE = "/root/reference/lins/include"
+_defs = importlib.import_module("lins---lidar-inertial-slam_amd._ctypes_defs")
+Params, ScanPairC, ResultC, Result, Point = _defs.Params, _defs.ScanPairC, _defs.ResultC, _defs.Result, _defs.Point
+CORR_DTYPE = _defs.CORR_DTYPE
+
+E_OOB = -2  # the reference itself would read out of bounds on this input (empty target cloud / more queries than targets)
+
+_LIB = None
+
+
+def can_build():
+    return os.path.isdir(REFERENCE_INCLUDE)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "_ref"])
+
+
+def available():
+    """True when the library exists (built here, or shipped with the snapshot) or can be built now."""
+    return os.path.exists(_SO) or can_build()
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if can_build():
+            build()  # make decides whether anything is stale
+        if not os.path.exists(_SO):
+            raise RuntimeError("oracle/_ref/liblins_ref.so is missing and /root/reference is not here to build it")
+        L = C.CDLL(_SO)
+        dp = C.POINTER(C.c_double)
+        L.ref_describe.restype = C.c_char_p
+        L.ref_perform_ieskf.argtypes = [C.POINTER(Params), C.POINTER(ScanPairC), C.POINTER(ResultC), dp]
+        L.ref_perform_ieskf_batch.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(ScanPairC), C.POINTER(ResultC),
+                                              C.POINTER(C.c_int32), C.c_int]
+        L.ref_perform_ieskf_batch.restype = C.c_int
+        L.ref_correspondences.argtypes = [C.POINTER(Params), C.POINTER(ScanPairC), dp, C.c_int, C.c_void_p, C.c_void_p]
+        L.ref_icp.argtypes = [C.POINTER(Params), C.POINTER(ScanPairC), dp, dp, C.POINTER(C.c_int32)]
+        L.ref_transform.argtypes = [C.POINTER(Params), dp, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ref_bench.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(ScanPairC), C.c_int, dp, C.POINTER(C.c_uint64)]
+        L.ref_extract_features.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_filter_run.argtypes = [C.c_void_p, dp, dp, dp, C.c_int, dp, C.c_int, dp, dp]
+        for f in (L.ref_perform_ieskf, L.ref_correspondences, L.ref_icp, L.ref_transform, L.ref_bench,
+                  L.ref_extract_features, L.ref_filter_run):
+            f.restype = C.c_int
+        for name, n_in in (("ref_quat2axis", 1), ("ref_axis2quat", 1), ("ref_rinvleft", 1), ("ref_rpy2quat", 1),
+                           ("ref_box_plus", 2), ("ref_box_minus", 2)):
+            getattr(L, name).argtypes = [dp] * (n_in + 1)
+            getattr(L, name).restype = None
+        _LIB = L
+    return _LIB
+
+
+def _d(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _vecfn(name, nout, *xs):
+    xs = [np.ascontiguousarray(x, dtype=np.float64) for x in xs]
+    o = np.zeros(nout)
+    getattr(lib(), name)(*[_d(x) for x in xs], _d(o))
+    return o
+
+
+def quat2axis(q):
+    return _vecfn("ref_quat2axis", 3, q)
+
+
+def axis2quat(a):
+    return _vecfn("ref_axis2quat", 4, a)
+
+
+def rinvleft(a):
+    return _vecfn("ref_rinvleft", 9, a).reshape(3, 3)
+
+
+def rpy2quat(rpy):
+    return _vecfn("ref_rpy2quat", 4, rpy)
+
+
+def box_plus(s, dx):
+    return _vecfn("ref_box_plus", 19, s, dx)
+
+
+def box_minus(a, b):
+    return _vecfn("ref_box_minus", 18, a, b)
+
+
+def _copy_params(prm, **kw):
+    p = Params()
+    C.memmove(C.byref(p), C.byref(prm), C.sizeof(Params))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _perform_once(prm, c):
+    r = ResultC()
+    dx = np.zeros(18)
+    rc = lib().ref_perform_ieskf(C.byref(prm), C.byref(c), C.byref(r), _d(dx))
+    return rc, r, dx
+
+
+def perform_ieskf(prm, pair, with_dx=False):
+    """StateEstimator::performIESKF() (SE:465-600), divergence branch included, reference stop rule (the reference has
+    no fixed-iteration mode: prm.fixed_iters must be 0).  Returns None when the reference would read out of bounds."""
+    assert prm.fixed_iters == 0, "the reference stops on ||dx|| <= 1e-2 (SE:575-578); it has no fixed-iteration mode"
+    c = pair.as_c()
+    rc, r, dx = _perform_once(prm, c)
+    if rc == E_OOB:
+        return None
+    assert rc == 0, rc
+    if r.iters < 0:  # not derivable from the query count: replay with NUM_ITER = 1, 2, ... until nothing changes
+        full = (bytes(r.state), bytes(r.cov), r.diverged)
+        for k in range(1, prm.num_iter + 1):
+            _, rk, _ = _perform_once(_copy_params(prm, num_iter=k), c)
+            if (bytes(rk.state), bytes(rk.cov), rk.diverged) == full:
+                r.iters = k
+                break
+    res = Result(r)
+    return (res, dx) if with_dx else res
+
+
+def perform_ieskf_batch(prm, pairs, threads=None):
+    """perform_ieskf over independent pairs on `threads` host threads (ICP_FREQ must be 1 and every pair must have
+    features, so that the iteration count follows from the query count).  None entries: the reference would read out of
+    bounds on that pair."""
+    assert prm.fixed_iters == 0 and prm.icp_freq == 1
+    arr = _defs.pairs_to_c(pairs)
+    res = (ResultC * len(pairs))()
+    rc = (C.c_int32 * len(pairs))()
+    r = lib().ref_perform_ieskf_batch(C.byref(prm), len(pairs), arr, res, rc, threads or os.cpu_count() or 1)
+    assert r == 0, r
+    out = []
+    for i in range(len(pairs)):
+        assert rc[i] in (0, E_OOB), rc[i]
+        assert rc[i] != 0 or res[i].iters >= 0
+        out.append(Result(res[i]) if rc[i] == 0 else None)
+    return out
+
+
+def replay(prm, pair, max_iters=None):
+    """The linearisation trajectory of performIESKF, recovered without touching the reference's text: running it with
+    NUM_ITER = k returns linState_ after k iterations (and the Joseph covariance built from iteration k-1).
+    -> list of (Result, dx of the last executed iteration) for k = 1 .. until converged / diverged / max_iters."""
+    c = pair.as_c()
+    out = []
+    for k in range(1, (max_iters or prm.num_iter) + 1):
+        rc, r, dx = _perform_once(_copy_params(prm, num_iter=k, fixed_iters=0), c)
+        assert rc == 0, rc
+        if r.iters < 0:
+            r.iters = k
+        out.append((Result(r), dx))
+        if r.converged or r.diverged or r.iters < k:
+            break
+    return out
+
+
+def correspondences(prm, pair, lin_state, it):
+    c = pair.as_c()
+    lin_state = np.ascontiguousarray(lin_state, dtype=np.float64)
+    surf = np.zeros(c.n_surf_flat, dtype=CORR_DTYPE)
+    corner = np.zeros(c.n_corner_sharp, dtype=CORR_DTYPE)
+    rc = lib().ref_correspondences(C.byref(prm), C.byref(c), _d(lin_state), it, surf.ctypes.data, corner.ctypes.data)
+    if rc == E_OOB:
+        return None
+    assert rc == 0, rc
+    return surf, corner
+
+
+def icp(prm, pair, t, q):
+    c = pair.as_c()
+    t = np.array(t, dtype=np.float64)
+    q = np.array(q, dtype=np.float64)
+    it = C.c_int32(0)
+    rc = lib().ref_icp(C.byref(prm), C.byref(c), _d(t), _d(q), C.byref(it))
+    if rc == E_OOB:
+        return None
+    assert rc == 0, rc
+    return t, q, it.value
+
+
+def transform(prm, lin_state, pts, to_end=False):
+    """transformToStart (SE:1066-1080) / transformToEnd (SE:1083-1101) with linState_ = lin_state (19 f64)."""
+    pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 4)
+    lin_state = np.ascontiguousarray(lin_state, dtype=np.float64)
+    out = np.empty_like(pts)
+    rc = lib().ref_transform(C.byref(prm), _d(lin_state), int(to_end), len(pts), pts.ctypes.data, out.ctypes.data)
+    assert rc == 0, rc
+    return out
+
+
+def bench(prm, pairs, threads=1):
+    arr = _defs.pairs_to_c(pairs)
+    sec = C.c_double(0)
+    its = C.c_uint64(0)
+    rc = lib().ref_bench(C.byref(prm), len(pairs), arr, threads, C.byref(sec), C.byref(its))
+    assert rc == 0, rc
+    return sec.value, its.value
+
+
+def extract_features(prm, seg):
+    """processPCL's feature stage (SE:289-292) on a segmented scan given as oracle.fe_segment()'s dict."""
+    host = importlib.import_module("lins---lidar-inertial-slam_amd.host")
+    n = int(seg["n"])
+    keep = [np.ascontiguousarray(seg["cloud"], np.float32), np.ascontiguousarray(seg["range"], np.float32),
+            np.ascontiguousarray(seg["col"], np.uint32), np.ascontiguousarray(seg["ground"], np.uint8)]
+    s = host.SegmentedScanC()
+    s.cloud = keep[0].ctypes.data_as(C.POINTER(Point))
+    s.range = keep[1].ctypes.data_as(C.POINTER(C.c_float))
+    s.col = keep[2].ctypes.data_as(C.POINTER(C.c_uint32))
+    s.ground = keep[3].ctypes.data_as(C.POINTER(C.c_uint8))
+    s.n = n
+    for k in range(16):
+        s.start_ring[k] = int(seg["start_ring"][k])
+        s.end_ring[k] = int(seg["end_ring"][k])
+    s.start_ori, s.end_ori, s.ori_diff = [float(v) for v in seg["orientation"]]
+    s.n_outlier = int(seg.get("n_outlier", 0))
+    bufs = [np.zeros((cap, 4), np.float32) for cap in (192, 1920, 1024, _defs.CLOUD_MAX)]
+    f = host.Features()
+    f.corner_sharp, f.corner_less_sharp, f.surf_flat, f.surf_less_flat = [b.ctypes.data_as(C.POINTER(Point)) for b in bufs]
+    und = np.zeros((max(n, 1), 4), np.float32)
+    rc = lib().ref_extract_features(C.byref(prm), C.byref(s), C.byref(f), und.ctypes.data)
+    assert rc == 0, rc
+    return dict(corner_sharp=bufs[0][:f.n_corner_sharp].copy(), corner_less_sharp=bufs[1][:f.n_corner_less_sharp].copy(),
+                surf_flat=bufs[2][:f.n_surf_flat].copy(), surf_less_flat=bufs[3][:f.n_surf_less_flat].copy(),
+                undistorted=und[:n])
+
+
+def filter_run(fprm, vn, ba, bw, imu, reset1=False):
+    """StatePredictor: initialization(0, 0, vn, ba, bw) -> predict() per row of imu (dt, acc, gyr) -> optional reset(1).
+    fprm: host.FilterParams.  Returns (state19, cov 18x18)."""
+    imu = np.ascontiguousarray(imu, dtype=np.float64).reshape(-1, 7)
+    v = [np.ascontiguousarray(x, dtype=np.float64) for x in (vn, ba, bw)]
+    st, cov = np.zeros(19), np.zeros(324)
+    rc = lib().ref_filter_run(C.byref(fprm), _d(v[0]), _d(v[1]), _d(v[2]), len(imu), _d(imu), int(reset1), _d(st), _d(cov))
+    assert rc == 0, rc
+    return st, cov.reshape(18, 18)

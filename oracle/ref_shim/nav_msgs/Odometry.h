@@ -1,0 +1,1 @@
+// <nav_msgs/Odometry.h> — STAND-IN (oracle/ref_shim/README.md): nothing of this header is used on the compiled path.

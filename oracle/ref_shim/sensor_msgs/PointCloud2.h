@@ -1,0 +1,1 @@
+// <sensor_msgs/PointCloud2.h> — STAND-IN (oracle/ref_shim/README.md): nothing of this header is used on the compiled path.

@@ -1,0 +1,1 @@
+// <tf/transform_broadcaster.h> — STAND-IN (oracle/ref_shim/README.md): nothing of this header is used on the compiled path.

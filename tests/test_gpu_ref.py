@@ -1,0 +1,109 @@
+"""The HIP path, through the C ABI, against the REFERENCE'S OWN SOURCES (oracle/_ref/liblins_ref.so =
+/root/reference/lins/include/StateEstimator.hpp compiled verbatim against stand-in third-party headers; it is
+built in the container that has /root/reference and travels to the GPU box with the snapshot), and the batch
+bench.py times — all 1024 scans of it — against the oracle's faithful dense form.
+
+Bars (BASELINE.json north_star / SURVEY.md §8d): index triplets and accepted sets bit-exact; f32 rows and
+de-skewed points bit-exact up to <= 1 ulp on <= 1e-3 of the values (ocml vs glibc sin / cos / atan2 in the last f64
+ulp before the cast); flags and iteration counts equal; |dp| <= 1e-6 m, |dq| <= 1e-7, max|dP| <= 1e-9 max|P|.
+"""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_corr_equal, assert_result_close
+from test_ref import widen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle import ref as r
+
+    if not r.available():
+        pytest.skip("oracle/_ref/liblins_ref.so did not travel and /root/reference is not here to build it")
+    r.lib()
+    return r
+
+
+def cores():
+    return min(64, os.cpu_count() or 1)
+
+
+@pytest.mark.parametrize("search", ["auto", "mr", "lds", "lds1", "binned", "brute"])
+def test_correspondences_bit_exact_along_the_references_trajectory(pkg, ieskf, host, ref, search):
+    """Device findCorresponding*Features at every linearisation state the REFERENCE visits (its own performIESKF,
+    replayed with NUM_ITER = 1, 2, ...), against the reference's own pointSearch*Ind / coefficient rows."""
+    prm = pkg.default_params(num_iter=30)
+    with ieskf.IeskfContext(prm, max_batch=1, max_targets=16384, search=search) as ctx:
+        for idx in (0, 3, 41):
+            pair = host.synth_pair(idx)
+            states = [pair.state] + [r.state for r, _ in ref.replay(prm, pair)]
+            for k, lin in enumerate(states[:-1]):
+                want_s, want_c = ref.correspondences(prm, pair, lin, k)
+                surf, corner = ctx.correspondences(pair, lin, k)
+                assert_corr_equal(surf, want_s, f"pair{idx}.iter{k}.surf")
+                assert_corr_equal(corner, want_c, f"pair{idx}.iter{k}.corner")
+
+
+@pytest.mark.parametrize("search", ["auto", "mr", "lds", "lds1", "binned", "brute"])
+@pytest.mark.parametrize("wide", [False, True], ids=["shipped-prior", "wide-prior"])
+def test_update_matches_the_references_perform_ieskf(pkg, ieskf, host, ref, search, wide):
+    """performIESKF (reference stop rule, NUM_ITER 30) on 96 seeded pairs, as one batch: HIP vs the reference's code."""
+    prm = pkg.default_params(num_iter=30)
+    start = 3000 if not wide else 8000
+    pairs = host.synth_batch(96, start=start)
+    if wide:
+        widen(pairs, start)
+    want = ref.perform_ieskf_batch(prm, pairs, threads=cores())
+    with ieskf.IeskfContext(prm, max_batch=len(pairs), max_targets=16384, search=search) as ctx:
+        got = ctx.update_batch(pairs)
+    for g, w in zip(got, want):
+        assert_result_close(g, w)
+
+
+def test_divergence_and_fallback_match_the_reference(pkg, ieskf, ref):
+    """SE:566-570 -> SE:585-592 through lins_host_perform_ieskf (device loop, device ICP) vs the reference."""
+    from diverging import make_diverging_pair
+
+    prm = pkg.default_params(num_iter=30)
+    pair = make_diverging_pair(pkg)
+    want = ref.perform_ieskf(prm, pair)
+    assert want.diverged == 1
+    with ieskf.IeskfContext(prm, max_batch=1, max_targets=16384) as ctx:
+        raw = ctx.update(pair)
+        assert (raw.diverged, raw.iters) == (want.diverged, want.iters)
+        got, used_fallback = ctx.perform_ieskf(pair)
+        assert used_fallback
+    assert np.abs(got.state[:3] - want.state[:3]).max() <= 1e-6 and np.abs(got.state[6:10] - want.state[6:10]).max() <= 1e-7
+    assert np.abs(got.cov - want.cov).max() <= 1e-9 * max(1.0, np.abs(want.cov).max())
+
+
+def test_bench_batch_all_1024_scans_against_the_dense_oracle_and_the_reference(pkg, ieskf, host, oracle, ref):
+    """BASELINE.json configs[3], exactly what bench.py times: host.synth_pair(0..1023), search "auto" (=> the
+    multi-resident kernel), 10 fixed iterations — every scan against the oracle's faithful dense M x M form with
+    kd-tree neighbours (SE:542-549); and the same batch under the reference's stop rule against the reference's
+    own code (which has no fixed-iteration mode)."""
+    n = 1024
+    with ThreadPoolExecutor(cores()) as ex:
+        pairs = list(ex.map(host.synth_pair, range(n)))
+    fixed = pkg.default_params(num_iter=10, fixed_iters=1)
+    with ieskf.IeskfContext(fixed, max_batch=n, max_targets=16384, search="auto") as ctx:
+        ctx.upload(pairs)  # the staged path bench.py uses
+        ctx.run()
+        ctx.sync()
+        got = ctx.download()
+    with ThreadPoolExecutor(cores()) as ex:
+        want = list(ex.map(lambda p: oracle.ieskf(fixed, p, oracle.FORM_DENSE, oracle.NN_KDTREE), pairs))
+    assert sum(w.iters for w in want) == 10 * n
+    for g, w in zip(got, want):
+        assert_result_close(g, w)
+    stop = pkg.default_params(num_iter=30)
+    want = ref.perform_ieskf_batch(stop, pairs, threads=cores())
+    with ieskf.IeskfContext(stop, max_batch=n, max_targets=16384, search="auto") as ctx:
+        got = ctx.update_batch(pairs)
+    for g, w in zip(got, want):
+        assert_result_close(g, w)

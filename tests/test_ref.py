@@ -1,0 +1,287 @@
+"""Pins the from-scratch oracle (oracle/lins_oracle.cpp, frontend_oracle.cpp) and the product's host pieces to the
+REFERENCE'S OWN SOURCES: oracle/_ref/liblins_ref.so is /root/reference/lins/include/StateEstimator.hpp (+ what it
+includes) compiled verbatim against stand-in third-party headers (oracle/ref_shim/, oracle/Makefile target _ref,
+driver oracle/ref_driver.cpp).  Everything asserted here is "the reference's statements computed X".
+
+Bars: index triplets, accepted sets, f32 rows and de-skewed points bit-exact; flags / iteration counts equal;
+state <= 1e-12, covariance <= 1e-12 relative (the dense M x M algebra runs through different loop orders on the
+two sides; everything else is the same IEEE operations and agrees to the last bit or two).
+"""
+import ctypes as C
+import glob
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from diverging import make_diverging_pair
+from test_frontend_oracle import turned
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+STATE_TOL, COV_REL = 1e-12, 1e-12
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle import ref as r
+
+    if not r.available():
+        pytest.skip("oracle/_ref/liblins_ref.so not built and /root/reference not present")
+    r.lib()
+    return r
+
+
+def flags(r):
+    return (r.iters, r.converged, r.diverged, r.m_surf, r.m_corner)
+
+
+def assert_same_result(got, want, what=""):
+    assert flags(got) == flags(want), (what, got, want)
+    assert np.abs(got.state - want.state).max() <= STATE_TOL, what
+    assert np.abs(got.cov - want.cov).max() <= COV_REL * np.abs(want.cov).max(), what
+    assert abs(got.residual_norm - want.residual_norm) <= 1e-12 * max(1.0, want.residual_norm), what
+    assert abs(got.update_norm - want.update_norm) <= 1e-12, what
+
+
+def assert_corr_bit_exact(got, want, what):
+    for f in ("ind1", "ind2", "ind3", "accepted"):
+        assert np.array_equal(got[f], want[f]), f"{what}.{f} differs at {np.nonzero(got[f] != want[f])[0][:8]}"
+    for f in ("coeff", "sel"):
+        assert np.array_equal(got[f].view(np.int32), want[f].view(np.int32)), f"{what}.{f} not bit-equal"
+
+
+def widen(pairs, start):
+    """The 'prior that matters' of tools/parity_sweep.py: a seeded, fully correlated SPD block added to every prior."""
+    scale = np.array([0.05] * 3 + [0.1] * 3 + [0.009] * 3 + [0.02] * 3 + [0.002] * 3 + [0.01] * 3)
+    for k, p in enumerate(pairs):
+        m = np.random.default_rng(900000 + start + k).normal(size=(18, 18)) / np.sqrt(18.0)
+        p.cov = np.ascontiguousarray(p.cov + (scale[:, None] * (m @ m.T + 0.5 * np.eye(18)) * scale[None, :]))
+    return pairs
+
+
+def test_the_library_is_the_references_text(ref):
+    assert b"StateEstimator.hpp" in ref.lib().ref_describe()
+    mk = open(os.path.join(HERE, "..", "oracle", "Makefile")).read()
+    assert "-I $(REF_INC)" in mk and "ref_driver.cpp" in mk
+    drv = open(os.path.join(HERE, "..", "oracle", "ref_driver.cpp")).read()
+    assert "#include <StateEstimator.hpp>" in drv
+
+
+# ---- math_utils.h / KalmanFilter.hpp -------------------------------------------------------------------------
+def test_small_math_box_plus_minus(ref, oracle):
+    rng = np.random.default_rng(11)
+    for k in range(200):
+        ax = rng.normal(size=3) * (1e-12 if k % 10 == 0 else 0.7 if k % 3 else 3.0)
+        assert np.array_equal(ref.axis2quat(ax), oracle.axis2quat(ax))
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        assert np.array_equal(ref.quat2axis(q), oracle.quat2axis(q))
+        assert np.array_equal(ref.rinvleft(ax), oracle.rinvleft(ax))
+        s = rng.normal(size=19)
+        s[6:10] /= np.linalg.norm(s[6:10])
+        s2 = rng.normal(size=19)
+        s2[6:10] /= np.linalg.norm(s2[6:10])
+        dx = rng.normal(size=18) * 0.2
+        # (a quaternion's squared norm is summed w-first in the oracle, x-first — Eigen's storage order — in the
+        # stand-in: normalized() and inverse() may differ in the last bit)
+        assert np.abs(ref.box_plus(s, dx) - oracle.box_plus(s, dx)).max() <= 1e-15
+        assert np.abs(ref.box_minus(s, s2) - oracle.box_minus(s, s2)).max() <= 4e-15
+
+
+def test_transform_to_start_and_to_end_bit_exact(pkg, ref, oracle, host):
+    prm = pkg.default_params()
+    rng = np.random.default_rng(3)
+    pts = np.zeros((4000, 4), np.float32)
+    pts[:, :3] = rng.normal(size=(4000, 3)) * 15
+    pts[:, 3] = rng.integers(0, 16, 4000) + rng.uniform(0, 0.1, 4000)
+    for seed in range(3):
+        st = np.zeros(19)
+        st[:3] = rng.normal(size=3) * 0.5
+        q = np.array([1.0, *(rng.normal(size=3) * 0.03)])
+        st[6:10] = q / np.linalg.norm(q)
+        st[18] = -9.81
+        assert np.array_equal(ref.transform(prm, st, pts).view(np.int32), oracle.transform_to_start(prm, st, pts).view(np.int32))
+        end = ref.transform(prm, st, pts, to_end=True)
+        assert np.array_equal(end.view(np.int32), oracle.fe_transform_to_end(st[:3], st[6:10], pts).view(np.int32))
+        assert np.array_equal(end.view(np.int32), host.transform_to_end(st[:3], st[6:10], pts).view(np.int32))
+
+
+def test_state_predictor_mirror_equals_the_references(ref, host):
+    """csrc/host/state_predictor.cpp (the product's StatePredictor mirror that makes the synthetic priors) against
+    filter::StatePredictor itself: initialization, 40 predict() steps, reset(1) (KF:125-186, 225-234, 320-352)."""
+    L = host.lib()
+    dp = C.POINTER(C.c_double)
+    rng = np.random.default_rng(5)
+    for trial in range(4):
+        fp = host.FilterParams()
+        L.lins_filter_default_params(C.byref(fp))
+        if trial == 3:
+            fp.init_pos_std[:] = [0.02, 0.03, 0.01]
+            fp.init_att_std[:] = [0.5, 0.4, 0.3]
+        f = host.Filter()
+        vn, ba, bw = rng.normal(size=3) * 3, rng.normal(size=3) * 0.05, rng.normal(size=3) * 0.003
+        L.lins_filter_init(C.byref(f), C.byref(fp), vn.ctypes.data_as(dp), ba.ctypes.data_as(dp), bw.ctypes.data_as(dp))
+        imu = np.zeros((40, 7))
+        imu[:, 0] = 0.0025
+        imu[:, 1:4] = rng.normal(size=(40, 3)) * 0.3 + [0, 0, 9.81]
+        imu[:, 4:7] = rng.normal(size=(40, 3)) * 0.05
+        for r in imu:
+            acc, gyr = np.ascontiguousarray(r[1:4]), np.ascontiguousarray(r[4:7])
+            L.lins_filter_predict(C.byref(f), r[0], acc.ctypes.data_as(dp), gyr.ctypes.data_as(dp))
+        st, cov = ref.filter_run(fp, vn, ba, bw, imu)
+        assert np.abs(np.array(f.state[:]) - st).max() <= 1e-14
+        assert np.abs(np.array(f.cov[:]).reshape(18, 18) - cov).max() <= 1e-14 * np.abs(cov).max()
+        L.lins_filter_reset1(C.byref(f))
+        st, cov = ref.filter_run(fp, vn, ba, bw, imu, reset1=True)
+        assert np.abs(np.array(f.state[:]) - st).max() <= 1e-14
+        assert np.abs(np.array(f.cov[:]).reshape(18, 18) - cov).max() <= 1e-14 * np.abs(cov).max()
+
+
+# ---- findCorresponding*Features, performIESKF ----------------------------------------------------------------
+@pytest.mark.parametrize("idx", [0, 1, 2, 3, 40, 41, 977])
+def test_correspondences_rows_and_trajectory_bit_exact(pkg, host, oracle, ref, idx):
+    """At every linearisation state of the update: the reference's pointSearch*Ind, its pushed coefficient rows and its
+    transformToStart, against the oracle's (brute-force and kd-tree neighbours); and the trajectory itself
+    (NUM_ITER = k replays of the reference) against the oracle's trace."""
+    prm = pkg.default_params(num_iter=30)
+    pair = host.synth_pair(idx)
+    res, tr = oracle.ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_BRUTE, trace=True)
+    for k in range(res.iters):
+        surf, corner = ref.correspondences(prm, pair, tr["lin_state"][k], k)
+        assert_corr_bit_exact(surf, tr["surf"][k], f"pair{idx}.iter{k}.surf")
+        assert_corr_bit_exact(corner, tr["corner"][k], f"pair{idx}.iter{k}.corner")
+        s2, c2 = oracle.correspondences(prm, pair, tr["lin_state"][k], k, oracle.NN_KDTREE)
+        assert_corr_bit_exact(surf, s2, "kd.surf"), assert_corr_bit_exact(corner, c2, "kd.corner")
+    steps = ref.replay(prm, pair)
+    assert len(steps) == res.iters
+    for k, (r, dx) in enumerate(steps):
+        nxt = tr["lin_state"][k + 1] if k + 1 < res.iters else res.state
+        assert np.abs(r.state - nxt).max() <= STATE_TOL
+        assert np.abs(dx - tr["dx"][k]).max() <= STATE_TOL
+        assert (r.m_surf, r.m_corner) == (int(tr["surf"][k]["accepted"].sum()), int(tr["corner"][k]["accepted"].sum()))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(HERE, "golden", "pair_*.npz"))), ids=os.path.basename)
+def test_reference_reproduces_the_committed_goldens(pkg, ref, path):
+    """tests/golden/*.npz were written by the oracle (make_golden.py); the reference's own code returns them."""
+    z = np.load(path)
+    pair = pkg.ScanPair(z["surf_flat"], z["corner_sharp"], z["surf_last"], z["corner_last"], z["state"], z["cov"])
+    prm = pkg.default_params(num_iter=30)
+    got = ref.perform_ieskf(prm, pair)
+    assert list(flags(got)) == list(z["out_flags"])
+    assert np.abs(got.state - z["out_state"]).max() <= STATE_TOL
+    assert np.abs(got.cov - z["out_cov"]).max() <= COV_REL * np.abs(z["out_cov"]).max()
+    for k in range(len(z["lin_state"])):
+        surf, corner = ref.correspondences(prm, pair, z["lin_state"][k], k)
+        assert np.array_equal(np.stack([surf[f] for f in ("ind1", "ind2", "ind3")], -1), z["surf_ind"][k])
+        assert np.array_equal(np.stack([corner[f] for f in ("ind1", "ind2")], -1), z["corner_ind"][k])
+        assert np.array_equal(surf["accepted"], z["surf_acc"][k]) and np.array_equal(corner["accepted"], z["corner_acc"][k])
+        assert np.array_equal(surf["coeff"].view(np.int32), z["surf_coeff"][k].view(np.int32))
+        assert np.array_equal(corner["coeff"].view(np.int32), z["corner_coeff"][k].view(np.int32))
+
+
+@pytest.mark.parametrize("wide", [False, True], ids=["shipped-prior", "wide-prior"])
+def test_1024_seeded_pairs_oracle_equals_reference(pkg, host, oracle, ref, wide):
+    """performIESKF (reference stop rule, NUM_ITER 30) on 1024 seeded scan pairs — the reference's own code vs the
+    oracle's dense form and vs its reduced 6x6 form; 'wide' adds a fully correlated prior block so that gain, solve
+    and Joseph update carry weight (with the shipped init_*_std = 0 the posterior hardly depends on them)."""
+    n, start = (1024, 2000) if not wide else (512, 7000)
+    prm = pkg.default_params(num_iter=30)
+    workers = min(32, os.cpu_count() or 1)
+    with ThreadPoolExecutor(workers) as ex:
+        pairs = list(ex.map(host.synth_pair, range(start, start + n)))
+        if wide:
+            widen(pairs, start)
+        want = list(ex.map(lambda p: oracle.perform_ieskf(prm, p, oracle.FORM_DENSE, oracle.NN_KDTREE), pairs))
+        reduced = list(ex.map(lambda p: oracle.perform_ieskf(prm, p, oracle.FORM_REDUCED, oracle.NN_BRUTE), pairs))
+    got = ref.perform_ieskf_batch(prm, pairs, threads=workers)
+    assert sum(w.iters for w in want) > 3 * n
+    for i, (g, w, r) in enumerate(zip(got, want, reduced)):
+        assert g is not None
+        assert_same_result(g, w, f"pair {start + i}")
+        assert flags(r) == flags(g)
+        assert np.abs(r.state - g.state).max() <= 1e-10 and np.abs(r.cov - g.cov).max() <= 1e-10 * np.abs(g.cov).max()
+
+
+@pytest.mark.parametrize("freq", [2, 3])
+def test_icp_freq_reuses_indices_like_the_reference(pkg, host, oracle, ref, freq):
+    prm = pkg.default_params(num_iter=30, icp_freq=freq)
+    for idx in (0, 1, 7):
+        pair = host.synth_pair(idx)
+        assert_same_result(ref.perform_ieskf(prm, pair), oracle.perform_ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_BRUTE))
+
+
+def test_divergence_branch_and_icp_fallback(pkg, host, oracle, ref):
+    """SE:566-570 (residual blow-up) -> SE:585-592: estimateTransform's result goes into the filter state, Pk_ is
+    passed through un-updated."""
+    prm = pkg.default_params(num_iter=30)
+    pair = make_diverging_pair(pkg)
+    got = ref.perform_ieskf(prm, pair)
+    want = oracle.perform_ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_BRUTE)
+    assert got.diverged == 1 and want.diverged == 1 and got.iters == want.iters == 2
+    assert np.abs(got.state - want.state).max() <= STATE_TOL and np.array_equal(got.cov, pair.cov.reshape(18, 18))
+    # estimateTransform / calculateTransformation on ordinary pairs, from a poor start
+    for idx in (0, 5, 9):
+        pair = host.synth_pair(idx)
+        t0, q0 = np.zeros(3), np.array([1.0, 0, 0, 0])
+        a, b = oracle.icp(prm, pair, t0, q0, oracle.NN_BRUTE), ref.icp(prm, pair, t0, q0)
+        assert a[2] == b[2]
+        assert np.abs(a[0] - b[0]).max() <= 1e-11 and np.abs(a[1] - b[1]).max() <= 1e-11
+        a, b = oracle.icp(prm, pair, pair.state[:3], pair.state[6:10], oracle.NN_KDTREE), ref.icp(prm, pair, pair.state[:3], pair.state[6:10])
+        assert a[2] == b[2] and np.abs(a[0] - b[0]).max() <= 1e-11 and np.abs(a[1] - b[1]).max() <= 1e-11
+
+
+def test_nan_branch(pkg, oracle, ref):
+    """SE:552-563: a NaN in updateVec_ — here from a NaN prior covariance entry on the position block."""
+    pair = make_diverging_pair(pkg)
+    pair.cov = pair.cov.copy()
+    pair.cov.reshape(18, 18)[0, 0] = np.nan
+    prm = pkg.default_params(num_iter=30)
+    got = ref.perform_ieskf(prm, pair)
+    want = oracle.perform_ieskf(prm, pair, oracle.FORM_DENSE, oracle.NN_BRUTE)
+    assert got.diverged == want.diverged == 2 and got.iters == want.iters
+
+
+def test_inputs_on_which_the_reference_reads_out_of_bounds_are_refused(pkg, host, ref):
+    pair = host.synth_pair(0)
+    prm = pkg.default_params(num_iter=30)
+    empty = np.zeros((0, 4), np.float32)
+    no_targets = pkg.ScanPair(pair.surf_flat, pair.corner_sharp, empty, pair.corner_last, pair.state, pair.cov)
+    assert ref.perform_ieskf(prm, no_targets) is None  # pointSearchSqDis[0] of an empty result, SE:851
+    more_queries = pkg.ScanPair(pair.surf_flat, pair.corner_sharp, pair.surf_last[:50], pair.corner_last, pair.state, pair.cov)
+    assert ref.perform_ieskf(prm, more_queries) is None  # j < surfPointsFlatNum walks past the target cloud, SE:859
+    no_queries = pkg.ScanPair(empty, empty, pair.surf_last, pair.corner_last, pair.state, pair.cov)
+    got = ref.perform_ieskf(prm, no_queries)  # M = 0: updateVec_ = 0, converged after one iteration, state kept
+    assert got.iters == 1 and got.converged == 1 and np.abs(got.state - pair.state).max() <= 1e-15
+
+
+# ---- feature stage (SE:619-827) ------------------------------------------------------------------------------
+@pytest.mark.parametrize("idx", [0, 1, 5, 12, 33])
+def test_feature_stage_picks_equal_the_references(pkg, host, oracle, ref, idx):
+    """undistortPcl ... extractFeatures compiled from the reference vs the libm checker (oracle/frontend_oracle.cpp)
+    and vs the product's host restatement (csrc/host/frontend.cpp, what the device kernel is bit-compared with):
+    the same sharp / less-sharp / flat picks in the same order, the same voxels.  Left open by the reference itself
+    and therefore not bit-compared: the f32 centroid's last bits (VoxelGrid sums a voxel's points in the order
+    std::sort's introsort leaves them) and, for the product, the relative-time tag (its fixed-sequence atan2f vs
+    libm: <= 2.5e-7, bounded in tests/test_frontend_oracle.py)."""
+    prm = pkg.default_params()
+    for k in (0, 1):
+        raw = turned(host.synth_raw_scan(idx, k))
+        o = oracle.fe_segment(raw)
+        fr = ref.extract_features(prm, o)
+        fo = oracle.fe_features(o)
+        hs = host.segmented_from_arrays(o["cloud"], o["range"], o["col"], o["ground"], o["n"], o["start_ring"], o["end_ring"],
+                                        o["orientation"], o["n_outlier"])
+        fh = host.frontend_extract_segmented(hs)
+        assert np.array_equal(fr["undistorted"].view(np.int32), fo["undistorted"].view(np.int32))
+        for name in ("corner_sharp", "corner_less_sharp", "surf_flat"):
+            assert np.array_equal(fr[name].view(np.int32), fo[name].view(np.int32)), name
+            assert np.array_equal(fr[name][:, :3], fh[name][:, :3]), name
+            assert (np.abs(fr[name][:, 3] - fh[name][:, 3]) <= 2.5e-7 * np.maximum(1.0, np.abs(fr[name][:, 3]))).all(), name
+        for f in (fo, fh):
+            a, b = fr["surf_less_flat"], f["surf_less_flat"]
+            assert a.shape == b.shape
+            assert np.abs(a[:, :3] - b[:, :3]).max() <= 4e-6  # a few f32 ulps at <= 40 m: the summation order inside a voxel
+            assert np.abs(a[:, 3] - b[:, 3]).max() <= 4e-6
+            assert np.array_equal(np.floor(a[:, 3]), np.floor(b[:, 3]))  # same ring
