@@ -10,7 +10,15 @@
 //
 // Scene: ground z=-1.8 m, 40 x 30 m room with 6 m walls, 24 poles r=0.15 m,
 // 8 boxes 2x2x2 m.  Sensor: rings -15..+15 deg step 2 deg (parameters.h:82-84),
-// 1800 firings of 0.2 deg, clockwise, range noise N(0, 0.02 m), max 100 m.
+// 1800 firings of 0.2 deg, clockwise, range noise N(0, 0.02 m), max 100 m.  Like a real sensor's, the firing
+// azimuths are generic: firing f sits at (f + c_f) * 0.2 deg with c_f = phase + 0.1 (f / 1800 - 1/2) + e_f — a seeded
+// per-scan phase in (-0.3, 0.3) of a column, a slow drift of a tenth of a column per revolution (a rotor turning 56 ppm
+// slow) and a per-firing jitter e_f ~ N(0, 0.004) clamped to +-0.01.  So |c_f| < 0.36: no firing sits within 0.14
+// column (0.028 deg) of a rounding edge of image_projection_node's column index (IP:225), and the firings a quarter,
+// half and three-quarter turn after the first one — which sit exactly on the reference's unwrap thresholds
+// (SE:632-645: start - pi/2, start + pi, start + 3 pi/2, end - 3 pi/2, end + pi/2) when the spacing is exactly 0.2 deg
+// — are >= 0.005 column (1.7e-5 rad) off them, two orders above any atan2f's error.  (Rounds 1-2 fired at exactly
+// (f + 0.5) * 0.2 deg: every point on a column edge, where the column hangs on the last bit of whichever atan2f is used.)
 // Motion: planar, constant forward speed U(0,10) m/s and yaw rate U(-0.5,0.5).
 
 #include <cmath>
@@ -150,12 +158,18 @@ double cast(const Scene& s, const double o[3], const double d[3]) {
 // raw distorted cloud of scan k (k-th 0.1 s interval), firing order
 int raw_scan(const Scene& s, uint32_t seed, uint32_t scan_index, int k, lins_point* out, int cap) {
   Rng noise(((uint64_t)seed << 32) ^ ((uint64_t)scan_index << 8) ^ (uint64_t)(k + 1) * 0xD1B54A32D192ED03ull);
+  Rng azr(((uint64_t)seed << 32) ^ ((uint64_t)scan_index << 9) ^ (uint64_t)(k + 1) * 0x9FB21C651E98DF25ull);
+  const double phase = azr.uni(-0.3, 0.3);  // of a column, per scan
   int n = 0;
   for (int f = 0; f < LINS_SCAN_NUM; ++f) {
     double tau = k * kScanPeriod + kScanPeriod * f / LINS_SCAN_NUM;
     double sx, sy, yaw;
     pose_at(s, tau, sx, sy, yaw);
-    double az = M_PI - (f + 0.5) * (2 * M_PI / LINS_SCAN_NUM);  // clockwise from -x
+    double jit = 0.004 * azr.gauss();
+    jit = jit > 0.01 ? 0.01 : (jit < -0.01 ? -0.01 : jit);
+    jit += 0.1 * ((double)f / LINS_SCAN_NUM - 0.5);
+    // clockwise from -x; IP:225 rounds (f + phase + jit) - 900: the firing lands in column f (mod wrap), off the edges
+    double az = M_PI - (f + phase + jit) * (2 * M_PI / LINS_SCAN_NUM);
     for (int l = 0; l < LINS_LINE_NUM; ++l) {
       double el = (-15.0 + 2.0 * l) * M_PI / 180.0;
       double ds[3] = {std::cos(el) * std::cos(az), std::cos(el) * std::sin(az), std::sin(el)};

@@ -3,17 +3,22 @@ this box's libm atan2f / sinf / cosf where the reference calls them, size_t row 
   CPU: the product's host restatement of image_projection_node + StateEstimator's feature stage (csrc/host/) —
        what the device kernels are bit-compared with elsewhere — against that checker;
   GPU: the device kernels (lins_segment_batch, lins_extract_features_batch, lins_transform_to_end_batch) against it.
-The synthetic sensor fires exactly on the column edges of IP:225 (every azimuth a multiple of 0.2 deg), where a
-point's column hangs on the last bit of atan2f; the comparisons therefore run on clouds turned by 0.1 deg (points at
-the column centres, like a real sensor's generic azimuths).  tools/frontend_vs_libm.py measures both placements."""
+The comparisons run on the stock synthetic scans: since round 3 the generator's firings carry a seeded phase and
+jitter (csrc/host/synth.cpp), so no point sits on a column edge of IP:225 — rounds 1-2 fired exactly on the edges,
+where a point's column hangs on the last bit of whichever atan2f is used, and these tests had to turn the clouds by
+0.1 deg first.  `on_column_edges` below rebuilds such a cloud on purpose, to keep that hazard measured."""
 import numpy as np
 import pytest
 
 
-def turned(raw, deg=0.1):
-    ca, sa = np.float32(np.cos(np.radians(deg))), np.float32(np.sin(np.radians(deg)))
+def on_column_edges(raw):
+    """Snap every point's azimuth to the nearest column EDGE of IP:225 (a half-integer multiple of 0.2 deg off the
+    column centres), keeping range and elevation: the adversarial placement the round 1-2 generator produced."""
     r = raw.copy()
-    r[:, 0], r[:, 1] = ca * raw[:, 0] - sa * raw[:, 1], sa * raw[:, 0] + ca * raw[:, 1]
+    rho = np.hypot(raw[:, 0].astype(np.float64), raw[:, 1].astype(np.float64))
+    az = np.degrees(np.arctan2(raw[:, 0].astype(np.float64), raw[:, 1].astype(np.float64)))  # IP:224: atan2(x, y)
+    az = (np.floor(az / 0.2) + 0.5) * 0.2
+    r[:, 0], r[:, 1] = rho * np.sin(np.radians(az)), rho * np.cos(np.radians(az))
     return r
 
 
@@ -43,7 +48,7 @@ def assert_same_features(fo, fx):
 @pytest.mark.parametrize("idx", [0, 1, 5, 12])
 def test_host_restatement_equals_the_independent_checker(host, oracle, idx):
     for k in (0, 1):
-        raw = turned(host.synth_raw_scan(idx, k))
+        raw = host.synth_raw_scan(idx, k)
         o = oracle.fe_segment(raw)
         assert_same_segmentation(o, host.frontend_segment(raw))
         hs = host.segmented_from_arrays(o["cloud"], o["range"], o["col"], o["ground"], o["n"], o["start_ring"], o["end_ring"],
@@ -51,10 +56,25 @@ def test_host_restatement_equals_the_independent_checker(host, oracle, idx):
         assert_same_features(oracle.fe_features(o), host.frontend_extract_segmented(hs))
 
 
+def test_stock_scans_are_off_the_column_edges_and_edge_aligned_clouds_are_not(host, oracle):
+    """The generator's promise (no firing within 0.1 column of an edge) as the libm checker and the product's
+    fixed-sequence atan2f see it: identical range images on stock scans; on a cloud snapped onto the edges the two
+    disagree on a visible share of the cells — which is why the generator avoids them."""
+    raw = host.synth_raw_scan(7, 0)
+    o, s = oracle.fe_segment(raw), host.frontend_segment(raw)
+    assert s.n == o["n"] and np.array_equal(s.col[: s.n], o["col"][: s.n])
+    az = np.degrees(np.arctan2(raw[:, 0].astype(np.float64), raw[:, 1].astype(np.float64))) / 0.2
+    assert np.abs(az - np.floor(az) - 0.5).max() <= 0.37  # |distance to the column CENTRE| (IP:225 rounds az / 0.2): edges are 0.5 away
+    edge = on_column_edges(raw)
+    o, s = oracle.fe_segment(edge), host.frontend_segment(edge)
+    m = min(s.n, o["n"])
+    assert s.n != o["n"] or not np.array_equal(s.col[:m], o["col"][:m])
+
+
 def test_rows_between_minus_one_and_zero_land_on_row_0_like_the_references_size_t(host, oracle):
     """IP:207, 220-221: rowIdn is a size_t — a vertical angle just below -15.1 deg gives (angle + 15.1) / 2 in (-1, 0),
     which truncates to row 0 (and is NOT dropped); <= -1 wraps to a huge index and is dropped."""
-    raw = turned(host.synth_raw_scan(2, 0))
+    raw = host.synth_raw_scan(2, 0)
     extra = []
     for az in np.radians([10.0, 100.0, 200.0]):
         for elev, keep in ((-15.5, True), (-16.9, True), (-17.2, False)):
@@ -87,7 +107,7 @@ def test_reprojection_restatement_equals_the_independent_checker(host, oracle):
 
 @pytest.mark.gpu
 def test_device_front_end_equals_the_independent_checker(pkg, ieskf, host, oracle):
-    raws = [turned(host.synth_raw_scan(20 + i // 2, i % 2)) for i in range(24)]
+    raws = [host.synth_raw_scan(20 + i // 2, i % 2) for i in range(24)]
     segs_o = [oracle.fe_segment(r) for r in raws]
     with ieskf.IeskfContext(pkg.default_params(), max_batch=len(raws), max_targets=16384) as c:
         for o, s in zip(segs_o, c.segment_batch(raws)):
