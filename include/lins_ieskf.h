@@ -143,11 +143,6 @@ const char* lins_last_hip_error(const lins_ctx* ctx);
  *            workgroup per scan and CU, 3 lanes per query — shortest latency for one scan
  *   "mr"     multi-resident: the low part of the grid in LDS, the rest in a sorted global
  *            copy, 512 threads, 1 lane per query, two scans per CU — batch throughput
- *   "split"  two kernels: "mr" for the first iterations (the linearisation point still moves by
- *            decimetres), then a grid-free LIST kernel for the rest — every query re-decides its three
- *            points among a candidate list the first kernel gathered, accepts the decision only when it
- *            is certified exact, and otherwise searches its cloud exhaustively; four scans per CU.
- *            Needs ICP_FREQ = 1 and VLP-16 sized query sets, else runs as "mr".
  *   "lds1"   whole grid in LDS, 384 threads, 1 lane per query
  *   "binned" the grid in global memory (any cloud size; automatic fallback of the above)
  *   "brute"  all-pairs search + the literal index walk (any input; the fallback for
@@ -172,9 +167,9 @@ int lins_batch_download(lins_ctx* ctx, int n, lins_result* out);
  * lins_batch_run(): the persistent IESKF kernel ("lds*" modes: without the small Joseph
  * covariance kernel that follows it; "binned"/"brute": both).                       */
 int lins_last_kernel_ms(lins_ctx* ctx, float* ms);
-/* "split" mode: the two kernels of the last lins_batch_run() separately (their sum is what
- * lins_last_kernel_ms reports); LINS_E_STATE when the last run did not take the split path. */
-int lins_last_split_ms(lins_ctx* ctx, float* grid_ms, float* list_ms);
+/* The kernel family the last batch / pass actually ran ("mr", "lds", "lds1", "binned", "brute"): the requested
+ * mode after "auto" and the eligibility fall-backs; "" before the first run.  Static storage.               */
+const char* lins_last_search(const lins_ctx* ctx);
 /* Algorithmic bytes of one iteration summed over the uploaded batch
  * (16*(Nsharp+Nflat+Nls+Nlf) + 8*19 + 8*28 per scan).          */
 int lins_batch_bytes_per_iter(lins_ctx* ctx, uint64_t* bytes);

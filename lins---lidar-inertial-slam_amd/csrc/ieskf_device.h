@@ -28,7 +28,7 @@ constexpr int kAzSurf = 128;         // azimuth columns per ring, surf targets
 constexpr int kAzCorner = 64;        // azimuth columns per ring, corner targets
 constexpr int kMaxRing = LINS_MAX_RING;
 
-enum { SEARCH_BRUTE = 0, SEARCH_BINNED = 1, SEARCH_LDS = 2, SEARCH_LDS3 = 3, SEARCH_MR = 4, SEARCH_AUTO = 5, SEARCH_SPLIT = 6 };
+enum { SEARCH_BRUTE = 0, SEARCH_BINNED = 1, SEARCH_LDS = 2, SEARCH_LDS3 = 3, SEARCH_MR = 4, SEARCH_AUTO = 5 };
 
 struct ScanDesc {  // one IESKF problem in the device arena (offsets in points)
   int off_surf_q, n_surf_q;
@@ -50,8 +50,7 @@ struct DevParams {
   int pad;            // debug / profiling flags (LINS_DEBUG_SKIP)
   float margin_cold;  // certificate margins of the LDS search [m] (ieskf_lds.hip)
   float margin_warm;
-  int split_iters;     // split path: iterations the grid kernel runs before the list kernel takes over
-  float split_margin;  // ... and the margin [m] of the candidate lists' completeness radii (ieskf_split.h)
+  int pad2[2];
 };
 
 struct IterConst {  // per-iteration constants, hoisted (the reference recomputes per point)

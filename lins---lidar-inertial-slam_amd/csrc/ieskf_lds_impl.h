@@ -17,8 +17,7 @@
 //
 // One workgroup owns one scan pair for the whole iterated update.  Both target clouds of
 // the scan are counting-sorted ONCE into (ring x azimuth-column) grids of 16-byte records
-// (x, y, z, original index bits — one ds_read_b128 per candidate; the SoA layout of round 1
-// stays behind LINS_LDS_AOS): after that single coalesced pass over the scan's ~125 KB in
+// (x, y, z, original index bits — one ds_read_b128 per candidate): after that single coalesced pass over the scan's ~125 KB in
 // HBM, every iteration's correspondence search is LDS traffic (mr: plus rare L2 reads) —
 // the candidate windows are staged in LDS, not re-gathered from L2.
 //
@@ -34,7 +33,6 @@
 //   LINS_LDS_NS         namespace of this instantiation
 //   LINS_LDS_CAP        grid positions resident in LDS
 //   LINS_LDS_NMAX       target points a scan may have (> CAP: hybrid LDS / global storage)
-//   LINS_LDS_REGREDUCE  1: rows -> 28 sums through register butterflies (no row slots in LDS)
 //   LINS_LDS_SCANBATCH  points whose LDS reads are in flight together in the scan loops
 //   LINS_LDS_WAVES      waves of the largest workgroup shape instantiated
 //   LINS_LDS_MINW       minimum waves per SIMD the register allocation must allow
@@ -60,7 +58,6 @@
 #include "ieskf_device.h"
 #include "icp_math.h"
 #include "ieskf_rowsum.h"
-#include "ieskf_split.h"
 
 #ifndef LINS_SPREAD_S
 // waves the plane / line queries of a 512-thread workgroup are spread over.  Measured on the batch workload (91 plane
@@ -86,25 +83,12 @@ constexpr int kMaxLWaves = LINS_LDS_WAVES;  // waves of the largest workgroup sh
 constexpr int kNpCap = LINS_LDS_CAP;   // grid positions (corner cloud first, then surf ring-major) resident in LDS
 constexpr int kNpMax = LINS_LDS_NMAX;  // target points of an eligible scan
 constexpr bool kHybrid = kNpMax > kNpCap;  // positions >= kNpCap live in the sorted global copy
-constexpr bool kRegReduce = LINS_LDS_REGREDUCE != 0;
 constexpr int kScanBatch = LINS_LDS_SCANBATCH;  // points per trip of the scan loops
-constexpr int kSlotCap = 384;         // >= queries per round, row slots of 7 doubles
 constexpr int kCellsSurf = kRingsBinned * kAzSurf, kCellsCorner = kRingsBinned * kAzCorner;
 static_assert(kNpMax >= kNpCap && kNpMax <= 16384, "positions are u16, indices u16");
 
-__constant__ unsigned char kLPairA[28] = {0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 2, 2, 2,
-                                          2, 3, 3, 3, 4, 4, 5, 0, 1, 2, 3, 4, 5, 6};
-__constant__ unsigned char kLPairB[28] = {0, 1, 2, 3, 4, 5, 1, 2, 3, 4, 5, 2, 3, 4,
-                                          5, 3, 4, 5, 4, 5, 5, 6, 6, 6, 6, 6, 6, 6};
-
 struct LdsStore {
-#ifdef LINS_LDS_AOS
   float4 pt[kNpCap];  // grid-sorted targets, one 16-byte record (x, y, z, original index bits) per position
-#else
-  float px[kNpCap], py[kNpCap], pz[kNpCap];  // grid-sorted targets: corner cells, then surf cells
-  unsigned short pidx[kNpCap];               // original index inside its cloud
-#endif
-  double slots[kRegReduce ? 1 : kSlotCap * 7];  // H rows (slot reduction only)
   // exclusive end (absolute position) per cell, corner cells first; during the build the same
   // words are the histogram / scatter counters (two u16 counters per 32-bit LDS atomic).  A union,
   // and the library is built with -fno-strict-aliasing: the 16- and 32-bit views DO alias.
@@ -151,23 +135,15 @@ struct LCloud {  // one target cloud's grid (all pointers into LDS)
 // the others are read from the sorted global copy (L2): rare — the searches end in the low rings.
 __device__ __forceinline__ void pt_xyz(const LdsStore& L, const LCloud& c, int p, float& x, float& y, float& z) {
   if (!kHybrid || p < c.n_lds) {
-#ifdef LINS_LDS_AOS
     const float4 v = L.pt[p];
     x = v.x, y = v.y, z = v.z;
-#else
-    x = L.px[p], y = L.py[p], z = L.pz[p];
-#endif
   } else {
     const float4 g = c.gs[p];
     x = g.x, y = g.y, z = g.z;
   }
 }
 __device__ __forceinline__ int pt_idx(const LdsStore& L, const LCloud& c, int p) {
-#ifdef LINS_LDS_AOS
   if (!kHybrid || p < c.n_lds) return __float_as_int(L.pt[p].w);
-#else
-  if (!kHybrid || p < c.n_lds) return (int)L.pidx[p];
-#endif
   return __float_as_int(c.gs[p].w);
 }
 __device__ __forceinline__ float pt_sqdist(const LdsStore& L, const LCloud& c, int p, float sx, float sy, float sz) {
@@ -332,12 +308,8 @@ __device__ __forceinline__ void scan_cols(const LdsStore& L, const LCloud& c, in
 #pragma unroll
       for (int u = 0; u < kScanBatch; ++u) {
         const int pu = p + u < el ? p + u : el - 1;
-#ifdef LINS_LDS_AOS
         const float4 v = L.pt[pu];
         x[u] = v.x, y[u] = v.y, z[u] = v.z, j[u] = __float_as_int(v.w);
-#else
-        x[u] = L.px[pu], y[u] = L.py[pu], z[u] = L.pz[pu], j[u] = (int)L.pidx[pu];
-#endif
       }
 #pragma unroll
       for (int u = 0; u < kScanBatch; ++u) f(x[u], y[u], z[u], j[u], p + u, p + u < el);
@@ -782,12 +754,7 @@ __device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, 
         // order inside a cell is irrelevant (keyed ties)
         const int pos = (int)((atomicAdd(&cnt32[cell >> 1], 1u << sh) >> sh) & 0xFFFFu);
         if (!kHybrid || pos < kNpCap) {
-#ifdef LINS_LDS_AOS
           L.pt[pos] = make_float4(p.x, p.y, p.z, __int_as_float(jj));
-#else
-          L.px[pos] = p.x, L.py[pos] = p.y, L.pz[pos] = p.z;
-          L.pidx[pos] = (unsigned short)jj;
-#endif
         } else {
           gsorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(jj));
         }
@@ -981,164 +948,26 @@ __device__ __noinline__ void icp_solve_and_update(int tid, int iter) {
 }
 
 // ---------------------------------------------------------------------------
-// split path (ieskf_split.h): the candidate list of one query, gathered around its de-skewed position at the
-// state the list kernel starts from, with the exact selection (p1, p2, p3: grid positions, -1 = none) of the
-// search that has just run at that position.  Claims: everything within r_nn (all rings, all indices);
-// on the rings of the second / third point's class everything the index walk can reach within r2 / r3.
-// ---------------------------------------------------------------------------
-// Out of line on purpose: inlined into the iteration loop its register needs slow every iteration down (measured:
-// +15 % on the three iterations before the hand-off); a call keeps them on the hand-off path.
-struct GatherArgs {
-  int is_surf, nq, n_corner_t, n_surf_t, n_lds, p1, p2, p3, rho0, stride, pad;
-  float thr, margin, ax, ay, az;
-};
-__device__ __noinline__ void split_gather(const GatherArgs ga, const float4* gs, SplitQ* out, float4* cb) {
-  const LdsStore& L = g_lds;
-  const bool is_surf = ga.is_surf != 0;
-  const LCloud c = is_surf ? LCloud{L.cell_end + kCellsCorner, L.ring_start[0], &L.el_ang[0][0], kAzSurf, 1, ga.n_corner_t, ga.n_surf_t, gs, ga.n_lds}
-                           : LCloud{L.cell_end, L.ring_start[1], &L.el_ang[1][0], kAzCorner, kAzSurf / kAzCorner, 0, ga.n_corner_t, gs, ga.n_lds};
-  const int nq = ga.nq, p1 = ga.p1, p2 = ga.p2, p3 = ga.p3, rho0 = ga.rho0, stride = ga.stride;
-  const float ax = ga.ax, ay = ga.ay, az = ga.az;
-  QueryPolar qp;
-  qp.rho = sqrtf(ax * ax + ay * ay);
-  qp.qn3 = sqrtf(qp.rho * qp.rho + az * az);
-  qp.el = atan2f(az, qp.rho);
-  qp.inv_unused = 0.f;
-  qp.a0_surf_or_corner = az_bin_lds(ax, ay, c.naz);
-  SplitQ rec{ax, ay, az, 0.f, ax, ay, az, 0.f, 0.f, 0, -1, -1};
-  if (p1 >= 0 && !(ga.pad & 128)) {  // (pad & 128: timing aid, no lists)
-    const float thr = ga.thr, M = ga.margin;
-    const int j1 = pt_idx(L, c, p1);
-    const int fend = nq < c.n ? nq : c.n;
-    const WalkCtx w = make_walk_ctx(c, nq, j1, rho0);
-    // indices the walk reaches at all, by class (the cloud is ring-sorted): same ring / other rings
-    const int rs = c.ring_start[rho0], re = c.ring_start[rho0 + 1];
-    const bool any_same = j1 > (w.b_lo > rs ? w.b_lo : rs) || (j1 + 1 < (w.f_hi < re ? w.f_hi : re));
-    const bool any_other = rs > w.b_lo || w.f_hi > re;
-    const float r_none = sqrtf(thr) * (1.f + 2e-6f) + M;  // "nobody within the search radius", with the margin
-    auto radius = [&](int pos) { return sqrtf(pt_sqdist(L, c, pos, ax, ay, az)) * (1.f + 2e-6f) + M; };
-    const float r_nn = radius(p1);
-    const bool any2 = is_surf ? any_same : any_other, any3 = is_surf && any_other;
-    // A class without a winner would need everything the walk reaches within the whole search radius (+ margin)
-    // to certify "still none": wide windows for one lane.  (pad & 512, experiment: leave it to the list kernel, whose
-    // first encounter sweeps the walk's index range with the whole workgroup and re-establishes the claim —
-    // measured: no faster here, slower there.)
-    const bool lazy_none = (ga.pad & 512) != 0;
-    const float r_none_here = lazy_none ? r_nn : r_none;
-    const float r2 = !any2 ? r_nn : (p2 >= 0 ? fmaxf(radius(p2), r_nn) : r_none_here);
-    const float r3 = !any3 ? (is_surf ? r_nn : 0.f) : (p3 >= 0 ? fmaxf(radius(p3), r_nn) : r_none_here);
-    const int flags = lazy_none ? 0 : (((any2 && p2 < 0) ? (int)SPLITQ_NONE2 : 0) | ((any3 && p3 < 0) ? (int)SPLITQ_NONE3 : 0));
-    const float t_nn = r_nn * r_nn * (1.f + 4e-6f);
-    const int a0 = qp.a0_surf_or_corner;
-    // window bounds of the three radii, once: [0] r_nn, [1] r2, [2] r3
-    float delta[3];
-    int reachK[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float rb = (k == 0 ? r_nn : (k == 1 ? r2 : r3)) * (1.f + 2e-6f) + 1e-6f;
-      delta[k] = reach_elev(qp.qn3, rb), reachK[k] = reach(c, qp.rho, rb);
-    }
-    int count = 0;
-    // Rings in a wave-friendly order: the five rings around rho0 first (every lane has work there, the class
-    // claims live there), then whatever else the all-points radius reaches — found with one cheap wedge test per
-    // ring, normally nothing.
-    unsigned far = 0;
-#pragma unroll
-    for (int r = 0; r < kRingsBinned; ++r) {
-      const int dr = r - rho0;
-      if ((dr < -2 || dr > 2) && ring_nonempty(c, r) && ring_in_reach(c, r, qp.el, delta[0])) far |= 1u << r;
-    }
-#pragma unroll 1
-    for (int k = 0; k < 5 || far; ++k) {
-      int r;
-      if (k < 5) {
-        r = rho0 + (k == 0 ? 0 : (k == 1 ? -1 : (k == 2 ? 1 : (k == 3 ? -2 : 2))));
-        if (r < 0 || r >= kRingsBinned) continue;
-      } else {
-        r = __ffs(far) - 1;
-        far &= far - 1;
-      }
-      const int dr = r - rho0, adr = dr < 0 ? -dr : dr;
-      const int cls = is_surf ? (dr == 0 ? 2 : (adr <= 2 ? 3 : 0)) : ((adr >= 1 && adr <= 2) ? 2 : 0);
-      // beyond r_nn a ring is only worth visiting for indices the walk can reach: every index of a lower ring
-      // and of the nearest neighbour's own ring, the indices below the forward end on the rings above
-      const bool reachable = cls != 0 && (dr <= 0 || c.ring_start[r] < fend);
-      const int which = !reachable ? 0 : (cls == 2 ? 1 : 2);
-      if (!ring_nonempty(c, r) || !ring_in_reach(c, r, qp.el, which == 0 ? delta[0] : (which == 1 ? delta[1] : delta[2]))) continue;
-      const float rad = which == 0 ? r_nn : (which == 1 ? r2 : r3);
-      const bool none = reachable && (cls == 2 ? (flags & SPLITQ_NONE2) != 0 : (flags & SPLITQ_NONE3) != 0);
-      const int K = which == 0 ? reachK[0] : (which == 1 ? reachK[1] : reachK[2]);
-      const float t_r = rad * rad * (1.f + 4e-6f);
-      scan_cols(L, c, r, a0 - K, a0 + K, [&](float x, float y, float z, int j, int p, bool ok) {
-        const float d = sqdist3(x, y, z, ax, ay, az);
-        bool take = ok && d <= t_r;
-        if (take && d > t_nn) {  // beyond the all-points radius: only what the walk claims cover
-          int rk;
-          if (none)
-            take = walk_rank(w, j, rk);
-          else if (dr > 0)
-            take = j < fend;
-        }
-        if (take) {
-          if (count < kSplitK) cb[(size_t)count * stride] = split_pack(x, y, z, j, r);
-          ++count;
-        }
-      });
-    }
-    rec.j1 = j1;
-    if (count <= kSplitK) {  // (an overflowing list claims nothing: the list kernel searches exhaustively)
-      rec.r_nn = r_nn, rec.r2 = r2, rec.r3 = r3;
-      rec.meta = count | (rho0 << 8) | (flags << 16);
-    } else {
-      rec.meta = rho0 << 8;
-    }
-  } else if (!(ga.pad & 128)) {
-    // No target inside the search radius (SE:851 leaves such a feature out).  To keep saying so without searching,
-    // the list kernel needs to know that nothing comes close: everything within the search radius + margin of the
-    // anchor is listed (normally nothing at all) — "still none" then holds while the query drifts less than the margin.
-    const float r_nn = sqrtf(ga.thr) * (1.f + 2e-6f) + ga.margin;
-    const float rb = r_nn * (1.f + 2e-6f) + 1e-6f, t_nn = r_nn * r_nn * (1.f + 4e-6f);
-    const float delta = reach_elev(qp.qn3, rb);
-    const int K = reach(c, qp.rho, rb), a0 = qp.a0_surf_or_corner;
-    int count = 0;
-#pragma unroll 1
-    for (int r = 0; r < kRingsBinned; ++r) {
-      if (!ring_nonempty(c, r) || !ring_in_reach(c, r, qp.el, delta)) continue;
-      scan_cols(L, c, r, a0 - K, a0 + K, [&](float x, float y, float z, int j, int p, bool ok) {
-        if (ok && sqdist3(x, y, z, ax, ay, az) <= t_nn) {
-          if (count < kSplitK) cb[(size_t)count * stride] = split_pack(x, y, z, j, r);
-          ++count;
-        }
-      });
-    }
-    if (count <= kSplitK) rec.r_nn = r_nn, rec.meta = count | (0xFF << 8);  // (rho0 = 255: no class claims)
-  }
-  *out = rec;
-}
-
-// ---------------------------------------------------------------------------
 // the kernel.  PASS_ONLY: one correspondence pass at a caller-supplied linearisation
 // state (lins_correspondences / lins_reduce_pass), dumping records / sums.
 // ---------------------------------------------------------------------------
-template <int BLOCK, int LANES, bool PASS_ONLY, bool PROF, bool ICP = false, bool SPLIT = false>
+template <int BLOCK, int LANES, bool PASS_ONLY, bool PROF, bool ICP = false>
 #if LINS_LDS_MINW > 1
-// (second argument: waves per SIMD the register allocation must allow.  A 256-thread workgroup — LINS_LDS_CARRY2 —
-// has half the waves, so two resident workgroups leave each wave twice the registers.)
-__global__ __launch_bounds__(BLOCK, BLOCK >= 512 ? LINS_LDS_MINW : LINS_LDS_MINW / 2) void ieskf_lds_kernel(
+// (second argument: waves per SIMD the register allocation must allow)
+__global__ __launch_bounds__(BLOCK, LINS_LDS_MINW) void ieskf_lds_kernel(
 #else
 __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #endif
-    DevParams prm, const ScanDesc* __restrict__ descs, const float4* __restrict__ arena, float4* __restrict__ sorted,
+    DevParams prm, const ScanDesc* __restrict__ descs, const int* __restrict__ order, const float4* __restrict__ arena,
+    float4* __restrict__ sorted,
     const double* __restrict__ state_in, const double* __restrict__ cov_in, const double* __restrict__ lin_in,
     int iter_arg, double* __restrict__ state_out, double* __restrict__ a6_out, OutRec* __restrict__ out,
     int4* __restrict__ idx_store, lins_pose_record* __restrict__ poses, int scan_id_base,
     lins_corr* __restrict__ dump, double* __restrict__ sums_out, int* __restrict__ counts_out,
-    long long* __restrict__ prof_buf, SplitScan* __restrict__ hand = nullptr, SplitQ* __restrict__ hq = nullptr,
-    float4* __restrict__ hcand = nullptr) {
-  static_assert(!SPLIT || (LANES == 1 && !PASS_ONLY && !ICP), "the split hand-off exists for the one-owner-lane update kernel");
+    long long* __restrict__ prof_buf) {
   constexpr bool prof = PROF;  // phase profile compiled in only for the debug variant
   constexpr int kLBlock = BLOCK, kQPerWave = 64 / LANES, kQPerRound = (BLOCK / 64) * kQPerWave;
-  static_assert((kRegReduce || kQPerRound <= kSlotCap) && BLOCK >= 256 && BLOCK / 64 <= kMaxLWaves, "block shape");
+  static_assert(BLOCK >= 256 && BLOCK / 64 <= kMaxLWaves, "block shape");
   // (LANES > 1 is dispatched for single-round scans only, see effective_search() in lins_capi.hip)
   LdsStore& L = g_lds;
   // optional phase profile: [0] setup+grid build [1] correspondence [2] reduction [3] solve [4] update [5] total
@@ -1148,7 +977,10 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   if (prof && threadIdx.x < 16) g_lds.prof_acc[threadIdx.x] = 0;
   const long long t_begin = prof ? clock64() : 0, t_wall_begin = prof ? wall_clock64() : 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int scan = blockIdx.x;
+  // Launch order: workgroup b takes scan order[b] — the host lists the scans longest-expected-first (lins_capi.hip
+  // launch_order: by the prior's translation, the best predictor of a scan's search work the host has), so that the
+  // dispatcher, which hands workgroups out in index order as slots free up, ends the launch with the short ones.
+  const int scan = order ? order[blockIdx.x] : (int)blockIdx.x;
   const ScanDesc sd = descs[scan];
   const int total = sd.n_surf_q + sd.n_corner_q;
   // hybrid storage: this scan's slice of the sorted copy (same offsets as its targets in the arena:
@@ -1199,18 +1031,6 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   float lb1 = 0.f, lb2 = 0.f, lb3 = 0.f, certA[3] = {0.f, 0.f, 0.f}, certB[3] = {0.f, 0.f, 0.f};
   bool have_cert = false;
   bool searched = false;  // a search iteration has run: certificates and warm candidates exist (uniform)
-#ifdef LINS_LDS_CARRY2
-  // A scan with more queries than lanes (up to twice as many) takes TWO rounds per iteration, and every lane keeps
-  // the tracked candidates and certificates of BOTH its queries: the set of the round that is not running waits in
-  // the shadow registers below, the two sets are exchanged after each round (2 x 19 register moves — the round body
-  // exists once).  This is what lets the batch kernel run as 256-thread workgroups: half the waves, twice the
-  // registers per wave, no scratch.
-  int sh_i[9] = {-1, -1, -1, -1, -1, -1, -1, -1, -1};
-  float sh_f[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  constexpr bool kCarry2 = LANES == 1;
-#else
-  constexpr bool kCarry2 = false;
-#endif
 
   for (;;) {
     const int iter = L.iter;
@@ -1239,8 +1059,6 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     }
     const bool spread = LANES == 1 && (spread_s | spread_c) != 0;
     const int span = spread ? kQPerRound : (aligned ? surf_waves * kQPerWave + sd.n_corner_q : total);  // row slots in use
-    const bool two_rounds = kCarry2 && span > kQPerRound && span <= 2 * kQPerRound;  // both rounds' state is carried
-    const int per_wave2 = (total + BLOCK / 64 - 1) / (BLOCK / 64);  // two rounds: queries per wave, 64 in the first round
     int4 held = make_int4(0, 0, 0, -1);  // (ICP, ICP_FREQ > 1, single round) a corner triplet waiting for the plane-row count
     for (int base = 0; base < span; base += kQPerRound) {
       const int vslot = base + wave * kQPerWave + q_in_wave;  // position in the (padded) layout
@@ -1257,12 +1075,8 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         else
           slot = vslot - surf_waves * kQPerWave + sd.n_surf_q;
       }
-      if (two_rounds) {  // wave w serves queries [w * per, (w + 1) * per): its first 64 in round 0, the rest in round 1
-        const int k = (base ? 64 : 0) + lane;
-        slot = wave * per_wave2 + k, active = k < per_wave2 && slot < total;
-      }
       double row[7] = {0, 0, 0, 0, 0, 0, 0};
-      if (span > kQPerRound && !two_rounds) {  // several rounds: the lane <-> query mapping changes, nothing carries over
+      if (span > kQPerRound) {  // several rounds: the lane <-> query mapping changes, nothing carries over
         a1 = b1c = ra1 = rb1 = a2 = b2c = a3 = b3c = sel1 = -1, have_cert = false;
         lb1 = lb2 = lb3 = 0.f;
       }
@@ -1276,7 +1090,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         const int qi = is_surf ? slot : slot - sd.n_surf_q;
         const LCloud& c = is_surf ? cs : cc;
         const float thr = prm.nearest_f;
-        const bool single_round = span <= kQPerRound || two_rounds;  // (the lane <-> query mapping is fixed)
+        const bool single_round = span <= kQPerRound;  // (the lane <-> query mapping is fixed)
         const bool warm_iter = single_round && searched;  // certificates / warm candidates exist (uniform)
         const float margin = warm_iter ? prm.margin_warm : prm.margin_cold;
         const bool verify = (prm.pad & 8) != 0;  // test aid: search anyway and count disagreements
@@ -1729,52 +1543,16 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         if (prof && tid == 0) L.prof_acc[9] += clock64() - s3;
 #endif
       }
-#ifdef LINS_LDS_CARRY2
-      if (two_rounds) {  // the other round's set becomes current
-        auto xi = [](int& a, int& b) { const int t = a; a = b, b = t; };
-        auto xf = [](float& a, float& b) { const float t = a; a = b, b = t; };
-        xi(a1, sh_i[0]), xi(b1c, sh_i[1]), xi(ra1, sh_i[2]), xi(rb1, sh_i[3]), xi(a2, sh_i[4]), xi(b2c, sh_i[5]);
-        xi(a3, sh_i[6]), xi(b3c, sh_i[7]), xi(sel1, sh_i[8]);
-        xf(lb1, sh_f[0]), xf(lb2, sh_f[1]), xf(lb3, sh_f[2]);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) xf(certA[k], sh_f[3 + k]), xf(certB[k], sh_f[6 + k]);
-      }
-#endif
-      if (kRegReduce) {
-        if (prof) t1 = clock64();
+      if (prof) t1 = clock64();
 #ifdef LINS_PROF_WAVES  // (experiment: per-wave correspondence time of the late iterations in slots 6..13)
-        if (prof && lane == 0 && iter >= LINS_PROF_WAVES) L.prof_acc[6 + wave] += t1 - t0;
+      if (prof && lane == 0 && iter >= LINS_PROF_WAVES) L.prof_acc[6 + wave] += t1 - t0;
 #endif
-        if (!(prm.pad & 0x40000)) acc += wave_reduce_rows(row, lane);  // no LDS, no barrier: the rows never leave registers
-      } else {
-        if (lane_used && role == 0) {
-          const int local = wave * kQPerWave + q_in_wave;
-#pragma unroll
-          for (int k = 0; k < 7; ++k) L.slots[local * 7 + k] = row[k];
-        }
-        __syncthreads();
-        if (prof) t1 = clock64();
-        // rows -> 28 sums, every wave takes part: half-wave h of wave w folds rows 2w+h, 2w+h+G, ...
-        // (G = 2 * waves) in order, the two halves are added, then the wave partials are folded in
-        // wave order.  The tree is fixed, so the sums are bit-reproducible from run to run.
-        const int nrows = span - base < kQPerRound ? span - base : kQPerRound;
-        {
-          constexpr int G = 2 * (BLOCK / 64);
-          const int k = lane & 31;
-          const int a = kLPairA[k < 28 ? k : 0], b = kLPairB[k < 28 ? k : 0];
-#pragma unroll 2
-          for (int r = 2 * wave + (lane >> 5); r < nrows; r += G) acc += L.slots[r * 7 + a] * L.slots[r * 7 + b];
-        }
-        __syncthreads();
-      }
+      if (!(prm.pad & 0x40000)) acc += wave_reduce_rows(row, lane);  // no LDS, no barrier: the rows never leave registers
     }
     if (do_search) searched = true;
-    if (kRegReduce) {
+    {
       const int sidx28 = reduce_sum_index(lane);
       if (sidx28 >= 0) L.partial[wave * 28 + sidx28] = acc;
-    } else {
-      acc += __shfl_down(acc, 32);
-      if (lane < 28) L.partial[wave * 28 + lane] = acc;
     }
     if (ms) atomicAdd(&L.m_surf, ms);
     if (mc) atomicAdd(&L.m_corner, mc);
@@ -1805,70 +1583,6 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       icp_solve_and_update(tid, iter);
     else
       t3 = solve_and_update(prm.r2, prm.fixed_iters, prm.pad, tid, iter, prof);
-    if constexpr (SPLIT) {
-      // split path (ieskf_split.h): after the update of iteration split_iters - 1 the remaining iterations go to the
-      // list kernel.  Every query leaves its candidate list, gathered around its position de-skewed with the NEW
-      // state (the "anchor") with radii from this iteration's winners — still candidates, so their distances to the
-      // anchor bound the new winners'.  (A search pass at the new state before gathering gives exact radii and
-      // fewer exhaustive searches in the list kernel, but costs more than it saves: measured.)
-      if (iter + 1 >= prm.split_iters && iter + 1 < prm.num_iter && !L.conv && !L.div) {
-        constexpr int kW = BLOCK / 64, kSS = LINS_SPREAD_S > 0 && BLOCK == 512 ? LINS_SPREAD_S : (kW * 5 + 4) / 8;
-        int sw = (sd.n_surf_q + kQPerWave - 1) / kQPerWave;
-        const bool al = sw * kQPerWave + sd.n_corner_q <= kQPerRound;
-        int sp_s = 0, sp_c = 0;
-        {
-          const int ws = kSS, wc = LINS_SPREAD_C > 0 && BLOCK == 512 ? LINS_SPREAD_C : kW - ws;
-          const int ps = (sd.n_surf_q + ws - 1) / ws, pc = wc > 0 ? (sd.n_corner_q + wc - 1) / wc : 65;
-          if (ws < kW && ps <= 64 && pc <= 64) sp_s = ps, sp_c = pc, sw = ws;
-        }
-        const bool spr = (sp_s | sp_c) != 0;
-        const int spn = spr ? kQPerRound : (al ? sw * kQPerWave + sd.n_corner_q : total);
-        const int vs = wave * kQPerWave + q_in_wave;
-        int slot = vs;
-        bool active = lane_used && vs < spn;
-        if (spr) {
-          if (wave < sw)
-            slot = wave * sp_s + lane, active = lane < sp_s && slot < sd.n_surf_q;
-          else
-            slot = sd.n_surf_q + (wave - sw) * sp_c + lane, active = lane < sp_c && slot < total;
-        } else if (al) {
-          if (wave < sw)
-            active = active && vs < sd.n_surf_q;
-          else
-            slot = vs - sw * kQPerWave + sd.n_surf_q;
-        }
-        active = active && slot < total;
-        if (active) {
-          const bool is_surf = slot < sd.n_surf_q;
-          const int qi = is_surf ? slot : slot - sd.n_surf_q;
-          const LCloud& c = is_surf ? cs : cc;
-          const float4 q = arena[(is_surf ? sd.off_surf_q : sd.off_corner_q) + qi];
-          const V3 phi = L.ic.phi, t{L.ic.lin[0], L.ic.lin[1], L.ic.lin[2]};
-          float ax, ay, az;
-          transform_to_start(prm, phi, t, q, ax, ay, az, g_lds.trig);
-          // (a tracked candidate beyond the search radius is no winner)
-          const float thr = prm.nearest_f;
-          const int w1 = (a1 >= 0 && pt_sqdist(L, c, a1, ax, ay, az) < thr) ? a1 : -1;
-          const int w2 = (a2 >= 0 && pt_sqdist(L, c, a2, ax, ay, az) < thr) ? a2 : -1;
-          const int w3 = (a3 >= 0 && pt_sqdist(L, c, a3, ax, ay, az) < thr) ? a3 : -1;
-          split_gather(GatherArgs{is_surf, is_surf ? sd.n_surf_q : sd.n_corner_q, sd.n_corner_t, sd.n_surf_t, n_lds, w1, w2, w3, ra1,
-                                  total, prm.pad, prm.nearest_f, prm.split_margin, ax, ay, az},
-                       gs, hq + sd.slot_base + slot, hcand + (size_t)kSplitK * sd.slot_base + slot);
-        }
-        SplitScan* hs = hand + scan;
-        if (tid < 19) hs->lin[tid] = L.ic.lin[tid];
-        if (tid >= 32 && tid < 32 + 2 * (kRingsBinned + 1)) {
-          const int k = tid - 32, cl = k / (kRingsBinned + 1), r = k % (kRingsBinned + 1);
-          hs->ring_start[cl][r] = L.ring_start[cl][r];
-        }
-        if (tid == 0) {
-          hs->res_prev = L.res_prev, hs->res_last = L.res_last, hs->upd_norm = L.upd_norm;
-          hs->iter = iter + 1, hs->status = SPLIT_CONTINUE;
-          hs->dbg[0] = L.dbg[0], hs->dbg[1] = L.dbg[1], hs->dbg[2] = L.dbg[2], hs->dbg[3] = 0;
-        }
-        return;
-      }
-    }
     if (prof) {
       long long t4 = clock64();
       if (tid == 0) {
@@ -1891,7 +1605,6 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     for (int k = 0; k < 16; ++k) prof_out[(size_t)scan * 16 + k] = L.prof_acc[k];
   }
 
-  if (SPLIT && tid == 0) hand[scan].status = SPLIT_DONE;  // finished here (converged / diverged / out of iterations)
   // ---- hand-off to the Joseph kernel / the caller (SE:585-598) ---------------
   const int div = L.div;
   if (ICP) {  // filterState with rn_, qbn_ replaced (SE:590-592); the covariance is the caller's, un-updated

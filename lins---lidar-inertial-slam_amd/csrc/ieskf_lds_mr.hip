@@ -15,44 +15,35 @@
 // <= 128 / 80 VGPRs even when LDS would allow it); three workgroups per CU at 96 VGPRs (588 B of
 // scratch per lane: no faster than two).
 #define LINS_LDS_NS lds_mr
-// 16-byte point records (x, y, z, original index bits): a candidate is ONE ds_read_b128 instead of three b32 reads and a
-// u16 read at four different addresses; 4224 instead of 4736 positions fit (measured: -2.9 % kernel time; LDS
-// instructions and bank conflicts in DESIGN.md section 7).  The full-residency shapes keep the 14-byte SoA layout: their
-// point is to hold a whole scan.
-#define LINS_LDS_AOS 1
+// (16-byte point records (x, y, z, original index bits): a candidate is ONE ds_read_b128; round 1's 14-byte SoA layout
+// held 4736 instead of 4224 positions but cost four reads per candidate: +2.9 % kernel time, removed in round 3)
 #define LINS_LDS_CAP 4208  // (4224 until 16 positions made room for the de-skew's coefficient table)
 #define LINS_LDS_NMAX 12288
 #ifndef LINS_LDS_SCANBATCH
 #define LINS_LDS_SCANBATCH 2  // (measured: 1 -> 7.9, 2 -> 8.1, 3 -> 8.0, 4 -> 7.75, 8 -> 7.1 M it/s at 128 VGPRs;
                               // re-timed at the end of round 2: 3 -> -0.5 % (noise, 18 spilled registers), 4 -> +2 %)
 #endif
-#define LINS_LDS_REGREDUCE 1
 #define LINS_LDS_WAVES 8
 #define LINS_LDS_MINW 4
-#ifndef LINS_MR_BLOCK
 #define LINS_MR_BLOCK 512
-#endif
-#if LINS_MR_BLOCK == 256
-#define LINS_LDS_CARRY2 1
-#endif
 #define LINS_LDS_BYTES 80896
 #include "ieskf_lds_impl.h"
 
 namespace lins {
 
 #define LINS_LAUNCH(NS, B, LN, PR)                                                                                  \
-  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, false, PR>), dim3(n), dim3(B), 0, stream, prm, descs, arena, sorted, \
+  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, false, PR>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, \
                      state_in, cov_in, (const double*)nullptr, 0, state_out, a6, (NS::OutRec*)out, idx_store, poses,  \
                      scan_id_base, (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof)
 #define LINS_LAUNCH_PASS(NS, B, LN)                                                                                    \
-  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, true, false>), dim3(n), dim3(B), 0, stream, prm, descs, arena, sorted, \
+  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, true, false>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, \
                      filt_state, (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr,           \
                      (NS::OutRec*)nullptr, idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out,        \
                      (long long*)nullptr)
 
 int lds_mr_np_cap() { return lds_mr::kNpMax; }
 
-void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
+void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const int* order, const float4* arena,
                    float4* sorted, const double* state_in, const double* cov_in, double* state_out, double* a6,
                    void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof) {
   if (prof)
@@ -61,23 +52,12 @@ void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDe
     LINS_LAUNCH(lds_mr, LINS_MR_BLOCK, 1, false);
 }
 
-// split path (ieskf_split.h): the first prm.split_iters iterations + the candidate lists for the list kernel
-void launch_lds_mr_split(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
-                         float4* sorted, const double* state_in, const double* cov_in, double* state_out, double* a6,
-                         void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, void* hand, void* hq,
-                         float4* hcand) {
-  hipLaunchKernelGGL((lds_mr::ieskf_lds_kernel<512, 1, false, false, false, true>), dim3(n), dim3(512), 0, stream, prm, descs,
-                     arena, sorted, state_in, cov_in, (const double*)nullptr, 0, state_out, a6, (lds_mr::OutRec*)out, idx_store,
-                     poses, scan_id_base, (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, (long long*)nullptr,
-                     (SplitScan*)hand, (SplitQ*)hq, hcand);
-}
-
 // ICP / Gauss-Newton fallback (estimateTransform, SE:1163-1320) on the same grid and searches:
 // state_in = the pose to start from (the filter's), state_out = that state with rn_, qbn_ replaced
 void launch_lds_mr_icp(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
                        float4* sorted, const double* state_in, double* state_out, void* out, int4* idx_store) {
   hipLaunchKernelGGL((lds_mr::ieskf_lds_kernel<512, 1, false, false, true>), dim3(n), dim3(512), 0, stream, prm, descs,
-                     arena, sorted, state_in, state_in /*unused: no covariance on this path*/, (const double*)nullptr, 0,
+                     (const int*)nullptr, arena, sorted, state_in, state_in /*unused: no covariance on this path*/, (const double*)nullptr, 0,
                      state_out, (double*)nullptr, (lds_mr::OutRec*)out, idx_store, (lins_pose_record*)nullptr, 0,
                      (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, (long long*)nullptr);
 }
@@ -85,6 +65,7 @@ void launch_lds_mr_icp(hipStream_t stream, int n, const DevParams& prm, const Sc
 void launch_lds_mr_pass(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
                         float4* sorted, const double* lin_state, const double* filt_state, int iter,
                         int4* idx_store, lins_corr* dump, double* sums_out, int* counts_out) {
+  const int* order = nullptr;
   LINS_LAUNCH_PASS(lds_mr, 512, 1);
 }
 

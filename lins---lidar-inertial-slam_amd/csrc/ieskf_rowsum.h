@@ -1,5 +1,5 @@
 // ieskf_rowsum.h — register-level building blocks shared by the persistent LDS kernel (ieskf_lds_impl.h) and
-// the list kernel of the split path (ieskf_k1.hip): the 6x6 solve, the next iteration's constants and the
+// (until round 3 also the list kernel of the split path): the 6x6 solve, the next iteration's constants and the
 // wave-level reduction of the H rows to the 28 sums.  Pure functions of their arguments (no LDS, no globals).
 #pragma once
 

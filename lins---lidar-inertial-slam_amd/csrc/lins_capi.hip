@@ -30,27 +30,20 @@ void launch_persistent(hipStream_t, int, const DevParams&, const ScanDesc*, cons
 void launch_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const double*, const double*,
                  int, int4*, lins_corr*, double*, int*, float4*);
 void launch_joseph(hipStream_t, int, const DevParams&, const double*, const double*, const void*, double*);
-void launch_lds(hipStream_t, int, const DevParams&, int, const ScanDesc*, const float4*, const double*, const double*,
+void launch_lds(hipStream_t, int, const DevParams&, int, const ScanDesc*, const float4*, float4*, const double*, const double*,
                 double*, double*, void*, int4*, lins_pose_record*, int, long long*);
-void launch_lds_pass(hipStream_t, int, const DevParams&, int, const ScanDesc*, const float4*, const double*,
+void launch_lds_pass(hipStream_t, int, const DevParams&, int, const ScanDesc*, const float4*, float4*, const double*,
                      const double*, int, int4*, lins_corr*, double*, int*);
 int lds_np_cap();
-void launch_lds_mr(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, float4*, const double*,
+void launch_lds_mr(hipStream_t, int, const DevParams&, const ScanDesc*, const int*, const float4*, float4*, const double*,
                    const double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*);
 void launch_lds_mr_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, float4*, const double*,
                         const double*, int, int4*, lins_corr*, double*, int*);
 int lds_mr_np_cap();
-void launch_lds_mr_split(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, float4*, const double*,
-                         const double*, double*, double*, void*, int4*, lins_pose_record*, int, void*, void*, float4*);
-void launch_k1(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const void*, const void*, const float4*,
-               const double*, const double*, double*, double*, void*, lins_pose_record*, int, lins_corr*, int, long long*);
 void launch_debug_math(hipStream_t, int, int, int, int, const double*, double*);
 void launch_debug_cycles(hipStream_t, int, int, const double*, double*);
 void launch_debug_wave_solve(hipStream_t, int, int, const double*, double*);
 void launch_debug_reduce_rows(hipStream_t, int, int, const double*, double*);
-size_t split_scan_size();
-size_t split_q_size();
-size_t split_cand_slots();
 void launch_lds_mr_icp(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, float4*, const double*, double*,
                        void*, int4*);
 void launch_transform_to_end(hipStream_t, int, int, const void*, const float4*, float4*, float4*);
@@ -102,16 +95,7 @@ struct lins_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;  // IESKF kernel start / end, Joseph kernel end
   hipStream_t copy_stream = nullptr;  // lins_ieskf_update_batch: uploads of the next chunk beside the running one
   hipEvent_t ev_copy = nullptr;
-  hipEvent_t ev_k0 = nullptr;  // split path: end of the grid kernel (ev0 .. ev_k0 = grid kernel, ev_k0 .. ev1 = list kernel)
-  // split path (ieskf_split.h): hand-off buffers, allocated on first use for the uploaded query slots
-  void *d_split_hand = nullptr, *d_split_q = nullptr;
-  float4* d_split_c = nullptr;
-  size_t split_slots = 0;       // slots the hand-off buffers hold
   size_t slots_uploaded = 0;    // query slots of the uploaded batch
-  bool split_ok = false;        // every uploaded scan can take the split path
-  bool last_split = false;      // the last batch ran the split path
-  lins_corr* d_split_dump = nullptr;  // debug: the list kernel's correspondences of one iteration (lins_debug_split_dump)
-  int split_dump_iter = -1;
   lins_params prm{};
   DevParams dprm{};
   int max_batch = 0, max_targets = 0;
@@ -126,6 +110,8 @@ struct lins_ctx {
   float4* d_arena = nullptr;
   float4* d_binned = nullptr;  // (ring x column)-sorted copies of the target clouds
   ScanDesc* d_desc = nullptr;
+  bool use_order = true;  // (LINS_LAUNCH_ORDER=0 with the debug gate: index order, for A/B timing)
+  int *h_order = nullptr, *d_order = nullptr;  // launch order of the uploaded batch (longest-expected-first), see launch_order()
   double *d_state_in = nullptr, *d_cov_in = nullptr, *d_state_out = nullptr, *d_cov_out = nullptr;
   double* d_lin = nullptr;
   float4* d_aux = nullptr;     // third point arena (YZX copies of the re-projection), lazily allocated
@@ -250,8 +236,6 @@ void make_dev_params(const lins_params& p, int search, DevParams& d) {
   d.pad = 0;
   d.margin_cold = 0.20f;  // (metres; swept on the batch workload after the late iterations got cheaper: 0.10 / 0.04 -> 0.789 ms, 0.20 / 0.08 -> 0.771 ms)
   d.margin_warm = 0.08f;
-  d.split_iters = 3;
-  d.split_margin = 0.10f;
   // Tuning / profiling knobs, honoured only when LINS_ENABLE_DEBUG_KNOBS=1 is set as well: a stray variable in a
   // production environment changes nothing.  The margins only trade search work for certificate hits (any value
   // >= 0 gives the same results); LINS_DEBUG_SKIP deliberately breaks the searches (profiling aid).
@@ -259,8 +243,6 @@ void make_dev_params(const lins_params& p, int search, DevParams& d) {
   if (gate && gate[0] == '1') {
     if (const char* e = std::getenv("LINS_MARGIN_COLD")) d.margin_cold = std::max(0.f, (float)std::atof(e));
     if (const char* e = std::getenv("LINS_MARGIN_WARM")) d.margin_warm = std::max(0.f, (float)std::atof(e));
-    if (const char* e = std::getenv("LINS_SPLIT_ITERS")) d.split_iters = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("LINS_SPLIT_MARGIN")) d.split_margin = std::max(0.f, (float)std::atof(e));
     if (const char* e = std::getenv("LINS_DEBUG_SKIP")) d.pad = std::atoi(e);  // 1 = skip walks, 2 = skip search, 8 = verify
   }
 }
@@ -271,7 +253,6 @@ void make_dev_params(const lins_params& p, int search, DevParams& d) {
 // front-end can emit) take the 1-lane shapes, whose several-rounds path is the tested one.
 int effective_search(const lins_ctx* ctx, int n) {
   int s = ctx->dprm.search;
-  if (s == SEARCH_SPLIT) s = SEARCH_MR;  // (the split path exists for lins_batch_run; its grid half IS the mr kernel)
   if (s == SEARCH_AUTO) s = n > ctx->n_cu ? (int)SEARCH_MR : (int)SEARCH_LDS3;
   if (s == SEARCH_LDS3 && !ctx->lds3_ok) s = SEARCH_LDS;
   return s;
@@ -368,7 +349,7 @@ struct CallTrace {
 };
 
 struct RangeFlags {  // which kernel families the scans of a range can take
-  bool lds_ok = true, mr_ok = true, lds3_ok = true, split_ok = true;
+  bool lds_ok = true, mr_ok = true, lds3_ok = true;
 };
 
 // pass 1 (serial, cheap): argument checks and the arena layout of the whole batch
@@ -436,14 +417,10 @@ RangeFlags range_flags(const lins_ctx* ctx, int lo, int hi) {
   for (int s = lo; s < hi; ++s) {
     const ScanDesc& d = ctx->h_desc[s];
     const bool grid = d.surf_sorted && d.corner_sorted;
-    // split path: one round of the 512-lane grid kernel (its lane <-> query layout spreads <= 5 x 64 plane and
-    // <= 3 x 64 line queries over the eight waves), 16-bit candidate indices
-    if (d.n_surf_q > 320 || d.n_corner_q > 192 || d.n_surf_t > 65535 || d.n_corner_t > 65535) fl.split_ok = false;
     if (!grid || d.n_surf_t + d.n_corner_t > lds_np_cap()) fl.lds_ok = false;
     if (!grid || d.n_surf_t + d.n_corner_t > lds_mr_np_cap()) fl.mr_ok = false;
     if (d.n_surf_q + d.n_corner_q > 336) fl.lds3_ok = false;  // (16 waves x 21 query slots = the VLP-16 caps, 144 flat + 192 sharp)
   }
-  fl.split_ok = fl.split_ok && fl.mr_ok;
   return fl;
 }
 
@@ -461,10 +438,28 @@ int h2d_range(lins_ctx* ctx, int lo, int hi, size_t arena_end, hipStream_t st) {
 
 void set_batch_state(lins_ctx* ctx, int n, const RangeFlags& fl, size_t slots, uint64_t bytes) {
   ctx->n_uploaded = n;
-  ctx->lds_ok = fl.lds_ok, ctx->mr_ok = fl.mr_ok, ctx->lds3_ok = fl.lds3_ok, ctx->split_ok = fl.split_ok;
+  ctx->lds_ok = fl.lds_ok, ctx->mr_ok = fl.mr_ok, ctx->lds3_ok = fl.lds3_ok;
   ctx->slots_uploaded = slots;
   ctx->ran = false;
   ctx->bytes_per_iter = bytes;
+}
+
+// Launch order of a batch on the multi-resident kernel: 1024 workgroups on 512 slots is two "rounds", and the dispatcher
+// hands workgroups out in index order — so the launch ends when the slowest pairing of an early and a late workgroup
+// does.  Listing the scans longest-expected-first (LPT) lets the short ones fill the end.  What the host knows before
+// the launch: cloud sizes (R^2 = 0.004 against measured workgroup times — useless) and the prior; the prior's
+// translation |p| (= how far the clouds are apart before the first iteration, hence how many re-searches the first
+// iterations need) correlates 0.40.  Measured on the batch workload (tools/wg_cost_model.py, list-scheduling model on
+// measured per-workgroup times: as submitted 843 us, by |p| 731 us, by the true durations 726 us, perfectly divisible
+// work 583 us).  Results do not depend on the order (one workgroup per scan, no cross-scan state).
+void launch_order(lins_ctx* ctx, int n) {
+  std::vector<std::pair<double, int>> key(n);
+  for (int s = 0; s < n; ++s) {
+    const double* st = ctx->h_state + (size_t)s * 19;
+    key[s] = {-(st[0] * st[0] + st[1] * st[1] + st[2] * st[2]), s};
+  }
+  std::sort(key.begin(), key.end());
+  for (int s = 0; s < n; ++s) ctx->h_order[s] = key[s].second;
 }
 
 int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
@@ -476,6 +471,8 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
   if ((rc = parallel_scans(n, [&](int s) { return pack_one(ctx, in, s); }))) return rc;
   const RangeFlags fl = range_flags(ctx, 0, n);
   if ((rc = h2d_range(ctx, 0, n, off, ctx->stream))) return rc;
+  launch_order(ctx, n);
+  if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->h_order, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   set_batch_state(ctx, n, fl, slots, bytes);
   return LINS_OK;
@@ -486,7 +483,6 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
 // not depend on how the batch was cut)
 int run_range(lins_ctx* ctx, int lo, int cnt, int n_total, const RangeFlags& fl, lins_pose_record* poses, int32_t scan_id_base) {
   int s = ctx->dprm.search;
-  if (s == SEARCH_SPLIT) s = SEARCH_MR;
   if (s == SEARCH_AUTO) s = n_total > ctx->n_cu ? (int)SEARCH_MR : (int)SEARCH_LDS3;
   if (s == SEARCH_LDS3 && !fl.lds3_ok) s = SEARCH_LDS;
   const bool want_lds = s >= SEARCH_LDS, want_mr = s == SEARCH_MR;
@@ -499,10 +495,10 @@ int run_range(lins_ctx* ctx, int lo, int cnt, int n_total, const RangeFlags& fl,
   lins_pose_record* ps = poses ? poses + lo : nullptr;
   if (use_mr || use_lds) {
     if (use_mr)
-      launch_lds_mr(ctx->stream, cnt, ctx->dprm, desc, ctx->d_arena, ctx->d_binned, st_in, cov_in, st_out, a6, out, ctx->d_idx, ps,
+      launch_lds_mr(ctx->stream, cnt, ctx->dprm, desc, nullptr, ctx->d_arena, ctx->d_binned, st_in, cov_in, st_out, a6, out, ctx->d_idx, ps,
                     scan_id_base + lo, nullptr);
     else
-      launch_lds(ctx->stream, cnt, ctx->dprm, s == SEARCH_LDS3 ? 3 : 1, desc, ctx->d_arena, st_in, cov_in, st_out, a6, out,
+      launch_lds(ctx->stream, cnt, ctx->dprm, s == SEARCH_LDS3 ? 3 : 1, desc, ctx->d_arena, ctx->d_binned, st_in, cov_in, st_out, a6, out,
                  ctx->d_idx, ps, scan_id_base + lo, nullptr);
     launch_joseph(ctx->stream, cnt, ctx->dprm, cov_in, a6, out, cov_out);
   } else {
@@ -546,6 +542,9 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   ctx->device = device;
   ctx->prm = *params;
   make_dev_params(*params, SEARCH_AUTO, ctx->dprm);  // (ineligible clouds fall back to the exact exhaustive paths)
+  if (const char* g = std::getenv("LINS_ENABLE_DEBUG_KNOBS"))
+    if (g[0] == '1')
+      if (const char* e = std::getenv("LINS_LAUNCH_ORDER")) ctx->use_order = e[0] != '0';
   ctx->max_batch = max_batch;
   ctx->max_targets = max_targets;
   ctx->arena_cap = (size_t)max_batch * (2 * align4(max_targets) + 2 * LINS_MAX_QUERY);
@@ -572,10 +571,11 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   CREATE_TRY(hipEventCreate(&ctx->ev0));
   CREATE_TRY(hipEventCreate(&ctx->ev1));
   CREATE_TRY(hipEventCreate(&ctx->ev2));
-  CREATE_TRY(hipEventCreate(&ctx->ev_k0));
   const size_t nb = (size_t)max_batch;
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_arena, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_desc, nb * sizeof(ScanDesc)));
+  CREATE_TRY(hipHostMalloc((void**)&ctx->h_order, nb * sizeof(int)));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_order, nb * sizeof(int)));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_state, nb * 19 * 8));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_cov, nb * 324 * 8));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_out, nb * sizeof(OutRecHost)));
@@ -605,6 +605,7 @@ void lins_destroy(lins_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   (void)hipHostFree(ctx->h_arena);
   (void)hipHostFree(ctx->h_desc);
+  (void)hipHostFree(ctx->h_order), (void)hipFree(ctx->d_order);
   (void)hipHostFree(ctx->h_state);
   (void)hipHostFree(ctx->h_cov);
   (void)hipHostFree(ctx->h_out);
@@ -631,10 +632,8 @@ void lins_destroy(lins_ctx* ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
-  if (ctx->ev_k0) (void)hipEventDestroy(ctx->ev_k0);
   if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
-  (void)hipFree(ctx->d_split_hand), (void)hipFree(ctx->d_split_q), (void)hipFree(ctx->d_split_c), (void)hipFree(ctx->d_split_dump);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -651,13 +650,25 @@ int lins_set_search(lins_ctx* ctx, const char* mode) {
     ctx->dprm.search = SEARCH_LDS;
   else if (!std::strcmp(mode, "mr"))  // multi-resident: part of the grid in LDS, 2 scans per CU
     ctx->dprm.search = SEARCH_MR;
-  else if (!std::strcmp(mode, "split"))  // grid kernel for the first iterations, list kernel for the rest (ieskf_split.h)
-    ctx->dprm.search = SEARCH_SPLIT;
   else if (!std::strcmp(mode, "auto"))  // "mr" for batches larger than the CU count, "lds" otherwise
     ctx->dprm.search = SEARCH_AUTO;
   else
     return LINS_E_ARG;
   return LINS_OK;
+}
+
+/* The kernel family the last batch (or pass) actually ran: the requested mode after "auto" and the eligibility
+ * fall-backs were applied; "" before the first run. */
+const char* lins_last_search(const lins_ctx* ctx) {
+  if (!ctx) return "";
+  switch (ctx->last_search) {
+    case SEARCH_BRUTE: return "brute";
+    case SEARCH_BINNED: return "binned";
+    case SEARCH_LDS: return "lds1";
+    case SEARCH_LDS3: return "lds";
+    case SEARCH_MR: return "mr";
+    default: return "";
+  }
 }
 
 int lins_batch_upload(lins_ctx* ctx, int n, const lins_scan_pair* in) { return upload(ctx, n, in); }
@@ -666,44 +677,19 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   if (!ctx) return LINS_E_ARG;
   if (ctx->n_uploaded <= 0) return LINS_E_STATE;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  // split path: asked for by name; needs the reference's shipped ICP_FREQ = 1 (a search every iteration) and
-  // something left for the list kernel to do
-  const bool use_split = ctx->dprm.search == SEARCH_SPLIT && ctx->split_ok && ctx->dprm.icp_freq == 1 &&
-                         ctx->dprm.num_iter > ctx->dprm.split_iters;
-  if (use_split && ctx->split_slots < ctx->slots_uploaded) {  // (grow-only hand-off buffers)
-    (void)hipFree(ctx->d_split_hand), (void)hipFree(ctx->d_split_q), (void)hipFree(ctx->d_split_c);
-    ctx->d_split_hand = ctx->d_split_q = nullptr, ctx->d_split_c = nullptr, ctx->split_slots = 0;
-    const size_t slots = ctx->slots_uploaded;
-    HIP_TRY(ctx, hipMalloc(&ctx->d_split_hand, (size_t)ctx->max_batch * split_scan_size()));
-    HIP_TRY(ctx, hipMalloc(&ctx->d_split_q, slots * split_q_size()));
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_split_c, slots * split_cand_slots() * sizeof(float4)));
-    ctx->split_slots = slots;
-  }
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const int search = effective_search(ctx, ctx->n_uploaded);
   const bool want_lds = search >= SEARCH_LDS, want_mr = search == SEARCH_MR;
   const bool use_mr = want_mr && ctx->mr_ok, use_lds = want_lds && !want_mr && ctx->lds_ok;
-  ctx->last_search = use_split ? (int)SEARCH_SPLIT : (use_mr ? (int)SEARCH_MR : (use_lds ? search : (want_lds ? (int)SEARCH_BINNED : search)));
-  ctx->last_split = use_split;
-  if (use_split) {
-    if (ctx->d_prof) HIP_TRY(ctx, hipMemsetAsync(ctx->d_prof, 0, (size_t)ctx->max_batch * 16 * sizeof(long long), ctx->stream));
-    launch_lds_mr_split(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_binned, ctx->d_state_in,
-                        ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx, (lins_pose_record*)d_poses,
-                        scan_id_base, ctx->d_split_hand, ctx->d_split_q, ctx->d_split_c);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-    launch_k1(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_split_hand, ctx->d_split_q,
-              ctx->d_split_c, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_out,
-              (lins_pose_record*)d_poses, scan_id_base, ctx->d_split_dump, ctx->split_dump_iter, ctx->d_prof);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    launch_joseph(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_cov_in, ctx->d_a6, ctx->d_out, ctx->d_cov_out);
-  } else if (use_mr || use_lds) {
+  ctx->last_search = use_mr ? (int)SEARCH_MR : (use_lds ? search : (want_lds ? (int)SEARCH_BINNED : search));
+  if (use_mr || use_lds) {
     if (use_mr)
-      launch_lds_mr(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_binned, ctx->d_state_in,
+      launch_lds_mr(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->use_order ? ctx->d_order : nullptr, ctx->d_arena, ctx->d_binned, ctx->d_state_in,
                     ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx, (lins_pose_record*)d_poses,
                     scan_id_base, ctx->d_prof);
     else
       launch_lds(ctx->stream, ctx->n_uploaded, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc,
-                 ctx->d_arena, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx,
+                 ctx->d_arena, ctx->d_binned, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx,
                  (lins_pose_record*)d_poses, scan_id_base, ctx->d_prof);
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     launch_joseph(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_cov_in, ctx->d_a6, ctx->d_out, ctx->d_cov_out);
@@ -715,7 +701,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
                       (lins_pose_record*)d_poses, scan_id_base, ctx->d_binned, ctx->d_prof);
   }
   HIP_TRY(ctx, hipGetLastError());
-  if (!(use_split || use_mr || use_lds)) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  if (!(use_mr || use_lds)) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
   ctx->ran = true;
   return LINS_OK;
@@ -761,48 +747,6 @@ int lins_debug_math(lins_ctx* ctx, int op, int n, const double* in, int n_in, do
   return LINS_OK;
 }
 
-/* Split path: durations of the two kernels of the last lins_batch_run (ms, HIP events on the context's stream). */
-int lins_last_split_ms(lins_ctx* ctx, float* grid_ms, float* list_ms) {
-  if (!ctx || !grid_ms || !list_ms) return LINS_E_ARG;
-  if (!ctx->ran || !ctx->last_split) return LINS_E_STATE;
-  HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
-  HIP_TRY(ctx, hipEventElapsedTime(grid_ms, ctx->ev0, ctx->ev_k0));
-  HIP_TRY(ctx, hipEventElapsedTime(list_ms, ctx->ev_k0, ctx->ev1));
-  return LINS_OK;
-}
-
-/* Debug aid (split path): the linearisation state the grid kernel handed over for scan `scan` in the last run. */
-int lins_debug_split_hand(lins_ctx* ctx, int scan, double* lin19, int* iter_status2) {
-  if (!ctx || !lin19 || !iter_status2 || !ctx->d_split_hand || scan < 0 || scan >= ctx->max_batch) return LINS_E_ARG;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  const char* base = (const char*)ctx->d_split_hand + (size_t)scan * split_scan_size();
-  HIP_TRY(ctx, hipMemcpy(lin19, base, 19 * 8, hipMemcpyDeviceToHost));
-  HIP_TRY(ctx, hipMemcpy(iter_status2, base + 22 * 8, 2 * 4, hipMemcpyDeviceToHost));
-  return LINS_OK;
-}
-
-/* Debug aid (split path): have the list kernel record the correspondences it decided in iteration `iter` of the
- * NEXT lins_batch_run (iter < 0: off); after that run, `out` (one lins_corr per uploaded query slot: per scan the
- * plane queries, then the line queries) receives them.  Iterations the grid kernel ran are not recorded. */
-int lins_debug_split_dump(lins_ctx* ctx, int iter, lins_corr* out, int n_slots) {
-  if (!ctx) return LINS_E_ARG;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (out) {
-    if (!ctx->d_split_dump || n_slots < 0 || (size_t)n_slots > ctx->slots_uploaded) return LINS_E_STATE;
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(out, ctx->d_split_dump, (size_t)n_slots * sizeof(lins_corr), hipMemcpyDeviceToHost));
-    return LINS_OK;
-  }
-  (void)hipFree(ctx->d_split_dump);
-  ctx->d_split_dump = nullptr;
-  ctx->split_dump_iter = iter;
-  if (iter >= 0) {
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_split_dump, std::max<size_t>(ctx->slots_uploaded, 1) * sizeof(lins_corr)));
-    HIP_TRY(ctx, hipMemset(ctx->d_split_dump, 0xFF, std::max<size_t>(ctx->slots_uploaded, 1) * sizeof(lins_corr)));
-  }
-  return LINS_OK;
-}
 
 /* Debug aid (not part of the drop-in surface): enable / read the per-workgroup phase
  * profile of the persistent kernel: 16 int64 shader-clock ticks per scan
@@ -1240,10 +1184,10 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
     const bool use_mr = want_mr && mr_ok, use_lds = want_lds && !want_mr && lds_ok;
     if (use_mr || use_lds) {
       if (use_mr)
-        launch_lds_mr(ctx->stream, n, ctx->dprm, t.d_desc, t.d_arena, t.d_sorted, ctx->d_state_in, ctx->d_cov_in,
+        launch_lds_mr(ctx->stream, n, ctx->dprm, t.d_desc, nullptr, t.d_arena, t.d_sorted, ctx->d_state_in, ctx->d_cov_in,
                       ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr);
       else
-        launch_lds(ctx->stream, n, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, t.d_desc, t.d_arena, ctx->d_state_in,
+        launch_lds(ctx->stream, n, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, t.d_desc, t.d_arena, t.d_sorted, ctx->d_state_in,
                    ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr);
       launch_joseph(ctx->stream, n, ctx->dprm, ctx->d_cov_in, ctx->d_a6, ctx->d_out, ctx->d_cov_out);
     } else {
@@ -1474,7 +1418,7 @@ int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins
   // Host buffers in and out: the whole call is bounded by validation + packing and PCIe, not by the kernels.  Large
   // batches are therefore PIPELINED: a pool of host threads validates and packs scan after scan into the pinned
   // staging arena; as soon as a chunk of scans is complete, the calling thread sends it (copy stream) and queues its
-  // kernels behind the copy (compute stream) while the pool is already packing the next chunks.  (The split path and
+  // kernels behind the copy (compute stream) while the pool is already packing the next chunks.  (The
   // the phase profile stay on the staged API: lins_batch_upload / _run.)
   int kChunk = 256;  // (measured: 4.6 / 4.2 / 4.1 / 5.7 ms per 1024 scans with chunks of 512 / 256 / 128 / 64)
   bool trace = false;
@@ -1485,7 +1429,7 @@ int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins
     }
   const auto t_begin = std::chrono::steady_clock::now();
   auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
-  if (n < 2 * kChunk || ctx->dprm.search == SEARCH_SPLIT || ctx->d_prof) {
+  if (n < 2 * kChunk || ctx->d_prof) {
     int rc = upload(ctx, n, in);
     if (rc) return rc;
     if (n == 0) return LINS_OK;
@@ -1518,7 +1462,6 @@ int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins
         if (e != hipSuccess) return fail_hip(ctx, e, "chunk hand-over (event record / stream wait)");
         if ((r = run_range(ctx, lo, hi - lo, n, fl, nullptr, 0))) return r;
         all.lds_ok = all.lds_ok && fl.lds_ok, all.mr_ok = all.mr_ok && fl.mr_ok, all.lds3_ok = all.lds3_ok && fl.lds3_ok;
-        all.split_ok = all.split_ok && fl.split_ok;
         return 0;
       });
   if (rc) {
@@ -1535,7 +1478,7 @@ int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
   set_batch_state(ctx, n, all, slots, bytes);
-  ctx->ran = true, ctx->last_split = false;
+  ctx->ran = true;
   return lins_batch_download(ctx, n, out);
 }
 
@@ -1594,7 +1537,7 @@ static int run_pass(lins_ctx* ctx, const lins_scan_pair* in, const double* lin_s
                        ctx->d_state_in, iter, ctx->d_idx, dump ? ctx->d_dump : nullptr, sums ? ctx->d_sums : nullptr,
                        sums ? ctx->d_counts : nullptr);
   } else if (want_lds && !want_mr && ctx->lds_ok) {
-    launch_lds_pass(ctx->stream, 1, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc, ctx->d_arena, ctx->d_lin, ctx->d_state_in, iter,
+    launch_lds_pass(ctx->stream, 1, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc, ctx->d_arena, ctx->d_binned, ctx->d_lin, ctx->d_state_in, iter,
                     ctx->d_idx, dump ? ctx->d_dump : nullptr, sums ? ctx->d_sums : nullptr,
                     sums ? ctx->d_counts : nullptr);
   } else {

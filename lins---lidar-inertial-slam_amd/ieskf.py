@@ -23,7 +23,7 @@ EXPORTS = [
     "lins_last_reproject_stats", "lins_icp_update_batch", "lins_extract_features_batch", "lins_last_frontend_stats",
     "lins_streams_init", "lins_streams_step", "lins_streams_stats", "lins_streams_peek", "lins_segment_batch",
     "lins_last_segment_ms", "lins_streams_step_raw", "lins_map_correspondences", "lins_scan2map_batch",
-    "lins_last_map_stats", "lins_last_split_ms",
+    "lins_last_map_stats", "lins_last_search",
 ]
 
 
@@ -341,27 +341,12 @@ class IeskfContext:
         self._check(lib().lins_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
-    def last_split_ms(self):
-        """(grid kernel ms, list kernel ms) of the last run in "split" mode."""
-        a, b = C.c_float(0), C.c_float(0)
-        self._check(lib().lins_last_split_ms(self._h, C.byref(a), C.byref(b)))
-        return a.value, b.value
-
-    def split_dump_arm(self, it):
-        """Debug: record the list kernel's correspondences of iteration `it` during the next run (it < 0: off)."""
-        L = lib()
-        L.lins_debug_split_dump.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
-        L.lins_debug_split_dump.restype = C.c_int
-        self._check(L.lins_debug_split_dump(self._h, it, None, 0))
-
-    def split_dump_read(self, n_slots):
-        import numpy as np
-
-        from ._ctypes_defs import CORR_DTYPE
-
-        out = np.zeros(n_slots, dtype=CORR_DTYPE)
-        self._check(lib().lins_debug_split_dump(self._h, 0, out.ctypes.data, n_slots))
-        return out
+    def last_search(self):
+        """Kernel family the last batch / pass actually ran (after "auto" and the eligibility fall-backs)."""
+        f = lib().lins_last_search
+        f.restype = C.c_char_p
+        f.argtypes = [C.c_void_p]
+        return f(self._h).decode()
 
     def bytes_per_iter(self):
         b = C.c_uint64(0)

@@ -55,7 +55,7 @@ def test_oracle_reproduces_golden_outputs(pkg, oracle, path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("search", ["lds", "lds1", "mr", "split", "auto", "binned", "brute"])
+@pytest.mark.parametrize("search", ["lds", "lds1", "mr", "auto", "binned", "brute"])
 @pytest.mark.parametrize("path", FILES, ids=os.path.basename)
 def test_hip_path_matches_golden(pkg, ieskf, path, search):
     z, pair = load(pkg, path)

@@ -108,7 +108,7 @@ def test_forward_walk_is_bounded_by_query_count(pkg, oracle, ctx, search):
                 assert np.abs(got.state - want.state).max() <= 1e-6 * max(1.0, np.abs(want.state).max())
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1", "mr", "split", "auto"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1", "mr", "auto"])
 def test_mixed_batch_with_one_oversized_scan(pkg, oracle, ctx, search):
     """One scan too large for LDS sends the whole batch down the global-memory grid path."""
     ctx.set_search(search)
@@ -136,7 +136,7 @@ def test_unsorted_rings_and_high_ring_ids_fall_back_exactly(pkg, oracle, ctx, se
         assert_same_corr(corner, wc, "corner")
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1", "mr", "split", "auto"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1", "mr", "auto"])
 def test_empty_and_ragged_inputs(pkg, oracle, ctx, search):
     ctx.set_search(search)
     prm = pkg.default_params(num_iter=5)
@@ -182,7 +182,7 @@ def test_icp_freq_reuses_indices(pkg, ieskf, oracle, pairs):
             assert np.abs(got.cov - want.cov).max() <= 1e-9 * np.abs(want.cov).max()
 
 
-@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1", "mr", "split", "auto"])
+@pytest.mark.parametrize("search", ["brute", "binned", "lds", "lds1", "mr", "auto"])
 def test_residual_blow_up_diverges_like_the_reference(pkg, ieskf, oracle, search):
     """SE:566-570 (diverged == 1): tests/diverging.py builds a pair whose second iteration's residual norm exceeds
     ten times the first's — one 1 mm row, then twenty 10 cm rows after the update jumped 10 m along the only free

@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """A/B kernel (and whole-step wall) timing of two builds of liblins_ieskf.so in ONE GPU call (boxes differ by several per cent, so two
 calls cannot be compared): alternates the libraries, several rounds, prints the medians.
-usage: tools/ab_timing.py libA.so libB.so [mode ...]   (modes default: mr split)"""
+usage: tools/ab_timing.py libA.so libB.so[:ENV=VAL[,ENV=VAL]] [mode ...]   (modes default: mr)
+A library may carry debug-knob settings after a colon (LINS_ENABLE_DEBUG_KNOBS=1 is set for it), e.g.
+  tools/ab_timing.py lib.so lib.so:LINS_LAUNCH_ORDER=0 lib.so:LINS_MARGIN_COLD=0.1,LINS_MARGIN_WARM=0.04"""
 import os
 import subprocess
 import sys
@@ -33,12 +35,7 @@ with ieskf.IeskfContext(prm, max_batch=batch, max_targets=16384, search=mode) as
     for _ in range(15):
         t0 = time.perf_counter(); ctx.run(); ctx.sync(); ws.append((time.perf_counter() - t0) * 1e3); ks.append(ctx.last_kernel_ms())
     print("WALL %%.4f" %% float(np.median(ws)))
-    extra = ""
-    try:
-        a, b = ctx.last_split_ms(); extra = " %%.4f %%.4f" %% (a, b)
-    except Exception:
-        pass
-    print("RESULT %%.4f%%s" %% (float(np.median(ks)), extra))
+    print("RESULT %%.4f" %% float(np.median(ks)))
 ''' % ROOT
 
 
@@ -46,7 +43,13 @@ WALL = {}
 
 
 def run(lib, mode, batch=1024):
-    e = dict(os.environ, LINS_IESKF_LIB=os.path.abspath(lib))
+    path, _, knobs = lib.partition(":")
+    e = dict(os.environ, LINS_IESKF_LIB=os.path.abspath(path))
+    if knobs:
+        e["LINS_ENABLE_DEBUG_KNOBS"] = "1"
+        for kv in knobs.split(","):
+            k, _, v = kv.partition("=")
+            e[k] = v
     p = subprocess.run([sys.executable, "-c", CHILD, str(batch), mode], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     wall = float("nan")
     for line in p.stdout.decode().splitlines():
@@ -58,8 +61,8 @@ def run(lib, mode, batch=1024):
     return [float("nan"), p.stderr.decode()[-200:]]
 
 
-libs = [a for a in sys.argv[1:] if a.endswith('.so')]
-modes = [a for a in sys.argv[1:] if not a.endswith('.so')] or ["mr", "split"]
+libs = [a for a in sys.argv[1:] if '.so' in a]
+modes = [a for a in sys.argv[1:] if '.so' not in a] or ["mr"]
 res = {(l, m): [] for l in libs for m in modes}
 for rnd in range(3):
     for m in modes:
@@ -67,7 +70,5 @@ for rnd in range(3):
             res[(l, m)].append(run(l, m))
 for m in modes:
     for l in libs:
-        r = np.array([x[:3] if len(x) >= 3 and isinstance(x[1], float) else [x[0], np.nan, np.nan] for x in res[(l, m)]], dtype=float)
-        med = np.nanmedian(r, axis=0)
-        print(f"{m:6s} {os.path.basename(l):28s} kernel {med[0]:.4f} ms" + (f" (grid {med[1]:.4f} + list {med[2]:.4f})" if not np.isnan(med[1]) else "")
-              + f"   step (run + sync, wall) {np.nanmedian(WALL.get((l, m), [np.nan])):.4f} ms")
+        r = np.array([x[0] if isinstance(x[0], float) else np.nan for x in res[(l, m)]], dtype=float)
+        print(f"{m:6s} {os.path.basename(l):60s} kernel {np.nanmedian(r):.4f} ms   step (run + sync, wall) {np.nanmedian(WALL.get((l, m), [np.nan])):.4f} ms")

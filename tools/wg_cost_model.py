@@ -62,6 +62,11 @@ dur = (end - start) / 100.0
 v = feats["|v|"]
 print("list-scheduling model, 512 slots: as submitted %.0f us; by |v| descending %.0f us; by measured duration descending %.0f us; ideal %.0f us" %
       (simulate(range(batch), dur), simulate(np.argsort(-v), dur), simulate(np.argsort(-dur), dur), dur.sum() / 512))
+# what the host can know before the launch: the four cloud sizes
+cd, *_ = np.linalg.lstsq(X, dur, rcond=None)
+print("  by the linear size model descending %.0f us (model coefficients per point [us]: %s); by n_surf_t descending %.0f us; by queries descending %.0f us" %
+      (simulate(np.argsort(-(X @ cd)), dur), np.round(cd, 4), simulate(np.argsort(-sizes[:, 2]), dur), simulate(np.argsort(-(sizes[:, 0] + sizes[:, 1])), dur)))
+print("  duration: mean %.1f us, std %.1f, min %.1f, max %.1f" % (dur.mean(), dur.std(), dur.min(), dur.max()))
 
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 res = ctx.download() if hasattr(ctx, "download") else None
