@@ -5,12 +5,20 @@ Workload (BASELINE.json configs[3], the largest single-GPU configuration): a bat
 of 1024 independent seeded synthetic 16x1800 VLP-16 scan pairs per GPU, exactly 10
 IESKF iterations each (fixed_iters throughput mode), inputs resident in HBM before
 the timed region.  One "step" = one pass of the hot path over the batch
-(lins_batch_run) + for N>1 the RCCL all-gather of the fixed-size pose records.
-N GPUs: one process per GPU, each with its own 1024 scans (weak scaling).
+(lins_batch_run: update kernel + Joseph covariance kernel) + for N>1 the RCCL
+all-gather of the fixed-size pose records (lins_pose_allgather, C ABI).  The steps of
+the timed region are enqueued back to back (the library's pipelined staged mode: the
+gather of step k travels on its own stream beside the kernels of step k + 1) and
+waited for ONCE, inside the timed region.  N GPUs: one process per GPU,
+each with its own 1024 scans (weak scaling).
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on the
-context's stream; `cpu_baseline` times the CPU oracle (kind "port": the reference
-cannot be compiled here) on a bounded sample of the same scans on this box's cores.
+context's stream; `cpu_baseline` times the REFERENCE'S OWN CODE (kind "reference":
+oracle/_ref = StateEstimator.hpp compiled verbatim against stand-in third-party
+headers, built where /root/reference exists and shipped with the snapshot) on a
+bounded sample of the same scans on this box's cores — or the oracle (kind "port")
+when that library did not travel; `parity_checked` compares the GPU results of the
+timed batch with that sample.
 """
 import argparse
 import importlib
@@ -50,7 +58,7 @@ def traffic_from_profiles(search):
         return None, f"PMC record is for search={rec.get('search')}"
     if rec.get("source_digest") != g._source_digest():
         return None, "stale: PMC record taken from other sources (" + os.path.basename(files[-1]) + ")"
-    keep = ("bytes_lo", "bytes_hi", "fetch_size_bytes", "write_size_bytes", "calibration", "kernel", "meaning")
+    keep = ("bytes_lo", "bytes_hi", "fetch_size_bytes", "write_size_bytes", "calibration", "kernel", "meaning", "valu")
     return {k: rec[k] for k in keep if k in rec}, os.path.basename(files[-1])
 
 
@@ -101,6 +109,103 @@ def single_scan_latency(pkg, ieskf, pair):
     return {"kernel": "lds_full::ieskf_lds_kernel<1024,3>", "kernel_ms": float(np.median(ks)), "iterations": int(its),
             "us_per_iteration": float(np.median(ks)) * 1e3 / max(int(its), 1), "update_call_ms_incl_pcie": float(np.median(e2e)),
             "stop_rule": "|dx| <= 1e-2 (SE:575-578), NUM_ITER 30"}
+
+
+def cpu_leg(pkg, args, prm, pairs, gpu_results):
+    """cpu_baseline + parity_checked.  The sample (first --cpu-sample scan pairs of the timed batch) goes through the
+    REFERENCE'S OWN CODE when oracle/_ref/liblins_ref.so travelled with the snapshot (kind "reference": performIESKF of
+    StateEstimator.hpp compiled verbatim, dense M x M gain, kd-tree; it has no fixed-iteration mode, so it runs its own
+    stop rule, NUM_ITER 30, and the rate counts the iterations it really executed) and through the oracle (same
+    algorithm restated; also the fixed-iteration form the GPU batch ran, which is what parity_checked compares)."""
+    import numpy as np
+    from oracle import oracle, ref
+
+    out = {}
+    sample = pairs[: min(args.cpu_sample, len(pairs))]
+    ncpu = os.cpu_count() or 1
+    sec1, it1 = oracle.bench(prm, sample, oracle.FORM_DENSE, oracle.NN_KDTREE, threads=1)
+    secn, itn = oracle.bench(prm, sample, oracle.FORM_DENSE, oracle.NN_KDTREE, threads=ncpu)
+    secr, itr = oracle.bench(prm, sample, oracle.FORM_REDUCED, oracle.NN_KDTREE, threads=1)
+    secrn, itrn = oracle.bench(prm, sample, oracle.FORM_REDUCED, oracle.NN_KDTREE, threads=ncpu)
+    port = {"value": it1 / sec1, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"first {len(sample)} scan pairs of the same batch x {args.iters} iterations (fixed), oracle dense MxM form + "
+                      "kd-tree (the reference's cost model), g++ -O3 no FMA",
+            "all_cores": {"value": itn / secn, "cores": ncpu},
+            "reduced_6x6_form_1core": {"value": itr / secr, "cores": 1},
+            "reduced_all_cores": {"value": itrn / secrn, "cores": ncpu}}
+    if ref.available():
+        stop = pkg.default_params(num_iter=30, fixed_iters=0)
+        rs1, ri1 = ref.bench(stop, sample, threads=1)
+        rsn, rin = ref.bench(stop, sample, threads=ncpu)
+        out["cpu_baseline"] = {
+            "value": ri1 / rs1, "unit": "iterations/s", "cores": 1, "kind": "reference",
+            "sample": f"first {len(sample)} scan pairs of the same batch through the reference's own performIESKF "
+                      "(StateEstimator.hpp compiled verbatim against stand-in Eigen / PCL headers, g++ -O3 no FMA, exact "
+                      f"kd-tree): its own stop rule, NUM_ITER 30, {ri1} iterations executed",
+            "all_cores": {"value": rin / rsn, "cores": ncpu},
+            "port": port}
+    else:
+        out["cpu_baseline"] = port
+    # parity of the timed batch's results (fixed iterations) against the oracle's dense form on the same sample
+    with ThreadPoolExecutor(max_workers=min(64, ncpu)) as ex:
+        want = list(ex.map(lambda p: oracle.ieskf(prm, p, oracle.FORM_DENSE, oracle.NN_KDTREE), sample))
+    got = gpu_results[: len(sample)]
+    flags = all((g.iters, g.converged, g.diverged, g.m_surf, g.m_corner) == (w.iters, w.converged, w.diverged, w.m_surf, w.m_corner)
+                for g, w in zip(got, want))
+    dp = max(float(np.abs(g.state[:3] - w.state[:3]).max()) for g, w in zip(got, want))
+    dq = max(float(np.abs(g.state[6:10] - w.state[6:10]).max()) for g, w in zip(got, want))
+    dc = max(float(np.abs(g.cov - w.cov).max() / np.abs(w.cov).max()) for g, w in zip(got, want))
+    ok = flags and dp <= 1e-6 and dq <= 1e-7 and dc <= 1e-9
+    out["parity_checked"] = {"scans": len(sample), "against": "oracle dense M x M form + kd-tree, same fixed iteration count",
+                             "flags_equal": bool(flags), "max_dp": dp, "max_dq": dq, "max_rel_dP": dc,
+                             "tolerances": {"dp": 1e-6, "dq": 1e-7, "rel_dP": 1e-9}, "ok": bool(ok)}
+    return out
+
+
+def e2e_rates(pkg, ieskf, host, pairs, args):
+    """What the C ABI delivers when the inputs are NOT resident: lins_ieskf_update_batch with host buffers in and out
+    (validation + packing + H2D + kernels + D2H, pipelined in chunks of 256 scans) and the device-resident streams
+    chain (lins_streams_step: front-end -> update -> re-projection, clouds staying in HBM between scans) as the C call
+    sees it.  PCIe-bound; never the headline value."""
+    import numpy as np
+
+    prm = pkg.default_params(num_iter=args.iters, fixed_iters=1)
+    n = len(pairs)
+    out = {}
+    with ieskf.IeskfContext(prm, max_batch=n, max_targets=16384, search=args.search) as c:
+        for _ in range(2):
+            c.update_batch(pairs)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            res = c.update_batch(pairs)
+            ts.append(time.perf_counter() - t0)
+        dt = float(np.median(ts))
+        out["update_batch_it_s"] = sum(r.iters for r in res) / dt
+        out["update_batch_ms"] = dt * 1e3
+    ns = min(n, 256)
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        seg0 = list(ex.map(lambda i: host.frontend_segment(host.synth_raw_scan(i, 0)), range(ns)))
+        seg1 = list(ex.map(lambda i: host.frontend_segment(host.synth_raw_scan(i, 1)), range(ns)))
+    boot = np.zeros((ns, 19))
+    for i, p in enumerate(pairs[:ns]):
+        boot[i, 0:3], boot[i, 6:10] = p.meta["true_t"], p.meta["true_q"]
+    st = np.stack([p.state for p in pairs[:ns]])
+    cv = np.stack([p.cov.reshape(18, 18) for p in pairs[:ns]])
+    with ieskf.IeskfContext(prm, max_batch=ns, max_targets=16384) as c:
+        c.streams_init(ns)
+        c.streams_step(seg0, boot, np.tile(np.eye(18)[None] * 1e-4, (ns, 1, 1)))
+        ts = []
+        for rep in range(4):
+            t0 = time.perf_counter()
+            c.streams_step(seg1 if rep % 2 == 0 else seg0, st, cv)
+            ts.append(time.perf_counter() - t0)
+        fe, up, rp = c.streams_stats()
+        out["streams_scans_s"] = ns / float(np.min(ts[1:]))
+        out["streams_scans_s_on_device"] = ns / ((fe + up + rp) * 1e-3)
+        out["streams"] = ns
+    out["note"] = "host buffers in and out (update_batch) / segmented clouds uploaded per scan (streams, incl. Python marshalling): PCIe-bound"
+    return out
 
 
 def self_launch(args):
@@ -219,20 +324,31 @@ def main():
     ctx = ieskf.IeskfContext(prm, device=local_rank, max_batch=len(pairs), max_targets=max(max_targets, 1024),
                              search=args.search)
     ctx.upload(pairs)
-    # The exchange step (dist.PoseGatherPipeline, the code tests/test_dist.py drives under gloo): the pose gather of
-    # step k is enqueued (RCCL's own stream) right after step k + 1's update has been launched and runs beside it;
-    # the last gather is issued and completed inside the timed region (barrier()).
-    pipe = dist_mod.PoseGatherPipeline(args.batch * world, rank, world, device="cuda", enabled=use_dist)
+    # The exchange step: one flat all-gather of the 192-byte pose records through the C ABI
+    # (lins_pose_allgather -> ncclAllGather on the context's communication stream).  torch.distributed only carries the
+    # RCCL unique id to the ranks and the two scalars of the timing reduction; shards are padded to the largest
+    # (dist.shard_range: sizes differ by at most one) and the padding is cut out on the host (dist.ordered_records).
+    spans = [dist_mod.shard_range(args.batch * world, r, world) for r in range(world)]
+    max_n = max(b - a for a, b in spans)
+    rec_bytes = dist_mod.RECORD_BYTES
+    poses = [torch.zeros(max(max_n, 1) * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    gathered = [torch.zeros(world * max(max_n, 1) * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)] if use_dist else None
+    if use_dist:
+        uid = [ctx.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.rccl_init(uid[0], rank, world)
+    ctx.set_pipelined(True)
+    n_steps = [0]
 
-    def step():
-        b, buf = pipe.begin_step()
-        ctx.run(buf.data_ptr(), lo)  # asynchronous launch
-        pipe.gather_newest()         # the previous step's records travel while this update computes
-        ctx.sync()
-        pipe.end_step(b)
+    def step():  # everything asynchronous: no host wait inside a step
+        b = n_steps[0] & 1
+        n_steps[0] += 1
+        ctx.run(poses[b].data_ptr(), lo)
+        if use_dist:
+            ctx.pose_allgather(poses[b].data_ptr(), max_n, gathered[b].data_ptr())
 
     def barrier():
-        pipe.drain()
+        ctx.sync()  # update kernels, Joseph kernels and gathers of every step enqueued so far (one host wait)
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -240,13 +356,12 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kernel_ms.append(ctx.last_kernel_ms())
     barrier()
     elapsed = time.perf_counter() - t0
+    kernel_ms = ctx.kernel_ms_history(min(args.steps, 64))  # HIP events on the context's stream, the timed steps
 
     # device-copy ceiling of this box: a streaming float4 copy inside the context's arenas,
     # measured after the timed region (it overwrites the uploaded clouds)
@@ -273,8 +388,10 @@ def main():
         elapsed_max, iters_all = elapsed, float(iters_local)
 
     if use_dist:  # the gathered pose records must be complete and in scan order (outside the timed region)
-        rec = pipe.records()  # (raises when out of order)
+        last = (n_steps[0] - 1) & 1
+        rec = dist_mod.ordered_records(gathered[last].cpu().numpy(), spans)  # (raises when out of order)
         assert int(rec["iters"].sum()) == int(iters_all), "pose gather incomplete"
+        ctx.rccl_destroy()
 
     if rank == 0:
         res = ctx.download()
@@ -301,7 +418,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"configs[3]: batch of {args.batch} independent scan pairs per GPU, "
-                            f"{args.iters} IESKF iterations each (fixed), 1 workgroup per scan, 2 scans resident per CU",
+                            f"{args.iters} IESKF iterations each (fixed), 1 workgroup per scan, 2 scans resident per CU; "
+                            "inputs resident in HBM before the timed region (PCIe-inclusive rates: see e2e)",
                 "scans_per_gpu": len(pairs),
                 "iters_per_scan": args.iters,
                 "search": args.search,
@@ -322,7 +440,11 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic[0]["bytes_hi"] if traffic[0] else None,  # fabric-side upper bound, see traffic_detail
-                "traffic_detail": traffic[0],
+                "traffic_detail": {k: v for k, v in traffic[0].items() if k != "valu"} if traffic[0] else None,
+                # VALU side ("report both the HBM fraction and the VALU fraction"): SQ counters of the
+                # same PMC record — busy_frac of the 1024 SIMDs' issue cycles, active lanes per VALU instruction (of 64)
+                "valu": ({k: traffic[0]["valu"].get(k) for k in ("busy_frac", "lanes_per_inst", "insts_valu_per_launch", "wave_wait_frac")}
+                         if traffic[0] and traffic[0].get("valu") else None),
                 "traffic_source": traffic[1],
                 "copy_ceiling_GBs": copy_gbs,  # measured stream-copy rate (read + write) on this box
                 "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
@@ -332,26 +454,11 @@ def main():
             },
         }
         if not args.no_cpu and args.cpu_sample > 0 and world == 1:  # (the CPU leg: single-GPU runs only)
-            from oracle import oracle
-
-            sample = pairs[: min(args.cpu_sample, len(pairs))]
-            sec1, it1 = oracle.bench(prm, sample, oracle.FORM_DENSE, oracle.NN_KDTREE, threads=1)
-            ncpu = os.cpu_count() or 1
-            secn, itn = oracle.bench(prm, sample, oracle.FORM_DENSE, oracle.NN_KDTREE, threads=ncpu)
-            secr, itr = oracle.bench(prm, sample, oracle.FORM_REDUCED, oracle.NN_KDTREE, threads=1)
-            out["cpu_baseline"] = {
-                "value": it1 / sec1,
-                "unit": "iterations/s",
-                "cores": 1,
-                "kind": "port",
-                "sample": f"first {len(sample)} scan pairs of the same batch x {args.iters} iterations, "
-                          "oracle dense MxM form + kd-tree (the reference's cost model), g++ -O3 no FMA",
-                "all_cores": {"value": itn / secn, "cores": ncpu},
-                "reduced_6x6_form_1core": {"value": itr / secr, "cores": 1},
-            }
+            out.update(cpu_leg(pkg, args, prm, pairs, res))
         if world == 1 and not args.no_extras:
             out["reference_stop_rule"] = reference_stop_rule_rate(pkg, ieskf, pairs, args, max_targets)
             out["single_scan"] = single_scan_latency(pkg, ieskf, pairs[0])
+            out["e2e"] = e2e_rates(pkg, ieskf, host, pairs, args)
     else:
         out = None
     ctx.close()
@@ -363,6 +470,9 @@ def main():
         sys.stdout.flush()
         dist.barrier()
         dist.destroy_process_group()
+    if out is not None and out.get("parity_checked") and not out["parity_checked"]["ok"]:
+        print(json.dumps(out), flush=True)
+        raise SystemExit("bench.py: the GPU results of the timed batch do not match the CPU checker (parity_checked)")
     if out is not None:
         # RCCL writes its version banner to the C stdout buffer, which would otherwise be flushed at exit — after a
         # line printed from Python.  Drain it first: the JSON line is the last thing on stdout.

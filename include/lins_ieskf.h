@@ -167,6 +167,37 @@ int lins_batch_download(lins_ctx* ctx, int n, lins_result* out);
  * lins_batch_run(): the persistent IESKF kernel ("lds*" modes: without the small Joseph
  * covariance kernel that follows it; "binned"/"brute": both).                       */
 int lins_last_kernel_ms(lins_ctx* ctx, float* ms);
+/* HIP-event times (ms) of the update kernels of the last n lins_batch_run() calls, oldest first (n <= 64 and <= the
+ * number of runs so far); waits for the newest of them.  lins_last_kernel_ms() is the n = 1 case.                 */
+int lins_kernel_ms_history(lins_ctx* ctx, int n, float* ms);
+
+/* --- pipelined staged mode: a stream of batches without a host wait per batch ---------------------------------- */
+/* Off by default.  With it on, lins_pose_allgather() leaves the exchange of a run's pose records on the context's
+ * communication stream, so that it travels beside the kernels of the NEXT lins_batch_run().  The caller alternates two
+ * pose-record buffers (run k -> buffer k & 1) and may enqueue any number of runs before ONE lins_sync(), which waits
+ * for everything.  While it is on, use only the staged calls (upload / run / pose_allgather / sync / download /
+ * total_iters / kernel-time queries); each of them re-joins the streams where it must.                            */
+int lins_set_pipelined(lins_ctx* ctx, int on);
+
+/* --- multi-GPU: the one exchange step of the path --------------------------------------- */
+/* Scan pairs are independent, so a batch shards over GPUs with no data-path collective; the results meet in ONE
+ * all-gather of the fixed-size 192-byte pose records over RCCL (xGMI).  One lins_ctx (= one GPU) per rank.
+ * librccl is dlopen()ed on first use (the copy already in the process when there is one), never linked:
+ * LINS_E_UNSUPPORTED when it is not installed.
+ *   lins_rccl_unique_id   one rank makes the id (LINS_RCCL_ID_BYTES bytes) and hands it to the others by whatever
+ *                         bootstrap the application has (MPI, a file, torch.distributed's store ...)
+ *   lins_rccl_init        collective over all ranks: ncclCommInitRank
+ *   lins_pose_allgather   every rank contributes n_records records at d_local (DEVICE pointer), d_all (DEVICE pointer,
+ *                         world x n_records records) receives them in rank order.  Stream-ordered after the last
+ *                         lins_batch_run() (pipelined mode: on the context's communication stream, beside the next
+ *                         run); no host wait — lins_sync() covers it.  Ragged shards: pad to the largest.
+ *   lins_rccl_destroy     ncclCommDestroy (lins_destroy() does it too)                                              */
+#define LINS_RCCL_ID_BYTES 128
+int lins_rccl_unique_id(lins_ctx* ctx, void* id);
+int lins_rccl_init(lins_ctx* ctx, const void* id, int rank, int world);
+int lins_pose_allgather(lins_ctx* ctx, const void* d_local, int n_records, void* d_all);
+int lins_rccl_destroy(lins_ctx* ctx);
+
 /* The kernel family the last batch / pass actually ran ("mr", "lds", "lds1", "binned", "brute"): the requested
  * mode after "auto" and the eligibility fall-backs; "" before the first run.  Static storage.               */
 const char* lins_last_search(const lins_ctx* ctx);

@@ -63,8 +63,8 @@
 // waves the plane / line queries of a 512-thread workgroup are spread over.  Measured on the batch workload (91 plane
 // + 164 line queries on average), one GPU call: 5 / 3 (round 1's choice) 0.692 ms, 4 / 4 0.685, 4 / 3 0.705, 3 / 3 0.711,
 // 3 / 5 0.712, 2 / 3 0.760 — using fewer than all eight waves never pays.
-#define LINS_SPREAD_S 4
-#define LINS_SPREAD_C 4
+#define LINS_SPREAD_S 5  // (round 3, with LINS_COOP_COLD = 2: see there)
+#define LINS_SPREAD_C 3
 #endif
 #ifndef LINS_GRID_PF
 #define LINS_GRID_PF 8  // steps of the grid build whose point reads are in flight together, in the histogram pass (measured:
@@ -450,6 +450,15 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
 // ---- wave-cooperative searches: which lanes need one, and who serves whom ------------------------
 #ifndef LINS_COOP_LANES
 #define LINS_COOP_LANES 8  // (re-timed at the end of round 2: 4, 8, 16 within 0.2 %)
+#endif
+#ifndef LINS_COOP_COLD
+// lanes per search in the cold iteration, where every query searches.  A wave gives each of its n searches
+// 64 / n lanes rounded down to a power of two, so this only bites when a wave holds <= 32 queries: with the plane
+// queries spread over five waves (~20 each) their searches — the long ones: five rings, dense ground — get two lanes,
+// the line queries (three waves, ~55 each) keep one.  Measured on the round-3 batch (A/B builds, one GPU call):
+// 1 lane, 4 + 4 waves 0.7348 ms; 2 lanes, 4 + 4 waves 0.7326; 2 lanes, 5 + 3 waves 0.7025; 4 lanes 0.7300 (4 + 4).
+// (Round 2 measured 1 lane best — on the scrambled range images of the old generator, 91 plane queries per scan.)
+#define LINS_COOP_COLD 2
 #endif
 constexpr int kCoopMaxLanes = LINS_COOP_LANES;  // (measured on the batch workload: 2 -> 8.4, 4 -> 8.9, 8 -> 8.9, 16 -> 8.85 M it/s)
 struct CoopMap {
@@ -1096,7 +1105,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         const bool verify = (prm.pad & 8) != 0;  // test aid: search anyway and count disagreements
         // the cold iteration searches for every query: one lane each (more lanes per wave cost more than the shorter
         // chains give back — measured); afterwards only the uncertified queries search, up to kCoopMaxLanes lanes each
-        const int coop_cap = warm_iter ? kCoopMaxLanes : 1;
+        const int coop_cap = warm_iter ? kCoopMaxLanes : LINS_COOP_COLD;
         const unsigned long long kNone = ~0ull;
         float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
         V3 phi = L.ic.phi;

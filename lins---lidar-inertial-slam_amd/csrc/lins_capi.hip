@@ -20,6 +20,9 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is dlopen()ed on first use (lins_rccl_*), never linked
+
 #include "../../include/lins_host.h"
 #include "ieskf_device.h"
 #include "lins_ctx_priv.h"
@@ -174,6 +177,30 @@ struct lins_ctx {
   uint64_t bytes_per_iter = 0;
   uint64_t total_iters = 0;
   std::string hip_err;
+  // ---- pipelined staged mode (lins_set_pipelined): the pose gather of run k travels on its own stream beside the
+  // kernels of run k + 1; the caller alternates two pose buffers, run k uses buffer k & 1
+  struct Pipe {
+    bool on = false;
+    hipStream_t s_comm = nullptr;
+    hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_comm[2] = {nullptr, nullptr};
+    bool comm_pending[2] = {false, false};
+    unsigned runs = 0;  // staged runs so far (parity = set)
+  } pipe;
+  // kernel-time history of lins_batch_run: start / end events of the last kHist update kernels
+  static constexpr int kHist = 64;
+  hipEvent_t hist0[kHist] = {}, hist1[kHist] = {};
+  unsigned hist_n = 0;
+  // RCCL (dlopen): one communicator per context
+  struct Rccl {
+    void* lib = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 0;
+    ncclResult_t (*get_unique_id)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*comm_init_rank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
+    const char* (*get_error_string)(ncclResult_t) = nullptr;
+  } rccl;
 };
 
 namespace lins {
@@ -204,6 +231,35 @@ int fail_hip(lins_ctx* ctx, hipError_t e, const char* what) {
   } while (0)
 
 inline size_t align4(size_t n) { return (n + 3) & ~size_t(3); }
+
+void pipe_free(lins_ctx* ctx) {
+  auto& q = ctx->pipe;
+  if (q.s_comm) (void)hipStreamSynchronize(q.s_comm), (void)hipStreamDestroy(q.s_comm);
+  for (int k = 0; k < 2; ++k) {
+    if (q.ev_main[k]) (void)hipEventDestroy(q.ev_main[k]);
+    if (q.ev_comm[k]) (void)hipEventDestroy(q.ev_comm[k]);
+  }
+  q = lins_ctx::Pipe{};
+}
+
+void rccl_free(lins_ctx* ctx) {
+  auto& r = ctx->rccl;
+  if (r.comm && r.comm_destroy) (void)r.comm_destroy(r.comm);
+  if (r.lib) (void)dlclose(r.lib);
+  r = lins_ctx::Rccl{};
+}
+
+// Everything the side streams of the pipelined mode still have in flight is ordered before what is enqueued on the
+// main stream next (no host wait).  Called by every staged entry point that touches buffers the side streams read.
+int pipe_join(lins_ctx* ctx) {
+  auto& q = ctx->pipe;
+  for (int k = 0; k < 2; ++k) {
+    if (q.comm_pending[k]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, q.ev_comm[k], 0));
+    q.comm_pending[k] = false;
+  }
+  return LINS_OK;
+}
+
 
 // input contract: finite fields, int(intensity) in [0, LINS_MAX_RING) — the relative-time
 // fraction may be slightly negative (SE:631-650 produces -0.025..0.125), and C truncation
@@ -463,6 +519,10 @@ void launch_order(lins_ctx* ctx, int n) {
 }
 
 int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
+  {  // (pipelined mode: the side streams may still read the inputs this call replaces)
+    int rcj = pipe_join(ctx);
+    if (rcj) return rcj;
+  }
   size_t off = 0, slots = 0;
   uint64_t bytes = 0;
   int rc = layout_batch(ctx, n, in, &off, &slots, &bytes);
@@ -571,6 +631,10 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   CREATE_TRY(hipEventCreate(&ctx->ev0));
   CREATE_TRY(hipEventCreate(&ctx->ev1));
   CREATE_TRY(hipEventCreate(&ctx->ev2));
+  for (int k = 0; k < lins_ctx::kHist; ++k) {
+    CREATE_TRY(hipEventCreate(&ctx->hist0[k]));
+    CREATE_TRY(hipEventCreate(&ctx->hist1[k]));
+  }
   const size_t nb = (size_t)max_batch;
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_arena, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_desc, nb * sizeof(ScanDesc)));
@@ -632,6 +696,12 @@ void lins_destroy(lins_ctx* ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+  for (int k = 0; k < lins_ctx::kHist; ++k) {
+    if (ctx->hist0[k]) (void)hipEventDestroy(ctx->hist0[k]);
+    if (ctx->hist1[k]) (void)hipEventDestroy(ctx->hist1[k]);
+  }
+  pipe_free(ctx);
+  rccl_free(ctx);
   if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -677,7 +747,16 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   if (!ctx) return LINS_E_ARG;
   if (ctx->n_uploaded <= 0) return LINS_E_STATE;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  auto& q = ctx->pipe;
+  const int set = q.on ? (int)(q.runs & 1u) : 0;
+  double* const a6 = ctx->d_a6;
+  void* const out = ctx->d_out;
+  if (q.on && q.comm_pending[set]) {  // this run rewrites the pose buffer the gather of run k - 2 read
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, q.ev_comm[set], 0));
+    q.comm_pending[set] = false;
+  }
+  const int h = (int)(ctx->hist_n % lins_ctx::kHist);
+  HIP_TRY(ctx, hipEventRecord(ctx->hist0[h], ctx->stream));
   const int search = effective_search(ctx, ctx->n_uploaded);
   const bool want_lds = search >= SEARCH_LDS, want_mr = search == SEARCH_MR;
   const bool use_mr = want_mr && ctx->mr_ok, use_lds = want_lds && !want_mr && ctx->lds_ok;
@@ -685,25 +764,167 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   if (use_mr || use_lds) {
     if (use_mr)
       launch_lds_mr(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->use_order ? ctx->d_order : nullptr, ctx->d_arena, ctx->d_binned, ctx->d_state_in,
-                    ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx, (lins_pose_record*)d_poses,
+                    ctx->d_cov_in, ctx->d_state_out, a6, out, ctx->d_idx, (lins_pose_record*)d_poses,
                     scan_id_base, ctx->d_prof);
     else
       launch_lds(ctx->stream, ctx->n_uploaded, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc,
-                 ctx->d_arena, ctx->d_binned, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx,
+                 ctx->d_arena, ctx->d_binned, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, a6, out, ctx->d_idx,
                  (lins_pose_record*)d_poses, scan_id_base, ctx->d_prof);
-    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    launch_joseph(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_cov_in, ctx->d_a6, ctx->d_out, ctx->d_cov_out);
+    HIP_TRY(ctx, hipEventRecord(ctx->hist1[h], ctx->stream));
+    if (q.on) HIP_TRY(ctx, hipEventRecord(q.ev_main[set], ctx->stream));  // (the pose records of this run are complete)
+    // The Joseph update (SE:594-598) follows on the same stream.  (Measured, round 3: on a side stream beside the next
+    // run's update kernel — at normal or at lowest stream priority — its 1024 small workgroups sit on LDS and wave
+    // slots the update kernel's second resident workgroup needs, and the update kernel takes 0.86 instead of 0.71 ms.)
+    launch_joseph(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_cov_in, a6, out, ctx->d_cov_out);
   } else {
     DevParams dp = ctx->dprm;
     dp.search = want_lds ? (int)SEARCH_BINNED : search;  // a scan does not fit LDS: global-memory grid
     launch_persistent(ctx->stream, ctx->n_uploaded, dp, ctx->d_desc, ctx->d_arena, ctx->d_state_in, ctx->d_cov_in,
-                      ctx->d_state_out, ctx->d_cov_out, ctx->d_a6, ctx->d_out, ctx->d_idx,
+                      ctx->d_state_out, ctx->d_cov_out, a6, out, ctx->d_idx,
                       (lins_pose_record*)d_poses, scan_id_base, ctx->d_binned, ctx->d_prof);
+    HIP_TRY(ctx, hipEventRecord(ctx->hist1[h], ctx->stream));
+    if (q.on) HIP_TRY(ctx, hipEventRecord(q.ev_main[set], ctx->stream));
   }
   HIP_TRY(ctx, hipGetLastError());
-  if (!(use_mr || use_lds)) HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
+  ctx->hist_n++;
+  if (q.on) q.runs++;
   ctx->ran = true;
+  return LINS_OK;
+}
+
+/* Pipelined staged mode (off by default).  With it on, lins_pose_allgather() leaves the exchange of a run's pose
+ * records on the context's communication stream, so that it travels beside the kernels of the NEXT lins_batch_run().
+ * The caller alternates two pose-record buffers (run k -> buffer k & 1) and may enqueue any number of runs before ONE
+ * lins_sync(), which waits for everything.  Only the staged calls (upload / run / pose_allgather / sync / download /
+ * total_iters / kernel-time queries) may be used while it is on; each of them re-joins the streams where it must.  */
+int lins_set_pipelined(lins_ctx* ctx, int on) {
+  if (!ctx) return LINS_E_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  auto& q = ctx->pipe;
+  if (on && !q.s_comm) {
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&q.s_comm, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+      HIP_TRY(ctx, hipEventCreateWithFlags(&q.ev_main[k], hipEventDisableTiming));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&q.ev_comm[k], hipEventDisableTiming));
+    }
+  }
+  int rc = pipe_join(ctx);
+  if (rc) return rc;
+  q.on = on != 0;
+  return LINS_OK;
+}
+
+/* HIP-event times (ms) of the update kernels of the last n lins_batch_run() calls, oldest first (n <= 64 and <= the
+ * runs so far); waits for the newest of them.                                                                       */
+int lins_kernel_ms_history(lins_ctx* ctx, int n, float* ms) {
+  if (!ctx || !ms || n < 0 || n > lins_ctx::kHist || (unsigned)n > ctx->hist_n) return LINS_E_ARG;
+  for (int k = 0; k < n; ++k) {
+    const int h = (int)((ctx->hist_n - n + k) % lins_ctx::kHist);
+    HIP_TRY(ctx, hipEventSynchronize(ctx->hist1[h]));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms[k], ctx->hist0[h], ctx->hist1[h]));
+  }
+  return LINS_OK;
+}
+
+/* ---- RCCL pose gather (ncclAllGather of the 192-byte pose records over xGMI) -------------
+ * librccl is dlopen()ed on first use — the one already in the process (e.g. PyTorch's) when there is one — and never
+ * linked: a build without RCCL still loads, and these calls return LINS_E_UNSUPPORTED.                            */
+static int rccl_load(lins_ctx* ctx) {
+  auto& r = ctx->rccl;
+  if (r.lib) return LINS_OK;
+  // The RCCL that belongs to the HIP runtime this library is running on: streams and events are runtime objects, so a
+  // librccl bound to ANOTHER copy of libamdhip64 (a Python process may hold PyTorch's bundled ROCm beside the system's)
+  // cannot take ours.  Look next to the runtime that resolved our own HIP calls first, then fall back to the loader.
+  void* lib = nullptr;
+  Dl_info info;
+  if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+    std::string dir(info.dli_fname);
+    const size_t slash = dir.rfind('/');
+    if (slash != std::string::npos) {
+      dir.resize(slash + 1);
+      lib = dlopen((dir + "librccl.so.1").c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (!lib) lib = dlopen((dir + "librccl.so").c_str(), RTLD_NOW | RTLD_LOCAL);
+    }
+  }
+  if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!lib) return LINS_E_UNSUPPORTED;
+  r.get_unique_id = reinterpret_cast<decltype(r.get_unique_id)>(dlsym(lib, "ncclGetUniqueId"));
+  r.comm_init_rank = reinterpret_cast<decltype(r.comm_init_rank)>(dlsym(lib, "ncclCommInitRank"));
+  r.all_gather = reinterpret_cast<decltype(r.all_gather)>(dlsym(lib, "ncclAllGather"));
+  r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(dlsym(lib, "ncclCommDestroy"));
+  r.get_error_string = reinterpret_cast<decltype(r.get_error_string)>(dlsym(lib, "ncclGetErrorString"));
+  if (!r.get_unique_id || !r.comm_init_rank || !r.all_gather || !r.comm_destroy) {
+    (void)dlclose(lib);
+    r = lins_ctx::Rccl{};
+    return LINS_E_UNSUPPORTED;
+  }
+  r.lib = lib;
+  return LINS_OK;
+}
+static int rccl_fail(lins_ctx* ctx, ncclResult_t e, const char* what) {
+  ctx->hip_err = std::string(what) + ": " + (ctx->rccl.get_error_string ? ctx->rccl.get_error_string(e) : "RCCL error");
+  return LINS_E_HIP;
+}
+
+/* id128: LINS_RCCL_ID_BYTES bytes, made by ONE rank and handed to the others by whatever bootstrap the application has. */
+int lins_rccl_unique_id(lins_ctx* ctx, void* id128) {
+  if (!ctx || !id128) return LINS_E_ARG;
+  int rc = rccl_load(ctx);
+  if (rc) return rc;
+  ncclUniqueId id;
+  ncclResult_t e = ctx->rccl.get_unique_id(&id);
+  if (e != ncclSuccess) return rccl_fail(ctx, e, "ncclGetUniqueId");
+  static_assert(sizeof(id) == LINS_RCCL_ID_BYTES, "ncclUniqueId");
+  std::memcpy(id128, &id, sizeof id);
+  return LINS_OK;
+}
+
+int lins_rccl_init(lins_ctx* ctx, const void* id128, int rank, int world) {
+  if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) return LINS_E_ARG;
+  if (ctx->rccl.comm) return LINS_E_STATE;
+  int rc = rccl_load(ctx);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof id);
+  ncclResult_t e = ctx->rccl.comm_init_rank(&ctx->rccl.comm, world, id, rank);
+  if (e != ncclSuccess) return rccl_fail(ctx, e, "ncclCommInitRank");
+  ctx->rccl.rank = rank, ctx->rccl.world = world;
+  return LINS_OK;
+}
+
+/* All-gather of fixed-size pieces: every rank contributes n_records pose records at d_local (device), d_all (device)
+ * receives world x n_records records in rank order.  Stream-ordered after the last lins_batch_run(): in pipelined mode
+ * on the context's communication stream (beside the next run), otherwise on the compute stream.  No host wait.     */
+int lins_pose_allgather(lins_ctx* ctx, const void* d_local, int n_records, void* d_all) {
+  if (!ctx || !d_local || !d_all || n_records < 0) return LINS_E_ARG;
+  if (!ctx->rccl.comm) return LINS_E_STATE;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  auto& q = ctx->pipe;
+  hipStream_t st = ctx->stream;
+  int set = 0;
+  if (q.on) {
+    if (q.runs == 0) return LINS_E_STATE;
+    set = (int)((q.runs - 1) & 1u);  // the run whose records these are
+    HIP_TRY(ctx, hipStreamWaitEvent(q.s_comm, q.ev_main[set], 0));
+    st = q.s_comm;
+  }
+  ncclResult_t e = ctx->rccl.all_gather(d_local, d_all, (size_t)n_records * sizeof(lins_pose_record), ncclChar, ctx->rccl.comm, st);
+  if (e != ncclSuccess) return rccl_fail(ctx, e, "ncclAllGather");
+  if (q.on) {
+    HIP_TRY(ctx, hipEventRecord(q.ev_comm[set], q.s_comm));
+    q.comm_pending[set] = true;
+  }
+  return LINS_OK;
+}
+
+int lins_rccl_destroy(lins_ctx* ctx) {
+  if (!ctx) return LINS_E_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->pipe.s_comm) HIP_TRY(ctx, hipStreamSynchronize(ctx->pipe.s_comm));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  rccl_free(ctx);
   return LINS_OK;
 }
 
@@ -1357,6 +1578,8 @@ int lins_last_reproject_stats(lins_ctx* ctx, float* kernel_ms, uint64_t* bytes) 
 int lins_sync(lins_ctx* ctx) {
   if (!ctx) return LINS_E_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int rc = pipe_join(ctx);  // (side streams of the pipelined mode: ordered before the wait below)
+  if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return LINS_OK;
 }
@@ -1365,6 +1588,10 @@ int lins_batch_download(lins_ctx* ctx, int n, lins_result* out) {
   if (!ctx || !out || n < 0) return LINS_E_ARG;
   if (!ctx->ran || n > ctx->n_uploaded) return LINS_E_STATE;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  {
+    int rc = pipe_join(ctx);
+    if (rc) return rc;
+  }
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state_out, (size_t)n * 19 * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cov, ctx->d_cov_out, (size_t)n * 324 * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)n * sizeof(OutRecHost), hipMemcpyDeviceToHost, ctx->stream));
@@ -1388,10 +1615,8 @@ int lins_batch_download(lins_ctx* ctx, int n, lins_result* out) {
 
 int lins_last_kernel_ms(lins_ctx* ctx, float* ms) {
   if (!ctx || !ms) return LINS_E_ARG;
-  if (!ctx->ran) return LINS_E_STATE;
-  HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
-  HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
-  return LINS_OK;
+  if (!ctx->ran || ctx->hist_n == 0) return LINS_E_STATE;
+  return lins_kernel_ms_history(ctx, 1, ms);
 }
 
 int lins_batch_bytes_per_iter(lins_ctx* ctx, uint64_t* bytes) {
@@ -1446,7 +1671,14 @@ int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins
     HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_copy, hipEventDisableTiming));
   }
   ctx->n_uploaded = 0, ctx->ran = false;
+  // the uploads below overwrite the inputs of whatever is still queued on the compute stream (an earlier asynchronous
+  // lins_batch_run, the side streams of the pipelined mode): order the copy stream behind it
+  if ((rc = pipe_join(ctx))) return rc;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_copy, ctx->stream));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_copy, 0));
 
+  // (kernel family per CHUNK: a scan that cannot take the grid kernels sends its own chunk of 256, not the whole batch,
+  // to the any-size kernel — every family returns the same results, so a scan's bits do not depend on the cut)
   RangeFlags all;
   rc = pack_pipelined(
       n, kChunk, [&](int s) { return pack_one(ctx, in, s); },
@@ -1458,7 +1690,7 @@ int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins
         if (r) return r;
         hipError_t e = hipEventRecord(ctx->ev_copy, ctx->copy_stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_copy, 0);
-        if (e == hipSuccess && lo == 0) e = hipEventRecord(ctx->ev0, ctx->stream);
+        if (e == hipSuccess && lo == 0) e = hipEventRecord(ctx->hist0[ctx->hist_n % lins_ctx::kHist], ctx->stream);
         if (e != hipSuccess) return fail_hip(ctx, e, "chunk hand-over (event record / stream wait)");
         if ((r = run_range(ctx, lo, hi - lo, n, fl, nullptr, 0))) return r;
         all.lds_ok = all.lds_ok && fl.lds_ok, all.mr_ok = all.mr_ok && fl.mr_ok, all.lds3_ok = all.lds3_ok && fl.lds3_ok;
@@ -1475,8 +1707,10 @@ int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins
     (void)hipStreamSynchronize(ctx->stream);
     std::fprintf(stderr, "kernels done at %.3f ms\n", now_ms());
   }
-  HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
+  // (the history entry of this call spans the whole pipelined region: the kernels of all chunks AND the copy waits
+  // between them — lins_last_kernel_ms() after lins_ieskf_update_batch() is an upper bound of the kernel time)
+  HIP_TRY(ctx, hipEventRecord(ctx->hist1[ctx->hist_n % lins_ctx::kHist], ctx->stream));
+  ctx->hist_n++;
   set_batch_state(ctx, n, all, slots, bytes);
   ctx->ran = true;
   return lins_batch_download(ctx, n, out);

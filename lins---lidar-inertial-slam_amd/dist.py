@@ -3,9 +3,12 @@
 Every scan pair is an independent IESKF problem, so the path shards with NO
 data-path collective: rank r owns the contiguous range shard_range(n, r, world) of
 the global batch.  The one exchange step is a flat all-gather of the fixed-size
-192-byte pose records (torch.distributed: backend "nccl" = RCCL over xGMI on the
-GPU box, "gloo" in the CPU tests).  The payload is ~190 KB per rank for 1024 scans
-— latency-bound, so a single flat collective is the right shape.
+192-byte pose records: on the GPU box through the C ABI (lins_pose_allgather ->
+ncclAllGather over xGMI, include/lins_ieskf.h — what bench.py runs), in the CPU
+tests through torch.distributed's gloo backend (PoseGatherPipeline below: the same
+sharding, padding and ordering logic — ordered_records — without a GPU).  The
+payload is ~190 KB per rank for 1024 scans — latency-bound, so a single flat
+collective is the right shape.
 """
 import numpy as np
 
@@ -32,6 +35,21 @@ def records_from_results(results, scan_id_base):
         rec[i]["iters"], rec[i]["converged"], rec[i]["diverged"] = r.iters, r.converged, r.diverged
         rec[i]["m_surf"], rec[i]["m_corner"] = r.m_surf, r.m_corner
         rec[i]["scan_id"] = scan_id_base + i
+    return rec
+
+
+def ordered_records(gathered_bytes, spans):
+    """Cut the padding out of an all-gather of equal pieces (one per rank, each padded to the largest shard) and return
+    the records of all ranks in scan order; raises when they are not.  gathered_bytes: host uint8 array."""
+    host = np.ascontiguousarray(gathered_bytes, dtype=np.uint8).reshape(-1)
+    max_n = max(max(b - a for a, b in spans), 1)
+    stride = max_n * RECORD_BYTES
+    parts = [np.frombuffer(host[r * stride: r * stride + (b - a) * RECORD_BYTES].tobytes(), dtype=POSE_DTYPE)
+             for r, (a, b) in enumerate(spans)]
+    rec = np.concatenate(parts) if parts else np.zeros(0, dtype=POSE_DTYPE)
+    n_total = spans[-1][1] if spans else 0
+    if not np.array_equal(rec["scan_id"], np.arange(n_total)):
+        raise AssertionError("pose gather out of order")
     return rec
 
 
@@ -62,7 +80,9 @@ def gather_pose_records(local_bytes, n_total, group=None):
 
 
 class PoseGatherPipeline:
-    """The benchmarked exchange step: a double-buffered, asynchronous all-gather of the ranks' pose records.
+    """The exchange step over torch.distributed (rounds 1-2 benchmarked this; since round 3 bench.py runs the same
+    double-buffered scheme inside the library — lins_set_pipelined + lins_pose_allgather — and this class is the CPU
+    / gloo stand-in the world-size-2 tests drive): a double-buffered, asynchronous all-gather of the pose records.
 
     Step k's update writes its records into pose buffer k & 1; their gather is enqueued right after step
     k + 1's update has been launched and travels while that update computes (RCCL's own stream on the GPU
@@ -129,11 +149,4 @@ class PoseGatherPipeline:
         if not self.enabled:
             host = self.poses[b].cpu().numpy()
             return np.frombuffer(host[: (self.hi - self.lo) * RECORD_BYTES].tobytes(), dtype=POSE_DTYPE)
-        host = self.gathered[b].cpu().numpy()
-        stride = max(self.max_n, 1) * RECORD_BYTES
-        parts = [np.frombuffer(host[r * stride: r * stride + (hi - lo) * RECORD_BYTES].tobytes(), dtype=POSE_DTYPE)
-                 for r, (lo, hi) in enumerate(self.spans)]
-        rec = np.concatenate(parts)
-        if not np.array_equal(rec["scan_id"], np.arange(self.n_total)):
-            raise AssertionError("pose gather out of order")
-        return rec
+        return ordered_records(self.gathered[b].cpu().numpy(), self.spans)

@@ -23,7 +23,8 @@ EXPORTS = [
     "lins_last_reproject_stats", "lins_icp_update_batch", "lins_extract_features_batch", "lins_last_frontend_stats",
     "lins_streams_init", "lins_streams_step", "lins_streams_stats", "lins_streams_peek", "lins_segment_batch",
     "lins_last_segment_ms", "lins_streams_step_raw", "lins_map_correspondences", "lins_scan2map_batch",
-    "lins_last_map_stats", "lins_last_search",
+    "lins_last_map_stats", "lins_last_search", "lins_kernel_ms_history", "lins_set_pipelined",
+    "lins_rccl_unique_id", "lins_rccl_init", "lins_pose_allgather", "lins_rccl_destroy",
 ]
 
 
@@ -65,6 +66,12 @@ def lib():
         L.lins_sync.argtypes = [vp]
         L.lins_batch_download.argtypes = [vp, C.c_int, C.POINTER(ResultC)]
         L.lins_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.lins_kernel_ms_history.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+        L.lins_set_pipelined.argtypes = [vp, C.c_int]
+        L.lins_rccl_unique_id.argtypes = [vp, C.c_void_p]
+        L.lins_rccl_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+        L.lins_pose_allgather.argtypes = [vp, vp, C.c_int, vp]
+        L.lins_rccl_destroy.argtypes = [vp]
         L.lins_batch_bytes_per_iter.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.lins_batch_total_iters.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.lins_correspondences.argtypes = [vp, C.POINTER(ScanPairC), dp, C.c_int, vp, vp]
@@ -76,7 +83,7 @@ def lib():
         L.lins_transform_to_end_batch.argtypes = [vp, C.c_int, C.POINTER(ReprojectJob)]
         L.lins_last_reproject_stats.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
         for name in EXPORTS:
-            if name not in ("lins_destroy", "lins_strerror", "lins_last_hip_error"):
+            if name not in ("lins_destroy", "lins_strerror", "lins_last_hip_error", "lins_last_search"):
                 if os.environ.get("LINS_IESKF_LIB") and not hasattr(L, name):
                     continue  # (an older build under A/B timing)
                 getattr(L, name).restype = C.c_int
@@ -340,6 +347,32 @@ class IeskfContext:
         ms = C.c_float(0)
         self._check(lib().lins_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def kernel_ms_history(self, n):
+        """HIP-event times (ms) of the update kernels of the last n run() calls, oldest first."""
+        ms = (C.c_float * n)()
+        self._check(lib().lins_kernel_ms_history(self._h, n, ms))
+        return [float(v) for v in ms]
+
+    def set_pipelined(self, on=True):
+        """Pipelined staged mode: Joseph kernel / pose gather of run k beside the update kernel of run k + 1."""
+        self._check(lib().lins_set_pipelined(self._h, 1 if on else 0))
+
+    # -- multi-GPU: RCCL all-gather of the pose records through the C ABI (include/lins_ieskf.h) ------
+    def rccl_unique_id(self):
+        buf = (C.c_char * 128)()
+        self._check(lib().lins_rccl_unique_id(self._h, buf))
+        return bytes(buf)
+
+    def rccl_init(self, uid, rank, world):
+        assert len(uid) == 128
+        self._check(lib().lins_rccl_init(self._h, C.c_char_p(uid), rank, world))
+
+    def pose_allgather(self, d_local_ptr, n_records, d_all_ptr):
+        self._check(lib().lins_pose_allgather(self._h, C.c_void_p(d_local_ptr), n_records, C.c_void_p(d_all_ptr)))
+
+    def rccl_destroy(self):
+        self._check(lib().lins_rccl_destroy(self._h))
 
     def last_search(self):
         """Kernel family the last batch / pass actually ran (after "auto" and the eligibility fall-backs)."""

@@ -123,6 +123,63 @@ def test_benchmarked_double_buffered_gather_world_size_2_gloo(n_total, steps):
     assert ret.get(0) is True and ret.get(1) is True
 
 
+def _real_records_worker(rank, world, port, n_total, ret):
+    """Each rank runs the (CPU) oracle on ITS shard of seeded scan pairs, packs the results the way the kernel writes
+    them on the device (records_from_results) and takes part in the gather; rank 0 compares what arrived with a
+    single-process run over the whole batch."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        pkg = importlib.import_module(PKG)
+        host = importlib.import_module(PKG + ".host")
+        dist_mod = importlib.import_module(PKG + ".dist")
+        from oracle import oracle
+
+        prm = pkg.default_params(num_iter=10, fixed_iters=1)
+        lo, hi = dist_mod.shard_range(n_total, rank, world)
+        mine = [oracle.ieskf(prm, host.synth_pair(600 + i), oracle.FORM_REDUCED, oracle.NN_KDTREE) for i in range(lo, hi)]
+        pipe = dist_mod.PoseGatherPipeline(n_total, rank, world, device="cpu")
+        b, buf = pipe.begin_step()
+        rec = dist_mod.records_from_results(mine, scan_id_base=lo)
+        buf[: rec.nbytes] = torch.from_numpy(rec.view(np.uint8).copy())
+        pipe.gather_newest()
+        pipe.end_step(b)
+        pipe.drain()
+        got = pipe.records()  # raises when out of order
+        ok = True
+        if rank == 0:
+            whole = [oracle.ieskf(prm, host.synth_pair(600 + i), oracle.FORM_REDUCED, oracle.NN_KDTREE) for i in range(n_total)]
+            want = dist_mod.records_from_results(whole, scan_id_base=0)
+            ok = got.tobytes() == want.tobytes() and int(got["iters"].sum()) == 10 * n_total
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gather_real_results_of_different_shards_world_size_2_gloo():
+    """SURVEY.md section 8e / BASELINE.json configs[4] in miniature: a batch of 5 scan pairs sharded 3 + 2 over two ranks,
+    every rank's real results (not synthetic records) gathered, bit-equal to the single-process run."""
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_real_records_worker, args=(r, 2, port, 5, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert ret.get(0) is True and ret.get(1) is True
+
+
 def _bench(*argv, env=None):
     import subprocess
     import sys

@@ -201,3 +201,32 @@ def test_launch_order_does_not_change_a_bit(pkg, ieskf, host, monkeypatch):
     for a, b in zip(*out):
         assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov)
         assert (a.iters, a.converged, a.diverged, a.m_surf, a.m_corner) == (b.iters, b.converged, b.diverged, b.m_surf, b.m_corner)
+
+
+def test_pipelined_staged_mode_returns_the_same_bits(pkg, ieskf, host):
+    """lins_set_pipelined: five runs enqueued back to back, ONE sync — the downloaded results equal the plain staged
+    run's, bit for bit, and so do those of a plain run after the mode is switched off again.  (The RCCL gather this
+    mode overlaps with the next run: tests/test_gpu_bench.py, in a process that imports torch first.)"""
+    prm = pkg.default_params(num_iter=10, fixed_iters=1)
+    batch = host.synth_batch(300, start=5000)
+    with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384, search="mr") as c:
+        c.upload(batch)
+        c.run()
+        c.sync()
+        plain = c.download()
+        c.set_pipelined(True)
+        for k in range(5):
+            c.run()
+        c.sync()
+        piped = c.download()
+        ms = c.kernel_ms_history(5)
+        assert len(ms) == 5 and all(m > 0 for m in ms)
+        assert c.total_iters() == sum(r.iters for r in plain)
+        c.set_pipelined(False)
+        c.run()
+        c.sync()
+        again = c.download()
+    for a, b, d in zip(plain, piped, again):
+        assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov)
+        assert np.array_equal(a.state, d.state) and np.array_equal(a.cov, d.cov)
+        assert (a.iters, a.m_surf, a.m_corner) == (b.iters, b.m_surf, b.m_corner)

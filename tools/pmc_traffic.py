@@ -27,19 +27,26 @@ OUT = os.path.join(ROOT, "gpurun_out")
 
 
 def counters(cmd, counter, tag):
-    d = os.path.join(OUT, f"_pmc_{tag}_{counter}")
+    """One rocprofv3 pass (PMC + kernel trace only).  counter: a name -> {kernel: (sum, dispatches)};
+    a list of names -> {kernel: {name: sum / dispatches}}."""
+    names = [counter] if isinstance(counter, str) else list(counter)
+    d = os.path.join(OUT, f"_pmc_{tag}_{names[0]}")
     subprocess.run(["rm", "-rf", d])
     env = dict(os.environ, TMPDIR="/tmp")
-    p = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "--"] + cmd, cwd="/tmp", env=env,
+    p = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + names + ["-d", d, "--"] + cmd, cwd="/tmp", env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
     res = {}
     if dbs:
         cur = sqlite3.connect(dbs[0]).cursor()
-        for name, val, n in cur.execute(
-                "select k.name, sum(p.counter_value), count(distinct k.dispatch_id) from pmc_events p join kernels k"
-                " on p.dispatch_id = k.dispatch_id where p.counter_name = ? group by k.name", (counter,)):
-            res[name] = (val, n)
+        for nm in names:
+            for name, val, n in cur.execute(
+                    "select k.name, sum(p.counter_value), count(distinct k.dispatch_id) from pmc_events p join kernels k"
+                    " on p.dispatch_id = k.dispatch_id where p.counter_name = ? group by k.name", (nm,)):
+                if isinstance(counter, str):
+                    res[name] = (val, n)
+                else:
+                    res.setdefault(name, {})[nm] = val / n
     subprocess.run(["rm", "-rf", d])
     return res, p.stdout.decode()[-400:]
 
@@ -85,6 +92,24 @@ def main():
         rec.update(kernel=dom, fetch_size_bytes=f, write_size_bytes=w, bytes_lo=f + w, bytes_hi=ff * f + max(wf, 1.0) * w,
                    meaning="per launch; fabric-side (L2 <-> Infinity Fabric) bytes, Infinity-Cache hits included: an upper bound "
                            "of HBM traffic; lo = counters as reported, hi = with the factors calibrated on a streaming copy")
+    # VALU side of the same kernel (SURVEY.md section 8d asks for both fractions): SQ counters are quad-cycles summed
+    # over all SIMDs; GRBM_GUI_ACTIVE is the launch in shader cycles
+    sq, tail = counters(bench, ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+                                "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"], tag + "sq")
+    if iesk and rec.get("kernel") in sq:
+        c = sq[rec["kernel"]]
+        n_simd = 256 * 4
+        act, thr = c.get("SQ_ACTIVE_INST_VALU", 0.0), c.get("SQ_THREAD_CYCLES_VALU", 0.0)
+        gui = c.get("GRBM_GUI_ACTIVE", 0.0)
+        rec["valu"] = {"insts_valu_per_launch": c.get("SQ_INSTS_VALU"), "active_inst_valu_quadcycles": act,
+                       "thread_cycles_valu": thr, "lanes_per_inst": (thr / act) if act else None,
+                       "gui_active_cycles": gui,
+                       "busy_frac": (act / (n_simd * gui / 4.0)) if gui else None,
+                       "wave_wait_frac": (c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]) if c.get("SQ_WAVE_CYCLES") else None,
+                       "meaning": "per launch of the dominant kernel; busy_frac = VALU-issuing quad-cycles summed over the SIMDs / (1024 SIMDs x "
+                                  "launch quad-cycles); lanes_per_inst = thread-cycles / instruction-cycles of VALU work (of 64)"}
+    else:
+        print("no SQ counters:", tail)
     path = os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_traffic.json")
     with open(path, "w") as fh:
         json.dump(rec, fh, indent=1)
