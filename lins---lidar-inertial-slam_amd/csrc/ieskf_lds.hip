@@ -21,12 +21,12 @@ namespace lins {
 
 #define LINS_LAUNCH(NS, B, LN, PR)                                                                                  \
   hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, false, PR>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, \
-                     state_in, cov_in, (const double*)nullptr, 0, state_out, a6, (NS::OutRec*)out, idx_store, poses,  \
+                     state_in, cov_in, (const double*)nullptr, 0, state_out, a6, cov_out, (NS::OutRec*)out, idx_store, poses,  \
                      scan_id_base, (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof)
 #define LINS_LAUNCH_PASS(NS, B, LN)                                                                                    \
   hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, true, false>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, \
                      filt_state, (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr,           \
-                     (NS::OutRec*)nullptr, idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out,        \
+                     (double*)nullptr, (NS::OutRec*)nullptr, idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out,        \
                      (long long*)nullptr)
 
 int lds_np_cap() { return lds_full::kNpMax; }
@@ -35,7 +35,7 @@ static const int* const order = nullptr;  // (one workgroup per CU: nothing to o
 
 void launch_lds(hipStream_t stream, int n, const DevParams& prm, int lanes, const ScanDesc* descs,
                 const float4* arena, float4* sorted, const double* state_in, const double* cov_in, double* state_out, double* a6,
-                void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof) {
+                double* cov_out, void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof) {
   if (lanes == 3) {
     if (prof)
       LINS_LAUNCH(lds_full, 1024, 3, true);

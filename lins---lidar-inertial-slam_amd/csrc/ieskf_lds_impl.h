@@ -957,6 +957,101 @@ __device__ __noinline__ void icp_solve_and_update(int tid, int iter) {
 }
 
 // ---------------------------------------------------------------------------
+// Joseph covariance update (SE:594-598) as the workgroup's epilogue, in a form that is a rank-6 update of the prior:
+// with S = {0,1,2,6,7,8}, C = P[:,S] (18 x 6), R = P[S,:], N = sigma^2 I + A P_SS, Y = N^-1 A, Z = Y N^-T (so that
+// KH = C Y E_S^T and K R K^T = sigma^2 C Z C^T),
+//   (I - KH) P (I - KH)^T + K R K^T  =  P  -  C Y R  -  C Y^T C^T  +  C (Y P_SS Y^T + sigma^2 Z) C^T
+// — the four 18 x 18 x 18 products of the textbook form collapse to 18 x 6 x 6 and 18 x 18 x 6 ones, and the two
+// 6 x 12 eliminations to ONE inverse: two waves run the 6 x 9 Gauss-Jordan of ieskf_rowsum.h side by side (left and
+// right half of the identity), no block-wide elimination with its fourteen barriers.  Rounds 1-2 ran this update as
+// a kernel of its own (ieskf_joseph_kernel, 128 threads per scan, ~20 us + a launch after every update kernel; a
+// fused version of that block-wide algorithm cost as much as it saved); this epilogue costs a few microseconds of a
+// workgroup that is about to exit.  The scratch is the grid's point storage, dead by now.  diverged: Pk_ is passed
+// through un-updated (SE:592).  Called by every thread (barriers inside).
+// ---------------------------------------------------------------------------
+template <int BLOCK>
+__device__ __noinline__ void joseph_epilogue(double r2, int diverged, double* __restrict__ out, int tid) {
+  LdsStore& L = g_lds;
+  const double* P = L.P;
+  if (diverged) {  // (block-uniform)
+    for (int k = tid; k < 324; k += BLOCK) out[k] = P[k];
+    return;
+  }
+  double* const sc = reinterpret_cast<double*>(L.pt);  // >= 66 KB, no longer read
+  double* const Ninv = sc;          // 36
+  double* const Y = sc + 36;        // 36  Y = N^-1 A
+  double* const T1 = sc + 72;       // 36  Y P_SS
+  double* const M = sc + 108;       // 36  Y P_SS Y^T + sigma^2 Z - Y^T
+  double* const D = sc + 144;       // 108 C M
+  double* const E2 = sc + 252;      // 108 C Y
+  double* const O = sc + 360;       // 324
+  static_assert(sizeof(L.pt) >= (360 + 324) * sizeof(double), "scratch of the Joseph epilogue");
+  __syncthreads();  // (every reader of the grid is done)
+  const int lane = tid & 63, wave = tid >> 6;
+  if (wave < 2) {  // N^-1, columns 3 wave .. 3 wave + 2
+    double v = 0.0;
+    if (lane < 54) {
+      const int i = lane / 9, j = lane % 9;
+      if (j < 6) {
+        v = (i == j ? r2 : 0.0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v += sym6(L.sums, i, k) * P[sidx(k) * 18 + sidx(j)];
+      } else {
+        v = (i == 3 * wave + (j - 6)) ? 1.0 : 0.0;
+      }
+    }
+    v = wave_gj_solve6x3(v, lane);
+    if (lane < 54 && lane % 9 >= 6) Ninv[(lane / 9) * 6 + 3 * wave + (lane % 9 - 6)] = v;
+  }
+  __syncthreads();
+  if (tid < 36) {
+    const int i = tid / 6, j = tid % 6;
+    double y = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) y += Ninv[i * 6 + k] * sym6(L.sums, k, j);
+    Y[tid] = y;
+  }
+  __syncthreads();
+  if (tid < 36) {
+    const int i = tid / 6, j = tid % 6;
+    double t = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t += Y[i * 6 + k] * P[sidx(k) * 18 + sidx(j)];
+    T1[tid] = t;
+  }
+  __syncthreads();
+  if (tid < 36) {
+    const int i = tid / 6, j = tid % 6;
+    double m = 0, z = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) m += T1[i * 6 + k] * Y[j * 6 + k], z += Y[i * 6 + k] * Ninv[j * 6 + k];
+    M[tid] = (m + r2 * z) - Y[j * 6 + i];
+  }
+  __syncthreads();
+  if (tid < 216) {
+    const int e = tid < 108 ? tid : tid - 108, i = e / 6, b = e % 6;
+    const double* W = tid < 108 ? M : Y;
+    double acc = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) acc += P[i * 18 + sidx(a)] * W[a * 6 + b];
+    (tid < 108 ? D : E2)[e] = acc;
+  }
+  __syncthreads();
+  for (int e = tid; e < 324; e += BLOCK) {
+    const int i = e / 18, j = e % 18;
+    double acc = P[e];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) acc += D[i * 6 + b] * P[j * 18 + sidx(b)] - E2[i * 6 + b] * P[sidx(b) * 18 + j];
+    O[e] = acc;
+  }
+  __syncthreads();
+  for (int e = tid; e < 324; e += BLOCK) {
+    const int i = e / 18, j = e % 18;
+    out[e] = 0.5 * (O[i * 18 + j] + O[j * 18 + i]);  // enforceSymmetry (MU:39-41)
+  }
+}
+
+// ---------------------------------------------------------------------------
 // the kernel.  PASS_ONLY: one correspondence pass at a caller-supplied linearisation
 // state (lins_correspondences / lins_reduce_pass), dumping records / sums.
 // ---------------------------------------------------------------------------
@@ -970,7 +1065,8 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     DevParams prm, const ScanDesc* __restrict__ descs, const int* __restrict__ order, const float4* __restrict__ arena,
     float4* __restrict__ sorted,
     const double* __restrict__ state_in, const double* __restrict__ cov_in, const double* __restrict__ lin_in,
-    int iter_arg, double* __restrict__ state_out, double* __restrict__ a6_out, OutRec* __restrict__ out,
+    int iter_arg, double* __restrict__ state_out, double* __restrict__ a6_out, double* __restrict__ cov_out,
+    OutRec* __restrict__ out,
     int4* __restrict__ idx_store, lins_pose_record* __restrict__ poses, int scan_id_base,
     lins_corr* __restrict__ dump, double* __restrict__ sums_out, int* __restrict__ counts_out,
     long long* __restrict__ prof_buf) {
@@ -1620,7 +1716,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     if (tid < 19) state_out[(size_t)scan * 19 + tid] = (tid < 3 || (tid >= 6 && tid < 10)) ? L.ic.lin[tid] : L.filt[tid];
   } else {
     if (tid < 19) state_out[(size_t)scan * 19 + tid] = div ? L.filt[tid] : L.ic.lin[tid];
-    if (tid < 21) a6_out[(size_t)scan * 21 + tid] = L.sums[tid];
+    if (a6_out && tid < 21) a6_out[(size_t)scan * 21 + tid] = L.sums[tid];
   }
   if (tid == 0) {
     OutRec r;
@@ -1641,6 +1737,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       pr->pad[0] = pr->pad[1] = 0;
     }
   }
+  if (!ICP && cov_out) joseph_epilogue<BLOCK>(prm.r2, div, cov_out + (size_t)scan * 324, tid);
 }
 
 }  // namespace LINS_LDS_NS

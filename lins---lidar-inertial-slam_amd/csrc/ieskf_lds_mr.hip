@@ -33,19 +33,19 @@ namespace lins {
 
 #define LINS_LAUNCH(NS, B, LN, PR)                                                                                  \
   hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, false, PR>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, \
-                     state_in, cov_in, (const double*)nullptr, 0, state_out, a6, (NS::OutRec*)out, idx_store, poses,  \
+                     state_in, cov_in, (const double*)nullptr, 0, state_out, a6, cov_out, (NS::OutRec*)out, idx_store, poses,  \
                      scan_id_base, (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof)
 #define LINS_LAUNCH_PASS(NS, B, LN)                                                                                    \
   hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, true, false>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, \
                      filt_state, (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr,           \
-                     (NS::OutRec*)nullptr, idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out,        \
+                     (double*)nullptr, (NS::OutRec*)nullptr, idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out,        \
                      (long long*)nullptr)
 
 int lds_mr_np_cap() { return lds_mr::kNpMax; }
 
 void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const int* order, const float4* arena,
                    float4* sorted, const double* state_in, const double* cov_in, double* state_out, double* a6,
-                   void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof) {
+                   double* cov_out, void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof) {
   if (prof)
     LINS_LAUNCH(lds_mr, LINS_MR_BLOCK, 1, true);
   else
@@ -58,7 +58,7 @@ void launch_lds_mr_icp(hipStream_t stream, int n, const DevParams& prm, const Sc
                        float4* sorted, const double* state_in, double* state_out, void* out, int4* idx_store) {
   hipLaunchKernelGGL((lds_mr::ieskf_lds_kernel<512, 1, false, false, true>), dim3(n), dim3(512), 0, stream, prm, descs,
                      (const int*)nullptr, arena, sorted, state_in, state_in /*unused: no covariance on this path*/, (const double*)nullptr, 0,
-                     state_out, (double*)nullptr, (lds_mr::OutRec*)out, idx_store, (lins_pose_record*)nullptr, 0,
+                     state_out, (double*)nullptr, (double*)nullptr, (lds_mr::OutRec*)out, idx_store, (lins_pose_record*)nullptr, 0,
                      (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, (long long*)nullptr);
 }
 

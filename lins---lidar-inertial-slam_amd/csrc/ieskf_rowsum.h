@@ -129,6 +129,32 @@ __device__ __forceinline__ void wave_gj_solve6(double a, int lane, double (&x)[6
   for (int r = 0; r < 6; ++r) x[r] = readlane_f64(a, r * 7 + 6);
 }
 
+// The same Gauss-Jordan for three right-hand sides at once: [N | B] is 6 x 9, element (i, j) in lane i * 9 + j
+// (54 lanes); after the six pivot steps column 6 + r of row i holds (N^-1 B)(i, r).  Used twice (two waves, B = the left
+// and the right half of the identity) for N^-1 in the Joseph epilogue.  Same pivoting rule as wave_gj_solve6.
+__device__ __forceinline__ double wave_gj_solve6x3(double a, int lane) {
+  const int i = lane < 54 ? lane / 9 : 7, j = lane < 54 ? lane % 9 : 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    int p = k;
+    unsigned best = (unsigned)__builtin_amdgcn_readlane(__double2hiint(a), k * 9 + k) & 0x7FFFFFFFu;
+#pragma unroll
+    for (int r = k + 1; r < 6; ++r) {
+      const unsigned h = (unsigned)__builtin_amdgcn_readlane(__double2hiint(a), r * 9 + k) & 0x7FFFFFFFu;
+      if (h > best) best = h, p = r;
+    }
+    if (p != k) {  // (wave-uniform) exchange rows k and p
+      const int src = i == k ? p * 9 + j : (i == p ? k * 9 + j : lane);
+      a = shfl_f64(a, src);
+    }
+    const double inv = 1.0 / readlane_f64(a, k * 9 + k);
+    const double aik = shfl_f64(a, (i < 6 ? i : 0) * 9 + k), akj = shfl_f64(a, k * 9 + j);
+    const double nkj = akj * inv;
+    if (i < 6 && j > k) a = i == k ? nkj : a - aik * nkj;
+  }
+  return a;  // lanes i * 9 + 6 + r: (N^-1 B)(i, r)
+}
+
 // Rinvleft(-phi)^T and phi from a unit quaternion without libm sin/cos.  Small rotations (w > 0, tan(|phi|/2) <= 1/8:
 // every scan-to-scan motion a lidar sees) take the short-series form phi_and_gt_small of lins_math.h — no square
 // root, one division, two fma chains.  Otherwise: with h = |phi|/2 the half angle, cos h = |w| / |q| and

@@ -34,12 +34,12 @@ void launch_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const floa
                  int, int4*, lins_corr*, double*, int*, float4*);
 void launch_joseph(hipStream_t, int, const DevParams&, const double*, const double*, const void*, double*);
 void launch_lds(hipStream_t, int, const DevParams&, int, const ScanDesc*, const float4*, float4*, const double*, const double*,
-                double*, double*, void*, int4*, lins_pose_record*, int, long long*);
+                double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*);
 void launch_lds_pass(hipStream_t, int, const DevParams&, int, const ScanDesc*, const float4*, float4*, const double*,
                      const double*, int, int4*, lins_corr*, double*, int*);
 int lds_np_cap();
 void launch_lds_mr(hipStream_t, int, const DevParams&, const ScanDesc*, const int*, const float4*, float4*, const double*,
-                   const double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*);
+                   const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*);
 void launch_lds_mr_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, float4*, const double*,
                         const double*, int, int4*, lins_corr*, double*, int*);
 int lds_mr_np_cap();
@@ -555,12 +555,11 @@ int run_range(lins_ctx* ctx, int lo, int cnt, int n_total, const RangeFlags& fl,
   lins_pose_record* ps = poses ? poses + lo : nullptr;
   if (use_mr || use_lds) {
     if (use_mr)
-      launch_lds_mr(ctx->stream, cnt, ctx->dprm, desc, nullptr, ctx->d_arena, ctx->d_binned, st_in, cov_in, st_out, a6, out, ctx->d_idx, ps,
+      launch_lds_mr(ctx->stream, cnt, ctx->dprm, desc, nullptr, ctx->d_arena, ctx->d_binned, st_in, cov_in, st_out, a6, cov_out, out, ctx->d_idx, ps,
                     scan_id_base + lo, nullptr);
     else
-      launch_lds(ctx->stream, cnt, ctx->dprm, s == SEARCH_LDS3 ? 3 : 1, desc, ctx->d_arena, ctx->d_binned, st_in, cov_in, st_out, a6, out,
-                 ctx->d_idx, ps, scan_id_base + lo, nullptr);
-    launch_joseph(ctx->stream, cnt, ctx->dprm, cov_in, a6, out, cov_out);
+      launch_lds(ctx->stream, cnt, ctx->dprm, s == SEARCH_LDS3 ? 3 : 1, desc, ctx->d_arena, ctx->d_binned, st_in, cov_in, st_out, a6, cov_out, out,
+                 ctx->d_idx, ps, scan_id_base + lo, nullptr);  // (the Joseph update is the kernels' epilogue)
   } else {
     DevParams dp = ctx->dprm;
     dp.search = want_lds ? (int)SEARCH_BINNED : s;  // a scan does not fit LDS: global-memory grid
@@ -764,18 +763,18 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   if (use_mr || use_lds) {
     if (use_mr)
       launch_lds_mr(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->use_order ? ctx->d_order : nullptr, ctx->d_arena, ctx->d_binned, ctx->d_state_in,
-                    ctx->d_cov_in, ctx->d_state_out, a6, out, ctx->d_idx, (lins_pose_record*)d_poses,
+                    ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx, (lins_pose_record*)d_poses,
                     scan_id_base, ctx->d_prof);
     else
       launch_lds(ctx->stream, ctx->n_uploaded, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc,
-                 ctx->d_arena, ctx->d_binned, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, a6, out, ctx->d_idx,
+                 ctx->d_arena, ctx->d_binned, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx,
                  (lins_pose_record*)d_poses, scan_id_base, ctx->d_prof);
     HIP_TRY(ctx, hipEventRecord(ctx->hist1[h], ctx->stream));
     if (q.on) HIP_TRY(ctx, hipEventRecord(q.ev_main[set], ctx->stream));  // (the pose records of this run are complete)
-    // The Joseph update (SE:594-598) follows on the same stream.  (Measured, round 3: on a side stream beside the next
-    // run's update kernel — at normal or at lowest stream priority — its 1024 small workgroups sit on LDS and wave
-    // slots the update kernel's second resident workgroup needs, and the update kernel takes 0.86 instead of 0.71 ms.)
-    launch_joseph(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_cov_in, a6, out, ctx->d_cov_out);
+    // (The Joseph update, SE:594-598, is the update kernel's epilogue since round 3: ieskf_lds_impl.h joseph_epilogue.
+    // Rounds 1-2 launched ieskf_joseph_kernel here, ~20 us + a launch per run; a side stream for it — measured at normal
+    // and at lowest stream priority — lets its 1024 small workgroups sit on the LDS and wave slots the NEXT run's update
+    // kernel needs for its second resident workgroup: that kernel then takes 0.86 instead of 0.71 ms.)
   } else {
     DevParams dp = ctx->dprm;
     dp.search = want_lds ? (int)SEARCH_BINNED : search;  // a scan does not fit LDS: global-memory grid
@@ -1406,11 +1405,10 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
     if (use_mr || use_lds) {
       if (use_mr)
         launch_lds_mr(ctx->stream, n, ctx->dprm, t.d_desc, nullptr, t.d_arena, t.d_sorted, ctx->d_state_in, ctx->d_cov_in,
-                      ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr);
+                      ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr);
       else
         launch_lds(ctx->stream, n, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, t.d_desc, t.d_arena, t.d_sorted, ctx->d_state_in,
-                   ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr);
-      launch_joseph(ctx->stream, n, ctx->dprm, ctx->d_cov_in, ctx->d_a6, ctx->d_out, ctx->d_cov_out);
+                   ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr);
     } else {
       DevParams dp = ctx->dprm;
       dp.search = want_lds ? (int)SEARCH_BINNED : search;
