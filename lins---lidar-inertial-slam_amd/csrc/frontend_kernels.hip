@@ -455,6 +455,11 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   // one wave per ring; 2048 keys (voxel index << 11 | order) sorted in registers, then only the order
   // and a run-start bit per sorted position go to LDS (the flags / columns / sector buffers are dead).
   // Sorted position e belongs to lane e / 32.
+  // Two phases since round 3: every ring sorts and counts its voxels first; after one block barrier the rings' output
+  // offsets are known and the centroids go straight to their final place (rounds 1-2 wrote them to a temporary place
+  // per ring and closed the gaps ring by ring afterwards: the less-flat cloud written twice and read once more, 32
+  // block barriers).
+  int vg_p = 0, vg_mine = 0, vg_incl = 0;  // this ring's keys per lane, this lane's run starts and their inclusive wave prefix
   {
     {
       const int ring = wave;
@@ -502,12 +507,6 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
               prev = kv[u];
             }
           }
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          // one centroid per run start — f32 sums of all four fields in stable (original) order — to the
-          // ring's temporary place in the output array, at the wave prefix of the start counts
-          const int e0 = lane * kP;
           int incl = mine;
 #pragma unroll
           for (int o = 1; o < 64; o <<= 1) {
@@ -515,20 +514,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
             if (lane >= o) incl += nb;
           }
           nvox = __shfl(incl, 63);
-          int pos = incl - mine;
-          for (int u = 0; u < kP; ++u) {
-            const int e = e0 + u;
-            if (e >= m || !(vs[e] & 0x8000u)) continue;
-            float sx = 0, sy = 0, sz = 0, si = 0;
-            int j = e;
-            do {
-              const float4 p = lfp[base + (int)(vs[j] & 2047u)];
-              sx += p.x, sy += p.y, sz += p.z, si += p.w;
-              ++j;
-            } while (j < m && !(vs[j] & 0x8000u));
-            const float cnt = (float)(j - e);
-            olf[base + pos++] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
-          }
+          vg_p = kP, vg_mine = mine, vg_incl = incl;
         };
         static_assert(kRingCap == 2048, "sort sizes below");
         const long long dz = maxb[2] - minb[2] + 1;
@@ -553,7 +539,6 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     __syncthreads();
   }
   FE_MARK(6)
-  // D2: close the gaps, ring by ring (a ring's final place never lies behind its temporary one)
   if (tid == 0) {
     int run = 0;
     for (int r = 0; r < kFeRows; ++r) L.ring_off[r] = run, run += L.ring_out[r];
@@ -561,15 +546,26 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     out_counts[scan * 4 + 3] = run;
   }
   __syncthreads();
-  for (int r = 0; r < kFeRows; ++r) {
-    const int c = L.ring_out[r], src = L.ring_base[r], dst = L.ring_off[r];
-    float4 v[2];
-    for (int u = 0; u < 2; ++u)
-      if (tid + u * kFeBlock < c) v[u] = olf[src + tid + u * kFeBlock];
-    __syncthreads();
-    for (int u = 0; u < 2; ++u)
-      if (tid + u * kFeBlock < c) olf[dst + tid + u * kFeBlock] = v[u];
-    __syncthreads();
+  {  // D2: one centroid per run start — f32 sums of all four fields in stable (original) order — at the ring's final
+     // offset + the wave prefix of the start counts (sorted position e belongs to lane e / vg_p)
+    const int ring = wave;
+    const int m = L.ring_m[ring], base = L.ring_base[ring];
+    const unsigned short* vs = L.vso[wave];
+    float4* dst = olf + L.ring_off[ring];
+    int pos = vg_incl - vg_mine;
+    for (int u = 0; u < vg_p; ++u) {
+      const int e = lane * vg_p + u;
+      if (e >= m || !(vs[e] & 0x8000u)) continue;
+      float sx = 0, sy = 0, sz = 0, si = 0;
+      int j = e;
+      do {
+        const float4 p = lfp[base + (int)(vs[j] & 2047u)];
+        sx += p.x, sy += p.y, sz += p.z, si += p.w;
+        ++j;
+      } while (j < m && !(vs[j] & 0x8000u));
+      const float cnt = (float)(j - e);
+      dst[pos++] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+    }
   }
 #ifdef LINS_FE_PROF
   FE_MARK(7)

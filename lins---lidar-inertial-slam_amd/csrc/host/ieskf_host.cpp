@@ -44,7 +44,8 @@ bool gauss_newton_step(const lins_params& prm, double* t, Q4& q, const lins_scan
   for (int i = 0; i < in.n_corner_sharp; ++i)
     if (cc[i].accepted) add_row(in.corner_sharp[i], cc[i]);
   double x[6];
-  icp_gn_solve(JTJ, JTb, iter, x);
+  double ws[kIcpWorkspace];
+  icp_gn_solve(JTJ, JTb, iter, x, ws);
   return icp_apply(x, t, q);
 }
 

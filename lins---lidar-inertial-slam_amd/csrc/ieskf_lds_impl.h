@@ -926,23 +926,41 @@ __device__ __noinline__ long long solve_and_update(double prm_r2, int prm_fixed_
   return t3;
 }
 
+// The Gauss-Newton row of the fallback, out of line: inlined into the search loop its rotation matrix and the 3 x 3
+// product (R(s phi), -R [p]x) cost the loop 124 spilled registers (1.7 KB of scratch per lane, round 2) for a path that
+// runs once per accepted row.  Scalars by value, the row comes back by value.
+struct IcpRow {
+  double v[7];
+};
+__device__ __noinline__ IcpRow icp_row_dev(double inv_period, double phx, double phy, double phz, float px, float py, float pz,
+                                           float intensity, float c0, float c1, float c2, float c3) {
+  IcpRow r;
+  const float c[4] = {c0, c1, c2, c3};
+  icp_row(inv_period, V3{phx, phy, phz}, px, py, pz, intensity, c, r.v, r.v[6]);
+  return r;
+}
+
 // ---------------------------------------------------------------------------
 // Serial tail of one ICP iteration (estimateTransform's loop body after the correspondences,
 // SE:1170-1195): needs >= 10 plane and >= 5 line rows, else the iteration is spent without a step
 // (SE:1175-1184); Gauss-Newton step + degeneracy projection + stop rule in icp_math.h.  A handful
-// of 6x6 factorizations per divergence: one lane, arrays in scratch — clarity over speed.
+// of 6x6 factorizations per divergence: one lane, its arrays in LDS.
 // ---------------------------------------------------------------------------
 __device__ __noinline__ void icp_solve_and_update(int tid, int iter) {
   LdsStore& L = g_lds;
   if (tid == 0) {
     int conv = 0;
     if (L.m_surf >= 10 && L.m_corner >= 5) {
-      double JTJ[36], JTb[6], x[6];
+      // every run-time-indexed array of the step lives in LDS (the wave partials and the solve's staging area are idle
+      // here): no private arrays, no scratch (round 2: 1.7 KB per lane, 124 spilled registers in this instantiation)
+      static_assert(sizeof(L.partial) >= kIcpWorkspace * sizeof(double) && sizeof(L.aug) >= 48 * sizeof(double), "ICP workspace");
+      double* const ws = L.partial;
+      double *const JTJ = &L.aug[0][0], *const JTb = JTJ + 36, *const x = JTJ + 42;
       for (int i = 0; i < 6; ++i) {
         for (int j = 0; j < 6; ++j) JTJ[i * 6 + j] = L.sums[i <= j ? tri6(i, j) : tri6(j, i)];
         JTb[i] = L.sums[21 + i];
       }
-      icp_gn_solve(JTJ, JTb, iter, x);
+      icp_gn_solve(JTJ, JTb, iter, x, ws);
       double t[3] = {L.ic.lin[0], L.ic.lin[1], L.ic.lin[2]};
       Q4 q{L.ic.lin[6], L.ic.lin[7], L.ic.lin[8], L.ic.lin[9]};
       conv = icp_apply(x, t, q) ? 1 : 0;
@@ -1432,7 +1450,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           }
           if (o.accepted) {
             if (ICP) {  // Gauss-Newton row of the fallback (SE:1246-1257): [c^T(-R(s phi)[p]x), c^T | -0.05 res]
-              icp_row(prm.inv_period, phi, q.x, q.y, q.z, q.w, o.c, row, row[6]);
+              const IcpRow ir = icp_row_dev(prm.inv_period, phi.x, phi.y, phi.z, q.x, q.y, q.z, q.w, o.c[0], o.c[1], o.c[2], o.c[3]);
+#pragma unroll
+              for (int k = 0; k < 7; ++k) row[k] = ir.v[k];
             } else {
               V3 cv{(double)o.c[0], (double)o.c[1], (double)o.c[2]};
               V3 u = cross(V3{(double)q.x, (double)q.y, (double)q.z}, mvec(L.ic.Rt, cv));
@@ -1620,7 +1640,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           }
           if (o.accepted) {
             if (ICP) {  // Gauss-Newton row of the fallback (SE:1246-1257): [c^T(-R(s phi)[p]x), c^T | -0.05 res]
-              icp_row(prm.inv_period, phi, q.x, q.y, q.z, q.w, o.c, row, row[6]);
+              const IcpRow ir = icp_row_dev(prm.inv_period, phi.x, phi.y, phi.z, q.x, q.y, q.z, q.w, o.c[0], o.c[1], o.c[2], o.c[3]);
+#pragma unroll
+              for (int k = 0; k < 7; ++k) row[k] = ir.v[k];
             } else {
               V3 cv{(double)o.c[0], (double)o.c[1], (double)o.c[2]};
               V3 u = cross(V3{(double)q.x, (double)q.y, (double)q.z}, mvec(L.ic.Rt, cv));
