@@ -59,19 +59,21 @@ def compare_features(fo, fx):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 64
     gpu = "--gpu" in sys.argv
+    if gpu:
+        import torch  # noqa: F401  (first: one HIP runtime in the process)
     tot_seg_host, tot_feat_host, tot_seg_dev, tot_feat_dev = {}, {}, {}, {}
     raws = [host.synth_raw_scan(i // 2, i % 2) for i in range(n)]
     turn = 0.0
     for a in sys.argv:
         if a.startswith("--turn="):
             turn = float(a.split("=")[1])
-    if turn:  # rotate the clouds about z: the synthetic sensor fires exactly ON the column edges of IP:225 (see below)
+    if turn:  # rotate the clouds about z (rounds 1-2: the synthetic sensor fired exactly ON the column edges of IP:225)
         ca, sa = np.float32(np.cos(np.radians(turn))), np.float32(np.sin(np.radians(turn)))
         for r in raws:
             x, y = r[:, 0].copy(), r[:, 1].copy()
             r[:, 0], r[:, 1] = ca * x - sa * y, sa * x + ca * y
-    print(f"clouds turned by {turn} deg about z" if turn else "clouds as generated: every firing azimuth is a multiple of 0.2 deg = a column EDGE "
-          "of round((az - 90) / 0.2) (IP:225), so each point's column hangs on the last bit of atan2f")
+    print(f"clouds turned by {turn} deg about z" if turn else "clouds as generated (round 3: seeded azimuth phase + drift + jitter, "
+          "no firing within 0.14 column of a rounding edge of IP:225)")
 
     def acc(t, d):
         for k, v in d.items():

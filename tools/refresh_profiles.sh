@@ -1,8 +1,8 @@
 #!/bin/bash
-# Regenerates the line-of-record artifacts for round $1 (default r02) on the GPU box into gpurun_out/; copy what is
+# Regenerates the line-of-record artifacts for round $1 (default r03) on the GPU box into gpurun_out/; copy what is
 # to be judged into profiles/ afterwards (tools/README.md).  PMC passes are separate rocprofv3 runs with
 # --kernel-trace only (never combined with other trace domains).
-tag=${1:-r02}
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out
@@ -36,10 +36,12 @@ cat $out/${tag}_aux_rates.txt
   python tools/cold_iter_time.py 2>&1 | tail -7
   echo "== tools/wg_cost_model.py 1024 mr  (tail of the launch)"
   python tools/wg_cost_model.py 1024 mr 2>&1 | tail -3
-  echo "== tools/split_timing.py"
-  python tools/split_timing.py 2>&1 | tail -6
+  echo "== tools/step_modes.py  (host sync per step / back to back / pipelined gather mode)"
+  python tools/step_modes.py 2>&1 | tail -3
 } > $out/${tag}_kernel_anatomy.txt 2>&1
 cat $out/${tag}_kernel_anatomy.txt
-bash tools/late_iter_pmc.sh mr > /dev/null 2>&1; tail -6 $out/late_iter_pmc.txt; cp $out/late_iter_pmc.txt $out/${tag}_late_iter_pmc.txt
+bash tools/aux_profiles.sh > /dev/null 2>&1; cp $out/aux_kernel_stats.csv $out/${tag}_rocprofv3_kernel_stats_aux.csv; cat $out/${tag}_rocprofv3_kernel_stats_aux.csv
+bash tools/aux_pmc.sh > /dev/null 2>&1; cp $out/aux_pmc.txt $out/${tag}_rocprofv3_pmc_aux.txt; cat $out/${tag}_rocprofv3_pmc_aux.txt
+python tools/frontend_vs_libm.py 256 --gpu > $out/${tag}_frontend_vs_libm.txt 2>&1; tail -12 $out/${tag}_frontend_vs_libm.txt
 bash tools/pmc_run.sh ${tag}pmc --batch 1024 --search auto > $out/${tag}_pmc_all.txt 2>&1
 tail -40 $out/${tag}_pmc_all.txt
