@@ -51,7 +51,8 @@ def compare_features(fo, fx):
         d[k + "_points_differ"] = int((~same_xyz).sum() + abs(len(a) - len(b)))
         tag = np.abs(a[:m, 3].view(np.int32).astype(np.int64) - b[:m, 3].view(np.int32).astype(np.int64))
         d[k + "_time_tag_ulp>0"] = int((tag[same_xyz] > 0).sum())
-        d[k + "_time_tag_ulp_max"] = int(tag[same_xyz].max(initial=0))
+        d[k + "_time_tag_ulp_max"] = int(tag[same_xyz].max(initial=0))  # (ulp distances explode for tags next to zero: ring 0, relTime ~ 0)
+        d[k + "_time_tag_absdiff_max"] = float(np.abs(a[:m, 3] - b[:m, 3])[same_xyz].max(initial=0))
         d[k + "_total"] = int(len(a))
     return d
 

@@ -40,12 +40,14 @@ def counters(cmd, counter, tag):
     if dbs:
         cur = sqlite3.connect(dbs[0]).cursor()
         for nm in names:
-            for name, val, n in cur.execute(
-                    "select k.name, sum(p.counter_value), count(distinct k.dispatch_id) from pmc_events p join kernels k"
+            for name, val, n, rows in cur.execute(
+                    "select k.name, sum(p.counter_value), count(distinct k.dispatch_id), count(*) from pmc_events p join kernels k"
                     " on p.dispatch_id = k.dispatch_id where p.counter_name = ? group by k.name", (nm,)):
                 if isinstance(counter, str):
                     res[name] = (val, n)
-                else:
+                elif nm.startswith("GRBM_"):  # one row per XCD, each the whole launch: the mean, not the sum
+                    res.setdefault(name, {})[nm] = val / rows
+                else:                         # SQ: one row per shader engine: the sum is the device total
                     res.setdefault(name, {})[nm] = val / n
     subprocess.run(["rm", "-rf", d])
     return res, p.stdout.decode()[-400:]
