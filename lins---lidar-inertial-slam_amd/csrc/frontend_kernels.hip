@@ -51,8 +51,7 @@ struct FeLds {
   };
   int first_half_end;      // first point with ori - startOri > pi (halfPassed flips after it)
   int ring_m[kFeRows];     // less-flat points of each ring
-  int ring_base[kFeRows];  // where the ring's index list / temporary centroids start (its first sector's start)
-  int ring_bb[kFeRows][6]; // ordered-int min xyz, max xyz of the ring's less-flat points
+  int ring_base[kFeRows];  // the ring's first sector's start: what its kept-point list is relative to
   int ring_out[kFeRows];   // voxels (= output points) of each ring
   int ring_off[kFeRows + 1];
   int bad;
@@ -115,8 +114,7 @@ __device__ __forceinline__ void wave_bitonic_sort(K (&v)[P], int lane) {
 __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     const FeScan* __restrict__ scans, const float4* __restrict__ cloud, const float* __restrict__ range,
     const unsigned* __restrict__ col, const unsigned char* __restrict__ ground, double scan_period,
-    float4* __restrict__ und, float* __restrict__ diff, int* __restrict__ picks, float4* __restrict__ out,
-    int* __restrict__ out_counts) {
+    float* __restrict__ tags, int* __restrict__ picks, float4* __restrict__ out, int* __restrict__ out_counts) {
   FeLds& L = g_fe;
 #ifdef LINS_FE_PROF
   long long fe_t0 = clock64(), fe_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -127,37 +125,46 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
 #endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int scan = blockIdx.x;
-  const FeScan sc = scans[scan];
+  const FeScan& sc = scans[scan];  // (read where it is used: a private copy indexed by the ring lives in scratch)
   const int n = sc.n;
   const float4* pts = cloud + sc.off;
   const float* rg = range + sc.off;
   const unsigned* cl = col + sc.off;
   const unsigned char* gd = ground + sc.off;
-  float4* un = und + sc.off;
-  float* df = diff + sc.off;
+  float* tg = tags + sc.off;  // relative-time tags (the .w of the de-skewed points): the only per-point array this kernel writes
   int* pk = picks + (size_t)scan * kFeRows * 6 * kPickStride;
   const double kPi = 3.14159265358979323846;
 
   if (tid == 0) L.first_half_end = n, L.bad = 0;
-  for (int i = tid; i < n + 16; i += kFeBlock) {
-    L.a.flags[i] = i < n && gd[i] ? 8 : 0;
-    L.a.col[i] = i < n ? (unsigned short)cl[i] : 0;
-  }
-  __syncthreads();
-
-  FE_MARK(0)
-  // ---- undistortPcl, pass 1: where does halfPassed flip?  (SE:631-638: first-half adjustment) ----
+  // ---- load + undistortPcl, pass 1: where does halfPassed flip?  (SE:631-638: first-half adjustment) ----
+  // One pass over the points: thread t owns the points t, t + 1024, ... and keeps each one's raw orientation and
+  // intensity in registers until the flip position is known (round 3; rounds 1-2 read the cloud twice and evaluated
+  // the arctangent twice).  The cloud is not read again before the less-flat stage.
   const double s_ori = (double)sc.start_ori, e_ori = (double)sc.end_ori;
+  constexpr int kOwn = (kFeMaxN + kFeBlock - 1) / kFeBlock;  // 29
+  float orv[kOwn], pwv[kOwn];
   {
     int first = n;
-    for (int i = tid; i < n; i += kFeBlock) {
-      const float4 p = pts[i];
-      double ori = (double)(-lins_atan2f(p.y, p.x));
-      if (ori < s_ori - kPi / 2)
-        ori += 2 * kPi;
-      else if (ori > s_ori + kPi * 3 / 2)
-        ori -= 2 * kPi;
-      if (ori - s_ori > kPi && i < first) first = i;
+#pragma unroll
+    for (int k = 0; k < kOwn; ++k) {
+      const int i = tid + k * kFeBlock;
+      float o = 0.f, w = 0.f;
+      if ((k & 3) == 0) asm volatile("" ::: "memory");  // (four point reads in flight at a time: the unrolled loop would hoist all 29)
+      if (i < n) {
+        const float4 p = pts[i];
+        o = -lins_atan2f(p.y, p.x), w = p.w;
+        double ori = (double)o;
+        if (ori < s_ori - kPi / 2)
+          ori += 2 * kPi;
+        else if (ori > s_ori + kPi * 3 / 2)
+          ori -= 2 * kPi;
+        if (ori - s_ori > kPi && i < first) first = i;
+        L.a.flags[i] = gd[i] ? 8 : 0;
+        L.a.col[i] = (unsigned short)cl[i];
+      } else if (i < n + 16) {
+        L.a.flags[i] = 0, L.a.col[i] = 0;
+      }
+      orv[k] = o, pwv[k] = w;
     }
     for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
     if (lane == 0) atomicMin(&L.first_half_end, first);
@@ -165,37 +172,45 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   __syncthreads();
   const int flip = L.first_half_end;
   FE_MARK(1)
-  // ---- pass 2: relative time tag; smoothness stencil; masks -------------------------------------
-  for (int i = tid; i < n; i += kFeBlock) {
-    float4 p = pts[i];
-    double ori = (double)(-lins_atan2f(p.y, p.x));
-    if (i <= flip) {
-      if (ori < s_ori - kPi / 2)
+  // ---- pass 2: relative time tag (from the registers); masks ---------------------------------------
+#pragma unroll
+  for (int k = 0; k < kOwn; ++k) {
+    const int i = tid + k * kFeBlock;
+    if (i < n) {
+      float o = orv[k];
+      asm volatile("" : "+v"(o));  // (keeps the compiler from carrying pass 1's f64 orientation across the barrier: 29 spilled doubles)
+      double ori = (double)o;
+      if (i <= flip) {
+        if (ori < s_ori - kPi / 2)
+          ori += 2 * kPi;
+        else if (ori > s_ori + kPi * 3 / 2)
+          ori -= 2 * kPi;
+      } else {
         ori += 2 * kPi;
-      else if (ori > s_ori + kPi * 3 / 2)
-        ori -= 2 * kPi;
-    } else {
-      ori += 2 * kPi;
-      if (ori < e_ori - kPi * 3 / 2)
-        ori += 2 * kPi;
-      else if (ori > e_ori + kPi / 2)
-        ori -= 2 * kPi;
+        if (ori < e_ori - kPi * 3 / 2)
+          ori += 2 * kPi;
+        else if (ori > e_ori + kPi / 2)
+          ori -= 2 * kPi;
+      }
+      const double rel = (ori - s_ori) / (double)sc.ori_diff;
+      tg[i] = (float)((double)(int)pwv[k] + scan_period * rel);
     }
-    const double rel = (ori - s_ori) / (double)sc.ori_diff;
-    p.w = (float)((double)(int)p.w + scan_period * rel);
-    un[i] = p;
+  }
+  // calculateSmoothness (SE:656-678) is evaluated where it is consumed — the sector sort below — from the range array
+  // (f32, left to right, as written in SE:660-666); cloudCurvature / cloudSmoothness are never materialised.
+  auto diff_at = [&](int i) {
     float d = 0.f;
-    if (i >= 5 && i < n - 5)  // calculateSmoothness (f32, left to right, as written in SE:660-666)
+    if (i >= 5 && i < n - 5)
       d = rg[i - 5] + rg[i - 4] + rg[i - 3] + rg[i - 2] + rg[i - 1] - rg[i] * 10 + rg[i + 1] + rg[i + 2] + rg[i + 3] +
           rg[i + 4] + rg[i + 5];
-    df[i] = d;
-  }
+    return d;
+  };
   unsigned* fw = reinterpret_cast<unsigned*>(L.a.flags);  // (marks are idempotent bit sets: 32-bit LDS atomics)
   auto mark = [&](int i) { atomicOr(&fw[i >> 2], 1u << ((i & 3) * 8)); };
   for (int i = tid; i < n; i += kFeBlock) {
     if (i >= 5 && i < n - 6) {  // markOccludedPoints (SE:680-713)
       const float d1 = rg[i], d2 = rg[i + 1];
-      int cd = (int)(cl[i + 1] - cl[i]);
+      int cd = (int)L.a.col[i + 1] - (int)L.a.col[i];
       cd = cd < 0 ? -cd : cd;
       if (cd < 10) {
         if (d1 - d2 > 0.3) {
@@ -213,7 +228,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   FE_MARK(2)
   // ---- extractFeatures: one wave per ring, sectors in order (marks of one sector reach the next) ---
   {
-    const int ring = wave;
+    const int ring = __builtin_amdgcn_readfirstlane(wave);
     unsigned long long* key = L.a.skey[ring];
     for (int j = 0; j < 6; ++j) {
       const int sp = (sc.start_ring[ring] * (6 - j) + sc.end_ring[ring] * j) / 6;
@@ -236,7 +251,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
 #pragma unroll
         for (int u = 0; u < kP; ++u) {
           const int e = lane * kP + u;
-          kv[u] = e < m ? ((unsigned long long)__float_as_uint(fabsf(df[sp + e])) << 32) | (unsigned)smooth_ind(sp + e) : ~0ull;
+          kv[u] = e < m ? ((unsigned long long)__float_as_uint(fabsf(diff_at(sp + e))) << 32) | (unsigned)smooth_ind(sp + e) : ~0ull;
           ground_here = ground_here || (e <= m && (g_fe.a.flags[smooth_ind(sp + e)] & 8));
         }
         wave_bitonic_sort<kP, unsigned long long>(kv, lane);  // ascending
@@ -267,7 +282,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         };
         auto sorted_ind = [&](int k) { return k == ep ? smooth_ind(ep) : (int)(unsigned)key[k - sp]; };
-        const float d_ep = fabsf(df[ep]);
+        const float d_ep = fabsf(diff_at(ep));
         auto curv_at = [&](int k) {  // cloudCurvature of the k-th element = the square of the sort key's value
           const double d = (double)(k == ep ? d_ep : __uint_as_float((unsigned)(key[k - sp] >> 32)));
           return d * d;
@@ -391,15 +406,20 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
       out_counts[scan * 4 + tid] = run;
     }
     __syncthreads();
+    auto und_pt = [&](int i) {  // the de-skewed point: coordinates as they came, the relative-time tag as intensity (SE:649-650)
+      float4 q = pts[i];
+      q.w = tg[i];
+      return q;
+    };
     for (int t = tid; t < kSec * 26; t += kFeBlock) {
       const int s2 = t / 26, k = t - s2 * 26;
       const int* spk = pk + s2 * kPickStride;
       if (k < 2) {
-        if (k < spk[26]) out[sc.o_sharp + cnt[3 * kSec + s2] + k] = un[spk[k]];
+        if (k < spk[26]) out[sc.o_sharp + cnt[3 * kSec + s2] + k] = und_pt(spk[k]);
       } else if (k < 22) {
-        if (k - 2 < spk[27]) out[sc.o_less_sharp + cnt[4 * kSec + s2] + (k - 2)] = un[spk[k]];
+        if (k - 2 < spk[27]) out[sc.o_less_sharp + cnt[4 * kSec + s2] + (k - 2)] = und_pt(spk[k]);
       } else {
-        if (k - 22 < spk[28]) out[sc.o_flat + cnt[5 * kSec + s2] + (k - 22)] = un[spk[k]];
+        if (k - 22 < spk[28]) out[sc.o_flat + cnt[5 * kSec + s2] + (k - 22)] = und_pt(spk[k]);
       }
     }
     __syncthreads();
@@ -407,14 +427,15 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
 
   FE_MARK(4)
   // ---- less-flat cloud: per ring, every point of its sectors with label <= 0 (SE:815-820) ... -----
-  // D0, one wave per ring: compact the kept points and take the bounding box VoxelGrid needs.
+  // D0, one wave per ring: the kept points' positions (relative to the ring's first sector) as a compact u16 list in
+  // LDS — the sector sort buffers are idle.  Round 3: the points themselves are not touched here (rounds 1-2 copied
+  // the kept points to a compact global list and read that list back twice).
   float4* olf = out + sc.o_less_flat;
-  float4* lfp = const_cast<float4*>(pts);  // the uploaded copy of the input cloud is dead: it becomes the per-ring
-                                           // compact lists of kept points (read back coalesced, no index chasing)
+  unsigned short* const kept = reinterpret_cast<unsigned short*>(L.a.skey[wave]);  // [kRingCap] of this ring
+  static_assert(sizeof(L.a.skey[0]) >= kRingCap * sizeof(unsigned short), "index list of a ring");
   {
-    const int ring = wave;
+    const int ring = __builtin_amdgcn_readfirstlane(wave);
     int m = 0, base = -1;
-    int mn[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, mx[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
     for (int j = 0; j < 6; ++j) {
       const int sp = (sc.start_ring[ring] * (6 - j) + sc.end_ring[ring] * j) / 6;
       const int ep = (sc.start_ring[ring] * (5 - j) + sc.end_ring[ring] * (j + 1)) / 6 - 1;
@@ -425,27 +446,19 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
         const bool keep = k <= ep && label_le0(k);
         const unsigned long long mask = __ballot(keep);
         if (keep) {
-          const int pos = __popcll(mask & ((1ull << lane) - 1ull));
-          const float4 p = un[k];
-          lfp[base + m + pos] = p;
-          const int ox = fe_ordered_int(p.x), oy = fe_ordered_int(p.y), oz = fe_ordered_int(p.z);
-          mn[0] = min(mn[0], ox), mn[1] = min(mn[1], oy), mn[2] = min(mn[2], oz);
-          mx[0] = max(mx[0], ox), mx[1] = max(mx[1], oy), mx[2] = max(mx[2], oz);
+          const int pos = m + __popcll(mask & ((1ull << lane) - 1ull));
+          if (pos < kRingCap) kept[pos] = (unsigned short)(k - base);
         }
         m += __popcll(mask);
       }
     }
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-      for (int o = 32; o > 0; o >>= 1) mn[a] = min(mn[a], __shfl_xor(mn[a], o)), mx[a] = max(mx[a], __shfl_xor(mx[a], o));
     if (lane == 0) {
       L.ring_m[ring] = m, L.ring_base[ring] = base < 0 ? 0 : base;
-      for (int a = 0; a < 3; ++a) L.ring_bb[ring][a] = mn[a], L.ring_bb[ring][3 + a] = mx[a];
-      if (m > kRingCap) L.bad = 1;  // cannot happen for a 16 x 1800 sensor; refuse rather than truncate silently
+      if (m > kRingCap || (m > 0 && sc.end_ring[ring] - base >= 65536)) L.bad = 1;  // cannot happen for a 16 x 1800 sensor; refuse rather than truncate silently
     }
   }
   __threadfence_block();
-  __syncthreads();
+  __syncthreads();  // (every reader of the flags is done: the voxel orders below overlay them)
   if (L.bad) {
     if (tid == 0) out_counts[scan * 4 + 3] = -1;
     return;
@@ -453,44 +466,69 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   FE_MARK(5)
   // D1, pcl::VoxelGrid 0.2 m with all-field averaging, output ordered by voxel index (SE:189, 822-825):
   // one wave per ring; 2048 keys (voxel index << 11 | order) sorted in registers, then only the order
-  // and a run-start bit per sorted position go to LDS (the flags / columns / sector buffers are dead).
-  // Sorted position e belongs to lane e / 32.
-  // Two phases since round 3: every ring sorts and counts its voxels first; after one block barrier the rings' output
-  // offsets are known and the centroids go straight to their final place (rounds 1-2 wrote them to a temporary place
-  // per ring and closed the gaps ring by ring afterwards: the less-flat cloud written twice and read once more, 32
-  // block barriers).
+  // and a run-start bit per sorted position go to LDS.  Sorted position e belongs to lane e / 32.
+  // The kept points are read ONCE here: each lane packs the voxel coordinates of its points (11 + 11 + 10 bits around
+  // zero: +-204 m / +-102 m) into one register per point, the wave folds the bounding box VoxelGrid needs
+  // (getMinMax3D), and the keys are built from the packed coordinates.  A ring that does not pack (never a VLP-16's)
+  // takes the same route with a second read of its points.
+  // Two phases: every ring sorts and counts its voxels first; after one block barrier the rings' output
+  // offsets are known and the centroids go straight to their final place.
   int vg_p = 0, vg_mine = 0, vg_incl = 0;  // this ring's keys per lane, this lane's run starts and their inclusive wave prefix
   {
     {
-      const int ring = wave;
+      const int ring = __builtin_amdgcn_readfirstlane(wave);
       const int m = L.ring_m[ring], base = L.ring_base[ring];
       unsigned short* vs = L.vso[wave];
       int nvox = 0;
       if (m > 0) {
         const float inv = 1.0f / 0.2f;
-        int minb[3], maxb[3];
-        for (int a = 0; a < 3; ++a) {
-          minb[a] = (int)floorf(fe_ordered_float(L.ring_bb[ring][a]) * inv);
-          maxb[a] = (int)floorf(fe_ordered_float(L.ring_bb[ring][3 + a]) * inv);
-        }
-        const long long dx = maxb[0] - minb[0] + 1, dy = maxb[1] - minb[1] + 1;
-        // the sort network and the centroid loop are sized to the ring: 64 x kP positions, position e on lane e / kP
-        auto voxel_grid = [&](auto tag, auto key_zero) {
+        auto voxel_grid = [&](auto tag) {
           constexpr int kP = decltype(tag)::value;
-          using K = decltype(key_zero);  // 32-bit keys when (voxel index << 11 | order) fits: half the shuffles and compares
           int mine = 0;
-          {
+          unsigned pkd[kP];  // (iz + 512) << 22 | (iy + 1024) << 11 | (ix + 1024); ~0u: no point
+          int mnx = 0x7FFFFFFF, mny = 0x7FFFFFFF, mnz = 0x7FFFFFFF, mxx = (int)0x80000000, mxy = (int)0x80000000, mxz = (int)0x80000000;
+          bool fits = true;
+#pragma unroll
+          for (int u = 0; u < kP; ++u) {
+            const int e = u * 64 + lane;  // (unsorted: any placement will do — this one reads the points coalesced)
+            pkd[u] = ~0u;
+            if ((u & 7) == 0) asm volatile("" ::: "memory");  // (eight point reads in flight, not all kP: registers)
+            if (e < m) {
+              const float4 p = pts[base + (int)kept[e]];
+              const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv), iz = (int)floorf(p.z * inv);
+              mnx = min(mnx, ix), mny = min(mny, iy), mnz = min(mnz, iz);
+              mxx = max(mxx, ix), mxy = max(mxy, iy), mxz = max(mxz, iz);
+              fits = fits && ix >= -1024 && ix < 1024 && iy >= -1024 && iy < 1024 && iz >= -512 && iz < 511;
+              pkd[u] = ((unsigned)(iz + 512) << 22) | ((unsigned)(iy + 1024) << 11) | (unsigned)(ix + 1024);
+            }
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            mnx = min(mnx, __shfl_xor(mnx, o)), mny = min(mny, __shfl_xor(mny, o)), mnz = min(mnz, __shfl_xor(mnz, o));
+            mxx = max(mxx, __shfl_xor(mxx, o)), mxy = max(mxy, __shfl_xor(mxy, o)), mxz = max(mxz, __shfl_xor(mxz, o));
+          }
+          const bool packed = __all(fits);
+          const long long dx = (long long)mxx - mnx + 1, dy = (long long)mxy - mny + 1, dz = (long long)mxz - mnz + 1;
+          const bool narrow = dx * dy * dz < (1ll << 21) - 1;  // every key below the 32-bit padding value
+          // PCL's linear voxel index of this lane's u-th point: from the packed coordinates (the common case: 32-bit
+          // arithmetic throughout), or — a ring whose box needs 64-bit keys or whose coordinates do not pack — from a
+          // second read of the point
+          auto sort_and_mark = [&](auto key_zero, auto from_pack) {
+            using K = decltype(key_zero);  // 32-bit keys when (voxel index << 11 | order) fits: half the shuffles and compares
             K kv[kP];
 #pragma unroll
             for (int u = 0; u < kP; ++u) {
-              const int e = lane * kP + u;
+              const int e = u * 64 + lane;
               K k = (K)~key_zero;
               if (e < m) {
-                const float4 p = lfp[base + e];
-                const long long ix = (long long)floorf(p.x * inv) - minb[0];
-                const long long iy = (long long)floorf(p.y * inv) - minb[1];
-                const long long iz = (long long)floorf(p.z * inv) - minb[2];
-                k = (K)(((unsigned long long)(ix + iy * dx + iz * dx * dy) << 11) | (unsigned)e);
+                if (decltype(from_pack)::value) {
+                  const int ix = (int)(pkd[u] & 2047u) - 1024, iy = (int)((pkd[u] >> 11) & 2047u) - 1024, iz = (int)(pkd[u] >> 22) - 512;
+                  k = (K)(((unsigned)((ix - mnx) + (iy - mny) * (int)dx + (iz - mnz) * (int)(dx * dy)) << 11) | (unsigned)e);
+                } else {
+                  const float4 p = pts[base + (int)kept[e]];
+                  const long long ix = (long long)floorf(p.x * inv), iy = (long long)floorf(p.y * inv), iz = (long long)floorf(p.z * inv);
+                  k = (K)(((unsigned long long)((ix - mnx) + (iy - mny) * dx + (iz - mnz) * dx * dy) << 11) | (unsigned)e);
+                }
               }
               kv[u] = k;
             }
@@ -506,7 +544,13 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
               mine += start ? 1 : 0;
               prev = kv[u];
             }
-          }
+          };
+          if (narrow && packed)
+            sort_and_mark(0u, FeInt<1>{});
+          else if (narrow)
+            sort_and_mark(0u, FeInt<0>{});
+          else
+            sort_and_mark(0ull, FeInt<0>{});
           int incl = mine;
 #pragma unroll
           for (int o = 1; o < 64; o <<= 1) {
@@ -517,21 +561,12 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           vg_p = kP, vg_mine = mine, vg_incl = incl;
         };
         static_assert(kRingCap == 2048, "sort sizes below");
-        const long long dz = maxb[2] - minb[2] + 1;
-        const bool narrow = dx * dy * dz < (1ll << 21) - 1;  // every key below the 32-bit padding value
-        if (narrow) {
-          if (m <= 512)
-            voxel_grid(FeInt<8>{}, 0u);
-          else if (m <= 1024)
-            voxel_grid(FeInt<16>{}, 0u);
-          else
-            voxel_grid(FeInt<32>{}, 0u);
-        } else {
-          if (m <= 1024)
-            voxel_grid(FeInt<16>{}, 0ull);
-          else
-            voxel_grid(FeInt<32>{}, 0ull);
-        }
+        if (m <= 512)
+          voxel_grid(FeInt<8>{});
+        else if (m <= 1024)
+          voxel_grid(FeInt<16>{});
+        else
+          voxel_grid(FeInt<32>{});
       }
       if (lane == 0) L.ring_out[ring] = nvox;
     }
@@ -548,7 +583,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   __syncthreads();
   {  // D2: one centroid per run start — f32 sums of all four fields in stable (original) order — at the ring's final
      // offset + the wave prefix of the start counts (sorted position e belongs to lane e / vg_p)
-    const int ring = wave;
+    const int ring = __builtin_amdgcn_readfirstlane(wave);
     const int m = L.ring_m[ring], base = L.ring_base[ring];
     const unsigned short* vs = L.vso[wave];
     float4* dst = olf + L.ring_off[ring];
@@ -559,8 +594,9 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
       float sx = 0, sy = 0, sz = 0, si = 0;
       int j = e;
       do {
-        const float4 p = lfp[base + (int)(vs[j] & 2047u)];
-        sx += p.x, sy += p.y, sz += p.z, si += p.w;
+        const int i = base + (int)kept[vs[j] & 2047u];
+        const float4 p = pts[i];
+        sx += p.x, sy += p.y, sz += p.z, si += tg[i];
         ++j;
       } while (j < m && !(vs[j] & 0x8000u));
       const float cnt = (float)(j - e);
@@ -576,10 +612,10 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
 }
 
 void launch_frontend(hipStream_t stream, int n_scans, const void* scans, const float4* cloud, const float* range,
-                     const unsigned* col, const unsigned char* ground, double scan_period, float4* und, float* diff,
-                     int* picks, float4* out, int* out_counts) {
+                     const unsigned* col, const unsigned char* ground, double scan_period, float* tags, int* picks,
+                     float4* out, int* out_counts) {
   hipLaunchKernelGGL(frontend_kernel, dim3(n_scans), dim3(kFeBlock), 0, stream, (const FeScan*)scans, cloud, range, col,
-                     ground, scan_period, und, diff, picks, out, out_counts);
+                     ground, scan_period, tags, picks, out, out_counts);
 }
 size_t fe_scan_size() { return sizeof(FeScan); }
 int fe_pick_stride() { return kFeRows * 6 * kPickStride; }
