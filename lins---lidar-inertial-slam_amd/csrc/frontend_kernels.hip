@@ -454,7 +454,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     }
     if (lane == 0) {
       L.ring_m[ring] = m, L.ring_base[ring] = base < 0 ? 0 : base;
-      if (m > kRingCap || (m > 0 && sc.end_ring[ring] - base >= 65536)) L.bad = 1;  // cannot happen for a 16 x 1800 sensor; refuse rather than truncate silently
+      if (m > kRingCap || (m > 0 && sc.end_ring[ring] - base >= 2048)) L.bad = 1;  // cannot happen for a 16 x 1800 sensor; refuse rather than truncate silently
     }
   }
   __threadfence_block();
@@ -473,7 +473,6 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   // takes the same route with a second read of its points.
   // Two phases: every ring sorts and counts its voxels first; after one block barrier the rings' output
   // offsets are known and the centroids go straight to their final place.
-  int vg_p = 0, vg_mine = 0, vg_incl = 0;  // this ring's keys per lane, this lane's run starts and their inclusive wave prefix
   {
     {
       const int ring = __builtin_amdgcn_readfirstlane(wave);
@@ -513,6 +512,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           // PCL's linear voxel index of this lane's u-th point: from the packed coordinates (the common case: 32-bit
           // arithmetic throughout), or — a ring whose box needs 64-bit keys or whose coordinates do not pack — from a
           // second read of the point
+          unsigned startmask = 0;  // bit u: this lane's u-th sorted position starts a voxel
           auto sort_and_mark = [&](auto key_zero, auto from_pack) {
             using K = decltype(key_zero);  // 32-bit keys when (voxel index << 11 | order) fits: half the shuffles and compares
             K kv[kP];
@@ -540,11 +540,14 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
             for (int u = 0; u < kP; ++u) {
               const int e = lane * kP + u;
               const bool start = e < m && (e == 0 || (prev >> 11) != (kv[u] >> 11));
-              vs[e] = (unsigned short)((start ? 0x8000u : 0u) | (unsigned)(kv[u] & 2047u));
+              // sorted position e -> (run start, the point's position relative to the ring's base): D2 needs no second lookup
+              vs[e] = (unsigned short)((start ? 0x8000u : 0u) | (e < m ? (unsigned)kept[kv[u] & 2047u] : 0u));
               mine += start ? 1 : 0;
+              startmask |= start ? (1u << u) : 0u;
               prev = kv[u];
             }
           };
+
           if (narrow && packed)
             sort_and_mark(0u, FeInt<1>{});
           else if (narrow)
@@ -558,7 +561,15 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
             if (lane >= o) incl += nb;
           }
           nvox = __shfl(incl, 63);
-          vg_p = kP, vg_mine = mine, vg_incl = incl;
+          // the list of kept points has been folded into vs: its place now takes, for every run start, the voxel's
+          // position in the ring's output (every lane of the wave has finished reading the list)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          int run = incl - mine;
+#pragma unroll
+          for (int u = 0; u < kP; ++u)
+            if ((startmask >> u) & 1u) kept[lane * kP + u] = (unsigned short)run++;
         };
         static_assert(kRingCap == 2048, "sort sizes below");
         if (m <= 512)
@@ -581,26 +592,28 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     out_counts[scan * 4 + 3] = run;
   }
   __syncthreads();
-  {  // D2: one centroid per run start — f32 sums of all four fields in stable (original) order — at the ring's final
-     // offset + the wave prefix of the start counts (sorted position e belongs to lane e / vg_p)
-    const int ring = __builtin_amdgcn_readfirstlane(wave);
+  // D2: one centroid per run start — f32 sums of all four fields in stable (original) order — at the ring's final
+  // offset + the voxel's position in the ring.  The whole workgroup takes the rings one after the other (round 3; one
+  // wave per ring before): a thread per sorted position, so the gathers of all sixteen waves fall into ONE ring's points
+  // at a time (they stay in the caches between the first touch of a line and the last) and neighbouring threads write
+  // neighbouring centroids.
+  for (int ring = 0; ring < kFeRows; ++ring) {
     const int m = L.ring_m[ring], base = L.ring_base[ring];
-    const unsigned short* vs = L.vso[wave];
+    const unsigned short* vs = L.vso[ring];
+    const unsigned short* slot = reinterpret_cast<const unsigned short*>(L.a.skey[ring]);
     float4* dst = olf + L.ring_off[ring];
-    int pos = vg_incl - vg_mine;
-    for (int u = 0; u < vg_p; ++u) {
-      const int e = lane * vg_p + u;
-      if (e >= m || !(vs[e] & 0x8000u)) continue;
+    for (int e = tid; e < m; e += kFeBlock) {
+      if (!(vs[e] & 0x8000u)) continue;
       float sx = 0, sy = 0, sz = 0, si = 0;
       int j = e;
       do {
-        const int i = base + (int)kept[vs[j] & 2047u];
+        const int i = base + (int)(vs[j] & 2047u);
         const float4 p = pts[i];
         sx += p.x, sy += p.y, sz += p.z, si += tg[i];
         ++j;
       } while (j < m && !(vs[j] & 0x8000u));
       const float cnt = (float)(j - e);
-      dst[pos++] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+      dst[slot[e]] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
     }
   }
 #ifdef LINS_FE_PROF
