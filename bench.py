@@ -345,19 +345,40 @@ def main():
     rec_bytes = dist_mod.RECORD_BYTES
     poses = [torch.zeros(max(max_n, 1) * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
     gathered = [torch.zeros(world * max(max_n, 1) * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)] if use_dist else None
+    c_abi_gather = use_dist
     if use_dist:
-        uid = [ctx.rccl_unique_id() if rank == 0 else None]
+        ok = 1
+        try:
+            uid = [ctx.rccl_unique_id() if rank == 0 else None]
+        except Exception as e:  # (rank 0 could not load RCCL through the library: every rank takes the fallback)
+            uid, ok = [None], 0
+            print(f"bench.py: lins_rccl_unique_id failed ({e}); pose gather falls back to torch.distributed", file=sys.stderr)
         dist.broadcast_object_list(uid, src=0)
-        ctx.rccl_init(uid[0], rank, world)
-    ctx.set_pipelined(True)
+        if uid[0] is None:
+            ok = 0
+        else:
+            try:
+                ctx.rccl_init(uid[0], rank, world)
+            except Exception as e:
+                ok = 0
+                print(f"bench.py: lins_rccl_init failed on rank {rank} ({e}); pose gather falls back to torch.distributed", file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # one rank without a communicator: nobody uses it
+        c_abi_gather = bool(flag.item())
+        if not c_abi_gather and ok:
+            ctx.rccl_destroy()
+    ctx.set_pipelined(c_abi_gather or not use_dist)
     n_steps = [0]
 
     def step():  # everything asynchronous: no host wait inside a step
         b = n_steps[0] & 1
         n_steps[0] += 1
         ctx.run(poses[b].data_ptr(), lo)
-        if use_dist:
+        if c_abi_gather:
             ctx.pose_allgather(poses[b].data_ptr(), max_n, gathered[b].data_ptr())
+        elif use_dist:  # fallback only (see above): the records leave through torch.distributed, one host wait per step
+            ctx.sync()
+            dist.all_gather_into_tensor(gathered[b], poses[b])
 
     def barrier():
         ctx.sync()  # update kernels, Joseph kernels and gathers of every step enqueued so far (one host wait)
@@ -403,7 +424,8 @@ def main():
         last = (n_steps[0] - 1) & 1
         rec = dist_mod.ordered_records(gathered[last].cpu().numpy(), spans)  # (raises when out of order)
         assert int(rec["iters"].sum()) == int(iters_all), "pose gather incomplete"
-        ctx.rccl_destroy()
+        if c_abi_gather:
+            ctx.rccl_destroy()
 
     if rank == 0:
         res = ctx.download()
@@ -439,7 +461,8 @@ def main():
                                "n_less_sharp_last": float(sizes[:, 2].mean()),
                                "n_less_flat_last": float(sizes[:, 3].mean())},
                 "diverged_scans": n_div,
-                "parallelism": f"scan-sharded x{world}" + (", RCCL all-gather of 192 B pose records" if use_dist else ""),
+                "parallelism": f"scan-sharded x{world}" + ((", RCCL all-gather of 192 B pose records through the C ABI (lins_pose_allgather)" if c_abi_gather
+                                                           else ", RCCL all-gather of 192 B pose records through torch.distributed (fallback)") if use_dist else ""),
                 "gen_seconds": round(gen_s, 2),
             },
             "roofline": {
