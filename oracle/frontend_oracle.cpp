@@ -2,7 +2,10 @@
 // kernels of those rows (SURVEY.md §8f-2, §8f-3 and the projection / segmentation stage before them).
 //
 // TEST INFRASTRUCTURE ONLY: loaded by tests/ and tools/ through ctypes, never linked by the product.
-// PARITY UNPINNED: the reference cannot be built here (ROS, PCL, OpenCV, Eigen absent) and ships no vectors.
+// PARITY: the feature stage (SE:619-827) and transformToEnd are pinned through oracle/_ref since round 3 (tests/test_ref.py holds
+// the product's host restatement against the reference's own compiled undistortPcl ... extractFeatures; this libm-based
+// checker is held against that restatement by tests/test_frontend_oracle.py).  The image projection / segmentation part
+// (IP:191-415, a ROS node's .cpp) stays PARITY UNPINNED: it cannot be built here and ships no vectors.
 //
 // Independence: this file includes NOTHING from csrc/ (in particular not csrc/lins_math.h, whose fixed-sequence
 // lins_atan2f the device kernels and the product's host restatement share) and nothing from include/.  Every

@@ -1,7 +1,7 @@
 // lins_oracle.cpp — CPU oracle for the LINS IESKF update path.
 //
-// TEST INFRASTRUCTURE ONLY (see lins_oracle.h).  PARITY UNPINNED by the
-// reference (it has no tests / fixtures and cannot be built here).
+// TEST INFRASTRUCTURE ONLY (see lins_oracle.h).  Pinned to the reference's own
+// compiled text, oracle/_ref (tests/test_ref.py; lins_oracle.h says how).
 //
 // A from-scratch restatement (flat arrays, own linear algebra, no PCL/Eigen) of
 // the behaviour of, relative to /root/reference/lins/include:

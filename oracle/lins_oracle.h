@@ -6,11 +6,19 @@
  * map).  Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline`
  * leg may load it; the product (liblins_ieskf.so) never links or calls it.
  *
- * PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors
- * for this path, and cannot be compiled here (needs ROS/PCL/Eigen/OpenCV, none
- * on disk).  The oracle is pinned only by (a) hand-computed known-answer
- * geometry, (b) algebraic identities, (c) scipy.cKDTree for the 1-NN indices,
- * (d) its own dense-vs-reduced cross-check.  See DESIGN.md §3.
+ * PINNED since round 3: the reference ships no tests, fixtures or golden
+ * vectors for this path and its build needs ROS/PCL/Eigen/OpenCV (none on
+ * disk) — but the path is header-only, and oracle/_ref/liblins_ref.so is the
+ * reference's own StateEstimator.hpp compiled verbatim against stand-in
+ * headers (oracle/ref_shim, oracle/ref_driver.cpp, `make -C oracle _ref`).
+ * tests/test_ref.py holds this oracle against it: correspondence indices,
+ * accepted sets and f32 rows bit for bit, states and covariances to 1e-12 on
+ * 1536 seeded pairs, the ICP fallback, the divergence and NaN branches.  What
+ * the stand-ins can only restate (Eigen's summation order, FLANN's and
+ * std::sort's tie order) is listed in DESIGN.md §3.  Before round 3 the oracle
+ * was pinned only by (a) hand-computed known-answer geometry, (b) algebraic
+ * identities, (c) scipy.cKDTree for the 1-NN indices, (d) its own
+ * dense-vs-reduced cross-check — those tests still run.
  */
 #ifndef LINS_ORACLE_H_
 #define LINS_ORACLE_H_

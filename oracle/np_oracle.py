@@ -1,7 +1,8 @@
 """SECOND, independently written CPU restatement of the IESKF update path (numpy / pure Python).
 
 TEST INFRASTRUCTURE ONLY — imported by tests/ (never by the product package, never timed).
-PARITY UNPINNED (like oracle/lins_oracle.cpp: the reference ships no vectors and cannot be built here).
+Written in rounds 1-2, when the reference could not be run here at all; since round 3 oracle/lins_oracle.cpp is pinned
+to the reference's own compiled text (oracle/_ref, tests/test_ref.py) and this file is pinned through it.
 
 Why it exists: the only other ground truth is oracle/lins_oracle.cpp.  This file was written straight from the
 reference's lines, sharing no code and no helper with that oracle (nor with csrc/), so that a misreading of the

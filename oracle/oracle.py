@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg — never by the product package.
-PARITY UNPINNED (see lins_oracle.h).
+Pinned against oracle/_ref — the reference's own headers compiled verbatim — by tests/test_ref.py (see lins_oracle.h).
 """
 import ctypes as C
 import importlib
