@@ -5,7 +5,8 @@
 // PARITY: the feature stage (SE:619-827) and transformToEnd are pinned through oracle/_ref since round 3 (tests/test_ref.py holds
 // the product's host restatement against the reference's own compiled undistortPcl ... extractFeatures; this libm-based
 // checker is held against that restatement by tests/test_frontend_oracle.py).  The image projection / segmentation part
-// (IP:191-415, a ROS node's .cpp) stays PARITY UNPINNED: it cannot be built here and ships no vectors.
+// (IP:174-415) is pinned the same way: oracle/ref_ip_driver.cpp compiles image_projection_node.cpp verbatim and tests/test_ref.py
+// holds the host restatement against what the node publishes, bit for bit.
 //
 // Independence: this file includes NOTHING from csrc/ (in particular not csrc/lins_math.h, whose fixed-sequence
 // lins_atan2f the device kernels and the product's host restatement share) and nothing from include/.  Every

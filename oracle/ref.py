@@ -245,6 +245,25 @@ def extract_features(prm, seg):
                 undistorted=und[:n])
 
 
+def segment(raw):
+    """image_projection_node's cloudHandler (IP:174-415: findStartEndAngle, projectPointCloud, groundRemoval,
+    cloudSegmentation) on one raw cloud in firing order -> the host package's Segmented view of what the node publishes
+    (segmented cloud, cloud_info, number of outlier points)."""
+    host = importlib.import_module("lins---lidar-inertial-slam_amd.host")
+    raw = np.ascontiguousarray(raw, dtype=np.float32).reshape(-1, 4)
+    cloud = np.zeros((_defs.CLOUD_MAX, 4), np.float32)
+    rng = np.zeros(_defs.CLOUD_MAX, np.float32)
+    col = np.zeros(_defs.CLOUD_MAX, np.uint32)
+    ground = np.zeros(_defs.CLOUD_MAX, np.uint8)
+    c = host.SegmentedScanC()
+    rc = lib().ref_segment(raw.ctypes.data_as(C.POINTER(Point)), len(raw), cloud.ctypes.data_as(C.POINTER(Point)),
+                           rng.ctypes.data_as(C.POINTER(C.c_float)), col.ctypes.data_as(C.POINTER(C.c_uint32)),
+                           ground.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(c))
+    if rc != 0:
+        raise RuntimeError(f"ref_segment: {rc}")
+    return host.Segmented(cloud, rng, col, ground, c)
+
+
 def filter_run(fprm, vn, ba, bw, imu, reset1=False):
     """StatePredictor: initialization(0, 0, vn, ba, bw) -> predict() per row of imu (dt, acc, gyr) -> optional reset(1).
     fprm: host.FilterParams.  Returns (state19, cov 18x18)."""

@@ -1,7 +1,7 @@
 // "cloud_msgs/cloud_info.h" — STAND-IN for the header catkin generates from cloud_msgs/msg/cloud_info.msg
 // (oracle/ref_shim/README.md): the message's fields with the C++ types roscpp's generator gives them
 // (int32[] -> std::vector<int32_t>, bool[] -> std::vector<uint8_t>, uint32[] -> std::vector<uint32_t>,
-// float32[] -> std::vector<float>).  The header field is omitted (unused on the compiled path).
+// float32[] -> std::vector<float>).
 //
 // One departure, for defined behaviour: segmentedCloudColInd is a vector whose operator[] tolerates the index -1.
 // extractFeatures' neighbour-masking loop (StateEstimator.hpp:763-777, 795-811) reads
@@ -14,6 +14,8 @@
 #ifndef LINS_REF_SHIM_CLOUD_INFO_
 #define LINS_REF_SHIM_CLOUD_INFO_
 #include <boost/shared_ptr.hpp>
+#include <std_msgs/Header.h>
+
 #include <cstddef>
 #include <cstdint>
 #include <vector>
@@ -38,6 +40,7 @@ struct cloud_info {
   typedef boost::shared_ptr<cloud_info> Ptr;
   typedef boost::shared_ptr<const cloud_info> ConstPtr;
   cloud_info() : startOrientation(0.f), endOrientation(0.f), orientationDiff(0.f) {}
+  std_msgs::Header header;
   std::vector<int32_t> startRingIndex;
   std::vector<int32_t> endRingIndex;
   float startOrientation;

@@ -1,0 +1,22 @@
+// <std_msgs/Header.h> — STAND-IN (oracle/ref_shim/README.md): the three fields of the message.
+#ifndef LINS_REF_SHIM_STD_MSGS_HEADER_
+#define LINS_REF_SHIM_STD_MSGS_HEADER_
+#include <cstdint>
+#include <string>
+namespace ros {
+struct Time {
+  double sec_;
+  Time() : sec_(0.0) {}
+  double toSec() const { return sec_; }
+  static Time now() { return Time(); }
+};
+}  // namespace ros
+namespace std_msgs {
+struct Header {
+  std::uint32_t seq;
+  ros::Time stamp;
+  std::string frame_id;
+  Header() : seq(0) {}
+};
+}  // namespace std_msgs
+#endif

@@ -107,3 +107,33 @@ def test_bench_batch_all_1024_scans_against_the_dense_oracle_and_the_reference(p
         got = ctx.update_batch(pairs)
     for g, w in zip(got, want):
         assert_result_close(g, w)
+
+
+def test_device_segmentation_and_front_end_against_the_references_two_nodes(pkg, ieskf, host, ref):
+    """Raw clouds through the device chain (lins_segment_batch -> lins_extract_features_batch) against the reference's
+    own image_projection_node.cpp and StateEstimator feature stage (both compiled verbatim, oracle/_ref): the segmented
+    cloud, ranges, columns, ground flags, ring indices and outlier count bit for bit (orientations: libm's atan2f vs the
+    product's fixed sequence, <= 4 ulp); the feature clouds with the same picks and voxels (coordinates bit-equal where
+    the order is, centroids to a few f32 ulps; time tags <= 2.5e-7 relative)."""
+    from test_ref import assert_same_picks, assert_same_segmentation
+
+    prm = pkg.default_params()
+    raws = [host.synth_raw_scan(400 + i // 2, i & 1) for i in range(24)]
+    with ieskf.IeskfContext(prm, max_batch=1, max_targets=1024) as c:
+        got = c.segment_batch(raws)
+        feats = c.extract_features_batch(got)
+    with ThreadPoolExecutor(cores()) as ex:
+        want = list(ex.map(ref.segment, raws))
+    for i, (g, r) in enumerate(zip(got, want)):
+        assert_same_segmentation(r, g, f"scan {i}")
+    for i in (0, 5, 11, 18):
+        r = want[i]
+        k = r.n
+        seg = dict(cloud=r.cloud[:k], range=r.range[:k], col=r.col[:k], ground=r.ground[:k], n=k, start_ring=list(r.c.start_ring),
+                   end_ring=list(r.c.end_ring), orientation=(r.c.start_ori, r.c.end_ori, r.c.ori_diff), n_outlier=r.c.n_outlier)
+        fr = ref.extract_features(prm, seg)
+        fd = feats[i]
+        for name in ("corner_sharp", "corner_less_sharp", "surf_flat"):
+            assert_same_picks(fr[name][:, :3], fd[name][:, :3], seg, fr["undistorted"][:, :3], name)
+        a, b = fr["surf_less_flat"], fd["surf_less_flat"]
+        assert a.shape == b.shape and np.abs(a - b).max() <= 4e-6

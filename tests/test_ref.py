@@ -336,3 +336,66 @@ def test_feature_stage_picks_equal_the_references(pkg, host, oracle, ref, idx):
             assert np.abs(a[:, :3] - b[:, :3]).max() <= 4e-6  # a few f32 ulps at <= 40 m: the summation order inside a voxel
             assert np.abs(a[:, 3] - b[:, 3]).max() <= 4e-6
             assert np.array_equal(np.floor(a[:, 3]), np.floor(b[:, 3]))  # same ring
+
+
+# ---- image_projection_node.cpp (IP:174-415), the node in front of StateEstimator ---------------------------------------
+def assert_same_segmentation(r, w, what):
+    """r: what the reference's node published; w: the product's host restatement (what the device kernel is bit-compared
+    with).  Everything bit for bit, except the two orientations: the node calls libm's atan2f, the product its
+    fixed-sequence lins_atan2f (shared by host and device, csrc/lins_math.h) — observed 1 ulp, allowed 4."""
+    k = w.n
+    assert r.n == k and r.c.n_outlier == w.c.n_outlier, what
+    assert list(r.c.start_ring) == list(w.c.start_ring) and list(r.c.end_ring) == list(w.c.end_ring), what
+    assert np.array_equal(r.cloud[:k].view(np.int32), w.cloud[:k].view(np.int32)), what
+    assert np.array_equal(r.range[:k].view(np.int32), w.range[:k].view(np.int32)), what
+    assert np.array_equal(r.col[:k], w.col[:k]) and np.array_equal(r.ground[:k], w.ground[:k]), what
+    a = np.array([r.c.start_ori, r.c.end_ori, r.c.ori_diff], np.float32).view(np.int32)
+    b = np.array([w.c.start_ori, w.c.end_ori, w.c.ori_diff], np.float32).view(np.int32)
+    assert np.abs(a - b).max() <= 4, (what, a - b)
+
+
+def test_image_projection_node_equals_the_host_restatement(host, ref):
+    """The reference's own image_projection_node.cpp (compiled verbatim, oracle/ref_ip_driver.cpp: cloudHandler on a raw
+    cloud, the published segmented cloud / cloud_info / outlier cloud read back) against lins_frontend_segment on 64
+    stock scans: projection with its size_t row truncation, last-point-wins cells, ground removal, the BFS labelling
+    with its uint8 neighbour table (-1 stored as 255: the adjacency is directed, IP:72, 133-144), segment validity,
+    the ground decimation and the +-5 ring indices."""
+    for i in range(32):
+        for k in (0, 1):
+            raw = host.synth_raw_scan(200 + i, k)
+            assert_same_segmentation(ref.segment(raw), host.frontend_segment(raw), f"scan {200 + i}/{k}")
+
+
+def test_image_projection_node_on_a_wide_hall_and_on_repeated_packets(host, ref):
+    """Rings of 1800 segmented points (a hall whose wall every beam meets) and a raw cloud with more points than cells
+    (a driver that repeats packets: the later point takes the cell over, IP:238-240)."""
+    import test_gpu_edge_cases as T
+
+    for raw in (T._wide_room_raw_scan(5), T._wide_room_raw_scan(6, 60.0, 2.0)):
+        assert_same_segmentation(ref.segment(raw), host.frontend_segment(raw), "hall")
+    base = host.synth_raw_scan(3, 1)
+    rng = np.random.default_rng(11)
+    extra = base[rng.permutation(len(base))[:14000]].copy()
+    extra[:, :3] *= np.float32(1.01)
+    raw = np.ascontiguousarray(np.concatenate([base, extra]))
+    assert_same_segmentation(ref.segment(raw), host.frontend_segment(raw), "repeated packets")
+
+
+def test_raw_cloud_to_feature_clouds_through_the_references_two_nodes(pkg, host, ref):
+    """The whole chain in front of performIESKF in the reference's own code — image_projection_node's cloudHandler, then
+    StateEstimator's undistortPcl ... extractFeatures on what it published — against the product's host chain
+    (lins_frontend_segment -> lins_frontend_extract_segmented) on raw clouds: same picks (exact curvature ties apart),
+    same voxels."""
+    prm = pkg.default_params()
+    for i in (7, 21):
+        raw = host.synth_raw_scan(300 + i, 1)
+        r = ref.segment(raw)
+        k = r.n
+        seg = dict(cloud=r.cloud[:k], range=r.range[:k], col=r.col[:k], ground=r.ground[:k], n=k, start_ring=list(r.c.start_ring),
+                   end_ring=list(r.c.end_ring), orientation=(r.c.start_ori, r.c.end_ori, r.c.ori_diff), n_outlier=r.c.n_outlier)
+        fr = ref.extract_features(prm, seg)
+        fh = host.frontend_extract_segmented(host.frontend_segment(raw))
+        for name in ("corner_sharp", "corner_less_sharp", "surf_flat"):
+            assert_same_picks(fr[name][:, :3], fh[name][:, :3], seg, fr["undistorted"][:, :3], name)
+        a, b = fr["surf_less_flat"], fh["surf_less_flat"]
+        assert a.shape == b.shape and np.abs(a - b).max() <= 4e-6
