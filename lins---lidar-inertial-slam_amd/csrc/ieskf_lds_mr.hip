@@ -17,16 +17,25 @@
 #define LINS_LDS_NS lds_mr
 // (16-byte point records (x, y, z, original index bits): a candidate is ONE ds_read_b128; round 1's 14-byte SoA layout
 // held 4736 instead of 4224 positions but cost four reads per candidate: +2.9 % kernel time, removed in round 3)
-#define LINS_LDS_CAP 4208  // (4224 until 16 positions made room for the de-skew's coefficient table)
+#ifndef LINS_MR_CAP
+#define LINS_MR_CAP 4208  // (4224 until 16 positions made room for the de-skew's coefficient table)
+#endif
+#define LINS_LDS_CAP LINS_MR_CAP
 #define LINS_LDS_NMAX 12288
 #ifndef LINS_LDS_SCANBATCH
 #define LINS_LDS_SCANBATCH 2  // (measured: 1 -> 7.9, 2 -> 8.1, 3 -> 8.0, 4 -> 7.75, 8 -> 7.1 M it/s at 128 VGPRs;
                               // re-timed at the end of round 2: 3 -> -0.5 % (noise, 18 spilled registers), 4 -> +2 %)
 #endif
 #define LINS_LDS_WAVES 8
-#define LINS_LDS_MINW 4
+#ifndef LINS_MR_MINW
+#define LINS_MR_MINW 4
+#endif
+#define LINS_LDS_MINW LINS_MR_MINW
 #define LINS_MR_BLOCK 512
-#define LINS_LDS_BYTES 80896
+#ifndef LINS_MR_LDSBYTES
+#define LINS_MR_LDSBYTES 80896
+#endif
+#define LINS_LDS_BYTES LINS_MR_LDSBYTES
 #include "ieskf_lds_impl.h"
 
 namespace lins {
