@@ -460,6 +460,10 @@ def main():
                 "mean_sizes": {"n_sharp": float(sizes[:, 0].mean()), "n_flat": float(sizes[:, 1].mean()),
                                "n_less_sharp_last": float(sizes[:, 2].mean()),
                                "n_less_flat_last": float(sizes[:, 3].mean())},
+                "data_note": "round-3 scan generator (no firing on a range-image column edge: VERDICT r02 item 10): 8.7 k target points per "
+                             "scan, 144 KB algorithmic per iteration; rounds 1-2 timed 7.7 k / 127.5 KB scans — iterations/s of different "
+                             "rounds compare through roofline.frac (bytes per launch follow the scans), and DESIGN.md section 5.1 has the "
+                             "round-2 kernel on these scans (11.9 M it/s)",
                 "diverged_scans": n_div,
                 "parallelism": f"scan-sharded x{world}" + ((", RCCL all-gather of 192 B pose records through the C ABI (lins_pose_allgather)" if c_abi_gather
                                                            else ", RCCL all-gather of 192 B pose records through torch.distributed (fallback)") if use_dist else ""),
