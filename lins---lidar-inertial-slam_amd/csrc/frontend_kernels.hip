@@ -114,7 +114,7 @@ __device__ __forceinline__ void wave_bitonic_sort(K (&v)[P], int lane) {
 __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     const FeScan* __restrict__ scans, const float4* __restrict__ cloud, const float* __restrict__ range,
     const unsigned* __restrict__ col, const unsigned char* __restrict__ ground, double scan_period,
-    float* __restrict__ tags, int* __restrict__ picks, float4* __restrict__ out, int* __restrict__ out_counts) {
+    int* __restrict__ picks, float4* __restrict__ out, int* __restrict__ out_counts) {
   FeLds& L = g_fe;
 #ifdef LINS_FE_PROF
   long long fe_t0 = clock64(), fe_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -131,40 +131,43 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   const float* rg = range + sc.off;
   const unsigned* cl = col + sc.off;
   const unsigned char* gd = ground + sc.off;
-  float* tg = tags + sc.off;  // relative-time tags (the .w of the de-skewed points): the only per-point array this kernel writes
   int* pk = picks + (size_t)scan * kFeRows * 6 * kPickStride;
   const double kPi = 3.14159265358979323846;
 
   if (tid == 0) L.first_half_end = n, L.bad = 0;
   // ---- load + undistortPcl, pass 1: where does halfPassed flip?  (SE:631-638: first-half adjustment) ----
-  // One pass over the points: thread t owns the points t, t + 1024, ... and keeps each one's raw orientation and
-  // intensity in registers until the flip position is known (round 3; rounds 1-2 read the cloud twice and evaluated
-  // the arctangent twice).  The cloud is not read again before the less-flat stage.
+  // Round 3: no per-point array is written at all.  The relative-time tag of a point is a function of the point, its
+  // index and the flip position; the few consumers (the picked points, the kept points of the less-flat cloud: each
+  // point at most once) evaluate it where they read the point — rounds 1-2 stored a de-skewed copy of the whole cloud.
   const double s_ori = (double)sc.start_ori, e_ori = (double)sc.end_ori;
-  constexpr int kOwn = (kFeMaxN + kFeBlock - 1) / kFeBlock;  // 29
-  float orv[kOwn], pwv[kOwn];
   {
     int first = n;
+    constexpr int kIn = 4;  // points per thread whose reads are in flight together
+    for (int i0 = tid; i0 < n + 16; i0 += kIn * kFeBlock) {
+      float4 p[kIn];
+      unsigned char g[kIn];
+      unsigned c[kIn];
 #pragma unroll
-    for (int k = 0; k < kOwn; ++k) {
-      const int i = tid + k * kFeBlock;
-      float o = 0.f, w = 0.f;
-      if ((k & 3) == 0) asm volatile("" ::: "memory");  // (four point reads in flight at a time: the unrolled loop would hoist all 29)
-      if (i < n) {
-        const float4 p = pts[i];
-        o = -lins_atan2f(p.y, p.x), w = p.w;
-        double ori = (double)o;
-        if (ori < s_ori - kPi / 2)
-          ori += 2 * kPi;
-        else if (ori > s_ori + kPi * 3 / 2)
-          ori -= 2 * kPi;
-        if (ori - s_ori > kPi && i < first) first = i;
-        L.a.flags[i] = gd[i] ? 8 : 0;
-        L.a.col[i] = (unsigned short)cl[i];
-      } else if (i < n + 16) {
-        L.a.flags[i] = 0, L.a.col[i] = 0;
+      for (int u = 0; u < kIn; ++u) {
+        const int i = i0 + u * kFeBlock, ic = i < n ? i : n - 1;
+        p[u] = pts[ic], g[u] = gd[ic], c[u] = cl[ic];
       }
-      orv[k] = o, pwv[k] = w;
+#pragma unroll
+      for (int u = 0; u < kIn; ++u) {
+        const int i = i0 + u * kFeBlock;
+        if (i < n) {
+          double ori = (double)(-lins_atan2f(p[u].y, p[u].x));
+          if (ori < s_ori - kPi / 2)
+            ori += 2 * kPi;
+          else if (ori > s_ori + kPi * 3 / 2)
+            ori -= 2 * kPi;
+          if (ori - s_ori > kPi && i < first) first = i;
+          L.a.flags[i] = g[u] ? 8 : 0;
+          L.a.col[i] = (unsigned short)c[u];
+        } else if (i < n + 16) {
+          L.a.flags[i] = 0, L.a.col[i] = 0;
+        }
+      }
     }
     for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
     if (lane == 0) atomicMin(&L.first_half_end, first);
@@ -172,30 +175,24 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   __syncthreads();
   const int flip = L.first_half_end;
   FE_MARK(1)
-  // ---- pass 2: relative time tag (from the registers); masks ---------------------------------------
-#pragma unroll
-  for (int k = 0; k < kOwn; ++k) {
-    const int i = tid + k * kFeBlock;
-    if (i < n) {
-      float o = orv[k];
-      asm volatile("" : "+v"(o));  // (keeps the compiler from carrying pass 1's f64 orientation across the barrier: 29 spilled doubles)
-      double ori = (double)o;
-      if (i <= flip) {
-        if (ori < s_ori - kPi / 2)
-          ori += 2 * kPi;
-        else if (ori > s_ori + kPi * 3 / 2)
-          ori -= 2 * kPi;
-      } else {
+  const double ori_diff = (double)sc.ori_diff;
+  auto tag_of = [&](int i, const float4& p) {  // undistortPcl's intensity (SE:639-650) of point i
+    double ori = (double)(-lins_atan2f(p.y, p.x));
+    if (i <= flip) {
+      if (ori < s_ori - kPi / 2)
         ori += 2 * kPi;
-        if (ori < e_ori - kPi * 3 / 2)
-          ori += 2 * kPi;
-        else if (ori > e_ori + kPi / 2)
-          ori -= 2 * kPi;
-      }
-      const double rel = (ori - s_ori) / (double)sc.ori_diff;
-      tg[i] = (float)((double)(int)pwv[k] + scan_period * rel);
+      else if (ori > s_ori + kPi * 3 / 2)
+        ori -= 2 * kPi;
+    } else {
+      ori += 2 * kPi;
+      if (ori < e_ori - kPi * 3 / 2)
+        ori += 2 * kPi;
+      else if (ori > e_ori + kPi / 2)
+        ori -= 2 * kPi;
     }
-  }
+    const double rel = (ori - s_ori) / ori_diff;
+    return (float)((double)(int)p.w + scan_period * rel);
+  };
   // calculateSmoothness (SE:656-678) is evaluated where it is consumed — the sector sort below — from the range array
   // (f32, left to right, as written in SE:660-666); cloudCurvature / cloudSmoothness are never materialised.
   auto diff_at = [&](int i) {
@@ -239,6 +236,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
         if (lane < 3) spk[26 + lane] = 0;
         continue;
       }
+      int pick_entry = 0;  // lane k < 29 carries entry k of the sector's pick list: one 116-byte store at the end
       const int m = ep - sp;  // the sort covers [sp, ep) — ep itself keeps its place (SE:739-740)
       // cloudSmoothness[i].ind is i only where the stencil ran, [5, n - 5); elsewhere the value-initialised 0
       auto smooth_ind = [&](int i) { return (i >= 5 && i < n - 5) ? i : 0; };
@@ -324,12 +322,11 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
             if (lane == who) {
               if (n_ls < 2) {
                 L.a.flags[ind] = (unsigned char)((f & ~6) | (2 << 1) | 1);  // cloudLabel 2, picked
-                spk[n_sharp] = ind;
               } else {
                 L.a.flags[ind] = (unsigned char)((f & ~6) | (1 << 1) | 1);  // cloudLabel 1, picked
               }
-              spk[2 + n_ls] = ind;
             }
+            if ((n_ls < 2 && lane == n_sharp) || lane == 2 + n_ls) pick_entry = pind;
             n_sharp += n_ls < 2 ? 1 : 0;
             ++n_ls;
             wave_sync();
@@ -359,8 +356,8 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
             const bool last = n_flat + 1 >= 4;
             if (lane == who) {
               L.a.flags[ind] = (unsigned char)(f | (3 << 1) | (last ? 0 : 1));  // cloudLabel -1 (+ picked unless the 4th)
-              spk[22 + n_flat] = ind;
             }
+            if (lane == 22 + n_flat) pick_entry = pind;
             ++n_flat;
             wave_sync();
             if (last) {
@@ -372,7 +369,10 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
             passed = (2ull << who) - 1ull;
           }
         }
-        if (lane == 0) spk[26] = n_sharp, spk[27] = n_ls, spk[28] = n_flat;
+        if (lane == 26) pick_entry = n_sharp;
+        if (lane == 27) pick_entry = n_ls;
+        if (lane == 28) pick_entry = n_flat;
+        if (lane < 29) spk[lane] = pick_entry;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     __syncthreads();
     auto und_pt = [&](int i) {  // the de-skewed point: coordinates as they came, the relative-time tag as intensity (SE:649-650)
       float4 q = pts[i];
-      q.w = tg[i];
+      q.w = tag_of(i, q);
       return q;
     };
     for (int t = tid; t < kSec * 26; t += kFeBlock) {
@@ -602,18 +602,44 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     const unsigned short* vs = L.vso[ring];
     const unsigned short* slot = reinterpret_cast<const unsigned short*>(L.a.skey[ring]);
     float4* dst = olf + L.ring_off[ring];
-    for (int e = tid; e < m; e += kFeBlock) {
-      if (!(vs[e] & 0x8000u)) continue;
-      float sx = 0, sy = 0, sz = 0, si = 0;
-      int j = e;
-      do {
-        const int i = base + (int)(vs[j] & 2047u);
-        const float4 p = pts[i];
-        sx += p.x, sy += p.y, sz += p.z, si += tg[i];
-        ++j;
-      } while (j < m && !(vs[j] & 0x8000u));
-      const float cnt = (float)(j - e);
-      dst[slot[e]] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+    // A wave takes 64 consecutive sorted positions per step: every lane reads ITS point and forms its tag (one gather
+    // and one arctangent per lane, no divergence); a voxel's lanes are neighbours, so its first lane collects the
+    // others' values left to right with shuffles — the sums in the order VoxelGrid adds them (ascending original
+    // index).  Only a run that crosses the step's last lane is finished by its first lane alone.  (Issuing the next
+    // step's gather before working on the current one was measured: no faster — the other waves cover the latency.)
+    for (int e0 = wave * 64; e0 < m; e0 += kFeBlock) {
+      const int e = e0 + lane;
+      const bool valid = e < m;
+      const unsigned v = valid ? (unsigned)vs[e] : 0x8000u;
+      const bool start = valid && (v & 0x8000u);
+      const int i = base + (int)(v & 2047u);
+      float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+      float tg = 0.f;
+      if (valid) p = pts[i], tg = tag_of(i, p);
+      const unsigned long long bounds = __ballot(start || !valid);  // where a run ends: the next start, or the end of the ring
+      const unsigned long long above = lane < 63 ? bounds & ~((2ull << lane) - 1ull) : 0ull;
+      const int nxt = above ? __ffsll((long long)above) - 1 : 64;
+      const int len_in = nxt - lane;  // this run's points inside the step (meaningful for start lanes)
+      float sx = 0.f + p.x, sy = 0.f + p.y, sz = 0.f + p.z, si = 0.f + tg;
+      for (int d = 1; __any(start && d < len_in); ++d) {
+        const float ax = __shfl_down(p.x, d), ay = __shfl_down(p.y, d), az = __shfl_down(p.z, d), at = __shfl_down(tg, d);
+        if (start && d < len_in) sx += ax, sy += ay, sz += az, si += at;
+      }
+      if (start) {
+        int total = len_in;
+        if (nxt == 64) {  // the run may go on beyond this step
+          int j = e0 + 64;
+          while (j < m && !(vs[j] & 0x8000u)) {
+            const int i2 = base + (int)(vs[j] & 2047u);
+            const float4 p2 = pts[i2];
+            sx += p2.x, sy += p2.y, sz += p2.z, si += tag_of(i2, p2);
+            ++j;
+          }
+          total = j - e;
+        }
+        const float cnt = (float)total;
+        dst[slot[e]] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+      }
     }
   }
 #ifdef LINS_FE_PROF
@@ -625,10 +651,10 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
 }
 
 void launch_frontend(hipStream_t stream, int n_scans, const void* scans, const float4* cloud, const float* range,
-                     const unsigned* col, const unsigned char* ground, double scan_period, float* tags, int* picks,
-                     float4* out, int* out_counts) {
+                     const unsigned* col, const unsigned char* ground, double scan_period, int* picks, float4* out,
+                     int* out_counts) {
   hipLaunchKernelGGL(frontend_kernel, dim3(n_scans), dim3(kFeBlock), 0, stream, (const FeScan*)scans, cloud, range, col,
-                     ground, scan_period, tags, picks, out, out_counts);
+                     ground, scan_period, picks, out, out_counts);
 }
 size_t fe_scan_size() { return sizeof(FeScan); }
 int fe_pick_stride() { return kFeRows * 6 * kPickStride; }

@@ -53,7 +53,7 @@ void launch_transform_to_end(hipStream_t, int, int, const void*, const float4*, 
 size_t reproject_job_size();
 void launch_stream_copy(hipStream_t, const float4*, float4*, size_t);
 void launch_frontend(hipStream_t, int, const void*, const float4*, const float*, const unsigned*, const unsigned char*,
-                     double, float*, int*, float4*, int*);
+                     double, int*, float4*, int*);
 void launch_reproject_in_place(hipStream_t, int, int, const void*, const double*, float4*, double);
 size_t stream_cloud_size();
 void launch_segment(hipStream_t, int, const void*, const float4*, float, float, float, float, float, unsigned*, int*, void*, float4*,
@@ -126,7 +126,7 @@ struct lins_ctx {
     int cap = 0;
     void* d_scans = nullptr;
     float4 *d_cloud = nullptr, *d_out = nullptr;  // d_out: per scan [192 | 1920 | 384 | LINS_CLOUD_MAX]
-    float *d_range = nullptr, *d_tags = nullptr;  // d_tags: the relative-time tag of every point (the one per-point array the front-end writes)
+    float* d_range = nullptr;
     unsigned* d_col = nullptr;
     unsigned char* d_ground = nullptr;
     int *d_picks = nullptr, *d_counts = nullptr;
@@ -322,7 +322,7 @@ void streams_free(lins_ctx* ctx) {
 
 void fe_free(lins_ctx* ctx) {
   auto& f = ctx->fe;
-  void* ptrs[] = {f.d_scans, f.d_cloud, f.d_out, f.d_range, f.d_tags, f.d_col, f.d_ground, f.d_picks, f.d_counts};
+  void* ptrs[] = {f.d_scans, f.d_cloud, f.d_out, f.d_range, f.d_col, f.d_ground, f.d_picks, f.d_counts};
   for (void* p : ptrs) (void)hipFree(p);
   void* sg[] = {f.d_raw, f.d_raws, f.d_cellidx, f.d_segrows, f.d_outliers};
   for (void* p : sg) (void)hipFree(p);
@@ -1025,7 +1025,6 @@ static int fe_alloc(lins_ctx* ctx, int n) {
   HIP_TRY(ctx, hipMalloc(&f.d_scans, c * sizeof(FeScanHost)));
   HIP_TRY(ctx, hipMalloc((void**)&f.d_cloud, c * N * sizeof(float4)));
   HIP_TRY(ctx, hipMalloc((void**)&f.d_range, c * N * sizeof(float)));
-  HIP_TRY(ctx, hipMalloc((void**)&f.d_tags, c * N * sizeof(float)));
   HIP_TRY(ctx, hipMalloc((void**)&f.d_col, c * N * sizeof(unsigned)));
   HIP_TRY(ctx, hipMalloc((void**)&f.d_ground, c * N));
   HIP_TRY(ctx, hipMalloc((void**)&f.d_picks, c * fe_pick_stride() * sizeof(int)));
@@ -1116,8 +1115,8 @@ static int fe_run(lins_ctx* ctx, int n, const lins_segmented_scan* in, double sc
 static int fe_launch(lins_ctx* ctx, int n, double scan_period, float4* out_base, std::vector<int>& counts, uint64_t bytes) {
   auto& f = ctx->fe;
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  launch_frontend(ctx->stream, n, f.d_scans, f.d_cloud, f.d_range, f.d_col, f.d_ground, scan_period, f.d_tags, f.d_picks,
-                  out_base, f.d_counts);
+  launch_frontend(ctx->stream, n, f.d_scans, f.d_cloud, f.d_range, f.d_col, f.d_ground, scan_period, f.d_picks, out_base,
+                  f.d_counts);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
   counts.resize((size_t)n * 4);
