@@ -159,14 +159,41 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
     }
   }
   __syncthreads();
-  // the owner image goes to global memory (ground removal and the emission read it back), its LDS bytes become
-  // rangeMat (FLT_MAX: no return)
-  if (by_point) {
-    for (int c = tid; c < kSgCells; c += kSgBlock) {
-      const unsigned o = L.u.own[c];
-      ci[c] = o;
-      if (!o) L.u.range[c] = FLT_MAX;
+  // ---- groundRemoval (IP:243-278): one thread per column, rows bottom-up (a row is rewritten by the next) ----
+  // (straight off the owner image while it is still in LDS: rounds 1-2 ran it after the range image had taken the
+  // owner image's place and read the owners back from a global copy)
+  for (int j = tid; j < kSgCols; j += kSgBlock) {
+    int gi[kSgGroundScanInd + 1];
+#pragma unroll
+    for (int i = 0; i <= kSgGroundScanInd; ++i) gi[i] = (int)L.u.own[j + i * kSgCols] - 1;
+    float4 gp[kSgGroundScanInd + 1];
+#pragma unroll
+    for (int i = 0; i <= kSgGroundScanInd; ++i) gp[i] = pts[gi[i] >= 0 ? gi[i] : 0];
+    int g[kSgGroundScanInd + 1];
+#pragma unroll
+    for (int i = 0; i <= kSgGroundScanInd; ++i) g[i] = 0;
+#pragma unroll
+    for (int i = 0; i < kSgGroundScanInd; ++i) {
+      if (gi[i] < 0 || gi[i + 1] < 0) {  // fullCloud intensity -1: no point in one of the two cells
+        g[i] = -1;
+        continue;
+      }
+      const float dx = gp[i + 1].x - gp[i].x, dy = gp[i + 1].y - gp[i].y, dz = gp[i + 1].z - gp[i].z;
+      const float angle = (float)((double)(lins_atan2f(dz, sqrtf(dx * dx + dy * dy)) * 180) / kPi);
+      if (fabsf(angle - 0.0f) <= 10) g[i] = 1, g[i + 1] = 1;
     }
+#pragma unroll
+    for (int i = 0; i <= kSgGroundScanInd; ++i)
+      if (g[i] == 1) L.flags[j + i * kSgCols] = 8;
+  }
+  __syncthreads();  // (every reader of the owner image is done: its bytes may become the range image)
+
+
+  // the owner image's LDS bytes become rangeMat (FLT_MAX: no return); only the cell-by-cell path of oversized clouds
+  // keeps a global copy of it (its emission reads the owners back)
+  if (by_point) {
+    for (int c = tid; c < kSgCells; c += kSgBlock)
+      if (!L.u.own[c]) L.u.range[c] = FLT_MAX;
     __syncthreads();
     // (a cell's word is rewritten by its owner only; the other points of that cell compare it with their own
     // index + 1 and see either the owner's index or range bits — a range >= 0.1 m is no index — never their own)
@@ -204,33 +231,6 @@ __global__ __launch_bounds__(kSgBlock) void segment_kernel(const SgRaw* __restri
   __threadfence_block();
   __syncthreads();
   SG_MARK(1)
-
-  // ---- groundRemoval (IP:243-278): one thread per column, rows bottom-up (a row is rewritten by the next) ----
-  for (int j = tid; j < kSgCols; j += kSgBlock) {
-    int gi[kSgGroundScanInd + 1];
-#pragma unroll
-    for (int i = 0; i <= kSgGroundScanInd; ++i) gi[i] = (int)ci[j + i * kSgCols] - 1;
-    float4 gp[kSgGroundScanInd + 1];
-#pragma unroll
-    for (int i = 0; i <= kSgGroundScanInd; ++i) gp[i] = pts[gi[i] >= 0 ? gi[i] : 0];
-    int g[kSgGroundScanInd + 1];
-#pragma unroll
-    for (int i = 0; i <= kSgGroundScanInd; ++i) g[i] = 0;
-#pragma unroll
-    for (int i = 0; i < kSgGroundScanInd; ++i) {
-      if (gi[i] < 0 || gi[i + 1] < 0) {  // fullCloud intensity -1: no point in one of the two cells
-        g[i] = -1;
-        continue;
-      }
-      const float dx = gp[i + 1].x - gp[i].x, dy = gp[i + 1].y - gp[i].y, dz = gp[i + 1].z - gp[i].z;
-      const float angle = (float)((double)(lins_atan2f(dz, sqrtf(dx * dx + dy * dy)) * 180) / kPi);
-      if (fabsf(angle - 0.0f) <= 10) g[i] = 1, g[i + 1] = 1;
-    }
-#pragma unroll
-    for (int i = 0; i <= kSgGroundScanInd; ++i)
-      if (g[i] == 1) L.flags[j + i * kSgCols] = 8;
-  }
-  __syncthreads();
   SG_MARK(2)
 
   // ---- adjacency of labelComponents (IP:336-415) as three edge bits per eligible cell ------------------
