@@ -28,7 +28,7 @@ with ThreadPoolExecutor(32) as ex:
     t0 = time.time()
     want = list(ex.map(lambda p: oracle.ieskf(prm, p, oracle.FORM_REDUCED, oracle.NN_KDTREE), pairs))
 print(f"oracle: {n} scans in {time.time() - t0:.1f} s, iterations {sum(w.iters for w in want)}, diverged {sum(1 for w in want if w.diverged)}")
-for search in ("auto", "mr", "split", "lds", "lds1", "binned"):
+for search in ("auto", "mr", "lds", "lds1", "binned"):
     with ieskf.IeskfContext(prm, max_batch=n, max_targets=16384, search=search) as c:
         got = c.update_batch(pairs)
     bad_flags = sum((g.iters, g.converged, g.diverged, g.m_surf, g.m_corner) != (w.iters, w.converged, w.diverged, w.m_surf, w.m_corner)

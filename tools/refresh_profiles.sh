@@ -46,8 +46,8 @@ python tools/frontend_vs_libm.py 256 --gpu > $out/${tag}_frontend_vs_libm.txt 2>
 bash tools/pmc_run.sh ${tag}pmc --batch 1024 --search auto > $out/${tag}_pmc_all.txt 2>&1
 tail -40 $out/${tag}_pmc_all.txt
 {
-  python tools/parity_sweep.py 2048 60000 2>&1 | tail -4
-  python tools/parity_sweep.py 1024 70000 wide 2>&1 | tail -4
+  python tools/parity_sweep.py 2048 60000 2>&1 | tail -7
+  python tools/parity_sweep.py 1024 70000 wide 2>&1 | tail -7
   python tools/frontend_sweep.py 1024 50000 2>&1 | tail -2
 } > $out/${tag}_parity_sweep.txt 2>&1
 cat $out/${tag}_parity_sweep.txt
