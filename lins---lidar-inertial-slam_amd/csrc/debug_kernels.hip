@@ -13,10 +13,13 @@
 //   op 11 / 12  gj_solve6 in one lane (lins_solve6.h, the definition) / wave_gj_solve6 over a wave (what the kernels run)
 //   op 13 / 14  axis2quat_fast / quat2axis_fast (lins_math.h): the short-series forms of op 1 / op 0 the serial tail uses
 //   op 15       phi_and_Gt_general: op 5 with the small-rotation shortcut disabled
+//   op 16 / 17  icp_gn_solve in one lane (icp_math.h, the definition) / wave_icp_gn_solve over a wave (icp_wave.h, what the
+//               ICP kernel runs): in 36 (J^T J) + 6 (J^T b) + 1 (round), out 6
 #include <hip/hip_runtime.h>
 
 #include "ieskf_device.h"
 #include "ieskf_rowsum.h"
+#include "icp_wave.h"
 
 namespace lins {
 
@@ -195,6 +198,31 @@ __global__ void debug_reduce_rows_kernel(int op, const double* __restrict__ in, 
 }
 void launch_debug_reduce_rows(hipStream_t stream, int op, int n, const double* in, double* out) {
   hipLaunchKernelGGL(debug_reduce_rows_kernel, dim3(n), dim3(64), 0, stream, op, in, out);
+}
+
+// op 16 / 17: icp_gn_solve (icp_math.h, one lane, workspace in LDS — the definition) / wave_icp_gn_solve (icp_wave.h,
+// what the ICP kernel runs) on the same system: in 36 (J^T J row-major) + 6 (J^T b) + 1 (round index), out 6
+__global__ void debug_icp_gn_kernel(int wave_version, const double* __restrict__ in, double* __restrict__ out) {
+  __shared__ double ws[kIcpWorkspace + 48];
+  const int item = blockIdx.x, l = threadIdx.x;
+  const double* a = in + (size_t)item * 43;
+  double* JTJ = ws + kIcpWorkspace;
+  if (l < 42) JTJ[l] = a[l];
+  __syncthreads();
+  const int iter = (int)a[42];
+  if (wave_version) {
+    double x[6];
+    wave_icp_gn_solve(JTJ, JTJ + 36, iter, l, x, ws);
+    if (l == 0)
+      for (int k = 0; k < 6; ++k) out[(size_t)item * 6 + k] = x[k];
+  } else if (l == 0) {
+    double* x = JTJ + 42;
+    icp_gn_solve(JTJ, JTJ + 36, iter, x, ws);
+    for (int k = 0; k < 6; ++k) out[(size_t)item * 6 + k] = x[k];
+  }
+}
+void launch_debug_icp_gn(hipStream_t stream, int n, int wave_version, const double* in, double* out) {
+  hipLaunchKernelGGL(debug_icp_gn_kernel, dim3(n), dim3(64), 0, stream, wave_version, in, out);
 }
 
 void launch_debug_wave_solve(hipStream_t stream, int n, int gj, const double* in, double* out) {

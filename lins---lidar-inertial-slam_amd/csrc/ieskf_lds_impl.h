@@ -57,6 +57,7 @@
 #include "ieskf_binned.h"
 #include "ieskf_device.h"
 #include "icp_math.h"
+#include "icp_wave.h"
 #include "ieskf_rowsum.h"
 
 #ifndef LINS_SPREAD_S
@@ -946,32 +947,41 @@ __device__ __noinline__ IcpRow icp_row_dev(double inv_period, double phx, double
 // (SE:1175-1184); Gauss-Newton step + degeneracy projection + stop rule in icp_math.h.  A handful
 // of 6x6 factorizations per divergence: one lane, its arrays in LDS.
 // ---------------------------------------------------------------------------
-__device__ __noinline__ void icp_solve_and_update(int tid, int iter) {
+// (called by wave 0 only — the out-of-line call's register saves then cost one wave, not eight; the caller's barrier
+// publishes the new state)
+__device__ __noinline__ void icp_solve_and_update(int lane, int iter) {
   LdsStore& L = g_lds;
-  if (tid == 0) {
+  {  // the step over the wave (icp_wave.h: a matrix column per lane, the scalar routine's bits)
     int conv = 0;
-    if (L.m_surf >= 10 && L.m_corner >= 5) {
-      // every run-time-indexed array of the step lives in LDS (the wave partials and the solve's staging area are idle
-      // here): no private arrays, no scratch (round 2: 1.7 KB per lane, 124 spilled registers in this instantiation)
+    if (L.m_surf >= 10 && L.m_corner >= 5) {  // (uniform)
       static_assert(sizeof(L.partial) >= kIcpWorkspace * sizeof(double) && sizeof(L.aug) >= 48 * sizeof(double), "ICP workspace");
-      double* const ws = L.partial;
-      double *const JTJ = &L.aug[0][0], *const JTb = JTJ + 36, *const x = JTJ + 42;
-      for (int i = 0; i < 6; ++i) {
-        for (int j = 0; j < 6; ++j) JTJ[i * 6 + j] = L.sums[i <= j ? tri6(i, j) : tri6(j, i)];
-        JTb[i] = L.sums[21 + i];
+      double* const ws = L.partial;  // (the wave partials and the solve's staging area are idle here)
+      double *const JTJ = &L.aug[0][0], *const JTb = JTJ + 36;
+      if (lane < 36) {
+        const int i = lane / 6, j = lane % 6;
+        JTJ[lane] = L.sums[i <= j ? tri6(i, j) : tri6(j, i)];
       }
-      icp_gn_solve(JTJ, JTb, iter, x, ws);
+      if (lane < 6) JTb[lane] = L.sums[21 + lane];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double x[6];
+      wave_icp_gn_solve(JTJ, JTb, iter, lane, x, ws);
       double t[3] = {L.ic.lin[0], L.ic.lin[1], L.ic.lin[2]};
       Q4 q{L.ic.lin[6], L.ic.lin[7], L.ic.lin[8], L.ic.lin[9]};
       conv = icp_apply(x, t, q) ? 1 : 0;
-      L.ic.lin[0] = t[0], L.ic.lin[1] = t[1], L.ic.lin[2] = t[2];
-      L.ic.lin[6] = q.w, L.ic.lin[7] = q.x, L.ic.lin[8] = q.y, L.ic.lin[9] = q.z;
-      L.ic.phi = quat2axis(q);
+      const V3 phi = quat2axis(q);
+      if (lane == 0) {
+        L.ic.lin[0] = t[0], L.ic.lin[1] = t[1], L.ic.lin[2] = t[2];
+        L.ic.lin[6] = q.w, L.ic.lin[7] = q.x, L.ic.lin[8] = q.y, L.ic.lin[9] = q.z;
+        L.ic.phi = phi;
+      }
     }
-    L.conv = conv;
-    L.iter = iter + 1;
+    if (lane == 0) {
+      L.conv = conv;
+      L.iter = iter + 1;
+    }
   }
-  __syncthreads();
 }
 
 // ---------------------------------------------------------------------------
@@ -1706,9 +1716,10 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     }
 
     if (ICP && held.w >= 0 && L.m_surf >= 10) idx_store[held.w] = make_int4(held.x, held.y, held.z, 0);
-    if (ICP)
-      icp_solve_and_update(tid, iter);
-    else
+    if (ICP) {
+      if (tid < 64) icp_solve_and_update(tid, iter);
+      __syncthreads();
+    } else
       t3 = solve_and_update(prm.r2, prm.fixed_iters, prm.pad, tid, iter, prof);
     if (prof) {
       long long t4 = clock64();

@@ -46,6 +46,7 @@ int lds_mr_np_cap();
 void launch_debug_math(hipStream_t, int, int, int, int, const double*, double*);
 void launch_debug_cycles(hipStream_t, int, int, const double*, double*);
 void launch_debug_wave_solve(hipStream_t, int, int, const double*, double*);
+void launch_debug_icp_gn(hipStream_t, int, int, const double*, double*);
 void launch_debug_reduce_rows(hipStream_t, int, int, const double*, double*);
 void launch_lds_mr_icp(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, float4*, const double*, double*,
                        void*, int4*);
@@ -942,9 +943,9 @@ int lins_debug_math(lins_ctx* ctx, int op, int n, const double* in, int n_in, do
     (void)hipFree(d_in), (void)hipFree(d_out);
     return LINS_OK;
   }
-  static const int kIn[16] = {4, 3, 3, 37, 38, 4, 24, 42, 42, 448, 448, 42, 42, 3, 4, 4};
-  static const int kOut[16] = {3, 4, 9, 19, 18, 12, 3, 6, 6, 28, 28, 6, 6, 4, 3, 12};
-  if (!ctx || !in || !out || op < 0 || op > 15 || n < 0 || n_in != kIn[op] || n_out != kOut[op]) return LINS_E_ARG;
+  static const int kIn[18] = {4, 3, 3, 37, 38, 4, 24, 42, 42, 448, 448, 42, 42, 3, 4, 4, 43, 43};
+  static const int kOut[18] = {3, 4, 9, 19, 18, 12, 3, 6, 6, 28, 28, 6, 6, 4, 3, 12, 6, 6};
+  if (!ctx || !in || !out || op < 0 || op > 17 || n < 0 || n_in != kIn[op] || n_out != kOut[op]) return LINS_E_ARG;
   if (n == 0) return LINS_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   double *d_in = nullptr, *d_out = nullptr;
@@ -956,6 +957,8 @@ int lins_debug_math(lins_ctx* ctx, int op, int n, const double* in, int n_in, do
       launch_debug_reduce_rows(ctx->stream, op, n, d_in, d_out);
     else if (op == 8 || op == 12)
       launch_debug_wave_solve(ctx->stream, n, op == 12, d_in, d_out);
+    else if (op == 16 || op == 17)
+      launch_debug_icp_gn(ctx->stream, n, op == 17, d_in, d_out);
     else
       launch_debug_math(ctx->stream, op, n, n_in, n_out, d_in, d_out);
     e = hipGetLastError();

@@ -215,3 +215,31 @@ def test_row_reduction_on_the_valu_lane_paths_matches_the_shuffle_tree(ieskf, ct
     want = np.stack([(rows[:, :, i] * rows[:, :, j]).sum(axis=1) for i, j in zip(A, B)], axis=1)
     scale = np.stack([np.abs(rows[:, :, i] * rows[:, :, j]).sum(axis=1) for i, j in zip(A, B)], axis=1)
     assert (np.abs(a - want) <= 1e-13 * scale).all()
+
+
+def test_icp_gauss_newton_step_over_a_wave_is_bit_identical_to_the_one_lane_definition(ieskf, ctx):
+    """icp_wave.h (a matrix column per lane: what the ICP kernel runs) against icp_math.h's icp_gn_solve run by one
+    lane (the definition, shared with the host shim): column-pivoted Householder QR with Eigen's rank rule, and on round 0
+    the Jacobi eigen-decomposition + degenerate-direction projection (SE:1264-1302) — the same bits on well-conditioned
+    normal equations, on systems that force column exchanges, on rank-deficient ones and on ones with eigenvalues
+    below the degeneracy threshold (10)."""
+    rng = np.random.default_rng(77)
+    n = 400
+    J = rng.normal(size=(n, 40, 6)) * rng.choice([0.3, 1.0, 5.0], size=(n, 1, 6))
+    J[100:160, :, 2] *= 1e-3            # a weak direction: eigenvalue < 10 -> projection on round 0
+    J[160:200, :, 4] = J[160:200, :, 1]  # exactly rank-deficient (two equal columns)
+    J[200:220, :, 0] = 0.0               # a zero column
+    b = rng.normal(size=(n, 40)) * 0.05
+    A = np.einsum("nki,nkj->nij", J, J)
+    g = np.einsum("nki,nk->ni", J, b)
+    A[220:230] *= 1e-6                   # every eigenvalue below the threshold
+    rounds = np.where(np.arange(n) % 2 == 0, 0.0, 3.0)
+    x = np.concatenate([A.reshape(n, 36), g, rounds[:, None]], axis=1)
+    one = dev(ieskf, ctx, 16, x, 6)
+    wav = dev(ieskf, ctx, 17, x, 6)
+    assert np.array_equal(np.isnan(one), np.isnan(wav))
+    assert np.array_equal(one[~np.isnan(one)].view(np.uint64), wav[~np.isnan(wav)].view(np.uint64))
+    # and the definition does what it says on the plain systems: later rounds solve the normal equations
+    ok = (rounds == 3.0) & (np.arange(n) < 100)
+    sol = np.linalg.solve(A[ok], g[ok][:, :, None])[:, :, 0]
+    assert np.abs(one[ok] - sol).max() <= 1e-9 * np.abs(sol).max()
