@@ -367,7 +367,7 @@ def main():
         c_abi_gather = bool(flag.item())
         if not c_abi_gather and ok:
             ctx.rccl_destroy()
-    ctx.set_pipelined(c_abi_gather or not use_dist)
+    ctx.set_pipelined(c_abi_gather)  # (the gather's second stream and events: only where there is a gather)
     n_steps = [0]
 
     def step():  # everything asynchronous: no host wait inside a step
