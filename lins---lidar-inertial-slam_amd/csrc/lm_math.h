@@ -146,20 +146,20 @@ LINS_HD bool lm_step_from_sums(const double* sums, int iter, float* T, LmCarry& 
       }
     }
     lm_inv6(V, Vi);
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 6; ++j) {
-        float s = 0.f;
-        for (int k = 0; k < 6; ++k) s += Vi[i * 6 + k] * V2[k * 6 + j];
-        st.P[i * 6 + j] = s;
+    for (int i = 0; i < 6; ++i)  // matP = matV.inv() * matV2: like every Mat product of the path, accumulated in f64 over the
+      for (int j = 0; j < 6; ++j) {  // inner index and rounded once (OpenCV's small f32 GEMM accumulates in double)
+        double s = 0.0;
+        for (int k = 0; k < 6; ++k) s += (double)Vi[i * 6 + k] * (double)V2[k * 6 + j];
+        st.P[i * 6 + j] = (float)s;
       }
   }
   if (st.degenerate) {
     float X2[6];
     for (int i = 0; i < 6; ++i) X2[i] = X[i];
-    for (int i = 0; i < 6; ++i) {
-      float s = 0.f;
-      for (int k = 0; k < 6; ++k) s += st.P[i * 6 + k] * X2[k];
-      X[i] = s;
+    for (int i = 0; i < 6; ++i) {  // matX = matP * matX2
+      double s = 0.0;
+      for (int k = 0; k < 6; ++k) s += (double)st.P[i * 6 + k] * (double)X2[k];
+      X[i] = (float)s;
     }
   }
   for (int i = 0; i < 6; ++i) T[i] += X[i];

@@ -1,7 +1,9 @@
 // map_oracle.cpp — CPU oracle of the scan-to-map row.  TEST INFRASTRUCTURE ONLY:
-// nothing in the product may include, link or call it.  PARITY UNPINNED: the reference
-// (/root/reference/lins/src/lidar_mapping_node.cpp, "LM") cannot be built here (ROS, PCL, OpenCV,
-// GTSAM) and ships no tests; this is a plain restatement of
+// nothing in the product may include, link or call it.  Pinned since round 3 to the reference's own text as far as
+// that text goes: oracle/ref_map_driver.cpp compiles /root/reference/lins/src/lidar_mapping_node.cpp verbatim against
+// stand-in ROS / PCL / GTSAM / OpenCV headers and tests/test_ref.py holds this file against its
+// scan2MapOptimization (correspondences, selected rows, rounds, transform).  The OpenCV numerics themselves (below)
+// are restated, not pinned — OpenCV is not on this machine.  A plain restatement of
 //   pointAssociateToMap   LM:579-607      cornerOptimization LM:1351-1453
 //   surfOptimization      LM:1455-1521    LMOptimization     LM:1523-1633
 //   scan2MapOptimization  LM:1635-1652
@@ -20,6 +22,7 @@
 #include <vector>
 
 #include "../include/lins_map.h"
+#include "ref_shim/lins_ref_shim/cv_restated.h"
 
 namespace {
 
@@ -65,112 +68,18 @@ void knn5(const lins_point* pts, int n, P3 q, int* ind, float* sq) {
   }
 }
 
-// cyclic Jacobi for a symmetric N x N f32 matrix (row-major, destroyed); w descending, rows of V = eigenvectors
+// The OpenCV routines of the path (cv::eigen, cv::solve(DECOMP_QR), Mat::inv, Mat * Mat) are restated once, in
+// ref_shim/lins_ref_shim/cv_restated.h — the stand-in OpenCV header through which the reference's own text runs
+// (oracle/_ref) uses the same restatement, so that this file and the reference can only differ in the reference's own glue.
 template <int N>
 void jacobi_eig(float* a, float* w, float* V) {
-  float v[N * N];
-  for (int i = 0; i < N; ++i)
-    for (int j = 0; j < N; ++j) v[i * N + j] = i == j ? 1.f : 0.f;
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    float off = 0.f, diag = 0.f;
-    for (int i = 0; i < N; ++i) {
-      diag += std::fabs(a[i * N + i]);
-      for (int j = i + 1; j < N; ++j) off += std::fabs(a[i * N + j]);
-    }
-    if (!(off > 1e-12f * diag)) break;
-    for (int p = 0; p < N; ++p)
-      for (int q = p + 1; q < N; ++q) {
-        const float apq = a[p * N + q];
-        if (apq == 0.f) continue;
-        const float theta = (a[q * N + q] - a[p * N + p]) / (2.f * apq);
-        const float t = (theta >= 0.f ? 1.f : -1.f) / (std::fabs(theta) + std::sqrt(theta * theta + 1.f));
-        const float c = 1.f / std::sqrt(t * t + 1.f), s = t * c;
-        for (int k = 0; k < N; ++k) {
-          const float x = a[k * N + p], y = a[k * N + q];
-          a[k * N + p] = c * x - s * y, a[k * N + q] = s * x + c * y;
-        }
-        for (int k = 0; k < N; ++k) {
-          const float x = a[p * N + k], y = a[q * N + k];
-          a[p * N + k] = c * x - s * y, a[q * N + k] = s * x + c * y;
-        }
-        for (int k = 0; k < N; ++k) {
-          const float x = v[k * N + p], y = v[k * N + q];
-          v[k * N + p] = c * x - s * y, v[k * N + q] = s * x + c * y;
-        }
-      }
-  }
-  int ord[N];
-  for (int i = 0; i < N; ++i) ord[i] = i;
-  for (int i = 1; i < N; ++i)  // insertion sort, descending, stable
-    for (int j = i; j > 0 && a[ord[j] * N + ord[j]] > a[ord[j - 1] * N + ord[j - 1]]; --j) {
-      int tmp = ord[j];
-      ord[j] = ord[j - 1], ord[j - 1] = tmp;
-    }
-  for (int i = 0; i < N; ++i) {
-    w[i] = a[ord[i] * N + ord[i]];
-    for (int k = 0; k < N; ++k) V[i * N + k] = v[k * N + ord[i]];  // row i = eigenvector i
-  }
+  lins_cvr::jacobi_eig(a, N, w, V);
 }
-
-// least squares / linear solve by Householder QR in f32: A is M x N (row-major, destroyed), b has M entries
 template <int M, int N>
 void qr_solve(float* a, float* b, float* x) {
-  for (int k = 0; k < N; ++k) {
-    float nrm2 = 0.f;
-    for (int i = k; i < M; ++i) nrm2 += a[i * N + k] * a[i * N + k];
-    const float nrm = std::sqrt(nrm2);
-    if (nrm == 0.f) continue;
-    const float alpha = a[k * N + k] >= 0.f ? -nrm : nrm;
-    float v[M];
-    for (int i = 0; i < M; ++i) v[i] = i >= k ? a[i * N + k] : 0.f;
-    v[k] -= alpha;
-    float vv = 0.f;
-    for (int i = k; i < M; ++i) vv += v[i] * v[i];
-    if (vv == 0.f) continue;
-    for (int j = k; j < N; ++j) {
-      float s = 0.f;
-      for (int i = k; i < M; ++i) s += v[i] * a[i * N + j];
-      s = 2.f * s / vv;
-      for (int i = k; i < M; ++i) a[i * N + j] -= s * v[i];
-    }
-    float s = 0.f;
-    for (int i = k; i < M; ++i) s += v[i] * b[i];
-    s = 2.f * s / vv;
-    for (int i = k; i < M; ++i) b[i] -= s * v[i];
-  }
-  for (int i = N - 1; i >= 0; --i) {
-    float s = b[i];
-    for (int j = i + 1; j < N; ++j) s -= a[i * N + j] * x[j];
-    x[i] = s / a[i * N + i];
-  }
+  lins_cvr::qr_solve(a, M, N, b, x);
 }
-
-void inv6(const float* A, float* inv) {  // Gauss-Jordan, partial pivoting
-  const int n = 6;
-  float a[36];
-  std::memcpy(a, A, sizeof a);
-  for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) inv[i * n + j] = i == j ? 1.f : 0.f;
-  for (int k = 0; k < n; ++k) {
-    int p = k;
-    for (int i = k + 1; i < n; ++i)
-      if (std::fabs(a[i * n + k]) > std::fabs(a[p * n + k])) p = i;
-    if (p != k)
-      for (int j = 0; j < n; ++j) {
-        float t = a[k * n + j];
-        a[k * n + j] = a[p * n + j], a[p * n + j] = t;
-        t = inv[k * n + j];
-        inv[k * n + j] = inv[p * n + j], inv[p * n + j] = t;
-      }
-    const float d = a[k * n + k];
-    for (int j = 0; j < n; ++j) a[k * n + j] /= d, inv[k * n + j] /= d;
-    for (int i = 0; i < n; ++i) {
-      if (i == k) continue;
-      const float f = a[i * n + k];
-      for (int j = 0; j < n; ++j) a[i * n + j] -= f * a[k * n + j], inv[i * n + j] -= f * inv[k * n + j];
-    }
-  }
-}
+void inv6(const float* A, float* inv) { lins_cvr::inv(A, 6, inv); }
 
 // cornerOptimization's body for one point (LM:1354-1452)
 void corner_one(const Assoc& as, const lins_point* map, int n_map, const lins_point& ori, lins_map_corr& out) {
@@ -305,21 +214,12 @@ bool lm_step(float* T, const std::vector<lins_point>& ori, const std::vector<lin
       }
     }
     inv6(V, Vi);
-    for (int i = 0; i < 6; ++i)
-      for (int j = 0; j < 6; ++j) {
-        float s = 0.f;
-        for (int k = 0; k < 6; ++k) s += Vi[i * 6 + k] * V2[k * 6 + j];
-        st.P[i * 6 + j] = s;
-      }
+    lins_cvr::matmul(Vi, 6, 6, V2, 6, st.P);  // matP = matV.inv() * matV2
   }
   if (st.degenerate) {
     float X2[6];
     std::memcpy(X2, X, sizeof X);
-    for (int i = 0; i < 6; ++i) {
-      float s = 0.f;
-      for (int k = 0; k < 6; ++k) s += st.P[i * 6 + k] * X2[k];
-      X[i] = s;
-    }
+    lins_cvr::matmul(st.P, 6, 6, X2, 1, X);  // matX = matP * matX2
   }
   for (int i = 0; i < 6; ++i) T[i] += X[i];
   auto rad2deg = [](float a) { return (float)(a * 57.29578f); };

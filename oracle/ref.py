@@ -264,6 +264,32 @@ def segment(raw):
     return host.Segmented(cloud, rng, col, ground, c)
 
 
+def map_rows(problem):
+    """lidar_mapping_node's cornerOptimization + surfOptimization (LM:1351-1521) at problem.transform: the rows they push —
+    (pointOri (n, 4), coeff (n, 4)), corner rows first."""
+    c = problem.as_c()
+    cap = len(problem.scan_corner) + len(problem.scan_surf)
+    ori = np.zeros((max(cap, 1), 4), np.float32)
+    coeff = np.zeros((max(cap, 1), 4), np.float32)
+    L = lib()
+    L.ref_map_rows.argtypes = [C.POINTER(_defs.MapProblemC), C.c_void_p, C.c_void_p, C.c_int]
+    n = L.ref_map_rows(C.byref(c), ori.ctypes.data, coeff.ctypes.data, cap)
+    assert 0 <= n <= cap, n
+    return ori[:n], coeff[:n]
+
+
+def scan2map(problem):
+    """lidar_mapping_node's scan2MapOptimization (LM:1635-1652) -> the dict oracle.scan2map returns."""
+    c = problem.as_c()
+    r = _defs.MapResultC()
+    L = lib()
+    L.ref_scan2map.argtypes = [C.POINTER(_defs.MapProblemC), C.POINTER(_defs.MapResultC)]
+    rc = L.ref_scan2map(C.byref(c), C.byref(r))
+    assert rc == 0, rc
+    return dict(transform=np.array(r.transform[:], dtype=np.float32), iters=r.iters, converged=r.converged,
+                degenerate=r.degenerate, n_sel=r.n_sel)
+
+
 def filter_run(fprm, vn, ba, bw, imu, reset1=False):
     """StatePredictor: initialization(0, 0, vn, ba, bw) -> predict() per row of imu (dt, acc, gyr) -> optional reset(1).
     fprm: host.FilterParams.  Returns (state19, cov 18x18)."""

@@ -1,0 +1,2 @@
+// <gtsam/nonlinear/Marginals.h> — STAND-IN (oracle/ref_shim/README.md): see gtsam/lins_ref_gtsam.h
+#include <gtsam/lins_ref_gtsam.h>

@@ -54,6 +54,23 @@ class KdTreeFLANN {
     return static_cast<int>(best.size());
   }
 
+  // every point within `radius` (by the same f32 distance), ascending (distance, index); brute force — the reference
+  // only calls it from its key-frame bookkeeping, which the _ref drivers never run
+  int radiusSearch(const PointT& p, double radius, std::vector<int>& k_indices, std::vector<float>& k_sqr_distances, unsigned max_nn = 0) const {
+    std::vector<std::pair<float, int> > hits;
+    const float r2 = static_cast<float>(radius * radius);
+    for (std::size_t i = 0; i < order_.size(); ++i) {
+      const float dx = p.x - pts_[3 * i], dy = p.y - pts_[3 * i + 1], dz = p.z - pts_[3 * i + 2];
+      const float d = (dx * dx + dy * dy) + dz * dz;
+      if (d <= r2) hits.push_back(std::make_pair(d, static_cast<int>(i)));
+    }
+    std::sort(hits.begin(), hits.end());
+    if (max_nn && hits.size() > max_nn) hits.resize(max_nn);
+    k_indices.resize(hits.size()), k_sqr_distances.resize(hits.size());
+    for (std::size_t i = 0; i < hits.size(); ++i) k_sqr_distances[i] = hits[i].first, k_indices[i] = hits[i].second;
+    return static_cast<int>(hits.size());
+  }
+
  private:
   struct Node {
     int lo, hi;       // range in order_

@@ -22,6 +22,11 @@ class PointCloud {
     width = 0;
     height = 0;
   }
+  void resize(std::size_t n) {
+    points.resize(n);
+    width = static_cast<std::uint32_t>(n);
+    height = 1;
+  }
   std::size_t size() const { return points.size(); }
   bool empty() const { return points.empty(); }
   PointCloud& operator+=(const PointCloud& rhs) {

@@ -68,5 +68,11 @@ class NodeHandle {
 };
 inline void init(int&, char**, const std::string&) {}
 inline void spin() {}
+inline void spinOnce() {}
+inline bool ok() { return false; }
+struct Rate {
+  explicit Rate(double) {}
+  void sleep() {}
+};
 }  // namespace ros
 #endif

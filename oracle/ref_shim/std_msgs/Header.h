@@ -7,7 +7,12 @@ namespace ros {
 struct Time {
   double sec_;
   Time() : sec_(0.0) {}
+  explicit Time(double s) : sec_(s) {}
   double toSec() const { return sec_; }
+  Time& fromSec(double s) {
+    sec_ = s;
+    return *this;
+  }
   static Time now() { return Time(); }
 };
 }  // namespace ros

@@ -399,3 +399,73 @@ def test_raw_cloud_to_feature_clouds_through_the_references_two_nodes(pkg, host,
             assert_same_picks(fr[name][:, :3], fh[name][:, :3], seg, fr["undistorted"][:, :3], name)
         a, b = fr["surf_less_flat"], fh["surf_less_flat"]
         assert a.shape == b.shape and np.abs(a - b).max() <= 4e-6
+
+
+# ---- lidar_mapping_node.cpp's scan-to-map optimisation (LM:579-607, 1351-1652) ---------------------------------------------
+def _map_defs():
+    import importlib
+
+    return importlib.import_module("lins---lidar-inertial-slam_amd._ctypes_defs")
+
+
+def assert_same_map_rows(ref, oracle, prob, what):
+    ro, rc = ref.map_rows(prob)
+    c, s = oracle.map_correspondences(prob)
+    oo = np.concatenate([prob.scan_corner[c["accepted"] == 1], prob.scan_surf[s["accepted"] == 1]])
+    oc = np.concatenate([c["coeff"][c["accepted"] == 1], s["coeff"][s["accepted"] == 1]])
+    assert ro.shape == oo.shape and np.array_equal(ro.view(np.int32), oo.view(np.int32)), what
+    assert np.array_equal(rc.view(np.int32), oc.view(np.int32)), what
+    return len(ro)
+
+
+def assert_same_scan2map(ref, oracle, prob, what):
+    a, b = ref.scan2map(prob), oracle.scan2map(prob)
+    assert (a["iters"], a["converged"], a["degenerate"], a["n_sel"]) == (b["iters"], b["converged"], b["degenerate"], b["n_sel"]), (what, a, b)
+    assert np.array_equal(a["transform"].view(np.int32), b["transform"].view(np.int32)), (what, a, b)
+    return a
+
+
+def test_scan_to_map_optimisation_equals_the_mapping_nodes(oracle, ref):
+    """The reference's own lidar_mapping_node.cpp (compiled verbatim, oracle/ref_map_driver.cpp) against
+    oracle/map_oracle.cpp — the restatement the device kernels are bit-compared with: the rows cornerOptimization /
+    surfOptimization push (which queries, their coefficients) and scan2MapOptimization's rounds, flags and transform, bit
+    for bit.  Both sides run the same restated OpenCV numerics (lins_ref_shim/cv_restated.h: OpenCV is not on this
+    machine), so this pins what the reference itself wrote: pointAssociateToMap, the 5-neighbour gates, the line / plane
+    coefficient formulas and weights, the rows of the 6 x 6 system, the degeneracy projection, the update and the stop
+    rule — and the loop around them."""
+    from map_synth import make_corridor, make_problem
+
+    defs = _map_defs()
+    for seed in range(8):
+        prob, _ = make_problem(defs, 300 + seed)
+        assert assert_same_map_rows(ref, oracle, prob, f"room {seed}") > 900
+        assert assert_same_scan2map(ref, oracle, prob, f"room {seed}")["converged"] == 1
+    for seed in (5, 6):
+        prob, _ = make_corridor(defs, 40 + seed)
+        assert_same_map_rows(ref, oracle, prob, f"corridor {seed}")
+        assert assert_same_scan2map(ref, oracle, prob, f"corridor {seed}")["degenerate"] == 1
+    big, _ = make_problem(defs, 77, perturb=(0.05, 0.4))  # a start far from the solution: more rounds, fewer rows at first
+    assert_same_map_rows(ref, oracle, big, "far start")
+    assert_same_scan2map(ref, oracle, big, "far start")
+
+
+def test_scan_to_map_edge_cases_equal_the_mapping_nodes(oracle, ref):
+    """distance ties (duplicated map points, lattice coordinates), queries off the map, a scan without corner points,
+    maps below the node's size gate (LM:1636) and fewer than 50 selected rows (LM:1533)."""
+    from map_synth import make_problem
+
+    defs = _map_defs()
+    prob, _ = make_problem(defs, 21, n_map_surf=6000, n_map_corner=1000, n_scan_surf=400, n_scan_corner=120, noise=0.0)
+    ms = prob.map_surf.copy()
+    ms[:, :3] = np.round(ms[:, :3] * 8) / 8
+    ms[3000:] = ms[:3000]
+    sc = prob.scan_surf.copy()
+    sc[:50, :3] += 100.0
+    ties = defs.MapProblem(prob.map_corner, ms, prob.scan_corner, sc, prob.transform)
+    assert_same_map_rows(ref, oracle, ties, "ties")
+    assert_same_scan2map(ref, oracle, ties, "ties")
+    empty = np.zeros((0, 4), np.float32)
+    for p, what in ((defs.MapProblem(prob.map_corner, prob.map_surf, empty, prob.scan_surf, prob.transform), "no corner points"),
+                    (defs.MapProblem(prob.map_corner[:8], prob.map_surf, prob.scan_corner, prob.scan_surf, prob.transform), "map too small"),
+                    (defs.MapProblem(prob.map_corner, prob.map_surf, prob.scan_corner[:10], prob.scan_surf[:20], prob.transform), "too few rows")):
+        assert_same_scan2map(ref, oracle, p, what)
