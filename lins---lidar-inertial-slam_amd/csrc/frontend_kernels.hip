@@ -149,8 +149,9 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
       unsigned c[kIn];
 #pragma unroll
       for (int u = 0; u < kIn; ++u) {
-        const int i = i0 + u * kFeBlock, ic = i < n ? i : n - 1;
-        p[u] = pts[ic], g[u] = gd[ic], c[u] = cl[ic];
+        const int i = i0 + u * kFeBlock, ic = i < n ? i : n - 1;  // (clamped reads; an empty scan reads nothing)
+        p[u] = make_float4(0.f, 0.f, 0.f, 0.f), g[u] = 0, c[u] = 0;
+        if (n > 0) p[u] = pts[ic], g[u] = gd[ic], c[u] = cl[ic];
       }
 #pragma unroll
       for (int u = 0; u < kIn; ++u) {

@@ -580,3 +580,25 @@ def test_pipelined_batch_call_equals_the_staged_path(pkg, oracle, ieskf):
         assert all(np.isfinite(r.state).all() for r in again[:16])
     finally:
         c.close()
+
+
+def test_front_end_on_empty_and_tiny_segmented_scans(pkg, ieskf, host):
+    """A segmented scan without a single point (first, in the middle and last of a batch) and scans of a handful of
+    points: no feature, no fault, the neighbours' results untouched — and the host restatement says the same."""
+    full = [host.frontend_segment(host.synth_raw_scan(9, k)) for k in (0, 1)]
+
+    def cut(seg, n):
+        c = host.segmented_from_arrays(seg.cloud[:max(n, 1)].copy(), seg.range[:max(n, 1)].copy(), seg.col[:max(n, 1)].copy(),
+                                       seg.ground[:max(n, 1)].copy(), n, [-1 + 5] * 16 if n == 0 else list(np.minimum(seg.c.start_ring, n)),
+                                       [-1 - 5] * 16 if n == 0 else list(np.minimum(seg.c.end_ring, n - 1)),
+                                       (seg.c.start_ori, seg.c.end_ori, seg.c.ori_diff), 0)
+        return c
+
+    segs = [cut(full[0], 0), full[0], cut(full[1], 0), cut(full[0], 7), full[1], cut(full[1], 40), cut(full[0], 0)]
+    want = [host.frontend_extract_segmented(s) for s in segs]
+    with ieskf.IeskfContext(pkg.default_params(), max_batch=1, max_targets=1024) as c:
+        got = c.extract_features_batch(segs)
+    for i, (g, w) in enumerate(zip(got, want)):
+        for k in ("corner_sharp", "corner_less_sharp", "surf_flat", "surf_less_flat"):
+            assert g[k].shape == w[k].shape and np.array_equal(g[k], w[k]), (i, k)
+    assert all(len(got[i][k]) == 0 for i in (0, 2, 6) for k in ("corner_sharp", "corner_less_sharp", "surf_flat", "surf_less_flat"))
