@@ -152,6 +152,12 @@ int lins_set_search(lins_ctx* ctx, const char* mode);
 /* --- replaces StateEstimator::performIESKF() (SE:465-600) ----------------- */
 /* synchronous, host buffers in and out                                        */
 int lins_ieskf_update(lins_ctx* ctx, const lins_scan_pair* in, lins_result* out);
+/* n independent scan pairs.  Batches of 512 and more go through in chunks of 256: a pool of host threads validates
+ * and packs the next chunks while the copies and kernels of the previous ones run.  The kernel family ("auto" and the
+ * eligibility fall-backs, lins_set_search) is then chosen PER CHUNK from that chunk's scans — a scan's result does not
+ * depend on the family that computed it — so one oversized or unsorted scan sends its own chunk, not the batch, to the
+ * any-size kernel; lins_last_search() and lins_last_kernel_ms() report the LAST chunk.  A contract violation in any
+ * scan fails the whole call (results of earlier chunks are not delivered).                                         */
 int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in,
                             lins_result* out);
 
@@ -163,9 +169,9 @@ int lins_batch_upload(lins_ctx* ctx, int n, const lins_scan_pair* in);
 int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base);
 int lins_sync(lins_ctx* ctx);
 int lins_batch_download(lins_ctx* ctx, int n, lins_result* out);
-/* HIP-event time (ms), on the context's stream, of the dominant kernel of the last
- * lins_batch_run(): the persistent IESKF kernel ("lds*" modes: without the small Joseph
- * covariance kernel that follows it; "binned"/"brute": both).                       */
+/* HIP-event time (ms), on the context's stream, of the update kernel of the last lins_batch_run() (or of the last
+ * chunk of lins_ieskf_update_batch): the persistent IESKF kernel, whose epilogue is the Joseph covariance update in the
+ * "lds" / "mr" / "lds1" families; for "binned" / "brute" the update kernel and the separate Joseph kernel.        */
 int lins_last_kernel_ms(lins_ctx* ctx, float* ms);
 /* HIP-event times (ms) of the update kernels of the last n lins_batch_run() calls, oldest first (n <= 64 and <= the
  * number of runs so far); waits for the newest of them.  lins_last_kernel_ms() is the n = 1 case.                 */
