@@ -513,7 +513,9 @@ void launch_order(lins_ctx* ctx, int n) {
   std::vector<std::pair<double, int>> key(n);
   for (int s = 0; s < n; ++s) {
     const double* st = ctx->h_state + (size_t)s * 19;
-    key[s] = {-(st[0] * st[0] + st[1] * st[1] + st[2] * st[2]), s};
+    double k2 = -(st[0] * st[0] + st[1] * st[1] + st[2] * st[2]);
+    if (!(k2 == k2)) k2 = 0.0;  // (a NaN prior is the caller's business, not a reason to hand std::sort an unordered key)
+    key[s] = {k2, s};
   }
   std::sort(key.begin(), key.end());
   for (int s = 0; s < n; ++s) ctx->h_order[s] = key[s].second;
