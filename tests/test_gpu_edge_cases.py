@@ -602,3 +602,26 @@ def test_front_end_on_empty_and_tiny_segmented_scans(pkg, ieskf, host):
         for k in ("corner_sharp", "corner_less_sharp", "surf_flat", "surf_less_flat"):
             assert g[k].shape == w[k].shape and np.array_equal(g[k], w[k]), (i, k)
     assert all(len(got[i][k]) == 0 for i in (0, 2, 6) for k in ("corner_sharp", "corner_less_sharp", "surf_flat", "surf_less_flat"))
+
+
+@pytest.mark.parametrize("search", ["mr", "lds", "binned"])
+def test_non_finite_prior_states_take_the_nan_branch_like_the_oracle(pkg, ieskf, host, oracle, search):
+    """A prior state with a NaN or an infinity in it (position, quaternion, velocity, bias) is not an input error in the
+    reference: the first iteration produces NaN, SE:552-563 flags it (diverged = 2) and the filter keeps its state.  The
+    device does the same — same flags and row counts as the oracle, no hang — next to a healthy scan of the same batch."""
+    prm = pkg.default_params(num_iter=10)
+    base = [host.synth_pair(i) for i in range(4)]
+    cases = []
+    for k, (idx, val) in enumerate([(0, np.nan), (7, np.nan), (3, np.inf), (12, np.nan)]):
+        p = base[k]
+        st = p.state.copy()
+        st[idx] = val
+        cases.append(pkg.ScanPair(p.surf_flat, p.corner_sharp, p.surf_last, p.corner_last, st, p.cov))
+    cases.append(base[0])
+    with ieskf.IeskfContext(prm, max_batch=len(cases), max_targets=16384, search=search) as c:
+        got = c.update_batch(cases)
+    for g, p in zip(got, cases):
+        w = oracle.ieskf(prm, p, oracle.FORM_DENSE, oracle.NN_KDTREE)
+        assert (g.iters, g.converged, g.diverged, g.m_surf, g.m_corner) == (w.iters, w.converged, w.diverged, w.m_surf, w.m_corner)
+        assert np.array_equal(np.isnan(g.state), np.isnan(w.state))
+    assert [g.diverged for g in got] == [2, 2, 2, 2, 0]
