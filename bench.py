@@ -4,7 +4,10 @@
 Workload (BASELINE.json configs[3], the largest single-GPU configuration): a batch
 of 1024 independent seeded synthetic 16x1800 VLP-16 scan pairs per GPU, exactly 10
 IESKF iterations each (fixed_iters throughput mode), inputs resident in HBM before
-the timed region.  One "step" = one pass of the hot path over the batch
+the timed region — the scans and the search index of their target clouds, which
+lins_batch_upload builds as the reference builds its kd-trees in updatePointCloud
+(SE:1156-1160), outside performIESKF; `search_index` reports that kernel's time and
+the rate with it added to every step.  One "step" = one pass of the hot path over the batch
 (lins_batch_run: update kernel + Joseph covariance kernel) + for N>1 the RCCL
 all-gather of the fixed-size pose records (lins_pose_allgather, C ABI).  The steps of
 the timed region are enqueued back to back (the library's pipelined staged mode: the
@@ -335,7 +338,11 @@ def main():
     prm = pkg.default_params(num_iter=args.iters, fixed_iters=1)
     ctx = ieskf.IeskfContext(prm, device=local_rank, max_batch=len(pairs), max_targets=max(max_targets, 1024),
                              search=args.search)
-    ctx.upload(pairs)
+    ctx.upload(pairs)  # inputs resident in HBM, search index of the target clouds built (below: index_ms)
+    try:
+        index_ms = ctx.last_index_ms()
+    except Exception:
+        index_ms = None  # (a batch that cannot take the grid kernels: the any-size kernel bins for itself)
     # The exchange step: one flat all-gather of the 192-byte pose records through the C ABI
     # (lins_pose_allgather -> ncclAllGather on the context's communication stream).  torch.distributed only carries the
     # RCCL unique id to the ranks and the two scalars of the timing reduction; shards are padded to the largest
@@ -453,7 +460,8 @@ def main():
             "config": {
                 "workload": f"configs[3]: batch of {args.batch} independent scan pairs per GPU, "
                             f"{args.iters} IESKF iterations each (fixed), 1 workgroup per scan, 2 scans resident per CU; "
-                            "inputs resident in HBM before the timed region (PCIe-inclusive rates: see e2e)",
+                            "inputs resident in HBM before the timed region (PCIe-inclusive rates: see e2e), the target clouds' search "
+                            "index built with them (see search_index)",
                 "scans_per_gpu": len(pairs),
                 "iters_per_scan": args.iters,
                 "search": args.search,
@@ -492,6 +500,21 @@ def main():
                 "bytes_per_iter_mean": bytes_iter_local / len(pairs),
             },
         }
+        # Where the search index is built.  The reference builds its kd-trees where it produces the target clouds
+        # (setInputCloud in updatePointCloud, SE:1156-1160), not in performIESKF (SE:465-600), and the cpu_baseline below
+        # times performIESKF on estimators whose kd-trees exist (oracle/ref_driver.cpp: "Rigs ... built outside the timed
+        # region").  The device path has the same split since the end of round 3: grid_index_kernel at lins_batch_upload,
+        # the timed step = lins_batch_run = the iterated update.  with_build_each_step adds the build's own kernel time to
+        # every step: the rate of a pipeline that searches each index once (and what rounds 1-3 timed, the build then
+        # being the update kernel's first phase).
+        if index_ms is not None:
+            step_ms = elapsed_max / args.steps * 1e3
+            out["search_index"] = {
+                "built_at": "lins_batch_upload (outside the timed region): the reference's kd-tree build is in updatePointCloud "
+                            "(SE:1156-1160), outside performIESKF, and outside the cpu_baseline's timed region too",
+                "kernel": "grid_index_kernel", "kernel_ms": index_ms,
+                "with_build_each_step": {"ms_per_step": step_ms + index_ms, "value": iters_all / ((step_ms + index_ms) * 1e-3),
+                                         "frac": alg_bytes / ((k_ms + index_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}}
         if not args.no_cpu and args.cpu_sample > 0 and world == 1:  # (the CPU leg: single-GPU runs only)
             out.update(cpu_leg(pkg, args, prm, pairs, res))
         if world == 1 and not args.no_extras:

@@ -162,7 +162,15 @@ int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in,
                             lins_result* out);
 
 /* --- staged (device-resident) form of the same call, for batches ---------- */
+/* Takes the batch into HBM and builds the SEARCH INDEX of every scan's target clouds (grid_index_kernel: both clouds
+ * counting-sorted into a (ring x azimuth-column) grid — a sorted copy + cell tables per scan) — the device counterpart
+ * of kdtreeCorner_/kdtreeSurf_->setInputCloud(), which the reference runs where it produces the clouds
+ * (updatePointCloud, SE:1156-1160; SE:363-364 for the first scan), not inside performIESKF.  Every later
+ * lins_batch_run / lins_icp_update_batch / correspondence pass on this upload searches that index.  The host-buffer
+ * entry points (lins_ieskf_update, lins_ieskf_update_batch) build it inside the call.                                 */
 int lins_batch_upload(lins_ctx* ctx, int n, const lins_scan_pair* in);
+/* HIP-event time (ms) of the index build of the last upload; 0 when the batch cannot take the grid kernels.          */
+int lins_last_index_ms(lins_ctx* ctx, float* ms);
 /* Runs the full IESKF loop for the uploaded batch on the context's stream.
  * d_poses: optional DEVICE pointer to n lins_pose_record (e.g. a torch tensor
  * that RCCL gathers afterwards); may be NULL. Asynchronous; lins_sync() waits. */

@@ -20,11 +20,11 @@
 namespace lins {
 
 #define LINS_LAUNCH(NS, B, LN, PR)                                                                                  \
-  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, false, PR>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, \
+  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, false, PR>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, tabs, \
                      state_in, cov_in, (const double*)nullptr, 0, state_out, a6, cov_out, (NS::OutRec*)out, idx_store, poses,  \
                      scan_id_base, (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof)
 #define LINS_LAUNCH_PASS(NS, B, LN)                                                                                    \
-  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, true, false>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, \
+  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, true, false>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, tabs, \
                      filt_state, (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr,           \
                      (double*)nullptr, (NS::OutRec*)nullptr, idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out,        \
                      (long long*)nullptr)
@@ -34,7 +34,7 @@ int lds_np_cap() { return lds_full::kNpMax; }
 static const int* const order = nullptr;  // (one workgroup per CU: nothing to order)
 
 void launch_lds(hipStream_t stream, int n, const DevParams& prm, int lanes, const ScanDesc* descs,
-                const float4* arena, float4* sorted, const double* state_in, const double* cov_in, double* state_out, double* a6,
+                const float4* arena, const float4* sorted, const GridTables* tabs, const double* state_in, const double* cov_in, double* state_out, double* a6,
                 double* cov_out, void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof) {
   if (lanes == 3) {
     if (prof)
@@ -50,7 +50,7 @@ void launch_lds(hipStream_t stream, int n, const DevParams& prm, int lanes, cons
 }
 
 void launch_lds_pass(hipStream_t stream, int n, const DevParams& prm, int lanes, const ScanDesc* descs,
-                     const float4* arena, float4* sorted, const double* lin_state, const double* filt_state, int iter,
+                     const float4* arena, const float4* sorted, const GridTables* tabs, const double* lin_state, const double* filt_state, int iter,
                      int4* idx_store, lins_corr* dump, double* sums_out, int* counts_out) {
   if (lanes == 3)
     LINS_LAUNCH_PASS(lds_full, 1024, 3);

@@ -16,10 +16,13 @@
 //                             (coop_map / coop_lanes below).
 //
 // One workgroup owns one scan pair for the whole iterated update.  Both target clouds of
-// the scan are counting-sorted ONCE into (ring x azimuth-column) grids of 16-byte records
-// (x, y, z, original index bits — one ds_read_b128 per candidate): after that single coalesced pass over the scan's ~125 KB in
-// HBM, every iteration's correspondence search is LDS traffic (mr: plus rare L2 reads) —
-// the candidate windows are staged in LDS, not re-gathered from L2.
+// the scan come counting-sorted into (ring x azimuth-column) grids of 16-byte records
+// (x, y, z, original index bits — one ds_read_b128 per candidate) — the scan's search index, built once per target
+// cloud by grid_index_kernel (ieskf_grid.h: the reference's kd-tree build, setInputCloud in updatePointCloud,
+// SE:1156-1160, is outside performIESKF too).  The kernel copies the index's tables and its first LINS_LDS_CAP
+// records into LDS in one coalesced pass; after that every iteration's correspondence search is LDS traffic
+// (positions beyond the cap: rare L2 reads of the sorted copy) — the candidate windows are staged in LDS, not
+// re-gathered from L2.
 //
 // The kernel is bound by instruction issue and latency (~60 % VALU-busy
 // with 31 of 64 lanes at work), not by HBM, so what round 2 did to it is mostly about the
@@ -56,6 +59,7 @@
 
 #include "ieskf_binned.h"
 #include "ieskf_device.h"
+#include "ieskf_grid.h"
 #include "icp_math.h"
 #include "icp_wave.h"
 #include "ieskf_rowsum.h"
@@ -66,10 +70,6 @@
 // 3 / 5 0.712, 2 / 3 0.760 — using fewer than all eight waves never pays.
 #define LINS_SPREAD_S 5  // (round 3, with LINS_COOP_COLD = 2: see there)
 #define LINS_SPREAD_C 3
-#endif
-#ifndef LINS_GRID_PF
-#define LINS_GRID_PF 8  // steps of the grid build whose point reads are in flight together, in the histogram pass (measured:
-                        // 1 -> 4: -0.9 %, 8: as 4) and in the scatter pass (its re-read of the points, L2 hits: -0.5 %)
 #endif
 
 namespace lins {
@@ -85,18 +85,11 @@ constexpr int kNpCap = LINS_LDS_CAP;   // grid positions (corner cloud first, th
 constexpr int kNpMax = LINS_LDS_NMAX;  // target points of an eligible scan
 constexpr bool kHybrid = kNpMax > kNpCap;  // positions >= kNpCap live in the sorted global copy
 constexpr int kScanBatch = LINS_LDS_SCANBATCH;  // points per trip of the scan loops
-constexpr int kCellsSurf = kRingsBinned * kAzSurf, kCellsCorner = kRingsBinned * kAzCorner;
-static_assert(kNpMax >= kNpCap && kNpMax <= 16384, "positions are u16, indices u16");
+static_assert(kNpMax >= kNpCap && kNpMax <= kGridNpMax, "positions are u16, indices u16; the index kernel's cap");
 
 struct LdsStore {
   float4 pt[kNpCap];  // grid-sorted targets, one 16-byte record (x, y, z, original index bits) per position
-  // exclusive end (absolute position) per cell, corner cells first; during the build the same
-  // words are the histogram / scatter counters (two u16 counters per 32-bit LDS atomic).  A union,
-  // and the library is built with -fno-strict-aliasing: the 16- and 32-bit views DO alias.
-  union {
-    unsigned short cell_end[kCellsCorner + kCellsSurf];
-    unsigned cell_word[(kCellsCorner + kCellsSurf) / 2];
-  };
+  GridTables gt;  // cell ends, ring ranges, elevation wedges: copied from the scan's prebuilt index (ieskf_grid.h)
   double P[324];
   // Series coefficients of the de-skew's axis2Quat (lins_math.h axis2quat_tab), read from here where they are used: as
   // literals the compiler keeps all eighteen in registers across the search loop (6 -> 42 spilled registers, +7 %);
@@ -108,10 +101,6 @@ struct LdsStore {
   double partial[kMaxLWaves * 28];  // one partial 28-vector per wave
   double aug[3][42];  // one staging copy of [N | z] per solving wave
   double res_prev, res_last, upd_norm;
-  float2 el_ang[2][kRingsBinned];    // elevation wedge of each ring as angles (lo - slack, hi + slack);
-                                     // an empty ring gets (+inf, -inf): never within reach
-  int el_bits[2][kRingsBinned][2];
-  int ring_start[2][kRingsBinned + 1];  // per cloud, in (original) index space
   int scan_tmp[kMaxLWaves + 4];
   int m_surf, m_corner, iter, conv, div, pad;
   long long prof_acc[16];  // phase profile accumulators of the PROF variant (written by thread 0)
@@ -259,19 +248,7 @@ __device__ __forceinline__ bool certified(float d_now, float lb, float drift) {
 }
 
 // ---- azimuth column of a point on the LDS grid ---------------------------------------------
-// The grid only has to be CONSISTENT: a point within angular distance D of a query must sit within the query's
-// window of +-K columns, K = reach().  With columns of width w and a column function floor(g(theta) / w) whose angle
-// g is off by at most eps, |g(p) - g(q)| <= D + 2 eps, so the two columns differ by at most floor((D + 2 eps) / w) + 1
-// <= floor(D / w) + 2 as long as 2 eps < w — which is what reach() adds (its "+ 2": one column for the query's offset
-// inside its own column, one for rounding).  The finest columns are 2 pi / 128 = 0.049 rad wide, so an angle good to
-// 4e-3 rad is enough: lins_atan2_coarse (a dozen instructions, lins_math.h) instead of atan2f (~45) for the 7 700
-// points of the build and for every query of every iteration.  Results cannot change: every pruning decision stays a
-// superset decision, and ties are resolved on explicit keys.
-static_assert((kAzSurf & (kAzSurf - 1)) == 0 && (kAzCorner & (kAzCorner - 1)) == 0, "column counts are powers of two");
-__device__ __forceinline__ int az_bin_lds(float x, float y, int naz) {
-  int a = (int)((lins_atan2_coarse(y, x) + kPiF) * ((float)naz * (0.5f / kPiF)));
-  return a < 0 ? 0 : (a >= naz ? naz - 1 : a);
-}
+// (az_bin_lds, the column function shared by the build and the queries: ieskf_grid.h)
 
 // ---- columns / windows on the LDS grid ----------------------------------------------------
 // All lanes of a wave run the SAME code on different (ring, column-range) data: every
@@ -617,172 +594,41 @@ __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, boo
   merge_query_lanes<LANES>(c3, lane_base, role, ln);
 }
 
-// ---- grid build: both clouds of the scan, once -----------------------------------------------
+// ---- grid load: the scan's prebuilt index (grid_index_kernel, ieskf_grid.hip — the reference's setInputCloud,
+// SE:1156-1160, outside performIESKF) into LDS: the tables and the first n_lds records of the sorted copy as 16-byte
+// words, every read of a thread in flight before its first LDS write (~1 HBM round trip per scan).  Ends with a
+// barrier.
+// Every move is unconditional on a CLAMPED index (the threads past the end re-copy the last word: same value to the
+// same address), so that nothing ties a read to a branch: written with guards, the compiler sinks each read into its
+// guard and waits for it there — nine dependent HBM round trips instead of one.
+// Out of line on purpose.  Inlined, every in-flight formulation of this copy (clamped or guarded stores, with and
+// without __restrict__, with and without the SLP vectoriser) changed what the 1024 x 3 PASS instantiation's corner
+// walk returns — every second point grid position 0 — while the plain guarded loops, and the same code with a store
+// added in front of the walk's lane merges, did not: a code-generation sensitivity of that instantiation that was not
+// traced to its root (ROCm 7.2 clang).  As a separate function nothing of it is scheduled into the kernel body; the
+// GPU suite (golden pairs, adversarial clouds, reference parity, every search mode) is the guard.
 template <int BLOCK>
-__device__ __forceinline__ void build_lds_grid(LdsStore& L, const ScanDesc& sd, const float4* __restrict__ arena,
-                                               float4* __restrict__ gsorted, int tid) {
-  constexpr int kLBlock = BLOCK;
-  // cell c's counter is the u16 half (c & 1) of word c >> 1 of cell_end: counts and positions stay
-  // below 2^16, so a half never carries into its neighbour
-  unsigned* cnt32 = L.cell_word;
-  constexpr int ncell = kCellsSurf + kCellsCorner;
-  static_assert(ncell % 2 == 0, "two counters per word");
-  for (int c = tid; c < ncell / 2; c += kLBlock) cnt32[c] = 0;
-  if (tid < 2 * kRingsBinned) {
-    L.el_bits[tid / kRingsBinned][tid % kRingsBinned][0] = 0x7FFFFFFF;
-    L.el_bits[tid / kRingsBinned][tid % kRingsBinned][1] = (int)0x80000000;
-  }
-  __syncthreads();
-  const float4* ts = arena + sd.off_surf_t;
-  const float4* tc = arena + sd.off_corner_t;
-  const int n_all = sd.n_surf_t + sd.n_corner_t;
-  // Ownership: wave w owns the points [w * 64 P, (w + 1) * 64 P), P = ceil(n_all / BLOCK), lane l of it the points
-  // w * 64 P + 64 k + l — a wave's loads are as coalesced as with the strided ownership (tid + k * BLOCK) of round 1,
-  // but its consecutive steps are consecutive 64-point runs of the ring-sorted cloud, so the (cloud, ring) key of a
-  // step changes every ~7 steps instead of every step: see the elevation wedge below.  The cell of each point is
-  // kept in a register between the histogram pass and the scatter pass (no second atan2f, no second classification).
-  constexpr int kPerThread = (kNpMax + BLOCK - 1) / BLOCK;
-  const int per_lane = (n_all + kLBlock - 1) / kLBlock;
-  const int lane = tid & 63, j_first = (tid >> 6) * 64 * per_lane + lane;
-  int cell_of[kPerThread];
-  // Elevation wedge of a ring (min / max of z / rho over its points; atan is monotone, so the wedge is the atan of the
-  // extreme ratios — two atanf per ring at the end instead of an atan2f per point).  The 64 points of a wave's step
-  // nearly always lie on one ring of one cloud, and so do the steps before and after: every lane folds its points of
-  // the current RUN of equal keys into two registers, and only when the key changes (or at the end) does the wave
-  // fold the 64 partial results (six cross-lane steps) and ONE lane update LDS.  Round 1 issued 64 same-address
-  // atomics per step (processed one after the other, holding up the LDS pipeline for the co-resident workgroup as
-  // well); the first round-2 version folded the wave at every step: ~70 instructions per point for two numbers per ring.
-  int run_key = -1, run_lo = 0x7FFFFFFF, run_hi = (int)0x80000000;
-  auto flush_run = [&]() {
-    if (run_key >= 0) {  // (wave-uniform)
-      int lo = run_lo, hi = run_hi;
-      lo = min(lo, xor_lane_i32<1>(lo, lane)), hi = max(hi, xor_lane_i32<1>(hi, lane));
-      lo = min(lo, xor_lane_i32<2>(lo, lane)), hi = max(hi, xor_lane_i32<2>(hi, lane));
-      lo = min(lo, xor_lane_i32<4>(lo, lane)), hi = max(hi, xor_lane_i32<4>(hi, lane));
-      lo = min(lo, xor_lane_i32<8>(lo, lane)), hi = max(hi, xor_lane_i32<8>(hi, lane));
-      lo = min(lo, xor_lane_i32<16>(lo, lane)), hi = max(hi, xor_lane_i32<16>(hi, lane));
-      lo = min(lo, xor_lane_i32<32>(lo, lane)), hi = max(hi, xor_lane_i32<32>(hi, lane));
-      if (lane == 0) {
-        atomicMin(&L.el_bits[run_key / kRingsBinned][run_key % kRingsBinned][0], lo);
-        atomicMax(&L.el_bits[run_key / kRingsBinned][run_key % kRingsBinned][1], hi);
-      }
-    }
-    run_lo = 0x7FFFFFFF, run_hi = (int)0x80000000;
-  };
-  // The point reads of LINS_GRID_PF consecutive steps are issued together (clamped addresses, no branch in between):
-  // a wave pays the HBM latency once per chunk instead of once per step.
-  constexpr int kChunk = LINS_GRID_PF;
+__device__ __noinline__ void load_lds_grid(const GridTables* __restrict__ tab, const float4* __restrict__ gs, int n_lds, int tid) {
+  LdsStore& L = g_lds;
+  constexpr int kTabPer = (kGridTableWords + BLOCK - 1) / BLOCK, kPtPer = (kNpCap + BLOCK - 1) / BLOCK;
+  constexpr int kChunk = kPtPer < 12 ? kPtPer : 12;
+  const uint4* src = reinterpret_cast<const uint4*>(tab);
+  uint4* dst = reinterpret_cast<uint4*>(&L.gt);
+  uint4 tw[kTabPer];
 #pragma unroll
-  for (int k0 = 0; k0 < kPerThread; k0 += kChunk) {
-    float4 pbuf[kChunk];
-    if (k0 < per_lane) {  // (wave-uniform)
+  for (int u = 0; u < kTabPer; ++u) tw[u] = src[min(tid + u * BLOCK, kGridTableWords - 1)];
+  if (n_lds > 0) {  // (uniform)
 #pragma unroll
-      for (int u = 0; u < kChunk; ++u) {
-        const int j = j_first + (k0 + u) * 64, jc = j < n_all ? j : n_all - 1;
-        pbuf[u] = jc < sd.n_surf_t ? ts[jc] : tc[jc - sd.n_surf_t];
-      }
-    }
+    for (int k0 = 0; k0 < kPtPer; k0 += kChunk) {
+      float4 pbuf[kChunk];
 #pragma unroll
-    for (int u = 0; u < kChunk; ++u) {
-      const int k = k0 + u;
-      if (k >= kPerThread) break;
-      const int j = j_first + k * 64;
-      cell_of[k] = -1;
-      if (k < per_lane) {  // (wave-uniform)
-        int eb = 0, ek = -1;  // elevation bits, (cloud, ring) key of this lane's point
-        if (j < n_all) {
-          const bool is_s = j < sd.n_surf_t;
-          const float4 p = pbuf[u];
-          const int r = ring_of(p.w), naz = is_s ? kAzSurf : kAzCorner;
-          const int cell = (is_s ? kCellsCorner : 0) + r * naz + az_bin_lds(p.x, p.y, naz);
-          cell_of[k] = cell;
-          atomicAdd(&cnt32[cell >> 1], 1u << ((cell & 1) * 16));
-          // z / rho through the hardware's reciprocal square root (1 ulp): the ratio is off by < 2^-22 relative, the
-          // elevation by < 1.2e-7 rad — two orders below kSlack.  rho = 0: +-inf / 0 (atanf gives +-pi/2 / 0); a
-          // ratio that overflows to +-inf widens the wedge, never narrows it.
-          const float rho2 = p.x * p.x + p.y * p.y;
-          eb = ordered_int(rho2 > 0.f ? p.z * __frsqrt_rn(rho2) : (p.z > 0.f ? INFINITY : (p.z < 0.f ? -INFINITY : 0.f)));
-          ek = (is_s ? 0 : kRingsBinned) + r;
-        }
-        const unsigned long long have = __ballot(ek >= 0);
-        if (have) {  // (wave-uniform)
-          const int ek0 = __builtin_amdgcn_readlane(ek, __ffsll((long long)have) - 1);
-          if (__all(ek == ek0 || ek < 0)) {
-            if (ek0 != run_key) {
-              flush_run();
-              run_key = ek0;
-            }
-            if (ek >= 0) run_lo = min(run_lo, eb), run_hi = max(run_hi, eb);
-          } else {  // a step that straddles rings: its lanes update LDS themselves
-            flush_run();
-            run_key = -1;
-            if (ek >= 0) {
-              atomicMin(&L.el_bits[ek / kRingsBinned][ek % kRingsBinned][0], eb);
-              atomicMax(&L.el_bits[ek / kRingsBinned][ek % kRingsBinned][1], eb);
-            }
-          }
-        }
-      }
+      for (int u = 0; u < kChunk; ++u) pbuf[u] = gs[min(tid + (k0 + u) * BLOCK, n_lds - 1)];
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) L.pt[min(tid + (k0 + u) * BLOCK, n_lds - 1)] = pbuf[u];
     }
   }
-  flush_run();
-  __syncthreads();
-  // exclusive scan over all cells: corner cells first, so surf positions start at n_corner_t
-  constexpr int per = (ncell + kLBlock - 1) / kLBlock;
-  const int c_lo = tid * per < ncell ? tid * per : ncell;
-  const int c_hi = c_lo + per < ncell ? c_lo + per : ncell;
-  int local = 0;
-  for (int c = c_lo; c < c_hi; ++c) local += (int)L.cell_end[c];
-  int run = block_exclusive_scan(local, tid, L.scan_tmp);
-  for (int c = c_lo; c < c_hi; ++c) {
-    int n = (int)L.cell_end[c];
-    L.cell_end[c] = (unsigned short)run;  // (16-bit stores: neighbours in the same word are not touched)
-    run += n;
-  }
-  __syncthreads();
-  // (the second read of the points — L2 hits — chunked like the first: one round trip per chunk, not per step)
 #pragma unroll
-  for (int k0 = 0; k0 < kPerThread; k0 += kChunk) {
-    float4 pbuf[kChunk];
-    if (k0 < per_lane) {  // (wave-uniform)
-#pragma unroll
-      for (int u = 0; u < kChunk; ++u) {
-        const int j = j_first + (k0 + u) * 64, jc = j < n_all ? j : n_all - 1;
-        pbuf[u] = jc < sd.n_surf_t ? ts[jc] : tc[jc - sd.n_surf_t];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kChunk; ++u) {
-      const int k = k0 + u;
-      if (k >= kPerThread) break;
-      const int j = j_first + k * 64;
-      if (cell_of[k] >= 0) {
-        const bool is_s = j < sd.n_surf_t;
-        const int jj = is_s ? j : j - sd.n_surf_t;
-        const float4 p = pbuf[u];
-        const int cell = cell_of[k], sh = (cell & 1) * 16;
-        // order inside a cell is irrelevant (keyed ties)
-        const int pos = (int)((atomicAdd(&cnt32[cell >> 1], 1u << sh) >> sh) & 0xFFFFu);
-        if (!kHybrid || pos < kNpCap) {
-          L.pt[pos] = make_float4(p.x, p.y, p.z, __int_as_float(jj));
-        } else {
-          gsorted[pos] = make_float4(p.x, p.y, p.z, __int_as_float(jj));
-        }
-      }
-    }
-  }
-  __syncthreads();  // cell_end[c] is now the exclusive END of cell c
-  if (tid <= kRingsBinned) {
-    L.ring_start[1][tid] = tid == 0 ? 0 : (int)L.cell_end[tid * kAzCorner - 1];
-    L.ring_start[0][tid] = (int)L.cell_end[kCellsCorner + tid * kAzSurf - 1] - sd.n_corner_t;
-  }
-  if (tid < 2 * kRingsBinned) {
-    int cl = tid / kRingsBinned, r = tid % kRingsBinned;
-    // (atanf of the ratio vs the queries' atan2f(z, rho): a few ulp of an angle below 0.3 rad, ~1e-7 — inside kSlack)
-    float lo = atanf(ordered_float(L.el_bits[cl][r][0])) - kSlack, hi = atanf(ordered_float(L.el_bits[cl][r][1])) + kSlack;
-    const bool empty = L.el_bits[cl][r][0] == 0x7FFFFFFF;  // no point touched the ring's min/max
-    L.el_ang[cl][r] = empty ? make_float2(INFINITY, -INFINITY) : make_float2(lo, hi);
-  }
+  for (int u = 0; u < kTabPer; ++u) dst[min(tid + u * BLOCK, kGridTableWords - 1)] = tw[u];
   __syncthreads();
 }
 
@@ -1091,7 +937,7 @@ __global__ __launch_bounds__(BLOCK, LINS_LDS_MINW) void ieskf_lds_kernel(
 __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #endif
     DevParams prm, const ScanDesc* __restrict__ descs, const int* __restrict__ order, const float4* __restrict__ arena,
-    float4* __restrict__ sorted,
+    const float4* __restrict__ sorted, const GridTables* __restrict__ tabs,
     const double* __restrict__ state_in, const double* __restrict__ cov_in, const double* __restrict__ lin_in,
     int iter_arg, double* __restrict__ state_out, double* __restrict__ a6_out, double* __restrict__ cov_out,
     OutRec* __restrict__ out,
@@ -1118,7 +964,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   const int total = sd.n_surf_q + sd.n_corner_q;
   // hybrid storage: this scan's slice of the sorted copy (same offsets as its targets in the arena:
   // the corner targets follow the surf targets, so positions 0 .. n_all-1 fit)
-  float4* const gs = kHybrid ? sorted + sd.off_surf_t : nullptr;
+  const float4* const gs = sorted + sd.off_surf_t;
   const int n_all_t = sd.n_surf_t + sd.n_corner_t, n_lds = n_all_t < kNpCap ? n_all_t : kNpCap;
 
   for (int k = tid; k < 324; k += kLBlock) L.P[k] = (PASS_ONLY || ICP) ? 0.0 : cov_in[(size_t)scan * 324 + k];
@@ -1145,12 +991,12 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       for (int k = 0; k < 18; ++k) L.ic.d[k] = ic.d[k];
     }
   }
-  build_lds_grid<BLOCK>(L, sd, arena, gs, tid);  // ends with a barrier
+  load_lds_grid<BLOCK>(tabs + scan, gs, n_lds, tid);  // ends with a barrier
   if (prof && tid == 0) L.prof_acc[0] = clock64() - t_begin;
 
-  const LCloud cs{L.cell_end + kCellsCorner, L.ring_start[0], &L.el_ang[0][0], kAzSurf, 1, sd.n_corner_t, sd.n_surf_t,
+  const LCloud cs{L.gt.cell_end + kCellsCorner, L.gt.ring_start[0], &L.gt.el_ang[0][0], kAzSurf, 1, sd.n_corner_t, sd.n_surf_t,
                   gs, n_lds};
-  const LCloud cc{L.cell_end, L.ring_start[1], &L.el_ang[1][0], kAzCorner, kAzSurf / kAzCorner, 0, sd.n_corner_t,
+  const LCloud cc{L.gt.cell_end, L.gt.ring_start[1], &L.gt.el_ang[1][0], kAzCorner, kAzSurf / kAzCorner, 0, sd.n_corner_t,
                   gs, n_lds};
   const int role = lane % LANES, lane_base = lane - role, q_in_wave = lane / LANES;
   const bool lane_used = lane < kQPerWave * LANES;

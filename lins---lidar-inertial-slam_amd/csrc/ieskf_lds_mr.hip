@@ -41,11 +41,11 @@
 namespace lins {
 
 #define LINS_LAUNCH(NS, B, LN, PR)                                                                                  \
-  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, false, PR>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, \
+  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, false, PR>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, tabs, \
                      state_in, cov_in, (const double*)nullptr, 0, state_out, a6, cov_out, (NS::OutRec*)out, idx_store, poses,  \
                      scan_id_base, (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof)
 #define LINS_LAUNCH_PASS(NS, B, LN)                                                                                    \
-  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, true, false>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, \
+  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, true, false>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, tabs, \
                      filt_state, (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr,           \
                      (double*)nullptr, (NS::OutRec*)nullptr, idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out,        \
                      (long long*)nullptr)
@@ -53,7 +53,7 @@ namespace lins {
 int lds_mr_np_cap() { return lds_mr::kNpMax; }
 
 void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const int* order, const float4* arena,
-                   float4* sorted, const double* state_in, const double* cov_in, double* state_out, double* a6,
+                   const float4* sorted, const GridTables* tabs, const double* state_in, const double* cov_in, double* state_out, double* a6,
                    double* cov_out, void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof) {
   if (prof)
     LINS_LAUNCH(lds_mr, LINS_MR_BLOCK, 1, true);
@@ -64,15 +64,15 @@ void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDe
 // ICP / Gauss-Newton fallback (estimateTransform, SE:1163-1320) on the same grid and searches:
 // state_in = the pose to start from (the filter's), state_out = that state with rn_, qbn_ replaced
 void launch_lds_mr_icp(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
-                       float4* sorted, const double* state_in, double* state_out, void* out, int4* idx_store) {
+                       const float4* sorted, const GridTables* tabs, const double* state_in, double* state_out, void* out, int4* idx_store) {
   hipLaunchKernelGGL((lds_mr::ieskf_lds_kernel<512, 1, false, false, true>), dim3(n), dim3(512), 0, stream, prm, descs,
-                     (const int*)nullptr, arena, sorted, state_in, state_in /*unused: no covariance on this path*/, (const double*)nullptr, 0,
+                     (const int*)nullptr, arena, sorted, tabs, state_in, state_in /*unused: no covariance on this path*/, (const double*)nullptr, 0,
                      state_out, (double*)nullptr, (double*)nullptr, (lds_mr::OutRec*)out, idx_store, (lins_pose_record*)nullptr, 0,
                      (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, (long long*)nullptr);
 }
 
 void launch_lds_mr_pass(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
-                        float4* sorted, const double* lin_state, const double* filt_state, int iter,
+                        const float4* sorted, const GridTables* tabs, const double* lin_state, const double* filt_state, int iter,
                         int4* idx_store, lins_corr* dump, double* sums_out, int* counts_out) {
   const int* order = nullptr;
   LINS_LAUNCH_PASS(lds_mr, 512, 1);

@@ -25,6 +25,7 @@
 
 #include "../../include/lins_host.h"
 #include "ieskf_device.h"
+#include "ieskf_grid.h"
 #include "lins_ctx_priv.h"
 
 namespace lins {
@@ -33,14 +34,14 @@ void launch_persistent(hipStream_t, int, const DevParams&, const ScanDesc*, cons
 void launch_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const double*, const double*,
                  int, int4*, lins_corr*, double*, int*, float4*);
 void launch_joseph(hipStream_t, int, const DevParams&, const double*, const double*, const void*, double*);
-void launch_lds(hipStream_t, int, const DevParams&, int, const ScanDesc*, const float4*, float4*, const double*, const double*,
+void launch_lds(hipStream_t, int, const DevParams&, int, const ScanDesc*, const float4*, const float4*, const GridTables*, const double*, const double*,
                 double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*);
-void launch_lds_pass(hipStream_t, int, const DevParams&, int, const ScanDesc*, const float4*, float4*, const double*,
+void launch_lds_pass(hipStream_t, int, const DevParams&, int, const ScanDesc*, const float4*, const float4*, const GridTables*, const double*,
                      const double*, int, int4*, lins_corr*, double*, int*);
 int lds_np_cap();
-void launch_lds_mr(hipStream_t, int, const DevParams&, const ScanDesc*, const int*, const float4*, float4*, const double*,
+void launch_lds_mr(hipStream_t, int, const DevParams&, const ScanDesc*, const int*, const float4*, const float4*, const GridTables*, const double*,
                    const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*);
-void launch_lds_mr_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, float4*, const double*,
+void launch_lds_mr_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const float4*, const GridTables*, const double*,
                         const double*, int, int4*, lins_corr*, double*, int*);
 int lds_mr_np_cap();
 void launch_debug_math(hipStream_t, int, int, int, int, const double*, double*);
@@ -48,7 +49,7 @@ void launch_debug_cycles(hipStream_t, int, int, const double*, double*);
 void launch_debug_wave_solve(hipStream_t, int, int, const double*, double*);
 void launch_debug_icp_gn(hipStream_t, int, int, const double*, double*);
 void launch_debug_reduce_rows(hipStream_t, int, int, const double*, double*);
-void launch_lds_mr_icp(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, float4*, const double*, double*,
+void launch_lds_mr_icp(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const float4*, const GridTables*, const double*, double*,
                        void*, int4*);
 void launch_transform_to_end(hipStream_t, int, int, const void*, const float4*, float4*, float4*);
 size_t reproject_job_size();
@@ -112,7 +113,13 @@ struct lins_ctx {
   OutRecHost* h_out = nullptr;
   // device
   float4* d_arena = nullptr;
-  float4* d_binned = nullptr;  // (ring x column)-sorted copies of the target clouds
+  float4* d_binned = nullptr;  // (ring x column)-sorted copies of the target clouds (any-size kernel), re-projection output
+  // search index of the uploaded target clouds (ieskf_grid.h: grid-sorted copy + tables per scan), built by
+  // grid_index_kernel where the clouds arrive — the reference's setInputCloud (SE:1156-1160)
+  float4* d_gsorted = nullptr;
+  GridTables* d_gridtab = nullptr;
+  hipEvent_t ev_idx0 = nullptr, ev_idx1 = nullptr;
+  bool idx_timed = false;
   ScanDesc* d_desc = nullptr;
   bool use_order = true;  // (LINS_LAUNCH_ORDER=0 with the debug gate: index order, for A/B timing)
   int *h_order = nullptr, *d_order = nullptr;  // launch order of the uploaded batch (longest-expected-first), see launch_order()
@@ -152,7 +159,8 @@ struct lins_ctx {
   // scan's clouds) inside one arena, so that ScanDesc offsets address both
   struct Streams {
     int n = 0, cur = 0;           // slot the NEXT scan's features go to
-    float4 *d_arena = nullptr, *d_sorted = nullptr;
+    float4 *d_arena = nullptr, *d_sorted = nullptr, *d_gsorted = nullptr;
+    GridTables* d_gridtab = nullptr;
     ScanDesc* d_desc = nullptr;
     void* d_jobs = nullptr;
     std::vector<int> last_counts;  // per stream: less sharp, less flat of the resident last scan (-1: none yet)
@@ -318,6 +326,7 @@ int effective_search(const lins_ctx* ctx, int n) {
 void streams_free(lins_ctx* ctx) {
   auto& t = ctx->st;
   (void)hipFree(t.d_arena), (void)hipFree(t.d_sorted), (void)hipFree(t.d_desc), (void)hipFree(t.d_jobs);
+  (void)hipFree(t.d_gsorted), (void)hipFree(t.d_gridtab);
   t = lins_ctx::Streams{};
 }
 
@@ -481,6 +490,15 @@ RangeFlags range_flags(const lins_ctx* ctx, int lo, int hi) {
   return fl;
 }
 
+// search index of scans [lo, lo + cnt) of the uploaded descriptors, on the context's stream (grid kernels only: scans
+// that cannot take them run the any-size kernel, which bins for itself)
+int build_index_range(lins_ctx* ctx, int lo, int cnt, const RangeFlags& fl) {
+  if (cnt <= 0 || !(fl.lds_ok || fl.mr_ok)) return LINS_OK;
+  launch_grid_index(ctx->stream, cnt, ctx->d_desc + lo, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo);
+  HIP_TRY(ctx, hipGetLastError());
+  return LINS_OK;
+}
+
 // host -> device of scans [lo, hi) (their arena slice is contiguous), asynchronous on `st`
 int h2d_range(lins_ctx* ctx, int lo, int hi, size_t arena_end, hipStream_t st) {
   if (hi <= lo) return LINS_OK;
@@ -534,6 +552,12 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
   if ((rc = parallel_scans(n, [&](int s) { return pack_one(ctx, in, s); }))) return rc;
   const RangeFlags fl = range_flags(ctx, 0, n);
   if ((rc = h2d_range(ctx, 0, n, off, ctx->stream))) return rc;
+  // the target clouds have arrived: their search index (the reference builds its kd-trees where it produces the
+  // clouds, SE:1156-1160, not in performIESKF)
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_idx0, ctx->stream));
+  if ((rc = build_index_range(ctx, 0, n, fl))) return rc;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_idx1, ctx->stream));
+  ctx->idx_timed = true;
   launch_order(ctx, n);
   if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->h_order, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -558,10 +582,10 @@ int run_range(lins_ctx* ctx, int lo, int cnt, int n_total, const RangeFlags& fl,
   lins_pose_record* ps = poses ? poses + lo : nullptr;
   if (use_mr || use_lds) {
     if (use_mr)
-      launch_lds_mr(ctx->stream, cnt, ctx->dprm, desc, nullptr, ctx->d_arena, ctx->d_binned, st_in, cov_in, st_out, a6, cov_out, out, ctx->d_idx, ps,
+      launch_lds_mr(ctx->stream, cnt, ctx->dprm, desc, nullptr, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out, ctx->d_idx, ps,
                     scan_id_base + lo, nullptr);
     else
-      launch_lds(ctx->stream, cnt, ctx->dprm, s == SEARCH_LDS3 ? 3 : 1, desc, ctx->d_arena, ctx->d_binned, st_in, cov_in, st_out, a6, cov_out, out,
+      launch_lds(ctx->stream, cnt, ctx->dprm, s == SEARCH_LDS3 ? 3 : 1, desc, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out,
                  ctx->d_idx, ps, scan_id_base + lo, nullptr);  // (the Joseph update is the kernels' epilogue)
   } else {
     DevParams dp = ctx->dprm;
@@ -647,6 +671,10 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_out, nb * sizeof(OutRecHost)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_arena, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_binned, ctx->arena_cap * sizeof(float4)));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_gsorted, ctx->arena_cap * sizeof(float4)));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_gridtab, (size_t)ctx->max_batch * sizeof(GridTables)));
+  CREATE_TRY(hipEventCreate(&ctx->ev_idx0));
+  CREATE_TRY(hipEventCreate(&ctx->ev_idx1));
   CREATE_TRY(hipMalloc((void**)&ctx->d_desc, nb * sizeof(ScanDesc)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_state_in, nb * 19 * 8));
   CREATE_TRY(hipMalloc((void**)&ctx->d_cov_in, nb * 324 * 8));
@@ -677,6 +705,10 @@ void lins_destroy(lins_ctx* ctx) {
   (void)hipHostFree(ctx->h_out);
   (void)hipFree(ctx->d_arena);
   (void)hipFree(ctx->d_binned);
+  (void)hipFree(ctx->d_gsorted);
+  (void)hipFree(ctx->d_gridtab);
+  if (ctx->ev_idx0) (void)hipEventDestroy(ctx->ev_idx0);
+  if (ctx->ev_idx1) (void)hipEventDestroy(ctx->ev_idx1);
   (void)hipFree(ctx->d_desc);
   (void)hipFree(ctx->d_state_in);
   (void)hipFree(ctx->d_cov_in);
@@ -745,6 +777,18 @@ const char* lins_last_search(const lins_ctx* ctx) {
 
 int lins_batch_upload(lins_ctx* ctx, int n, const lins_scan_pair* in) { return upload(ctx, n, in); }
 
+/* HIP-event time (ms) of the search-index build of the last upload (grid_index_kernel over every scan of the batch:
+ * the device counterpart of the reference's kd-tree build, setInputCloud in updatePointCloud, SE:1156-1160); 0 when
+ * the batch cannot take the grid kernels (nothing was built).                                                       */
+int lins_last_index_ms(lins_ctx* ctx, float* ms) {
+  if (!ctx || !ms) return LINS_E_ARG;
+  *ms = 0.f;
+  if (!ctx->idx_timed) return LINS_E_STATE;
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev_idx1));
+  HIP_TRY(ctx, hipEventElapsedTime(ms, ctx->ev_idx0, ctx->ev_idx1));
+  return LINS_OK;
+}
+
 int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   if (!ctx) return LINS_E_ARG;
   if (ctx->n_uploaded <= 0) return LINS_E_STATE;
@@ -765,12 +809,12 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   ctx->last_search = use_mr ? (int)SEARCH_MR : (use_lds ? search : (want_lds ? (int)SEARCH_BINNED : search));
   if (use_mr || use_lds) {
     if (use_mr)
-      launch_lds_mr(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->use_order ? ctx->d_order : nullptr, ctx->d_arena, ctx->d_binned, ctx->d_state_in,
+      launch_lds_mr(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->use_order ? ctx->d_order : nullptr, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in,
                     ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx, (lins_pose_record*)d_poses,
                     scan_id_base, ctx->d_prof);
     else
       launch_lds(ctx->stream, ctx->n_uploaded, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc,
-                 ctx->d_arena, ctx->d_binned, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx,
+                 ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx,
                  (lins_pose_record*)d_poses, scan_id_base, ctx->d_prof);
     HIP_TRY(ctx, hipEventRecord(ctx->hist1[h], ctx->stream));
     if (q.on) HIP_TRY(ctx, hipEventRecord(q.ev_main[set], ctx->stream));  // (the pose records of this run are complete)
@@ -1305,6 +1349,8 @@ int lins_streams_init(lins_ctx* ctx, int n_streams) {
   if (pts >= (1ull << 31)) return LINS_E_CAPACITY;  // ScanDesc offsets are ints
   HIP_TRY(ctx, hipMalloc((void**)&t.d_arena, pts * sizeof(float4)));
   HIP_TRY(ctx, hipMalloc((void**)&t.d_sorted, pts * sizeof(float4)));
+  HIP_TRY(ctx, hipMalloc((void**)&t.d_gsorted, pts * sizeof(float4)));
+  HIP_TRY(ctx, hipMalloc((void**)&t.d_gridtab, (size_t)n_streams * sizeof(GridTables)));
   HIP_TRY(ctx, hipMalloc((void**)&t.d_desc, (size_t)n_streams * sizeof(ScanDesc)));
   HIP_TRY(ctx, hipMalloc(&t.d_jobs, (size_t)n_streams * 2 * sizeof(StreamCloudHost)));
   t.n = n_streams, t.cur = 0;
@@ -1401,16 +1447,20 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_state_in, ctx->h_state, (size_t)n * 19 * 8, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_cov_in, ctx->h_cov, (size_t)n * 324 * 8, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  bool idx_ready = false;
   {
     const int search = effective_search(ctx, n);
     const bool want_lds = search >= SEARCH_LDS, want_mr = search == SEARCH_MR;
     const bool use_mr = want_mr && mr_ok, use_lds = want_lds && !want_mr && lds_ok;
     if (use_mr || use_lds) {
+      idx_ready = true;
+      // the search index of the last scan's clouds (they were re-projected in place at the end of the previous step)
+      launch_grid_index(ctx->stream, n, t.d_desc, t.d_arena, t.d_gsorted, t.d_gridtab);
       if (use_mr)
-        launch_lds_mr(ctx->stream, n, ctx->dprm, t.d_desc, nullptr, t.d_arena, t.d_sorted, ctx->d_state_in, ctx->d_cov_in,
+        launch_lds_mr(ctx->stream, n, ctx->dprm, t.d_desc, nullptr, t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in, ctx->d_cov_in,
                       ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr);
       else
-        launch_lds(ctx->stream, n, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, t.d_desc, t.d_arena, t.d_sorted, ctx->d_state_in,
+        launch_lds(ctx->stream, n, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, t.d_desc, t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in,
                    ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr);
     } else {
       DevParams dp = ctx->dprm;
@@ -1453,7 +1503,11 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
       out[k].reserved[0] = LINS_E_UNSUPPORTED;
       continue;
     }
-    launch_lds_mr_icp(ctx->stream, 1, ctx->dprm, t.d_desc + k, t.d_arena, t.d_sorted, ctx->d_state_in + (size_t)k * 19,
+    if (!idx_ready) {  // (the update ran on the any-size kernel: no index yet)
+      launch_grid_index(ctx->stream, n, t.d_desc, t.d_arena, t.d_gsorted, t.d_gridtab);
+      idx_ready = true;
+    }
+    launch_lds_mr_icp(ctx->stream, 1, ctx->dprm, t.d_desc + k, t.d_arena, t.d_gsorted, t.d_gridtab + k, ctx->d_state_in + (size_t)k * 19,
                       ctx->d_state_out + (size_t)k * 19, (char*)ctx->d_out + (size_t)k * sizeof(OutRecHost), ctx->d_idx);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(out[k].state, ctx->d_state_out + (size_t)k * 19, 19 * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1693,6 +1747,7 @@ int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins
         if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_copy, 0);
         if (e == hipSuccess && lo == 0) e = hipEventRecord(ctx->hist0[ctx->hist_n % lins_ctx::kHist], ctx->stream);
         if (e != hipSuccess) return fail_hip(ctx, e, "chunk hand-over (event record / stream wait)");
+        if ((r = build_index_range(ctx, lo, hi - lo, fl))) return r;
         if ((r = run_range(ctx, lo, hi - lo, n, fl, nullptr, 0))) return r;
         all.lds_ok = all.lds_ok && fl.lds_ok, all.mr_ok = all.mr_ok && fl.mr_ok, all.lds3_ok = all.lds3_ok && fl.lds3_ok;
         return 0;
@@ -1738,7 +1793,7 @@ int lins_icp_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins_r
       if (in[s].n_surf_flat + in[s].n_corner_sharp > 512) return LINS_E_UNSUPPORTED;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_idx, 0xFF, ctx->slot_cap * sizeof(int4), ctx->stream));
   }
-  launch_lds_mr_icp(ctx->stream, n, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_binned, ctx->d_state_in,
+  launch_lds_mr_icp(ctx->stream, n, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in,
                     ctx->d_state_out, ctx->d_out, ctx->d_idx);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state_out, (size_t)n * 19 * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1768,11 +1823,11 @@ static int run_pass(lins_ctx* ctx, const lins_scan_pair* in, const double* lin_s
   const int search = effective_search(ctx, 1);
   const bool want_lds = search >= SEARCH_LDS, want_mr = search == SEARCH_MR;
   if (want_mr && ctx->mr_ok) {
-    launch_lds_mr_pass(ctx->stream, 1, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_binned, ctx->d_lin,
+    launch_lds_mr_pass(ctx->stream, 1, ctx->dprm, ctx->d_desc, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_lin,
                        ctx->d_state_in, iter, ctx->d_idx, dump ? ctx->d_dump : nullptr, sums ? ctx->d_sums : nullptr,
                        sums ? ctx->d_counts : nullptr);
   } else if (want_lds && !want_mr && ctx->lds_ok) {
-    launch_lds_pass(ctx->stream, 1, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc, ctx->d_arena, ctx->d_binned, ctx->d_lin, ctx->d_state_in, iter,
+    launch_lds_pass(ctx->stream, 1, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_lin, ctx->d_state_in, iter,
                     ctx->d_idx, dump ? ctx->d_dump : nullptr, sums ? ctx->d_sums : nullptr,
                     sums ? ctx->d_counts : nullptr);
   } else {

@@ -24,7 +24,7 @@ EXPORTS = [
     "lins_streams_init", "lins_streams_step", "lins_streams_stats", "lins_streams_peek", "lins_segment_batch",
     "lins_last_segment_ms", "lins_streams_step_raw", "lins_map_correspondences", "lins_scan2map_batch",
     "lins_last_map_stats", "lins_last_search", "lins_kernel_ms_history", "lins_set_pipelined",
-    "lins_rccl_unique_id", "lins_rccl_init", "lins_pose_allgather", "lins_rccl_destroy",
+    "lins_rccl_unique_id", "lins_rccl_init", "lins_pose_allgather", "lins_rccl_destroy", "lins_last_index_ms",
 ]
 
 
@@ -67,6 +67,7 @@ def lib():
         L.lins_batch_download.argtypes = [vp, C.c_int, C.POINTER(ResultC)]
         L.lins_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.lins_kernel_ms_history.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+        L.lins_last_index_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.lins_set_pipelined.argtypes = [vp, C.c_int]
         L.lins_rccl_unique_id.argtypes = [vp, C.c_void_p]
         L.lins_rccl_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
@@ -346,6 +347,12 @@ class IeskfContext:
     def last_kernel_ms(self):
         ms = C.c_float(0)
         self._check(lib().lins_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def last_index_ms(self):
+        """HIP-event time (ms) of the search-index build of the last upload (the reference's kd-tree build, SE:1156-1160)."""
+        ms = C.c_float(0)
+        self._check(lib().lins_last_index_ms(self._h, C.byref(ms)))
         return ms.value
 
     def kernel_ms_history(self, n):

@@ -203,6 +203,35 @@ def test_launch_order_does_not_change_a_bit(pkg, ieskf, host, monkeypatch):
         assert (a.iters, a.converged, a.diverged, a.m_surf, a.m_corner) == (b.iters, b.converged, b.diverged, b.m_surf, b.m_corner)
 
 
+def test_search_index_of_an_upload_serves_every_later_run(pkg, ieskf, host):
+    """The search index of the target clouds is built ONCE, at lins_batch_upload (grid_index_kernel — the reference
+    builds its kd-trees in updatePointCloud, SE:1156-1160, not in performIESKF): repeated runs, runs after the kernel
+    family was switched (the any-size kernel bins into its own buffer) and a correspondence pass in between all
+    search the same index and return the first run's bits; the build is timed by its own events."""
+    prm = pkg.default_params(num_iter=10, fixed_iters=1)
+    batch = host.synth_batch(40, start=7000)
+    with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384, search="mr") as c:
+        c.upload(batch)
+        assert 0.0 < c.last_index_ms() < 50.0
+        runs = []
+        for mode in ("mr", "binned", "mr", "lds", "lds1", "brute", "mr"):
+            c.set_search(mode)
+            c.run()
+            c.sync()
+            assert c.last_search() == mode
+            runs.append(c.download())
+        for later in runs[1:]:
+            for a, b in zip(runs[0], later):
+                assert (a.iters, a.converged, a.diverged, a.m_surf, a.m_corner) == (b.iters, b.converged, b.diverged, b.m_surf, b.m_corner)
+                assert np.abs(a.state - b.state).max() <= 1e-8 and np.abs(a.cov - b.cov).max() <= 1e-10 * np.abs(a.cov).max()
+        for k in (2, 6):  # the grid families agree with themselves bit for bit, whatever ran in between
+            for a, b in zip(runs[0], runs[k]):
+                assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov)
+    with ieskf.IeskfContext(prm, max_batch=4, max_targets=16384, search="mr") as c:  # nothing uploaded: no index time
+        with pytest.raises(ieskf.LinsError):
+            c.last_index_ms()
+
+
 def test_pipelined_staged_mode_returns_the_same_bits(pkg, ieskf, host):
     """lins_set_pipelined: five runs enqueued back to back, ONE sync — the downloaded results equal the plain staged
     run's, bit for bit, and so do those of a plain run after the mode is switched off again.  (The RCCL gather this
