@@ -22,16 +22,17 @@ namespace lins {
 #define LINS_LAUNCH(NS, B, LN, PR)                                                                                  \
   hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, false, PR>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, tabs, \
                      state_in, cov_in, (const double*)nullptr, 0, state_out, a6, cov_out, (NS::OutRec*)out, idx_store, poses,  \
-                     scan_id_base, (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof)
+                     scan_id_base, (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof, RELAY_ARGS)
 #define LINS_LAUNCH_PASS(NS, B, LN)                                                                                    \
   hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, true, false>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, tabs, \
                      filt_state, (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr,           \
                      (double*)nullptr, (NS::OutRec*)nullptr, idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out,        \
-                     (long long*)nullptr)
+                     (long long*)nullptr, 0, 0, 0, (double*)nullptr, (int*)nullptr, (int*)nullptr)
 
 int lds_np_cap() { return lds_full::kNpMax; }
 
 static const int* const order = nullptr;  // (one workgroup per CU: nothing to order)
+#define RELAY_ARGS 0, 0, 0, (double*)nullptr, (int*)nullptr, (int*)nullptr  // (the batch shape's two-part updates: not here)
 
 void launch_lds(hipStream_t stream, int n, const DevParams& prm, int lanes, const ScanDesc* descs,
                 const float4* arena, const float4* sorted, const GridTables* tabs, const double* state_in, const double* cov_in, double* state_out, double* a6,

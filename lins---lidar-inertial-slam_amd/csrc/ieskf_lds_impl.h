@@ -929,6 +929,19 @@ __device__ __noinline__ void joseph_epilogue(double r2, int diverged, double* __
 // the kernel.  PASS_ONLY: one correspondence pass at a caller-supplied linearisation
 // state (lins_correspondences / lins_reduce_pass), dumping records / sums.
 // ---------------------------------------------------------------------------
+// Hand-over words of the relay (below) cross workgroups — possibly XCDs, whose L2s are not coherent with one another for
+// ordinary accesses inside a kernel — as agent-scope relaxed atomics: each access carries the cache policy that makes it
+// coherent at device scope (sc1), instead of fences that write back / invalidate a whole L2 per workgroup (measured:
+// with __threadfence() on both sides the launch took 0.97 instead of 0.67 ms).
+__device__ __forceinline__ void relay_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int relay_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void relay_st(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<long long*>(p), __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double relay_ld(const double* p) {
+  return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
 template <int BLOCK, int LANES, bool PASS_ONLY, bool PROF, bool ICP = false>
 #if LINS_LDS_MINW > 1
 // (second argument: waves per SIMD the register allocation must allow)
@@ -943,7 +956,8 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     OutRec* __restrict__ out,
     int4* __restrict__ idx_store, lins_pose_record* __restrict__ poses, int scan_id_base,
     lins_corr* __restrict__ dump, double* __restrict__ sums_out, int* __restrict__ counts_out,
-    long long* __restrict__ prof_buf) {
+    long long* __restrict__ prof_buf,
+    int relay_n, int relay_at, int relay_gen, double* relay_hdr, int* relay_lane, int* relay_flag) {
   constexpr bool prof = PROF;  // phase profile compiled in only for the debug variant
   constexpr int kLBlock = BLOCK, kQPerWave = 64 / LANES, kQPerRound = (BLOCK / 64) * kQPerWave;
   static_assert(BLOCK >= 256 && BLOCK / 64 <= kMaxLWaves, "block shape");
@@ -959,7 +973,30 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   // Launch order: workgroup b takes scan order[b] — the host lists the scans longest-expected-first (lins_capi.hip
   // launch_order: by the prior's translation, the best predictor of a scan's search work the host has), so that the
   // dispatcher, which hands workgroups out in index order as slots free up, ends the launch with the short ones.
-  const int scan = order ? order[blockIdx.x] : (int)blockIdx.x;
+  // Relay (the batch shape only; relay_n = scans of the launch, 0 = off): the update of a scan is cut at iteration
+  // relay_at into two workgroups of one launch, so that a launch of 2 x (slots) scans is four rounds of shorter jobs
+  // instead of two rounds of whole updates: the end of the launch (slots idle while the last whole updates finish)
+  // shrinks with the job size — 0.672 -> 0.625 ms per 1024 scans cut at iteration 6 (tools/relay_sweep.py; 4: 0.659,
+  // 5: 0.643, 7: 0.626, 8: 0.641, 9: 0.660).  The launch list (lins_capi.hip launch_order) names every first part, then
+  // every second part.  The second part takes over the loop state through global memory (relay_out / relay_in below)
+  // and waits for it on a per-scan flag; blocks are handed out in list order (per XCD), so every first part is resident
+  // or done before a second part behind it starts: the wait cannot starve the workgroup it waits for.  Same arithmetic
+  // in the same order: results do not depend on the cut, bit for bit (tests/test_gpu_parity.py
+  // test_two_part_updates_return_the_whole_updates_bits).
+  constexpr bool kRelay = BLOCK == 512 && LANES == 1 && !PASS_ONLY && !ICP;
+  // (with the relay on, the launch list has 2 relay_n entries: scan | part << 30 — a second part anywhere behind its
+  // first part)
+  const int entry = order ? order[blockIdx.x] : (int)blockIdx.x;
+  const int part = (kRelay && relay_n > 0) ? entry >> 30 : 0, scan = (kRelay && relay_n > 0) ? entry & 0x3FFFFFFF : entry;
+  if (kRelay && part) {
+    if (tid == 0) {
+      int f;
+      while ((f = relay_ld(relay_flag + scan)) < relay_gen * 2 + 1) __builtin_amdgcn_s_sleep(32);
+      L.scan_tmp[0] = f;
+    }
+    __syncthreads();
+    if (L.scan_tmp[0] != relay_gen * 2 + 1) return;  // the first part finished the scan (stop rule, divergence)
+  }
   const ScanDesc sd = descs[scan];
   const int total = sd.n_surf_q + sd.n_corner_q;
   // hybrid storage: this scan's slice of the sorted copy (same offsets as its targets in the arena:
@@ -981,7 +1018,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     L.dbg[0] = L.dbg[1] = L.dbg[2] = L.dbg[3] = 0;
   }
   __syncthreads();
-  if (tid < 64) {  // wave 0, lane-redundant: constants of the first iteration
+  if (tid < 64 && !(kRelay && part)) {  // wave 0, lane-redundant: constants of the first iteration (a second part takes them over)
     IterConst ic;
     double filt[19];
     for (int k = 0; k < 19; ++k) ic.lin[k] = L.ic.lin[k], filt[k] = L.filt[k];
@@ -1010,10 +1047,36 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   float lb1 = 0.f, lb2 = 0.f, lb3 = 0.f, certA[3] = {0.f, 0.f, 0.f}, certB[3] = {0.f, 0.f, 0.f};
   bool have_cert = false;
   bool searched = false;  // a search iteration has run: certificates and warm candidates exist (uniform)
+  constexpr int kRelayHdr = 64;  // doubles per scan: IterConst (58), res_prev, res_last, upd_norm, then 6 ints
+  static_assert(sizeof(IterConst) == 58 * sizeof(double), "relay header layout");
+  if (kRelay && part) {  // relay_in: the loop state the first part left (the barrier of the grid load has passed)
+    const double* h = relay_hdr + (size_t)scan * kRelayHdr;
+    if (tid < 58) reinterpret_cast<double*>(&L.ic)[tid] = relay_ld(h + tid);
+    if (tid == 64) L.res_prev = relay_ld(h + 58), L.res_last = relay_ld(h + 59), L.upd_norm = relay_ld(h + 60);
+    if (tid == 65) {
+      const int* hi = reinterpret_cast<const int*>(h + 61);
+      L.iter = relay_ld(hi), L.dbg[0] = relay_ld(hi + 1), L.dbg[1] = relay_ld(hi + 2), L.dbg[2] = relay_ld(hi + 3), L.dbg[3] = relay_ld(hi + 4);
+    }
+    const int* ln = relay_lane + (size_t)scan * 18 * BLOCK + tid;
+    int w[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) w[k] = relay_ld(ln + k * BLOCK);
+    a1 = w[0], b1c = w[1], ra1 = w[2], rb1 = w[3], a2 = w[4], b2c = w[5], a3 = w[6], b3c = w[7], sel1 = w[8];
+    lb1 = __int_as_float(w[9]), lb2 = __int_as_float(w[10]), lb3 = __int_as_float(w[11]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) certA[k] = __int_as_float(w[12 + k]), certB[k] = __int_as_float(w[15 + k]);
+    searched = true;
+    __syncthreads();
+  }
+  bool relay_out = false;
 
   for (;;) {
     const int iter = L.iter;
     if (!PASS_ONLY && (iter >= prm.num_iter || L.conv || L.div)) break;
+    if (kRelay && relay_n > 0 && part == 0 && iter >= relay_at) {
+      relay_out = true;
+      break;
+    }
     __syncthreads();  // everyone has read the loop state before it is rewritten
     if (tid == 0) L.m_surf = 0, L.m_corner = 0;
 
@@ -1588,6 +1651,30 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     L.prof_acc[14] = t_wall_begin, L.prof_acc[15] = wall_clock64();
     for (int k = 0; k < 16; ++k) prof_out[(size_t)scan * 16 + k] = L.prof_acc[k];
   }
+
+  if (kRelay && relay_out) {  // the second part of this scan's update continues from here (see relay_in)
+    double* h = relay_hdr + (size_t)scan * kRelayHdr;
+    if (tid < 58) relay_st(h + tid, reinterpret_cast<const double*>(&L.ic)[tid]);
+    if (tid == 64) relay_st(h + 58, L.res_prev), relay_st(h + 59, L.res_last), relay_st(h + 60, L.upd_norm);
+    if (tid == 65) {
+      int* hi = reinterpret_cast<int*>(h + 61);
+      relay_st(hi, L.iter), relay_st(hi + 1, L.dbg[0]), relay_st(hi + 2, L.dbg[1]), relay_st(hi + 3, L.dbg[2]), relay_st(hi + 4, L.dbg[3]);
+    }
+    int* ln = relay_lane + (size_t)scan * 18 * BLOCK + tid;
+    const int w[18] = {a1, b1c, ra1, rb1, a2, b2c, a3, b3c, sel1, __float_as_int(lb1), __float_as_int(lb2), __float_as_int(lb3),
+                       __float_as_int(certA[0]), __float_as_int(certA[1]), __float_as_int(certA[2]),
+                       __float_as_int(certB[0]), __float_as_int(certB[1]), __float_as_int(certB[2])};
+#pragma unroll
+    for (int k = 0; k < 18; ++k) relay_st(ln + k * BLOCK, w[k]);
+    // every store of this thread has completed (device-coherent stores: at the memory side) before the barrier, the
+    // flag after it: whoever sees the flag sees the hand-over
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) relay_st(relay_flag + scan, relay_gen * 2 + 1);
+    return;
+  }
+  if (kRelay && relay_n > 0 && part == 0 && tid == 0)  // this part finished the scan: its second part has nothing to do
+    relay_st(relay_flag + scan, relay_gen * 2 + 2);
 
   // ---- hand-off to the Joseph kernel / the caller (SE:585-598) ---------------
   const int div = L.div;

@@ -40,7 +40,7 @@ void launch_lds_pass(hipStream_t, int, const DevParams&, int, const ScanDesc*, c
                      const double*, int, int4*, lins_corr*, double*, int*);
 int lds_np_cap();
 void launch_lds_mr(hipStream_t, int, const DevParams&, const ScanDesc*, const int*, const float4*, const float4*, const GridTables*, const double*,
-                   const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*);
+                   const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*, int, int, double*, int*, int*);
 void launch_lds_mr_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const float4*, const GridTables*, const double*,
                         const double*, int, int4*, lins_corr*, double*, int*);
 int lds_mr_np_cap();
@@ -120,6 +120,10 @@ struct lins_ctx {
   GridTables* d_gridtab = nullptr;
   hipEvent_t ev_idx0 = nullptr, ev_idx1 = nullptr;
   bool idx_timed = false;
+  // two-part updates of the batch kernel (ieskf_lds_impl.h "relay"): hand-over buffers, one flag per scan, launch counter
+  int relay_at = 6, relay_gen = 0;  // (relay_at: the iteration the second part starts at; 0 = whole updates)
+  double* d_relay_hdr = nullptr;
+  int *d_relay_lane = nullptr, *d_relay_flag = nullptr;
   ScanDesc* d_desc = nullptr;
   bool use_order = true;  // (LINS_LAUNCH_ORDER=0 with the debug gate: index order, for A/B timing)
   int *h_order = nullptr, *d_order = nullptr;  // launch order of the uploaded batch (longest-expected-first), see launch_order()
@@ -537,6 +541,19 @@ void launch_order(lins_ctx* ctx, int n) {
   }
   std::sort(key.begin(), key.end());
   for (int s = 0; s < n; ++s) ctx->h_order[s] = key[s].second;
+  // Two-part updates (lins_batch_run): a second list of 2 n entries, scan | part << 30 — every first part in the order
+  // above, then every second part in the same order.  A second part can only run once its first part is done and
+  // blocks are handed out in index order: by the time the last first part has been handed out, the scans that started at
+  // once are done, and the second parts of the others (the launch's critical chains: a first part behind a first part)
+  // come up as their first parts finish.  Measured (tools/relay_sweep.py, 1024 scans): this list 0.625 ms; second parts
+  // of the late scans first 0.627; either half reversed 0.643 / 0.658; second parts of the early scans dealt between the
+  // first parts of the late ones 0.762 (a second part handed out before its first part is done holds its slot waiting,
+  // and the duration estimate is too poor to avoid that); whole updates 0.672.
+  int* two = ctx->h_order + n;
+  for (int k = 0; k < n; ++k) {
+    const int sc = ctx->use_order ? ctx->h_order[k] : k;
+    two[k] = sc, two[n + k] = sc | (1 << 30);
+  }
 }
 
 int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
@@ -559,7 +576,7 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
   HIP_TRY(ctx, hipEventRecord(ctx->ev_idx1, ctx->stream));
   ctx->idx_timed = true;
   launch_order(ctx, n);
-  if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->h_order, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->h_order, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   set_batch_state(ctx, n, fl, slots, bytes);
   return LINS_OK;
@@ -583,7 +600,7 @@ int run_range(lins_ctx* ctx, int lo, int cnt, int n_total, const RangeFlags& fl,
   if (use_mr || use_lds) {
     if (use_mr)
       launch_lds_mr(ctx->stream, cnt, ctx->dprm, desc, nullptr, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out, ctx->d_idx, ps,
-                    scan_id_base + lo, nullptr);
+                    scan_id_base + lo, nullptr, 0, 0, nullptr, nullptr, nullptr);
     else
       launch_lds(ctx->stream, cnt, ctx->dprm, s == SEARCH_LDS3 ? 3 : 1, desc, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out,
                  ctx->d_idx, ps, scan_id_base + lo, nullptr);  // (the Joseph update is the kernels' epilogue)
@@ -629,8 +646,10 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   ctx->prm = *params;
   make_dev_params(*params, SEARCH_AUTO, ctx->dprm);  // (ineligible clouds fall back to the exact exhaustive paths)
   if (const char* g = std::getenv("LINS_ENABLE_DEBUG_KNOBS"))
-    if (g[0] == '1')
+    if (g[0] == '1') {
       if (const char* e = std::getenv("LINS_LAUNCH_ORDER")) ctx->use_order = e[0] != '0';
+      if (const char* e = std::getenv("LINS_RELAY_AT")) ctx->relay_at = std::max(0, std::atoi(e));  // (0: whole updates)
+    }
   ctx->max_batch = max_batch;
   ctx->max_targets = max_targets;
   ctx->arena_cap = (size_t)max_batch * (2 * align4(max_targets) + 2 * LINS_MAX_QUERY);
@@ -664,8 +683,8 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   const size_t nb = (size_t)max_batch;
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_arena, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_desc, nb * sizeof(ScanDesc)));
-  CREATE_TRY(hipHostMalloc((void**)&ctx->h_order, nb * sizeof(int)));
-  CREATE_TRY(hipMalloc((void**)&ctx->d_order, nb * sizeof(int)));
+  CREATE_TRY(hipHostMalloc((void**)&ctx->h_order, 3 * nb * sizeof(int)));  // (n entries: whole updates; 2 n: two-part updates)
+  CREATE_TRY(hipMalloc((void**)&ctx->d_order, 3 * nb * sizeof(int)));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_state, nb * 19 * 8));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_cov, nb * 324 * 8));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_out, nb * sizeof(OutRecHost)));
@@ -673,6 +692,14 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   CREATE_TRY(hipMalloc((void**)&ctx->d_binned, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_gsorted, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_gridtab, (size_t)ctx->max_batch * sizeof(GridTables)));
+  if (ctx->max_batch > 2 * ctx->n_cu) {  // (only batches beyond the device's workgroup slots are cut in two)
+    CREATE_TRY(hipMalloc((void**)&ctx->d_relay_hdr, (size_t)ctx->max_batch * 64 * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_relay_lane, (size_t)ctx->max_batch * 18 * 512 * sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_relay_flag, (size_t)ctx->max_batch * sizeof(int)));
+    CREATE_TRY(hipMemset(ctx->d_relay_flag, 0, (size_t)ctx->max_batch * sizeof(int)));
+  } else {
+    ctx->relay_at = 0;
+  }
   CREATE_TRY(hipEventCreate(&ctx->ev_idx0));
   CREATE_TRY(hipEventCreate(&ctx->ev_idx1));
   CREATE_TRY(hipMalloc((void**)&ctx->d_desc, nb * sizeof(ScanDesc)));
@@ -707,6 +734,7 @@ void lins_destroy(lins_ctx* ctx) {
   (void)hipFree(ctx->d_binned);
   (void)hipFree(ctx->d_gsorted);
   (void)hipFree(ctx->d_gridtab);
+  (void)hipFree(ctx->d_relay_hdr), (void)hipFree(ctx->d_relay_lane), (void)hipFree(ctx->d_relay_flag);
   if (ctx->ev_idx0) (void)hipEventDestroy(ctx->ev_idx0);
   if (ctx->ev_idx1) (void)hipEventDestroy(ctx->ev_idx1);
   (void)hipFree(ctx->d_desc);
@@ -807,11 +835,17 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   const bool want_lds = search >= SEARCH_LDS, want_mr = search == SEARCH_MR;
   const bool use_mr = want_mr && ctx->mr_ok, use_lds = want_lds && !want_mr && ctx->lds_ok;
   ctx->last_search = use_mr ? (int)SEARCH_MR : (use_lds ? search : (want_lds ? (int)SEARCH_BINNED : search));
+  // Two-part updates (the kernel's relay): when the batch has more scans than the device has workgroup slots (two per
+  // CU), the launch ends with slots idle while the last whole updates finish; cut at iteration relay_at the same work
+  // is twice as many shorter jobs and that end shrinks.  Not with the phase profile (one record per scan).
+  const bool relay = use_mr && ctx->relay_at > 0 && ctx->n_uploaded > 2 * ctx->n_cu && !ctx->d_prof && ctx->relay_at < ctx->prm.num_iter;
   if (use_mr || use_lds) {
     if (use_mr)
-      launch_lds_mr(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->use_order ? ctx->d_order : nullptr, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in,
+      launch_lds_mr(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc,
+                    relay ? ctx->d_order + ctx->n_uploaded : (ctx->use_order ? ctx->d_order : nullptr), ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in,
                     ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx, (lins_pose_record*)d_poses,
-                    scan_id_base, ctx->d_prof);
+                    scan_id_base, ctx->d_prof, ctx->relay_at, relay ? ++ctx->relay_gen : 0, relay ? ctx->d_relay_hdr : nullptr,
+                    ctx->d_relay_lane, ctx->d_relay_flag);
     else
       launch_lds(ctx->stream, ctx->n_uploaded, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc,
                  ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx,
@@ -1458,7 +1492,8 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
       launch_grid_index(ctx->stream, n, t.d_desc, t.d_arena, t.d_gsorted, t.d_gridtab);
       if (use_mr)
         launch_lds_mr(ctx->stream, n, ctx->dprm, t.d_desc, nullptr, t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in, ctx->d_cov_in,
-                      ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr);
+                      ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr, 0, 0, nullptr, nullptr,
+                      nullptr);
       else
         launch_lds(ctx->stream, n, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, t.d_desc, t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in,
                    ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr);

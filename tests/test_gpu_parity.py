@@ -232,6 +232,33 @@ def test_search_index_of_an_upload_serves_every_later_run(pkg, ieskf, host):
             c.last_index_ms()
 
 
+@pytest.mark.parametrize("stop_rule", [False, True])
+def test_two_part_updates_return_the_whole_updates_bits(pkg, ieskf, host, monkeypatch, stop_rule):
+    """Batches beyond the device's workgroup slots run every update as two workgroups of one launch (the kernel's relay:
+    the second takes the loop state over at iteration LINS_RELAY_AT, default 5).  Same arithmetic in the same order: the
+    results are the whole updates' (LINS_RELAY_AT=0) bit for bit — with fixed iterations and with the reference's stop
+    rule (updates that end before the cut never start a second part), run twice per context (the per-scan flags are
+    numbered by launch, never reset)."""
+    prm = pkg.default_params(num_iter=30) if stop_rule else pkg.default_params(num_iter=10, fixed_iters=1)
+    batch = host.synth_batch(600, start=9000)
+    monkeypatch.setenv("LINS_ENABLE_DEBUG_KNOBS", "1")
+    out = {}
+    for at in ("0", "5", "2", "9"):
+        monkeypatch.setenv("LINS_RELAY_AT", at)
+        with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384, search="mr") as c:
+            c.upload(batch)
+            for _ in range(2):
+                c.run()
+            c.sync()
+            out[at] = c.download()
+            assert c.last_search() == "mr"
+    for at in ("5", "2", "9"):
+        for a, b in zip(out["0"], out[at]):
+            assert (a.iters, a.converged, a.diverged, a.m_surf, a.m_corner) == (b.iters, b.converged, b.diverged, b.m_surf, b.m_corner)
+            assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov)
+            assert a.residual_norm == b.residual_norm and a.update_norm == b.update_norm
+
+
 def test_pipelined_staged_mode_returns_the_same_bits(pkg, ieskf, host):
     """lins_set_pipelined: five runs enqueued back to back, ONE sync — the downloaded results equal the plain staged
     run's, bit for bit, and so do those of a plain run after the mode is switched off again.  (The RCCL gather this
