@@ -27,12 +27,12 @@ namespace lins {
   hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, true, false>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, tabs, \
                      filt_state, (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr,           \
                      (double*)nullptr, (NS::OutRec*)nullptr, idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out,        \
-                     (long long*)nullptr, 0, 0, 0, (double*)nullptr, (int*)nullptr, (int*)nullptr)
+                     (long long*)nullptr, 0, 0, 0, 0, (double*)nullptr, (int*)nullptr, (int*)nullptr)
 
 int lds_np_cap() { return lds_full::kNpMax; }
 
 static const int* const order = nullptr;  // (one workgroup per CU: nothing to order)
-#define RELAY_ARGS 0, 0, 0, (double*)nullptr, (int*)nullptr, (int*)nullptr  // (the batch shape's two-part updates: not here)
+#define RELAY_ARGS 0, 0, 0, 0, (double*)nullptr, (int*)nullptr, (int*)nullptr  // (the batch shape's two-part updates: not here)
 
 void launch_lds(hipStream_t stream, int n, const DevParams& prm, int lanes, const ScanDesc* descs,
                 const float4* arena, const float4* sorted, const GridTables* tabs, const double* state_in, const double* cov_in, double* state_out, double* a6,

@@ -957,7 +957,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     int4* __restrict__ idx_store, lins_pose_record* __restrict__ poses, int scan_id_base,
     lins_corr* __restrict__ dump, double* __restrict__ sums_out, int* __restrict__ counts_out,
     long long* __restrict__ prof_buf,
-    int relay_n, int relay_at, int relay_gen, double* relay_hdr, int* relay_lane, int* relay_flag) {
+    int relay_n, int relay_at, int relay_parts, int relay_gen, double* relay_hdr, int* relay_lane, int* relay_flag) {
   constexpr bool prof = PROF;  // phase profile compiled in only for the debug variant
   constexpr int kLBlock = BLOCK, kQPerWave = 64 / LANES, kQPerRound = (BLOCK / 64) * kQPerWave;
   static_assert(BLOCK >= 256 && BLOCK / 64 <= kMaxLWaves, "block shape");
@@ -973,29 +973,30 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   // Launch order: workgroup b takes scan order[b] — the host lists the scans longest-expected-first (lins_capi.hip
   // launch_order: by the prior's translation, the best predictor of a scan's search work the host has), so that the
   // dispatcher, which hands workgroups out in index order as slots free up, ends the launch with the short ones.
-  // Relay (the batch shape only; relay_n = scans of the launch, 0 = off): the update of a scan is cut at iteration
-  // relay_at into two workgroups of one launch, so that a launch of 2 x (slots) scans is four rounds of shorter jobs
-  // instead of two rounds of whole updates: the end of the launch (slots idle while the last whole updates finish)
-  // shrinks with the job size — 0.672 -> 0.625 ms per 1024 scans cut at iteration 6 (tools/relay_sweep.py; 4: 0.659,
-  // 5: 0.643, 7: 0.626, 8: 0.641, 9: 0.660).  The launch list (lins_capi.hip launch_order) names every first part, then
-  // every second part.  The second part takes over the loop state through global memory (relay_out / relay_in below)
-  // and waits for it on a per-scan flag; blocks are handed out in list order (per XCD), so every first part is resident
-  // or done before a second part behind it starts: the wait cannot starve the workgroup it waits for.  Same arithmetic
-  // in the same order: results do not depend on the cut, bit for bit (tests/test_gpu_parity.py
-  // test_two_part_updates_return_the_whole_updates_bits).
+  // Relay (the batch shape only; relay_n = scans of the launch, 0 = off): the update of a scan is cut every relay_at
+  // iterations into parts that run as consecutive workgroups of one launch, so that a launch of 2 x (slots) scans is
+  // several rounds of shorter jobs instead of two rounds of whole updates: the end of the launch (slots idle while the
+  // last whole updates finish) shrinks with the job size — 0.665 -> 0.615 ms per 1024 scans x 10 iterations in parts of
+  // four iterations (tools/relay_sweep.py; parts of 2: 0.647, 3: 0.625, 5: 0.641, 6: 0.623, 7: 0.626, 8: 0.641).  The
+  // launch list (lins_batch_run) names every part 0, then every part 1, ...  A part takes over the loop state through
+  // global memory (relay_out / relay_in below) and waits for it on a per-scan flag; blocks are handed out in list order
+  // (per XCD), so the part a workgroup waits for is resident or done before the waiting one starts: the wait cannot
+  // starve its producer.  Same arithmetic in the same order: results do not depend on the cuts, bit for bit
+  // (tests/test_gpu_parity.py test_two_part_updates_return_the_whole_updates_bits).
   constexpr bool kRelay = BLOCK == 512 && LANES == 1 && !PASS_ONLY && !ICP;
-  // (with the relay on, the launch list has 2 relay_n entries: scan | part << 30 — a second part anywhere behind its
-  // first part)
+  // (with the relay on, the launch list has relay_parts x relay_n entries: scan | part << 27 — a part anywhere behind
+  // the part before it; part p runs iterations [p relay_at, (p + 1) relay_at), the last one to the end.  Flag of a scan:
+  // 16 gen + p once part p - 1 has handed over, 16 gen + 15 once the update is finished.)
   const int entry = order ? order[blockIdx.x] : (int)blockIdx.x;
-  const int part = (kRelay && relay_n > 0) ? entry >> 30 : 0, scan = (kRelay && relay_n > 0) ? entry & 0x3FFFFFFF : entry;
+  const int part = (kRelay && relay_n > 0) ? entry >> 27 : 0, scan = (kRelay && relay_n > 0) ? entry & 0x7FFFFFF : entry;
   if (kRelay && part) {
     if (tid == 0) {
       int f;
-      while ((f = relay_ld(relay_flag + scan)) < relay_gen * 2 + 1) __builtin_amdgcn_s_sleep(32);
+      while ((f = relay_ld(relay_flag + scan)) < relay_gen * 16 + part) __builtin_amdgcn_s_sleep(32);
       L.scan_tmp[0] = f;
     }
     __syncthreads();
-    if (L.scan_tmp[0] != relay_gen * 2 + 1) return;  // the first part finished the scan (stop rule, divergence)
+    if (L.scan_tmp[0] != relay_gen * 16 + part) return;  // an earlier part finished the scan (stop rule, divergence)
   }
   const ScanDesc sd = descs[scan];
   const int total = sd.n_surf_q + sd.n_corner_q;
@@ -1073,7 +1074,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   for (;;) {
     const int iter = L.iter;
     if (!PASS_ONLY && (iter >= prm.num_iter || L.conv || L.div)) break;
-    if (kRelay && relay_n > 0 && part == 0 && iter >= relay_at) {
+    if (kRelay && relay_n > 0 && part + 1 < relay_parts && iter >= (part + 1) * relay_at) {
       relay_out = true;
       break;
     }
@@ -1670,11 +1671,11 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     // flag after it: whoever sees the flag sees the hand-over
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
-    if (tid == 0) relay_st(relay_flag + scan, relay_gen * 2 + 1);
+    if (tid == 0) relay_st(relay_flag + scan, relay_gen * 16 + part + 1);
     return;
   }
-  if (kRelay && relay_n > 0 && part == 0 && tid == 0)  // this part finished the scan: its second part has nothing to do
-    relay_st(relay_flag + scan, relay_gen * 2 + 2);
+  if (kRelay && relay_n > 0 && part + 1 < relay_parts && tid == 0)  // this part finished the scan: the later parts have nothing to do
+    relay_st(relay_flag + scan, relay_gen * 16 + 15);
 
   // ---- hand-off to the Joseph kernel / the caller (SE:585-598) ---------------
   const int div = L.div;

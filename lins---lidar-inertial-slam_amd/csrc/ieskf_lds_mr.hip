@@ -48,18 +48,18 @@ namespace lins {
   hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, true, false>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, tabs, \
                      filt_state, (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr,           \
                      (double*)nullptr, (NS::OutRec*)nullptr, idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out,        \
-                     (long long*)nullptr, 0, 0, 0, (double*)nullptr, (int*)nullptr, (int*)nullptr)
+                     (long long*)nullptr, 0, 0, 0, 0, (double*)nullptr, (int*)nullptr, (int*)nullptr)
 
 int lds_mr_np_cap() { return lds_mr::kNpMax; }
 
-// relay_hdr != nullptr: every update is cut at iteration relay_at into two workgroups of the launch (2 n blocks), see
+// relay_hdr != nullptr: every update is cut every relay_at iterations into relay_parts workgroups of the launch, see
 // the kernel; relay_gen numbers the launch (the per-scan flags are never reset: a flag of an earlier launch is smaller)
 void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const int* order, const float4* arena,
                    const float4* sorted, const GridTables* tabs, const double* state_in, const double* cov_in, double* state_out, double* a6,
                    double* cov_out, void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof,
-                   int relay_at, int relay_gen, double* relay_hdr, int* relay_lane, int* relay_flag) {
-  const int relay_n = relay_hdr ? n : 0, grid = relay_n ? 2 * n : n;
-#define RELAY_ARGS relay_n, relay_at, relay_gen, relay_hdr, relay_lane, relay_flag
+                   int relay_at, int relay_parts, int relay_gen, double* relay_hdr, int* relay_lane, int* relay_flag) {
+  const int relay_n = relay_hdr ? n : 0, grid = relay_n ? relay_parts * n : n;
+#define RELAY_ARGS relay_n, relay_at, relay_parts, relay_gen, relay_hdr, relay_lane, relay_flag
   if (prof)
     LINS_LAUNCH(lds_mr, LINS_MR_BLOCK, 1, true);
   else
@@ -73,7 +73,7 @@ void launch_lds_mr_icp(hipStream_t stream, int n, const DevParams& prm, const Sc
   hipLaunchKernelGGL((lds_mr::ieskf_lds_kernel<512, 1, false, false, true>), dim3(n), dim3(512), 0, stream, prm, descs,
                      (const int*)nullptr, arena, sorted, tabs, state_in, state_in /*unused: no covariance on this path*/, (const double*)nullptr, 0,
                      state_out, (double*)nullptr, (double*)nullptr, (lds_mr::OutRec*)out, idx_store, (lins_pose_record*)nullptr, 0,
-                     (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, (long long*)nullptr, 0, 0, 0, (double*)nullptr,
+                     (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, (long long*)nullptr, 0, 0, 0, 0, (double*)nullptr,
                      (int*)nullptr, (int*)nullptr);
 }
 

@@ -40,7 +40,7 @@ void launch_lds_pass(hipStream_t, int, const DevParams&, int, const ScanDesc*, c
                      const double*, int, int4*, lins_corr*, double*, int*);
 int lds_np_cap();
 void launch_lds_mr(hipStream_t, int, const DevParams&, const ScanDesc*, const int*, const float4*, const float4*, const GridTables*, const double*,
-                   const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*, int, int, double*, int*, int*);
+                   const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*, int, int, int, double*, int*, int*);
 void launch_lds_mr_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const float4*, const GridTables*, const double*,
                         const double*, int, int4*, lins_corr*, double*, int*);
 int lds_mr_np_cap();
@@ -121,7 +121,9 @@ struct lins_ctx {
   hipEvent_t ev_idx0 = nullptr, ev_idx1 = nullptr;
   bool idx_timed = false;
   // two-part updates of the batch kernel (ieskf_lds_impl.h "relay"): hand-over buffers, one flag per scan, launch counter
-  int relay_at = 6, relay_gen = 0;  // (relay_at: the iteration the second part starts at; 0 = whole updates)
+  int relay_at = 4, relay_gen = 0;  // (relay_at: iterations per part; 0 = whole updates.  1024 scans x 10 iterations: 2 -> 0.647 ms,
+                                    // 3 -> 0.625, 4 -> 0.615, 5 -> 0.641, 6 -> 0.623, 7 -> 0.626, 8 -> 0.641; whole updates 0.665)
+  int relay_list_parts = 0;         // parts of the launch list that is on the device (0 = none yet for this upload)
   double* d_relay_hdr = nullptr;
   int *d_relay_lane = nullptr, *d_relay_flag = nullptr;
   ScanDesc* d_desc = nullptr;
@@ -232,6 +234,8 @@ const lins_params* ctx_params(const lins_ctx* ctx) { return &ctx->prm; }
 }  // namespace lins
 
 namespace {
+
+constexpr int kRelayMaxParts = 8;  // (flag values 16 gen + part: parts < 15)
 
 int fail_hip(lins_ctx* ctx, hipError_t e, const char* what) {
   if (ctx) ctx->hip_err = std::string(what) + ": " + hipGetErrorString(e);
@@ -541,19 +545,7 @@ void launch_order(lins_ctx* ctx, int n) {
   }
   std::sort(key.begin(), key.end());
   for (int s = 0; s < n; ++s) ctx->h_order[s] = key[s].second;
-  // Two-part updates (lins_batch_run): a second list of 2 n entries, scan | part << 30 — every first part in the order
-  // above, then every second part in the same order.  A second part can only run once its first part is done and
-  // blocks are handed out in index order: by the time the last first part has been handed out, the scans that started at
-  // once are done, and the second parts of the others (the launch's critical chains: a first part behind a first part)
-  // come up as their first parts finish.  Measured (tools/relay_sweep.py, 1024 scans): this list 0.625 ms; second parts
-  // of the late scans first 0.627; either half reversed 0.643 / 0.658; second parts of the early scans dealt between the
-  // first parts of the late ones 0.762 (a second part handed out before its first part is done holds its slot waiting,
-  // and the duration estimate is too poor to avoid that); whole updates 0.672.
-  int* two = ctx->h_order + n;
-  for (int k = 0; k < n; ++k) {
-    const int sc = ctx->use_order ? ctx->h_order[k] : k;
-    two[k] = sc, two[n + k] = sc | (1 << 30);
-  }
+  ctx->relay_list_parts = 0;  // (the list of the several-part updates is built by the first run that needs it)
 }
 
 int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
@@ -576,7 +568,7 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
   HIP_TRY(ctx, hipEventRecord(ctx->ev_idx1, ctx->stream));
   ctx->idx_timed = true;
   launch_order(ctx, n);
-  if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->h_order, (size_t)n * 3 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->h_order, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   set_batch_state(ctx, n, fl, slots, bytes);
   return LINS_OK;
@@ -600,7 +592,7 @@ int run_range(lins_ctx* ctx, int lo, int cnt, int n_total, const RangeFlags& fl,
   if (use_mr || use_lds) {
     if (use_mr)
       launch_lds_mr(ctx->stream, cnt, ctx->dprm, desc, nullptr, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out, ctx->d_idx, ps,
-                    scan_id_base + lo, nullptr, 0, 0, nullptr, nullptr, nullptr);
+                    scan_id_base + lo, nullptr, 0, 0, 0, nullptr, nullptr, nullptr);
     else
       launch_lds(ctx->stream, cnt, ctx->dprm, s == SEARCH_LDS3 ? 3 : 1, desc, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out,
                  ctx->d_idx, ps, scan_id_base + lo, nullptr);  // (the Joseph update is the kernels' epilogue)
@@ -683,8 +675,8 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   const size_t nb = (size_t)max_batch;
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_arena, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_desc, nb * sizeof(ScanDesc)));
-  CREATE_TRY(hipHostMalloc((void**)&ctx->h_order, 3 * nb * sizeof(int)));  // (n entries: whole updates; 2 n: two-part updates)
-  CREATE_TRY(hipMalloc((void**)&ctx->d_order, 3 * nb * sizeof(int)));
+  CREATE_TRY(hipHostMalloc((void**)&ctx->h_order, (1 + kRelayMaxParts) * nb * sizeof(int)));  // (n entries: whole updates; then parts x n)
+  CREATE_TRY(hipMalloc((void**)&ctx->d_order, (1 + kRelayMaxParts) * nb * sizeof(int)));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_state, nb * 19 * 8));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_cov, nb * 324 * 8));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_out, nb * sizeof(OutRecHost)));
@@ -839,12 +831,22 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   // CU), the launch ends with slots idle while the last whole updates finish; cut at iteration relay_at the same work
   // is twice as many shorter jobs and that end shrinks.  Not with the phase profile (one record per scan).
   const bool relay = use_mr && ctx->relay_at > 0 && ctx->n_uploaded > 2 * ctx->n_cu && !ctx->d_prof && ctx->relay_at < ctx->prm.num_iter;
+  // (parts: one per relay_at iterations the update may run, at most kRelayMaxParts — the last part runs to the end)
+  const int relay_parts = relay ? std::min(kRelayMaxParts, (ctx->prm.num_iter + ctx->relay_at - 1) / ctx->relay_at) : 1;
+  if (relay && ctx->relay_list_parts != relay_parts) {  // the launch list of this many parts: every part 0, then every part 1, ...
+    int* list = ctx->h_order + ctx->n_uploaded;
+    for (int p = 0; p < relay_parts; ++p)
+      for (int k = 0; k < ctx->n_uploaded; ++k) list[p * ctx->n_uploaded + k] = (ctx->use_order ? ctx->h_order[k] : k) | (p << 27);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order + ctx->n_uploaded, list, (size_t)relay_parts * ctx->n_uploaded * sizeof(int), hipMemcpyHostToDevice,
+                                ctx->stream));
+    ctx->relay_list_parts = relay_parts;
+  }
   if (use_mr || use_lds) {
     if (use_mr)
       launch_lds_mr(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc,
                     relay ? ctx->d_order + ctx->n_uploaded : (ctx->use_order ? ctx->d_order : nullptr), ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in,
                     ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx, (lins_pose_record*)d_poses,
-                    scan_id_base, ctx->d_prof, ctx->relay_at, relay ? ++ctx->relay_gen : 0, relay ? ctx->d_relay_hdr : nullptr,
+                    scan_id_base, ctx->d_prof, ctx->relay_at, relay_parts, relay ? ++ctx->relay_gen : 0, relay ? ctx->d_relay_hdr : nullptr,
                     ctx->d_relay_lane, ctx->d_relay_flag);
     else
       launch_lds(ctx->stream, ctx->n_uploaded, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc,
@@ -1492,7 +1494,7 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
       launch_grid_index(ctx->stream, n, t.d_desc, t.d_arena, t.d_gsorted, t.d_gridtab);
       if (use_mr)
         launch_lds_mr(ctx->stream, n, ctx->dprm, t.d_desc, nullptr, t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in, ctx->d_cov_in,
-                      ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr, 0, 0, nullptr, nullptr,
+                      ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr,
                       nullptr);
       else
         launch_lds(ctx->stream, n, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, t.d_desc, t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in,
