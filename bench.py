@@ -459,7 +459,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"configs[3]: batch of {args.batch} independent scan pairs per GPU, "
-                            f"{args.iters} IESKF iterations each (fixed), 1 workgroup per scan, 2 scans resident per CU; "
+                            f"{args.iters} IESKF iterations each (fixed), 2 scans resident per CU, an update = consecutive workgroups of "
+                            "one launch handing the loop state over every four iterations when the batch exceeds the 512 slots; "
                             "inputs resident in HBM before the timed region (PCIe-inclusive rates: see e2e), the target clouds' search "
                             "index built with them (see search_index)",
                 "scans_per_gpu": len(pairs),
