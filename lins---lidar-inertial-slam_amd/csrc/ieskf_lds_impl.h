@@ -990,9 +990,14 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   const int entry = order ? order[blockIdx.x] : (int)blockIdx.x;
   const int part = (kRelay && relay_n > 0) ? entry >> 27 : 0, scan = (kRelay && relay_n > 0) ? entry & 0x7FFFFFF : entry;
   if (kRelay && part) {
+    // (the wait is bounded: ~0.3 s, two orders beyond any launch.  A hand-over that has not come by then means the
+    // assumption about the dispatcher — blocks handed out in list order — does not hold on this device: the kernel
+    // aborts (the host sees a launch failure) instead of holding the device.  A version in which the waiting
+    // workgroup then ran the whole update on its own cost the loop ten more spilled registers: +5 % kernel time.)
     if (tid == 0) {
-      int f;
-      while ((f = relay_ld(relay_flag + scan)) < relay_gen * 16 + part) __builtin_amdgcn_s_sleep(32);
+      int f, spins = 0;
+      while ((f = relay_ld(relay_flag + scan)) < relay_gen * 16 + part && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(32);
+      if (f < relay_gen * 16 + part) __builtin_trap();
       L.scan_tmp[0] = f;
     }
     __syncthreads();
@@ -1050,7 +1055,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   bool searched = false;  // a search iteration has run: certificates and warm candidates exist (uniform)
   constexpr int kRelayHdr = 64;  // doubles per scan: IterConst (58), res_prev, res_last, upd_norm, then 6 ints
   static_assert(sizeof(IterConst) == 58 * sizeof(double), "relay header layout");
-  if (kRelay && part) {  // relay_in: the loop state the first part left (the barrier of the grid load has passed)
+  if (kRelay && part) {  // relay_in: the loop state the part before left (the barrier of the grid load has passed)
     const double* h = relay_hdr + (size_t)scan * kRelayHdr;
     if (tid < 58) reinterpret_cast<double*>(&L.ic)[tid] = relay_ld(h + tid);
     if (tid == 64) L.res_prev = relay_ld(h + 58), L.res_last = relay_ld(h + 59), L.upd_norm = relay_ld(h + 60);
