@@ -15,6 +15,8 @@
 //   op 15       phi_and_Gt_general: op 5 with the small-rotation shortcut disabled
 //   op 16 / 17  icp_gn_solve in one lane (icp_math.h, the definition) / wave_icp_gn_solve over a wave (icp_wave.h, what the
 //               ICP kernel runs): in 36 (J^T J) + 6 (J^T b) + 1 (round), out 6
+//   op 18 / 19  lm_step_from_sums by one thread (lm_math.h, the definition) / over a wave (lm_wave.h, what map_lm_kernel
+//               runs) — the kernel lives in map_kernels.hip (that file's build flags): in 72, out 44
 #include <hip/hip_runtime.h>
 
 #include "ieskf_device.h"

@@ -48,6 +48,8 @@ void launch_debug_math(hipStream_t, int, int, int, int, const double*, double*);
 void launch_debug_cycles(hipStream_t, int, int, const double*, double*);
 void launch_debug_wave_solve(hipStream_t, int, int, const double*, double*);
 void launch_debug_icp_gn(hipStream_t, int, int, const double*, double*);
+void launch_debug_lm_step(hipStream_t, int, int, const double*, double*, void*);
+size_t map_carry_size();
 void launch_debug_reduce_rows(hipStream_t, int, int, const double*, double*);
 void launch_lds_mr_icp(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const float4*, const GridTables*, const double*, double*,
                        void*, int4*);
@@ -1025,12 +1027,13 @@ int lins_debug_math(lins_ctx* ctx, int op, int n, const double* in, int n_in, do
     (void)hipFree(d_in), (void)hipFree(d_out);
     return LINS_OK;
   }
-  static const int kIn[18] = {4, 3, 3, 37, 38, 4, 24, 42, 42, 448, 448, 42, 42, 3, 4, 4, 43, 43};
-  static const int kOut[18] = {3, 4, 9, 19, 18, 12, 3, 6, 6, 28, 28, 6, 6, 4, 3, 12, 6, 6};
-  if (!ctx || !in || !out || op < 0 || op > 17 || n < 0 || n_in != kIn[op] || n_out != kOut[op]) return LINS_E_ARG;
+  static const int kIn[20] = {4, 3, 3, 37, 38, 4, 24, 42, 42, 448, 448, 42, 42, 3, 4, 4, 43, 43, 72, 72};
+  static const int kOut[20] = {3, 4, 9, 19, 18, 12, 3, 6, 6, 28, 28, 6, 6, 4, 3, 12, 6, 6, 44, 44};
+  if (!ctx || !in || !out || op < 0 || op > 19 || n < 0 || n_in != kIn[op] || n_out != kOut[op]) return LINS_E_ARG;
   if (n == 0) return LINS_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   double *d_in = nullptr, *d_out = nullptr;
+  void* d_lm = nullptr;
   HIP_TRY(ctx, hipMalloc((void**)&d_in, (size_t)n * n_in * 8));
   hipError_t e = hipMalloc((void**)&d_out, (size_t)n * n_out * 8);
   if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, (size_t)n * n_in * 8, hipMemcpyHostToDevice, ctx->stream);
@@ -1041,13 +1044,17 @@ int lins_debug_math(lins_ctx* ctx, int op, int n, const double* in, int n_in, do
       launch_debug_wave_solve(ctx->stream, n, op == 12, d_in, d_out);
     else if (op == 16 || op == 17)
       launch_debug_icp_gn(ctx->stream, n, op == 17, d_in, d_out);
+    else if (op == 18 || op == 19) {  // lm_step_from_sums: one thread (lm_math.h) / over a wave (lm_wave.h); 72 in, 44 out
+      e = hipMalloc(&d_lm, (size_t)n * map_carry_size());
+      if (e == hipSuccess) launch_debug_lm_step(ctx->stream, n, op == 19, d_in, d_out, d_lm);
+    }
     else
       launch_debug_math(ctx->stream, op, n, n_in, n_out, d_in, d_out);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, (size_t)n * n_out * 8, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  (void)hipFree(d_in), (void)hipFree(d_out);
+  (void)hipFree(d_in), (void)hipFree(d_out), (void)hipFree(d_lm);
   if (e != hipSuccess) return fail_hip(ctx, e, "lins_debug_math");
   return LINS_OK;
 }

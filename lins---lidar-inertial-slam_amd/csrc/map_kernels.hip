@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include "lm_math.h"
+#include "lm_wave.h"
 #include "map_math.h"
 
 namespace lins {
@@ -240,33 +241,85 @@ __global__ __launch_bounds__(kGridBlock) void map_grid_kernel(const MapGridJob* 
 // terms / the problem's "still running" flag are written where the correspondence kernel reads them — the ten
 // rounds of scan2MapOptimization run back to back without the host.
 // ---------------------------------------------------------------------------
-__global__ void map_lm_kernel(int n, int iter, int blocks_per_problem, MapDev* __restrict__ probs, MapRound* __restrict__ rounds,
-                              const double* __restrict__ partials, lins_map_result* __restrict__ results, LmCarry* __restrict__ carry) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
+__global__ __launch_bounds__(64) void map_lm_kernel(int n, int iter, int blocks_per_problem, MapDev* __restrict__ probs,
+                                                    MapRound* __restrict__ rounds, const double* __restrict__ partials,
+                                                    lins_map_result* __restrict__ results, LmCarry* __restrict__ carry) {
+  // One WAVE per problem (round 3: lm_wave.h — element (i, j) of the 6 x 6 matrices in lane 6 i + j; rounds 1-2 ran
+  // lm_math.h's one-thread definition here, ~100 us for round 0).  Everything outside the matrices is uniform.
+  __shared__ double sums[28];
+  const int k = blockIdx.x, lane = threadIdx.x;
   lins_map_result r = results[k];
   if (iter < 0) {  // initialisation: rotation terms of the given transform, counters
     r.iters = 0, r.converged = 0, r.degenerate = 0, r.n_sel = 0;
-    results[k] = r;
-    carry[k].degenerate = 0;
+    if (lane == 0) results[k] = r, carry[k].degenerate = 0;
   } else {
-    if (!probs[k].active) return;
-    double sums[28];
-    for (int t = 0; t < 28; ++t) sums[t] = 0.0;
-    for (int b = 0; b < blocks_per_problem; ++b)
-      for (int t = 0; t < 28; ++t) sums[t] += partials[((size_t)k * blocks_per_problem + b) * 28 + t];
+    if (!probs[k].active) return;  // (uniform)
+    if (lane < 28) {
+      double s = 0.0;
+      for (int b = 0; b < blocks_per_problem; ++b) s += partials[((size_t)k * blocks_per_problem + b) * 28 + lane];
+      sums[lane] = s;
+    }
+    __syncthreads();
     r.n_sel = (int)sums[27];
     r.iters = iter + 1;
-    LmCarry c = carry[k];
-    if (lm_step_from_sums(sums, iter, r.transform, c)) r.converged = 1, probs[k].active = 0;
-    r.degenerate = c.degenerate;
-    carry[k] = c;
-    results[k] = r;
+    float T[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) T[t] = r.transform[t];
+    int degenerate = 0;
+    const bool conv = wave_lm_step_from_sums(sums, iter, T, carry + k, lane, degenerate);
+#pragma unroll
+    for (int t = 0; t < 6; ++t) r.transform[t] = T[t];
+    if (conv) r.converged = 1;
+    r.degenerate = degenerate;
+    if (lane == 0) {
+      if (conv) probs[k].active = 0;
+      results[k] = r;
+    }
   }
   const MapRoundParams p = lm_make_round(r.transform);
-  MapRound rd;
-  rd.as = p.as, rd.tg = p.tg, rd.pad = 0.f;
-  rounds[k] = rd;
+  if (lane == 0) {
+    MapRound rd;
+    rd.as = p.as, rd.tg = p.tg, rd.pad = 0.f;
+    rounds[k] = rd;
+  }
+}
+
+// Debug aid (tests/test_gpu_math.py): lm_step_from_sums by one thread (lm_math.h, the definition) / over a wave
+// (lm_wave.h, what map_lm_kernel runs) on the same input: 28 sums, round, T[6], carry.degenerate, carry.P[36] (72
+// doubles) -> converged, T[6], degenerate, P[36] (44 doubles)
+__global__ __launch_bounds__(64) void debug_lm_step_kernel(int wave_version, const double* __restrict__ in, double* __restrict__ out,
+                                                           LmCarry* __restrict__ scratch) {
+  __shared__ double sums[28];
+  const int item = blockIdx.x, lane = threadIdx.x;
+  const double* a = in + (size_t)item * 72;
+  if (lane < 28) sums[lane] = a[lane];
+  LmCarry* c = scratch + item;
+  if (lane < 36) c->P[lane] = (float)a[36 + lane];
+  if (lane == 0) c->degenerate = (int)a[35];
+  __syncthreads();
+  const int iter = (int)a[28];
+  float T[6];
+  for (int t = 0; t < 6; ++t) T[t] = (float)a[29 + t];
+  bool conv = false;
+  if (wave_version) {
+    int deg = 0;
+    conv = wave_lm_step_from_sums(sums, iter, T, c, lane, deg);
+  } else if (lane == 0) {
+    LmCarry cc = *c;
+    conv = lm_step_from_sums(sums, iter, T, cc);
+    *c = cc;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    double* o = out + (size_t)item * 44;
+    o[0] = conv ? 1.0 : 0.0;
+    for (int t = 0; t < 6; ++t) o[1 + t] = (double)T[t];
+    o[7] = (double)c->degenerate;
+    for (int t = 0; t < 36; ++t) o[8 + t] = (double)c->P[t];
+  }
+}
+void launch_debug_lm_step(hipStream_t stream, int n, int wave_version, const double* in, double* out, void* scratch) {
+  hipLaunchKernelGGL(debug_lm_step_kernel, dim3(n), dim3(64), 0, stream, wave_version, in, out, (LmCarry*)scratch);
 }
 
 void launch_map_grid(hipStream_t stream, int n_jobs, const void* jobs, const float4* raw, float4* pts, int* cells) {
@@ -274,7 +327,7 @@ void launch_map_grid(hipStream_t stream, int n_jobs, const void* jobs, const flo
 }
 void launch_map_lm(hipStream_t stream, int n, int iter, int blocks_per_problem, void* probs, void* rounds, const double* partials,
                    lins_map_result* results, void* carry) {
-  hipLaunchKernelGGL(map_lm_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, n, iter, blocks_per_problem, (MapDev*)probs,
+  hipLaunchKernelGGL(map_lm_kernel, dim3(n), dim3(64), 0, stream, n, iter, blocks_per_problem, (MapDev*)probs,
                      (MapRound*)rounds, partials, results, (LmCarry*)carry);
 }
 size_t map_grid_job_size() { return sizeof(MapGridJob); }

@@ -243,3 +243,44 @@ def test_icp_gauss_newton_step_over_a_wave_is_bit_identical_to_the_one_lane_defi
     ok = (rounds == 3.0) & (np.arange(n) < 100)
     sol = np.linalg.solve(A[ok], g[ok][:, :, None])[:, :, 0]
     assert np.abs(one[ok] - sol).max() <= 1e-9 * np.abs(sol).max()
+
+
+def test_lm_step_over_a_wave_is_bit_identical_to_the_one_thread_definition(ieskf, ctx):
+    """lm_wave.h (element (i, j) of the 6 x 6 matrices in lane 6 i + j: what map_lm_kernel runs) against lm_math.h's
+    lm_step_from_sums run by one thread (the definition, shared with the host) — Householder QR every round; on round 0
+    the cyclic-Jacobi eigen-decomposition, the Gauss-Jordan inverse with row exchanges, the degeneracy projection
+    (LM:1583-1632): the same bits of the transform, the stop flag, isDegenerate and matP on well-conditioned normal
+    equations, on ones with eigenvalues below the threshold (100), on rank-deficient ones, with fewer than 50 rows, and
+    on later rounds that apply a carried projection."""
+    rng = np.random.default_rng(91)
+    n = 480
+    J = (rng.normal(size=(n, 300, 6)) * rng.choice([1.0, 2.0, 4.0], size=(n, 1, 6))).astype(np.float32).astype(np.float64)
+    J[100:180, :, 2] *= 1e-2             # a weak direction: eigenvalue < 100 -> projection
+    J[180:220, :, 4] = J[180:220, :, 1]   # exactly rank-deficient (two equal columns)
+    J[220:240, :, 0] = 0.0                # a zero column
+    b = rng.normal(size=(n, 300)) * 0.02
+    A = np.einsum("nki,nkj->nij", J, J)
+    g = np.einsum("nki,nk->ni", J, b)
+    A[240:260] *= 1e-4                    # every eigenvalue below the threshold
+    iu = np.triu_indices(6)
+    sums = np.zeros((n, 28))
+    sums[:, :21] = A[:, iu[0], iu[1]]
+    sums[:, 21:27] = g
+    sums[:, 27] = 300
+    sums[260:270, 27] = 49                # too few rows: nothing happens (LM:1530)
+    rounds = np.where(np.arange(n) % 3 == 0, 0.0, np.arange(n) % 3 + 1.0)
+    T0 = rng.normal(size=(n, 6)) * 0.1
+    deg_in = (rng.random(n) < 0.5).astype(np.float64)  # carried isDegenerate / matP of the later rounds
+    P_in = (np.eye(6)[None] + rng.normal(size=(n, 6, 6)) * 0.2).reshape(n, 36)
+    x = np.concatenate([sums, rounds[:, None], T0, deg_in[:, None], P_in], axis=1)
+    one = dev(ieskf, ctx, 18, x, 44)
+    wav = dev(ieskf, ctx, 19, x, 44)
+    assert np.array_equal(np.isnan(one), np.isnan(wav))
+    assert np.array_equal(one[~np.isnan(one)].view(np.uint64), wav[~np.isnan(wav)].view(np.uint64))
+    r0 = rounds == 0
+    assert one[r0 & (np.arange(n) >= 100) & (np.arange(n) < 260), 7].all() and not one[r0 & (np.arange(n) < 100), 7].any()
+    # and the definition does what it says: a well-conditioned later round without a projection solves the normal equations
+    ok = (~r0) & (deg_in == 0) & (np.arange(n) < 100)
+    sol = np.linalg.solve(A[ok], g[ok][:, :, None])[:, :, 0]
+    got = one[ok, 1:7] - T0[ok].astype(np.float32)
+    assert np.abs(got - sol).max() <= 2e-3 * np.abs(sol).max()
