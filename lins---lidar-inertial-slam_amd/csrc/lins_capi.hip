@@ -835,6 +835,10 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   const bool relay = use_mr && ctx->relay_at > 0 && ctx->n_uploaded > 2 * ctx->n_cu && !ctx->d_prof && ctx->relay_at < ctx->prm.num_iter;
   // (parts: one per relay_at iterations the update may run, at most kRelayMaxParts — the last part runs to the end)
   const int relay_parts = relay ? std::min(kRelayMaxParts, (ctx->prm.num_iter + ctx->relay_at - 1) / ctx->relay_at) : 1;
+  if (relay && ctx->relay_gen >= (1 << 26)) {  // (flags are 16 gen + part: start over long before the int runs out)
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_relay_flag, 0, (size_t)ctx->max_batch * sizeof(int), ctx->stream));
+    ctx->relay_gen = 0;
+  }
   if (relay && ctx->relay_list_parts != relay_parts) {  // the launch list of this many parts: every part 0, then every part 1, ...
     int* list = ctx->h_order + ctx->n_uploaded;
     for (int p = 0; p < relay_parts; ++p)
@@ -1811,6 +1815,10 @@ int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins
   // between them — lins_last_kernel_ms() after lins_ieskf_update_batch() is an upper bound of the kernel time)
   HIP_TRY(ctx, hipEventRecord(ctx->hist1[ctx->hist_n % lins_ctx::kHist], ctx->stream));
   ctx->hist_n++;
+  // the batch stays resident (inputs, search index): a later lins_batch_run finds its launch order too
+  launch_order(ctx, n);
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->h_order, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  ctx->idx_timed = false;  // (the index was built chunk by chunk between the copies: no single time to report)
   set_batch_state(ctx, n, all, slots, bytes);
   ctx->ran = true;
   return lins_batch_download(ctx, n, out);

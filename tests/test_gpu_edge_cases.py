@@ -552,9 +552,15 @@ def test_pipelined_batch_call_equals_the_staged_path(pkg, oracle, ieskf):
         for search in ("auto", "mr", "lds"):
             c.set_search(search)
             got = c.update_batch(pairs)
+            c.run()  # the batch of the call stays resident (inputs, search index, launch order): a staged run on it
+            c.sync()
+            rerun = c.download(len(pairs))
             c.upload(pairs)
             c.run()
             want = c.download()
+            for k, (g, w) in enumerate(zip(rerun, want)):
+                assert np.array_equal(g.state.view(np.int64), w.state.view(np.int64)), (search, k)
+                assert np.array_equal(g.cov.view(np.int64), w.cov.view(np.int64)), (search, k)
             for k, (g, w) in enumerate(zip(got, want)):
                 assert (g.iters, g.converged, g.diverged, g.m_surf, g.m_corner) == (w.iters, w.converged, w.diverged, w.m_surf, w.m_corner), (search, k)
                 assert np.array_equal(g.state.view(np.int64), w.state.view(np.int64)), (search, k)
