@@ -512,7 +512,8 @@ def main():
             step_ms = elapsed_max / args.steps * 1e3
             out["search_index"] = {
                 "built_at": "lins_batch_upload (outside the timed region): the reference's kd-tree build is in updatePointCloud "
-                            "(SE:1156-1160), outside performIESKF, and outside the cpu_baseline's timed region too",
+                            "(SE:1156-1160), outside performIESKF, and outside the timed region of cpu_baseline kind \"reference\" too "
+                            "(oracle/ref_driver.cpp ref_bench builds the estimators' kd-trees first; the port's figures include its own tree build)",
                 "kernel": "grid_index_kernel", "kernel_ms": index_ms,
                 "with_build_each_step": {"ms_per_step": step_ms + index_ms, "value": iters_all / ((step_ms + index_ms) * 1e-3),
                                          "frac": alg_bytes / ((k_ms + index_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}}
