@@ -174,6 +174,8 @@ int lins_last_index_ms(lins_ctx* ctx, float* ms);
 /* Runs the full IESKF loop for the uploaded batch on the context's stream.
  * d_poses: optional DEVICE pointer to n lins_pose_record (e.g. a torch tensor
  * that RCCL gathers afterwards); may be NULL. Asynchronous; lins_sync() waits. */
+/* A batch with more scans than the device has workgroup slots (two per CU) runs every update as consecutive workgroups
+ * of the one launch that hand the loop state over every four iterations — a shorter launch, bit-identical results.      */
 int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base);
 int lins_sync(lins_ctx* ctx);
 int lins_batch_download(lins_ctx* ctx, int n, lins_result* out);

@@ -2,9 +2,10 @@
 // batch-throughput path.  512-thread workgroups (8 waves: two per SIMD, so the placement of a
 // workgroup's waves is balanced whatever SIMD the dispatcher starts on), one owner lane per query (the
 // searches of the warm iterations are served by several lanes, see ieskf_lds_impl.h), whose
-// LDS holds only the first 4224 grid positions of the scan — the corner cloud and the low surf
-// rings, where nearly every search ends; the rest of the grid is a sorted copy in global memory
-// that the same loops fall through to.  At < 80 KB of LDS and 128 VGPRs two independent scans are
+// LDS holds only the first 4208 grid positions of the scan's prebuilt search index (ieskf_grid.h) — the
+// corner cloud and the low surf rings, where nearly every search ends; the rest of the grid is read from
+// the index's sorted copy in global memory, which the same loops fall through to.  Batches beyond the
+// device's workgroup slots run every update as consecutive workgroups of the launch (the kernel's relay).  At < 80 KB of LDS and 128 VGPRs two independent scans are
 // resident per CU and fill each other's barriers and serial tails (measured with the HW_ID /
 // wall-clock probe of the PROF variant, tools/residency.py).  Results are identical to the
 // full-residency kernel: the same loops run over the same grid, only the storage of a position

@@ -122,7 +122,7 @@ struct lins_ctx {
   GridTables* d_gridtab = nullptr;
   hipEvent_t ev_idx0 = nullptr, ev_idx1 = nullptr;
   bool idx_timed = false;
-  // two-part updates of the batch kernel (ieskf_lds_impl.h "relay"): hand-over buffers, one flag per scan, launch counter
+  // several-part updates of the batch kernel (ieskf_lds_impl.h "relay"): hand-over buffers, one flag per scan, launch counter
   int relay_at = 4, relay_gen = 0;  // (relay_at: iterations per part; 0 = whole updates.  1024 scans x 10 iterations: 2 -> 0.647 ms,
                                     // 3 -> 0.625, 4 -> 0.615, 5 -> 0.641, 6 -> 0.623, 7 -> 0.626, 8 -> 0.641; whole updates 0.665)
   int relay_list_parts = 0;         // parts of the launch list that is on the device (0 = none yet for this upload)
@@ -686,7 +686,7 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   CREATE_TRY(hipMalloc((void**)&ctx->d_binned, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_gsorted, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_gridtab, (size_t)ctx->max_batch * sizeof(GridTables)));
-  if (ctx->max_batch > 2 * ctx->n_cu) {  // (only batches beyond the device's workgroup slots are cut in two)
+  if (ctx->max_batch > 2 * ctx->n_cu) {  // (only batches beyond the device's workgroup slots are cut into parts)
     CREATE_TRY(hipMalloc((void**)&ctx->d_relay_hdr, (size_t)ctx->max_batch * 64 * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&ctx->d_relay_lane, (size_t)ctx->max_batch * 18 * 512 * sizeof(int)));
     CREATE_TRY(hipMalloc((void**)&ctx->d_relay_flag, (size_t)ctx->max_batch * sizeof(int)));
@@ -829,9 +829,10 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   const bool want_lds = search >= SEARCH_LDS, want_mr = search == SEARCH_MR;
   const bool use_mr = want_mr && ctx->mr_ok, use_lds = want_lds && !want_mr && ctx->lds_ok;
   ctx->last_search = use_mr ? (int)SEARCH_MR : (use_lds ? search : (want_lds ? (int)SEARCH_BINNED : search));
-  // Two-part updates (the kernel's relay): when the batch has more scans than the device has workgroup slots (two per
-  // CU), the launch ends with slots idle while the last whole updates finish; cut at iteration relay_at the same work
-  // is twice as many shorter jobs and that end shrinks.  Not with the phase profile (one record per scan).
+  // Several-part updates (the kernel's relay): when the batch has more scans than the device has workgroup slots (two
+  // per CU), the launch ends with slots idle while the last whole updates finish; cut every relay_at iterations the
+  // same work is several times as many shorter jobs and that end shrinks.  Not with the phase profile (one record per
+  // scan).
   const bool relay = use_mr && ctx->relay_at > 0 && ctx->n_uploaded > 2 * ctx->n_cu && !ctx->d_prof && ctx->relay_at < ctx->prm.num_iter;
   // (parts: one per relay_at iterations the update may run, at most kRelayMaxParts — the last part runs to the end)
   const int relay_parts = relay ? std::min(kRelayMaxParts, (ctx->prm.num_iter + ctx->relay_at - 1) / ctx->relay_at) : 1;

@@ -234,8 +234,8 @@ def test_search_index_of_an_upload_serves_every_later_run(pkg, ieskf, host):
 
 @pytest.mark.parametrize("stop_rule", [False, True])
 def test_two_part_updates_return_the_whole_updates_bits(pkg, ieskf, host, monkeypatch, stop_rule):
-    """Batches beyond the device's workgroup slots run every update as two workgroups of one launch (the kernel's relay:
-    the second takes the loop state over at iteration LINS_RELAY_AT, default 5).  Same arithmetic in the same order: the
+    """Batches beyond the device's workgroup slots run every update as consecutive workgroups of one launch (the kernel's
+    relay: each takes the loop state over from the one before, LINS_RELAY_AT iterations per part, default 4).  Same arithmetic in the same order: the
     results are the whole updates' (LINS_RELAY_AT=0) bit for bit — with fixed iterations and with the reference's stop
     rule (updates that end before the cut never start a second part), run twice per context (the per-scan flags are
     numbered by launch, never reset)."""
