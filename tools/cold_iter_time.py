@@ -13,6 +13,7 @@ n = 1024
 with ThreadPoolExecutor(16) as ex:
     pairs = list(ex.map(host.synth_pair, range(n)))
 os.environ["LINS_ENABLE_DEBUG_KNOBS"] = "1"
+os.environ.setdefault("LINS_RELAY_AT", "0")  # whole updates: these are slopes of one scan's chain, not of the launch
 cfgs = [(1, 0), (1, 3), (1, 2), (1, 1), (1, 0x5F0003), (2, 0), (2, 3)]
 ctxs = []
 for it, skip in cfgs:

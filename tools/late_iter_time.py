@@ -20,6 +20,7 @@ with ThreadPoolExecutor(16) as ex:
 if maxq:
     pairs = [p for p in pairs if len(p.surf_flat) + len(p.corner_sharp) <= maxq][:n]
 os.environ["LINS_ENABLE_DEBUG_KNOBS"] = "1"
+os.environ.setdefault("LINS_RELAY_AT", "0")  # whole updates: these are slopes of one scan's chain, not of the launch
 print("clock note: times are kernel ms (events); slope = (t10 - t7) / 3")
 for skip in skips:
     os.environ["LINS_DEBUG_SKIP"] = str(skip)
