@@ -2,6 +2,8 @@
 """Kernel time of the batch workload as a function of the (fixed) iteration count: the differences are the cost of
 iteration k, the intercept is the set-up (grid build).  usage: tools/iter_curve.py [search] [max_iter]"""
 import importlib, os, sys
+os.environ.setdefault("LINS_ENABLE_DEBUG_KNOBS", "1")
+os.environ.setdefault("LINS_RELAY_AT", "0")  # whole updates: the curve is a scan's chain against its iteration count
 from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
