@@ -89,6 +89,31 @@ def reference_stop_rule_rate(pkg, ieskf, pairs, args, max_targets):
             "diverged": int(sum(r.diverged for r in res)), "num_iter": 30, "stop_rule": "|dx| <= 1e-2 (SE:575-578)"}
 
 
+def two_batches_in_flight(pkg, ieskf, pairs, args, max_targets):
+    """The same batch and step from TWO contexts (two streams) whose launches overlap: the slots one launch leaves idle
+    at its end are taken by the other's workgroups — what a server with two batches in flight sees, by the wall clock.
+    Not the headline: `value` times one context, where every launch has a duration of its own."""
+    prm = pkg.default_params(num_iter=args.iters, fixed_iters=1)
+    ctxs = [ieskf.IeskfContext(prm, max_batch=len(pairs), max_targets=max(max_targets, 1024), search=args.search) for _ in range(2)]
+    try:
+        for c in ctxs:
+            c.upload(pairs)
+            c.run()
+            c.sync()
+        n = 2 * max(args.steps, 10)
+        t0 = time.perf_counter()
+        for k in range(n):
+            ctxs[k & 1].run()
+        for c in ctxs:
+            c.sync()
+        dt = (time.perf_counter() - t0) / n
+    finally:
+        for c in ctxs:
+            c.close()
+    return {"iterations_per_s": len(pairs) * args.iters / dt, "ms_per_launch": dt * 1e3,
+            "note": "two contexts, launches alternated, one wait at the end; wall clock"}
+
+
 def single_scan_latency(pkg, ieskf, pair):
     """BASELINE.json configs[2]: ONE scan pair, full on-device loop (the live lins_fusion_node case): kernel time
     of the single-scan kernel and the end-to-end latency of lins_ieskf_update (upload + kernels + download)."""
@@ -522,6 +547,7 @@ def main():
         if world == 1 and not args.no_extras:
             out["reference_stop_rule"] = reference_stop_rule_rate(pkg, ieskf, pairs, args, max_targets)
             out["single_scan"] = single_scan_latency(pkg, ieskf, pairs[0])
+            out["two_batches_in_flight"] = two_batches_in_flight(pkg, ieskf, pairs, args, max_targets)
             out["e2e"] = e2e_rates(pkg, ieskf, host, pairs, args)
     else:
         out = None
