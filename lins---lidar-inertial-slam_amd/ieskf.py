@@ -95,7 +95,7 @@ def lib():
 class IeskfContext:
     """lins_ctx wrapper: one HIP stream + device arena on one GPU."""
 
-    def __init__(self, params=None, device=0, max_batch=1, max_targets=8192, search="auto"):
+    def __init__(self, params=None, device=0, max_batch=1, max_targets=16384, search="auto"):
         self.params = params if params is not None else default_params()
         self._h = C.c_void_p()
         self._check(lib().lins_create(C.byref(self.params), device, max_batch, max_targets, C.byref(self._h)))

@@ -96,3 +96,10 @@ def test_pose_allgather_through_the_c_abi_world_of_one():
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.run([sys.executable, "-c", RCCL_SCRIPT % ROOT], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0 and b"RCCL_GATHER_OK" in p.stdout, p.stderr.decode()[-3000:]
+
+
+def test_driver_smoke_entry_point_runs():
+    """__graft_entry__.smoke() — what the driver runs before the bench — on the stock scan 0 with its default context."""
+    import __graft_entry__ as g
+
+    g.smoke()
