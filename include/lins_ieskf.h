@@ -174,14 +174,23 @@ int lins_last_index_ms(lins_ctx* ctx, float* ms);
 /* Runs the full IESKF loop for the uploaded batch on the context's stream.
  * d_poses: optional DEVICE pointer to n lins_pose_record (e.g. a torch tensor
  * that RCCL gathers afterwards); may be NULL. Asynchronous; lins_sync() waits. */
-/* A batch with more scans than the device has workgroup slots (two per CU) runs every update as consecutive workgroups
- * of the one launch that hand the loop state over every four iterations — a shorter launch, bit-identical results.      */
+/* A batch with more scans than the device has workgroup slots (two per CU) runs every update in PARTS that hand the
+ * loop state over through global memory: the first four iterations in the batch kernel, the rest in the tail kernel —
+ * a second launch behind it on the same stream that keeps four scans on a CU instead of two — a shorter step,
+ * bit-identical results (ICP_FREQ 1 and VLP-16 sized query sets; other batches run whole updates or the batch kernel's
+ * own parts).  A part never blocks the device: one whose hand-over does not come within a bounded wait runs the whole
+ * update itself.  lins_last_cut() reports how the last run was cut.                                                  */
 int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base);
+/* parts = pieces every update of the last lins_batch_run() was cut into (1 = whole updates); tail_kernel = 1 when the
+ * last of them ran as the tail kernel's launch.                                                                      */
+int lins_last_cut(const lins_ctx* ctx, int* parts, int* tail_kernel);
 int lins_sync(lins_ctx* ctx);
 int lins_batch_download(lins_ctx* ctx, int n, lins_result* out);
-/* HIP-event time (ms), on the context's stream, of the update kernel of the last lins_batch_run() (or of the last
- * chunk of lins_ieskf_update_batch): the persistent IESKF kernel, whose epilogue is the Joseph covariance update in the
- * "lds" / "mr" / "lds1" families; for "binned" / "brute" the update kernel and the separate Joseph kernel.        */
+/* HIP-event time (ms), on the context's stream, of the update kernel(s) of the last lins_batch_run(): the persistent
+ * IESKF kernel — batch kernel + tail kernel when the run was cut that way (lins_last_cut) — whose epilogue is the
+ * Joseph covariance update in the "lds" / "mr" / "lds1" families; for "binned" / "brute" the update kernel and the
+ * separate Joseph kernel.  After lins_ieskf_update_batch(): from the first chunk's kernels to the last chunk's, i.e.
+ * including the index builds and the waits for the copies in between — the call's device time, not one kernel's.   */
 int lins_last_kernel_ms(lins_ctx* ctx, float* ms);
 /* HIP-event times (ms) of the update kernels of the last n lins_batch_run() calls, oldest first (n <= 64 and <= the
  * number of runs so far); waits for the newest of them.  lins_last_kernel_ms() is the n = 1 case.                 */

@@ -53,6 +53,18 @@ struct DevParams {
   int pad2[2];
 };
 
+// Several-part updates of the batch kernel (ieskf_lds_impl.h "relay"): the update of every scan of a large batch is cut every
+// `at` iterations into `parts` parts; the first `launched` of them are workgroups of the batch kernel's launch, the last
+// one may be the tail kernel's launch behind it (launched == parts - 1) or the batch kernel's own last part.
+struct RelayArgs {
+  int at = 0, parts = 0, launched = 0, gen = 0;
+  int spins = 1 << 14;  // polls (~1 us each) a part waits for its hand-over before it runs the whole update alone
+  double* hdr = nullptr;  // per scan: 64 doubles of loop state
+  int* lane = nullptr;    // per scan: the carried state of every query lane (ieskf_lds_impl.h CarryWords)
+  int* flag = nullptr;    // per scan: 16 gen + next part, 16 gen + 15 = finished
+  int* err = nullptr;     // per context: protocol violations seen
+};
+
 struct IterConst {  // per-iteration constants, hoisted (the reference recomputes per point)
   double lin[19];   // linState_
   V3 phi;           // Quat2axis(linState_.qbn_)

@@ -19,44 +19,48 @@
 
 namespace lins {
 
-#define LINS_LAUNCH(NS, B, LN, PR)                                                                                  \
-  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, false, PR>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, tabs, \
-                     state_in, cov_in, (const double*)nullptr, 0, state_out, a6, cov_out, (NS::OutRec*)out, idx_store, poses,  \
-                     scan_id_base, (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof, RELAY_ARGS)
-#define LINS_LAUNCH_PASS(NS, B, LN)                                                                                    \
-  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, true, false>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, tabs, \
-                     filt_state, (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr,           \
-                     (double*)nullptr, (NS::OutRec*)nullptr, idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out,        \
-                     (long long*)nullptr, 0, 0, 0, 0, (double*)nullptr, (int*)nullptr, (int*)nullptr)
+template <class K>
+static void launch_args(K kernel, int grid, int block, hipStream_t stream, const lds_full::KernelArgs& ka, const float4* arena, const float4* sorted,
+                        int4* idx_store, lins_corr* dump = nullptr) {
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, ka, arena, sorted, idx_store, dump);
+}
 
 int lds_np_cap() { return lds_full::kNpMax; }
 
-static const int* const order = nullptr;  // (one workgroup per CU: nothing to order)
-#define RELAY_ARGS 0, 0, 0, 0, (double*)nullptr, (int*)nullptr, (int*)nullptr  // (the batch shape's two-part updates: not here)
-
+// (one workgroup per CU: nothing to order; the batch shape's several-part updates do not exist here)
 void launch_lds(hipStream_t stream, int n, const DevParams& prm, int lanes, const ScanDesc* descs,
                 const float4* arena, const float4* sorted, const GridTables* tabs, const double* state_in, const double* cov_in, double* state_out, double* a6,
                 double* cov_out, void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof) {
+  lds_full::KernelArgs ka{};
+  ka.prm = prm, ka.descs = descs, ka.tabs = tabs;
+  ka.state_in = state_in, ka.cov_in = cov_in, ka.state_out = state_out, ka.a6_out = a6, ka.cov_out = cov_out;
+  ka.out = (lds_full::OutRec*)out, ka.poses = poses, ka.scan_id_base = scan_id_base, ka.prof_buf = prof;
   if (lanes == 3) {
     if (prof)
-      LINS_LAUNCH(lds_full, 1024, 3, true);
+      launch_args(lds_full::ieskf_lds_kernel<1024, 3, false, true>, n, 1024, stream, ka, arena, sorted, idx_store);
+    else if (prm.pad)
+      launch_args(lds_full::ieskf_lds_kernel<1024, 3, false, false, false, true>, n, 1024, stream, ka, arena, sorted, idx_store);
     else
-      LINS_LAUNCH(lds_full, 1024, 3, false);
+      launch_args(lds_full::ieskf_lds_kernel<1024, 3, false, false, false, false>, n, 1024, stream, ka, arena, sorted, idx_store);
   } else {
     if (prof)
-      LINS_LAUNCH(lds_full, 384, 1, true);
+      launch_args(lds_full::ieskf_lds_kernel<384, 1, false, true>, n, 384, stream, ka, arena, sorted, idx_store);
     else
-      LINS_LAUNCH(lds_full, 384, 1, false);
+      launch_args(lds_full::ieskf_lds_kernel<384, 1, false, false>, n, 384, stream, ka, arena, sorted, idx_store);
   }
 }
 
 void launch_lds_pass(hipStream_t stream, int n, const DevParams& prm, int lanes, const ScanDesc* descs,
                      const float4* arena, const float4* sorted, const GridTables* tabs, const double* lin_state, const double* filt_state, int iter,
                      int4* idx_store, lins_corr* dump, double* sums_out, int* counts_out) {
+  lds_full::KernelArgs ka{};
+  ka.prm = prm, ka.descs = descs, ka.tabs = tabs;
+  ka.state_in = filt_state, ka.lin_in = lin_state, ka.iter_arg = iter;
+  ka.sums_out = sums_out, ka.counts_out = counts_out;
   if (lanes == 3)
-    LINS_LAUNCH_PASS(lds_full, 1024, 3);
+    launch_args(lds_full::ieskf_lds_kernel<1024, 3, true, false>, n, 1024, stream, ka, arena, sorted, idx_store, dump);
   else
-    LINS_LAUNCH_PASS(lds_full, 384, 1);
+    launch_args(lds_full::ieskf_lds_kernel<384, 1, true, false>, n, 384, stream, ka, arena, sorted, idx_store, dump);
 }
 
 }  // namespace lins

@@ -64,6 +64,15 @@
 #include "icp_wave.h"
 #include "ieskf_rowsum.h"
 
+#ifndef LINS_COLD_ARGS
+#define LINS_COLD_ARGS 1
+#endif
+#ifndef LINS_TAIL_STAGED
+#define LINS_TAIL_STAGED 0
+#endif
+#ifndef LINS_TAIL_OOL
+#define LINS_TAIL_OOL 1
+#endif
 #ifndef LINS_SPREAD_S
 // waves the plane / line queries of a 512-thread workgroup are spread over.  Measured on the batch workload (91 plane
 // + 164 line queries on average), one GPU call: 5 / 3 (round 1's choice) 0.692 ms, 4 / 4 0.685, 4 / 3 0.705, 3 / 3 0.711,
@@ -80,6 +89,44 @@ struct OutRec {
   int iters, converged, diverged, m_surf, m_corner, pad[3];
 };
 
+// The kernel's ONE parameter (by value: it lies at offset 0 of the kernarg segment).  Round 3 passed these as 28
+// separate arguments; the compiler loads every argument at the kernel's entry and keeps it in scalar registers to the
+// end — ~60 of the 106 SGPRs a wave has, which the loop then paid for in SGPR spills (568 v_readlane / v_writelane).
+// What the loop needs is read through `ka.`; what only the prologue or the epilogue needs (result pointers, the
+// relay's buffers) is read where it is used through cold_args(): a laundered pointer to the same kernarg bytes, so
+// that those s_loads stay where they are written instead of being hoisted to the entry.
+struct KernelArgs {
+  DevParams prm;
+  const ScanDesc* descs;
+  const int* order;
+  const GridTables* tabs;
+  const double* state_in;
+  const double* cov_in;
+  const double* lin_in;
+  double* state_out;
+  double* a6_out;
+  double* cov_out;
+  OutRec* out;
+  lins_pose_record* poses;
+  double* sums_out;
+  int* counts_out;
+  long long* prof_buf;
+  double* relay_hdr;
+  int* relay_lane;
+  int* relay_flag;
+  int* relay_err;  // one word per context: raised when a hand-over protocol violation was seen (checked at lins_batch_sync)
+  int iter_arg, scan_id_base, relay_n, relay_at, relay_parts, relay_gen;
+  int relay_spins;  // polls of ~1 us a part waits for its hand-over before it runs the whole update on its own
+  int tail_part;    // (tail kernel) the part this launch continues: the head handed over at iteration tail_part x relay_at
+  int tail_dense;   // (tail kernel) 1: dense wave-rounds of 64 queries, 0: the head's own query <-> lane layout (same bits)
+};
+typedef const KernelArgs __attribute__((address_space(4))) * ColdArgs;
+__device__ __forceinline__ ColdArgs cold_args() {
+  auto p = __builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));  // (launder: a load through p cannot move above this point)
+  return (ColdArgs)p;
+}
+
 constexpr int kMaxLWaves = LINS_LDS_WAVES;  // waves of the largest workgroup shape instantiated
 constexpr int kNpCap = LINS_LDS_CAP;   // grid positions (corner cloud first, then surf ring-major) resident in LDS
 constexpr int kNpMax = LINS_LDS_NMAX;  // target points of an eligible scan
@@ -87,6 +134,12 @@ constexpr bool kHybrid = kNpMax > kNpCap;  // positions >= kNpCap live in the so
 constexpr int kScanBatch = LINS_LDS_SCANBATCH;  // points per trip of the scan loops
 static_assert(kNpMax >= kNpCap && kNpMax <= kGridNpMax, "positions are u16, indices u16; the index kernel's cap");
 
+#ifndef LINS_LDS_TAIL
+#define LINS_LDS_TAIL 0
+#endif
+constexpr bool kTail = LINS_LDS_TAIL != 0;
+constexpr int kTailSlots = 384;  // queries of a scan the tail kernel takes (the VLP-16 caps: 144 + 192, SE:727-793)
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 struct LdsStore {
   float4 pt[kNpCap];  // grid-sorted targets, one 16-byte record (x, y, z, original index bits) per position
   GridTables gt;  // cell ends, ring ranges, elevation wedges: copied from the scan's prebuilt index (ieskf_grid.h)
@@ -105,6 +158,12 @@ struct LdsStore {
   int m_surf, m_corner, iter, conv, div, pad;
   long long prof_acc[16];  // phase profile accumulators of the PROF variant (written by thread 0)
   int dbg[4];  // [0] certificate disagreements (verify mode) [1] NN searches skipped [2] walks skipped
+#if LINS_LDS_TAIL
+  // tail kernel: the carried per-query state (CarryWords) of every query of the scan, by query index — a wave takes a
+  // wave-round's queries, loads their state from here and puts it back
+  v4u cw0[kTailSlots], cw1[kTailSlots], cw2[kTailSlots];
+  unsigned cw3[kTailSlots];
+#endif
 };
 static_assert(sizeof(LdsStore) <= LINS_LDS_BYTES, "LDS budget of one workgroup");
 
@@ -594,6 +653,111 @@ __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, boo
   merge_query_lanes<LANES>(c3, lane_base, role, ln);
 }
 
+// ---- the cooperative searches of one wave (LANES == 1 shapes): what the kernel's loop calls -------------------------
+// The cm.n searches a wave needs are served coop_lanes() lanes each; inputs travel from the owner lanes to the serving
+// lanes and the results back by wave shuffles (no LDS, no barrier).  Called by every lane of the wave (wave-uniform cm.n).
+struct NnOut {
+  int pos, ring, pos2, ring2;
+  float lb;
+};
+struct WalkOut {
+  int r2, r2b, r3, r3b;
+  float lb2, lb3;
+};
+__device__ __forceinline__ QueryPolar polar_of(float sx, float sy, float sz, int naz) {
+  QueryPolar qp;
+  qp.rho = sqrtf(sx * sx + sy * sy);
+  qp.qn3 = sqrtf(qp.rho * qp.rho + sz * sz);
+  qp.el = atan2f(sz, qp.rho);
+  qp.inv_unused = 0.f;
+  qp.a0_surf_or_corner = az_bin_lds(sx, sy, naz);
+  return qp;
+}
+__device__ __forceinline__ NnOut coop_nn(const LdsStore& L, const LCloud& c, const CoopMap& cm, int coop_cap, bool need_nn, int lane, float sx,
+                                         float sy, float sz, const QueryPolar& qp, int rq, int a1, int ra1, float thr, float margin,
+                                         bool skip) {
+  // lanes per search: as many as the wave can give each of its cm.n searches, a power of two
+  const int ln = coop_lanes(cm.n, coop_cap);
+  const int wrole = lane & (ln - 1), wbase = lane - wrole, item = lane / ln;
+  bool valid = need_nn;
+  float isx = sx, isy = sy, isz = sz;
+  QueryPolar iq = qp;
+  int i_rq = rq, i_a1 = a1, i_ra1 = ra1;  // (the kind is the wave-round's: nothing to ship)
+  if (ln > 1) {  // the inputs of search `item` travel from its owner to the ln lanes that serve it
+    valid = item < cm.n;
+    const int owner = __shfl(cm.owner_map, valid ? item : 0);
+    isx = __shfl(sx, owner), isy = __shfl(sy, owner), isz = __shfl(sz, owner);
+    iq.rho = __shfl(qp.rho, owner), iq.qn3 = __shfl(qp.qn3, owner), iq.el = __shfl(qp.el, owner);
+    iq.a0_surf_or_corner = __shfl(qp.a0_surf_or_corner, owner);
+    i_rq = __shfl(i_rq, owner);
+    i_a1 = __shfl(a1, owner), i_ra1 = __shfl(ra1, owner);
+  }
+  Best bb = best_init(thr);
+  if (valid && !skip)  // (profiling aid: LINS_DEBUG_SKIP=2 skips the search, 1 skips the walk)
+    bb = nn_lds<0>(L, c, isx, isy, isz, iq, thr, margin, i_rq, ln, wrole, wbase, i_a1, i_ra1);
+  NnOut r{bb.pos, bb.ring, bb.pos2, bb.ring2, cert_lb(bb, thr, margin)};
+  if (ln > 1) {  // hand back: the owner of rank r reads the first lane of group r
+    const int src = (cm.rank * ln) & 63;
+    r.pos = __shfl(r.pos, src), r.ring = __shfl(r.ring, src);
+    r.pos2 = __shfl(r.pos2, src), r.ring2 = __shfl(r.ring2, src), r.lb = __shfl(r.lb, src);
+  }
+  return r;
+}
+__device__ __forceinline__ WalkOut coop_walk(const LdsStore& L, const LCloud& c, bool is_surf, int nq, const CoopMap& cm, int coop_cap,
+                                             bool need_walk, int lane, float sx, float sy, float sz, const QueryPolar& qp, int j1, int rho1,
+                                             int w2, int w3, bool nn_changed, float thr, float margin, bool skip) {
+  const int ln = coop_lanes(cm.n, coop_cap);
+  const int wrole = lane & (ln - 1), wbase = lane - wrole, item = lane / ln;
+  bool valid = need_walk;
+  float isx = sx, isy = sy, isz = sz;
+  QueryPolar iq = qp;
+  int i_j1 = j1, i_rho1 = rho1, i_w2 = w2, i_w3 = w3, i_chk = nn_changed;
+  if (ln > 1) {
+    valid = item < cm.n;
+    const int owner = __shfl(cm.owner_map, valid ? item : 0);
+    isx = __shfl(sx, owner), isy = __shfl(sy, owner), isz = __shfl(sz, owner);
+    iq.rho = __shfl(qp.rho, owner), iq.qn3 = __shfl(qp.qn3, owner), iq.el = __shfl(qp.el, owner);
+    iq.a0_surf_or_corner = __shfl(qp.a0_surf_or_corner, owner);
+    i_j1 = __shfl(j1, owner), i_rho1 = __shfl(rho1, owner);
+    i_w2 = __shfl(w2, owner), i_w3 = __shfl(w3, owner), i_chk = __shfl((int)nn_changed, owner);
+  }
+  Best c2 = best_init(thr), c3 = c2;
+  if (valid && !skip)
+    walk_lds<0>(L, c, is_surf, nq, thr, i_j1, i_rho1, isx, isy, isz, iq, margin, ln, wrole, wbase, i_w2, i_w3, i_chk != 0, c2, c3);
+  WalkOut r{c2.pos, c2.pos2, c3.pos, c3.pos2, cert_lb(c2, thr, margin), cert_lb(c3, thr, margin)};
+  if (ln > 1) {
+    const int src = (cm.rank * ln) & 63;
+    r.r2 = __shfl(r.r2, src), r.r2b = __shfl(r.r2b, src), r.r3 = __shfl(r.r3, src), r.r3b = __shfl(r.r3b, src);
+    r.lb2 = __shfl(r.lb2, src), r.lb3 = __shfl(r.lb3, src);
+  }
+  return r;
+}
+// one target cloud's grid view of the workgroup's LDS block (cs / cc of the kernel)
+__device__ __forceinline__ LCloud make_cloud(const LdsStore& L, bool is_surf, const float4* gs, int n_corner_t, int n_surf_t, int n_lds) {
+  return is_surf ? LCloud{L.gt.cell_end + kCellsCorner, L.gt.ring_start[0], &L.gt.el_ang[0][0], kAzSurf, 1, n_corner_t, n_surf_t, gs, n_lds}
+                 : LCloud{L.gt.cell_end, L.gt.ring_start[1], &L.gt.el_ang[1][0], kAzCorner, kAzSurf / kAzCorner, 0, n_corner_t, gs, n_lds};
+}
+// The tail kernel's searches, OUT OF LINE: there they are rare (> 99 % of the late iterations' selections are certified),
+// and inlined their registers (three running bests, windows, the lane merges) are the loop's — which then has none left
+// for the six candidate records it keeps in flight.  As calls, a wave pays their register saves when it searches.
+// (the polar view of the query is only needed here: the tail's loop does not compute it)
+__device__ __noinline__ NnOut coop_nn_ool(bool is_surf, const float4* gs, int n_corner_t, int n_surf_t, int n_lds, int cm_n, int cm_rank,
+                                          int cm_owner_map, int coop_cap, bool need_nn, int lane, float sx, float sy, float sz, int rq,
+                                          int a1, int ra1, float thr, float margin, bool skip) {
+  const LdsStore& L = g_lds;
+  const LCloud c = make_cloud(L, is_surf, gs, n_corner_t, n_surf_t, n_lds);
+  return coop_nn(L, c, CoopMap{cm_n, cm_rank, cm_owner_map}, coop_cap, need_nn, lane, sx, sy, sz, polar_of(sx, sy, sz, c.naz), rq, a1, ra1, thr,
+                 margin, skip);
+}
+__device__ __noinline__ WalkOut coop_walk_ool(bool is_surf, const float4* gs, int n_corner_t, int n_surf_t, int n_lds, int nq, int cm_n,
+                                              int cm_rank, int cm_owner_map, int coop_cap, bool need_walk, int lane, float sx, float sy,
+                                              float sz, int j1, int rho1, int w2, int w3, bool nn_changed, float thr, float margin, bool skip) {
+  const LdsStore& L = g_lds;
+  const LCloud c = make_cloud(L, is_surf, gs, n_corner_t, n_surf_t, n_lds);
+  return coop_walk(L, c, is_surf, nq, CoopMap{cm_n, cm_rank, cm_owner_map}, coop_cap, need_walk, lane, sx, sy, sz, polar_of(sx, sy, sz, c.naz),
+                   j1, rho1, w2, w3, nn_changed, thr, margin, skip);
+}
+
 // ---- grid load: the scan's prebuilt index (grid_index_kernel, ieskf_grid.hip — the reference's setInputCloud,
 // SE:1156-1160, outside performIESKF) into LDS: the tables and the first n_lds records of the sorted copy as 16-byte
 // words, every read of a thread in flight before its first LDS write (~1 HBM round trip per scan).  Ends with a
@@ -930,9 +1094,9 @@ __device__ __noinline__ void joseph_epilogue(double r2, int diverged, double* __
 // state (lins_correspondences / lins_reduce_pass), dumping records / sums.
 // ---------------------------------------------------------------------------
 // Hand-over words of the relay (below) cross workgroups — possibly XCDs, whose L2s are not coherent with one another for
-// ordinary accesses inside a kernel — as agent-scope relaxed atomics: each access carries the cache policy that makes it
-// coherent at device scope (sc1), instead of fences that write back / invalidate a whole L2 per workgroup (measured:
-// with __threadfence() on both sides the launch took 0.97 instead of 0.67 ms).
+// ordinary accesses inside a kernel — as agent-scope relaxed atomics / sc1 buffer accesses: each access carries the cache
+// policy that makes it coherent at device scope (sc1), instead of fences that write back / invalidate a whole L2 per
+// workgroup (measured: with __threadfence() on both sides the launch took 0.97 instead of 0.67 ms).
 __device__ __forceinline__ void relay_st(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int relay_ld(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void relay_st(double* p, double v) {
@@ -941,23 +1105,70 @@ __device__ __forceinline__ void relay_st(double* p, double v) {
 __device__ __forceinline__ double relay_ld(const double* p) {
   return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+// A scan's flag only ever rises within a launch (16 gen + next part ... 16 gen + 15 = finished): raised with an atomic
+// max, so that a part that hands over late cannot take back the "finished" of a workgroup that ran the update alone.
+__device__ __forceinline__ void relay_raise(int* p, int v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <int BLOCK, int LANES, bool PASS_ONLY, bool PROF, bool ICP = false>
+// The per-query loop state a part hands to the next (and the tail kernel keeps in LDS between its wave-rounds): the
+// tracked candidates of the three selections as 16-bit grid positions (< 12288; -1 = none), the rings of the nearest
+// neighbour's two candidates, the certificates' bounds and the query positions they were established at: 13 words
+// (round 3 stored 18 words as 18 four-byte device-scope stores per lane, each a fabric write of its own: 264 MB written
+// per launch for 37 MB of hand-over).  In global memory: [scan][4][512 head lanes] 16-byte words, written and read as
+// dwordx4 with sc1 through a buffer descriptor — one 1 KB store per wave and word.
+struct CarryWords {
+  v4u w0, w1, w2;
+  unsigned w3;
+};
+constexpr int kRelayLanes = 512;                    // lanes of the head kernel: the hand-over is indexed by head lane
+constexpr int kRelayLaneInts = 4 * kRelayLanes * 4;  // ints per scan in relay_lane
+__device__ __forceinline__ void relay_st_carry(int* scan_base /*wave-uniform*/, int head_lane, const CarryWords& c) {
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(scan_base, 0, kRelayLaneInts * 4, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(c.w0, rs, (0 * kRelayLanes + head_lane) * 16, 0, 16);  // (aux 16 = sc1)
+  __builtin_amdgcn_raw_buffer_store_b128(c.w1, rs, (1 * kRelayLanes + head_lane) * 16, 0, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(c.w2, rs, (2 * kRelayLanes + head_lane) * 16, 0, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(v4u{c.w3, 0u, 0u, 0u}, rs, (3 * kRelayLanes + head_lane) * 16, 0, 16);
+}
+// (out of line: the packing arithmetic then cannot be scheduled into the loop the values come out of — inlined it cost the
+// batch kernel sixteen more spilled registers)
+__device__ __noinline__ void relay_out_carry(int* scan_base, int head_lane, int a1, int b1c, int ra1, int rb1, int a2, int b2c, int a3,
+                                             int b3c, int sel1, float lb1, float lb2, float lb3, float ca0, float ca1, float ca2, float cb0,
+                                             float cb1, float cb2) {
+  CarryWords c;
+  c.w0 = v4u{((unsigned)a1 & 0xFFFFu) | ((unsigned)b1c << 16), ((unsigned)a2 & 0xFFFFu) | ((unsigned)b2c << 16),
+             ((unsigned)a3 & 0xFFFFu) | ((unsigned)b3c << 16),
+             ((unsigned)sel1 & 0xFFFFu) | (((unsigned)ra1 & 0xFFu) << 16) | ((unsigned)rb1 << 24)};
+  c.w1 = v4u{__float_as_uint(lb1), __float_as_uint(lb2), __float_as_uint(lb3), __float_as_uint(ca0)};
+  c.w2 = v4u{__float_as_uint(ca1), __float_as_uint(ca2), __float_as_uint(cb0), __float_as_uint(cb1)};
+  c.w3 = __float_as_uint(cb2);
+  relay_st_carry(scan_base, head_lane, c);
+}
+__device__ __forceinline__ CarryWords relay_ld_carry(const int* scan_base /*wave-uniform*/, int head_lane) {
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(scan_base), 0, kRelayLaneInts * 4, 0x00020000);
+  CarryWords c;
+  c.w0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (0 * kRelayLanes + head_lane) * 16, 0, 16);
+  c.w1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (1 * kRelayLanes + head_lane) * 16, 0, 16);
+  c.w2 = __builtin_amdgcn_raw_buffer_load_b128(rs, (2 * kRelayLanes + head_lane) * 16, 0, 16);
+  c.w3 = __builtin_amdgcn_raw_buffer_load_b32(rs, (3 * kRelayLanes + head_lane) * 16, 0, 16);
+  return c;
+}
+
+// KNOBS: the counting aids and test modes of LINS_DEBUG_SKIP (DevParams::pad) compiled in.  The production instantiations
+// of the update kernels are built without them — twenty-odd tests of a run-time word in the hottest code of a kernel that is
+// short of scalar registers; the launchers take the KNOBS twin whenever pad != 0 (tools/, the certificate tests).
+template <int BLOCK, int LANES, bool PASS_ONLY, bool PROF, bool ICP = false, bool KNOBS = true>
 #if LINS_LDS_MINW > 1
 // (second argument: waves per SIMD the register allocation must allow)
 __global__ __launch_bounds__(BLOCK, LINS_LDS_MINW) void ieskf_lds_kernel(
 #else
 __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #endif
-    DevParams prm, const ScanDesc* __restrict__ descs, const int* __restrict__ order, const float4* __restrict__ arena,
-    const float4* __restrict__ sorted, const GridTables* __restrict__ tabs,
-    const double* __restrict__ state_in, const double* __restrict__ cov_in, const double* __restrict__ lin_in,
-    int iter_arg, double* __restrict__ state_out, double* __restrict__ a6_out, double* __restrict__ cov_out,
-    OutRec* __restrict__ out,
-    int4* __restrict__ idx_store, lins_pose_record* __restrict__ poses, int scan_id_base,
-    lins_corr* __restrict__ dump, double* __restrict__ sums_out, int* __restrict__ counts_out,
-    long long* __restrict__ prof_buf,
-    int relay_n, int relay_at, int relay_parts, int relay_gen, double* relay_hdr, int* relay_lane, int* relay_flag) {
+    const KernelArgs ka, const float4* __restrict__ arena, const float4* __restrict__ sorted, int4* __restrict__ idx_store,
+    lins_corr* __restrict__ dump) {
+  // (the four pointers the loop reads and writes through stay parameters of their own: only a parameter carries
+  // `noalias`, and without it the register allocation of every instantiation got worse)
+  const DevParams prm = ka.prm;
+  const int relay_n = ka.relay_n, relay_at = ka.relay_at, relay_parts = ka.relay_parts;
+  const int pad = KNOBS ? prm.pad : 0;  // (debug / counting flags: a constant 0 in the production instantiations)
   constexpr bool prof = PROF;  // phase profile compiled in only for the debug variant
   constexpr int kLBlock = BLOCK, kQPerWave = 64 / LANES, kQPerRound = (BLOCK / 64) * kQPerWave;
   static_assert(BLOCK >= 256 && BLOCK / 64 <= kMaxLWaves, "block shape");
@@ -969,7 +1180,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   // [6..9] thread 0's own de-skew / NN / walk / geometry  [10..15] per-iteration time of iterations 0..5
   if (prof && threadIdx.x < 16) g_lds.prof_acc[threadIdx.x] = 0;
   const long long t_begin = prof ? clock64() : 0, t_wall_begin = prof ? wall_clock64() : 0;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave: a scalar)
   // Launch order: workgroup b takes scan order[b] — the host lists the scans longest-expected-first (lins_capi.hip
   // launch_order: by the prior's translation, the best predictor of a scan's search work the host has), so that the
   // dispatcher, which hands workgroups out in index order as slots free up, ends the launch with the short ones.
@@ -983,48 +1194,68 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   // (per XCD), so the part a workgroup waits for is resident or done before the waiting one starts: the wait cannot
   // starve its producer.  Same arithmetic in the same order: results do not depend on the cuts, bit for bit
   // (tests/test_gpu_parity.py test_two_part_updates_return_the_whole_updates_bits).
-  constexpr bool kRelay = BLOCK == 512 && LANES == 1 && !PASS_ONLY && !ICP;
+  constexpr bool kRelay = BLOCK == 512 && LANES == 1 && !PASS_ONLY && !ICP && !kTail;
+  static_assert(!kTail || (LANES == 1 && !PASS_ONLY && !ICP && BLOCK == 256), "the tail kernel's shape");
   // (with the relay on, the launch list has relay_parts x relay_n entries: scan | part << 27 — a part anywhere behind
   // the part before it; part p runs iterations [p relay_at, (p + 1) relay_at), the last one to the end.  Flag of a scan:
-  // 16 gen + p once part p - 1 has handed over, 16 gen + 15 once the update is finished.)
-  const int entry = order ? order[blockIdx.x] : (int)blockIdx.x;
-  const int part = (kRelay && relay_n > 0) ? entry >> 27 : 0, scan = (kRelay && relay_n > 0) ? entry & 0x7FFFFFF : entry;
-  if (kRelay && part) {
-    // (the wait is bounded: ~0.3 s, two orders beyond any launch.  A hand-over that has not come by then means the
-    // assumption about the dispatcher — blocks handed out in list order — does not hold on this device: the kernel
-    // aborts (the host sees a launch failure) instead of holding the device.  A version in which the waiting
-    // workgroup then ran the whole update on its own cost the loop ten more spilled registers: +5 % kernel time.)
+  // 16 gen + p once part p - 1 has handed over, 16 gen + 15 once the update is finished; it only ever rises.)
+  // The TAIL kernel (ieskf_lds_tail.hip; kTail) is the last part as a launch of its own behind the head's on the same
+  // stream: stream order replaces the wait, the hand-over is the same.
+  const int entry = ka.order ? ka.order[blockIdx.x] : (int)blockIdx.x;
+  int part = kTail ? ka.tail_part : ((kRelay && relay_n > 0) ? entry >> 27 : 0);
+  const int scan = (kRelay && relay_n > 0) ? entry & 0x7FFFFFF : entry;
+  bool solo = false;  // (uniform) this workgroup runs the update from its start to its end, wherever the list put it
+  if ((kRelay && part) || kTail) {
+    // The wait is bounded (relay_spins polls of ~1 us).  Blocks are handed out in list order on the devices this was
+    // measured on, but nothing in HIP promises that: a hand-over that has not come by then — the part before not yet
+    // resident because another process, a debugger or a different dispatcher changed the order — makes THIS workgroup
+    // run the whole update on its own (part 0, no cuts; same arithmetic, same bits) and mark the scan finished; whoever
+    // else holds a part of that scan then finds nothing to do, or finds its own hand-over missing and does the same.
+    // Degraded, never stuck, never aborted (round 3 ended this wait in __builtin_trap()).
+    const int want = ka.relay_gen * 16 + part;
     if (tid == 0) {
-      int f, spins = 0;
-      while ((f = relay_ld(relay_flag + scan)) < relay_gen * 16 + part && ++spins < (1 << 18)) __builtin_amdgcn_s_sleep(32);
-      if (f < relay_gen * 16 + part) __builtin_trap();
+      int f = relay_ld(ka.relay_flag + scan);
+      if (!kTail)
+        for (int spins = 0; f < want && spins < ka.relay_spins; ++spins) {
+          __builtin_amdgcn_s_sleep(32);
+          f = relay_ld(ka.relay_flag + scan);
+        }
       L.scan_tmp[0] = f;
     }
     __syncthreads();
-    if (L.scan_tmp[0] != relay_gen * 16 + part) return;  // an earlier part finished the scan (stop rule, divergence)
+    const int f = L.scan_tmp[0];
+    if (f > want) return;  // the scan is finished (stop rule, divergence, or somebody ran it alone)
+    if (f < want) {
+      if (kTail) {  // (cannot happen behind the head's launch: every scan was handed over or finished)
+        if (tid == 0) atomicAdd(ka.relay_err, 1);
+        return;
+      }
+      part = 0, solo = true;
+    }
+    __syncthreads();  // (scan_tmp is reused below)
   }
-  const ScanDesc sd = descs[scan];
+  const ScanDesc sd = ka.descs[scan];
   const int total = sd.n_surf_q + sd.n_corner_q;
   // hybrid storage: this scan's slice of the sorted copy (same offsets as its targets in the arena:
   // the corner targets follow the surf targets, so positions 0 .. n_all-1 fit)
   const float4* const gs = sorted + sd.off_surf_t;
   const int n_all_t = sd.n_surf_t + sd.n_corner_t, n_lds = n_all_t < kNpCap ? n_all_t : kNpCap;
 
-  for (int k = tid; k < 324; k += kLBlock) L.P[k] = (PASS_ONLY || ICP) ? 0.0 : cov_in[(size_t)scan * 324 + k];
+  for (int k = tid; k < 324; k += kLBlock) L.P[k] = (PASS_ONLY || ICP) ? 0.0 : ka.cov_in[(size_t)scan * 324 + k];
   if (tid < 19) {
-    double v = state_in[(size_t)scan * 19 + tid];
+    double v = ka.state_in[(size_t)scan * 19 + tid];
     L.filt[tid] = v;
-    L.ic.lin[tid] = PASS_ONLY ? lin_in[(size_t)scan * 19 + tid] : v;
+    L.ic.lin[tid] = PASS_ONLY ? ka.lin_in[(size_t)scan * 19 + tid] : v;
   }
   if (tid < 28) L.sums[tid] = 0;
   if (tid == 64) lins_sinc_cos_table(L.trig);
   if (tid == 0) {
     L.res_prev = 1e6, L.res_last = 0, L.upd_norm = 0;
-    L.iter = PASS_ONLY ? iter_arg : 0, L.conv = 0, L.div = 0, L.m_surf = 0, L.m_corner = 0;
+    L.iter = PASS_ONLY ? ka.iter_arg : 0, L.conv = 0, L.div = 0, L.m_surf = 0, L.m_corner = 0;
     L.dbg[0] = L.dbg[1] = L.dbg[2] = L.dbg[3] = 0;
   }
   __syncthreads();
-  if (tid < 64 && !(kRelay && part)) {  // wave 0, lane-redundant: constants of the first iteration (a second part takes them over)
+  if (tid < 64 && !((kRelay && part) || kTail)) {  // wave 0, lane-redundant: constants of the first iteration (a later part takes them over)
     IterConst ic;
     double filt[19];
     for (int k = 0; k < 19; ++k) ic.lin[k] = L.ic.lin[k], filt[k] = L.filt[k];
@@ -1034,7 +1265,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       for (int k = 0; k < 18; ++k) L.ic.d[k] = ic.d[k];
     }
   }
-  load_lds_grid<BLOCK>(tabs + scan, gs, n_lds, tid);  // ends with a barrier
+  load_lds_grid<BLOCK>(ka.tabs + scan, gs, n_lds, tid);  // ends with a barrier
   if (prof && tid == 0) L.prof_acc[0] = clock64() - t_begin;
 
   const LCloud cs{L.gt.cell_end + kCellsCorner, L.gt.ring_start[0], &L.gt.el_ang[0][0], kAzSurf, 1, sd.n_corner_t, sd.n_surf_t,
@@ -1055,22 +1286,57 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   bool searched = false;  // a search iteration has run: certificates and warm candidates exist (uniform)
   constexpr int kRelayHdr = 64;  // doubles per scan: IterConst (58), res_prev, res_last, upd_norm, then 6 ints
   static_assert(sizeof(IterConst) == 58 * sizeof(double), "relay header layout");
-  if (kRelay && part) {  // relay_in: the loop state the part before left (the barrier of the grid load has passed)
-    const double* h = relay_hdr + (size_t)scan * kRelayHdr;
+  // carried state <-> its 13 hand-over words (CarryWords)
+  auto carry_pack = [&]() {
+    CarryWords c;
+    c.w0 = v4u{((unsigned)a1 & 0xFFFFu) | ((unsigned)b1c << 16), ((unsigned)a2 & 0xFFFFu) | ((unsigned)b2c << 16),
+               ((unsigned)a3 & 0xFFFFu) | ((unsigned)b3c << 16),
+               ((unsigned)sel1 & 0xFFFFu) | (((unsigned)ra1 & 0xFFu) << 16) | ((unsigned)rb1 << 24)};
+    c.w1 = v4u{__float_as_uint(lb1), __float_as_uint(lb2), __float_as_uint(lb3), __float_as_uint(certA[0])};
+    c.w2 = v4u{__float_as_uint(certA[1]), __float_as_uint(certA[2]), __float_as_uint(certB[0]), __float_as_uint(certB[1])};
+    c.w3 = __float_as_uint(certB[2]);
+    return c;
+  };
+  auto carry_unpack = [&](const CarryWords& c) {
+    a1 = (int)(short)(c.w0.x & 0xFFFFu), b1c = (int)c.w0.x >> 16;  // (-1 <-> 0xFFFF: positions are < 12288)
+    a2 = (int)(short)(c.w0.y & 0xFFFFu), b2c = (int)c.w0.y >> 16;
+    a3 = (int)(short)(c.w0.z & 0xFFFFu), b3c = (int)c.w0.z >> 16;
+    sel1 = (int)(short)(c.w0.w & 0xFFFFu), ra1 = (int)(signed char)((c.w0.w >> 16) & 0xFFu), rb1 = (int)c.w0.w >> 24;
+    lb1 = __uint_as_float(c.w1.x), lb2 = __uint_as_float(c.w1.y), lb3 = __uint_as_float(c.w1.z);
+    certA[0] = __uint_as_float(c.w1.w), certA[1] = __uint_as_float(c.w2.x), certA[2] = __uint_as_float(c.w2.y);
+    certB[0] = __uint_as_float(c.w2.z), certB[1] = __uint_as_float(c.w2.w), certB[2] = __uint_as_float(c.w3);
+  };
+  static_assert(kGridNpMax < 32768, "grid positions travel as signed 16-bit words");
+  if ((kRelay && part) || kTail) {  // take-over: the loop state the part before left (the barrier of the grid load has passed)
+    const double* h = ka.relay_hdr + (size_t)scan * kRelayHdr;
     if (tid < 58) reinterpret_cast<double*>(&L.ic)[tid] = relay_ld(h + tid);
     if (tid == 64) L.res_prev = relay_ld(h + 58), L.res_last = relay_ld(h + 59), L.upd_norm = relay_ld(h + 60);
     if (tid == 65) {
       const int* hi = reinterpret_cast<const int*>(h + 61);
       L.iter = relay_ld(hi), L.dbg[0] = relay_ld(hi + 1), L.dbg[1] = relay_ld(hi + 2), L.dbg[2] = relay_ld(hi + 3), L.dbg[3] = relay_ld(hi + 4);
     }
-    const int* ln = relay_lane + (size_t)scan * 18 * BLOCK + tid;
-    int w[18];
+    const int* ln = ka.relay_lane + (size_t)scan * kRelayLaneInts;
+    if constexpr (kTail) {
+#if LINS_LDS_TAIL
+      // every head lane's words go to the LDS slot of its query (the head's layout: plane queries spread over its first
+      // LINS_SPREAD_S waves, line queries over the other LINS_SPREAD_C — the host only sends scans laid out that way)
+      const int ps = (sd.n_surf_q + LINS_SPREAD_S - 1) / LINS_SPREAD_S, pc = (sd.n_corner_q + LINS_SPREAD_C - 1) / LINS_SPREAD_C;
 #pragma unroll
-    for (int k = 0; k < 18; ++k) w[k] = relay_ld(ln + k * BLOCK);
-    a1 = w[0], b1c = w[1], ra1 = w[2], rb1 = w[3], a2 = w[4], b2c = w[5], a3 = w[6], b3c = w[7], sel1 = w[8];
-    lb1 = __int_as_float(w[9]), lb2 = __int_as_float(w[10]), lb3 = __int_as_float(w[11]);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) certA[k] = __int_as_float(w[12 + k]), certB[k] = __int_as_float(w[15 + k]);
+      for (int hl = tid; hl < kRelayLanes; hl += BLOCK) {
+        const int w = hl >> 6, l = hl & 63;
+        const bool ks = w < LINS_SPREAD_S;
+        const int q = ks ? w * ps + l : (w - LINS_SPREAD_S) * pc + l;
+        if (l < (ks ? ps : pc) && q < (ks ? sd.n_surf_q : sd.n_corner_q)) {
+          const CarryWords c = relay_ld_carry(ln, hl);
+          const int slot = (ks ? 0 : sd.n_surf_q) + q;
+          L.cw0[slot] = c.w0, L.cw1[slot] = c.w1, L.cw2[slot] = c.w2, L.cw3[slot] = c.w3;
+        }
+      }
+      for (int k = tid; k < kMaxLWaves * 28; k += BLOCK) L.partial[k] = 0.0;  // (wave-rounds a scan does not have stay 0)
+#endif
+    } else {
+      carry_unpack(relay_ld_carry(ln, tid));
+    }
     searched = true;
     __syncthreads();
   }
@@ -1079,7 +1345,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   for (;;) {
     const int iter = L.iter;
     if (!PASS_ONLY && (iter >= prm.num_iter || L.conv || L.div)) break;
-    if (kRelay && relay_n > 0 && part + 1 < relay_parts && iter >= (part + 1) * relay_at) {
+    if (kRelay && relay_n > 0 && !solo && part + 1 < relay_parts && iter >= (part + 1) * relay_at) {
       relay_out = true;
       break;
     }
@@ -1090,33 +1356,48 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     double acc = 0;
     int ms = 0, mc = 0;
     long long t0 = prof ? clock64() : 0, t1 = t0, t2 = t0, t3 = t0;
-    // Query -> lane layout.  When both kinds fit one round with the corner queries starting on
-    // a wave boundary, do that: no wave then mixes plane and line code paths.
+    // Query -> lane layout.
+    // LANES == 1: WAVE-ROUNDS — a wave takes, per round, up to 64 queries of ONE kind (plane or line), so that the kind, the
+    // target cloud's grid (LCloud) and every branch on them are wave-uniform: scalar selects and scalar branches instead of
+    // per-lane selects with both clouds' parameters live across the search code (the round-3 kernel sat at the 106-SGPR
+    // limit with ~280 v_readlane / v_writelane in the per-iteration path for it).  One lane per query means a wave runs
+    // the union of its lanes' search paths, so its time grows with the number of active lanes: when they fit, the plane
+    // queries (the costlier kind: two walks over five rings) are spread evenly over the first kSpreadSurf waves and the
+    // line queries over the rest — one round, the lane <-> query mapping fixed for the whole update.  Larger query sets:
+    // dense wave-rounds of 64, dealt to the waves round after round (nothing carries over between iterations then).
+    // LANES == 3: when both kinds fit one round with the corner queries starting on a wave boundary, do that: no wave
+    // then mixes plane and line code paths.
     int surf_waves = (sd.n_surf_q + kQPerWave - 1) / kQPerWave;
     const bool aligned = surf_waves * kQPerWave + sd.n_corner_q <= kQPerRound;
-    // One lane per query: a wave runs the union of its lanes' search paths, so its time grows with
-    // the number of active lanes — spread the queries over ALL waves instead of filling them one by
-    // one: plane queries (the costlier kind: two walks over five rings) evenly over the first
-    // kSpreadSurf waves, line queries evenly over the rest.
     constexpr int kWaves = BLOCK / 64, kSpreadSurf = LINS_SPREAD_S > 0 && BLOCK == 512 ? LINS_SPREAD_S : (kWaves * 5 + 4) / 8;
-    int spread_s = 0, spread_c = 0;  // queries per wave of either kind (0 = not spread)
+    int wr_ns = 0, wr_per_s = 64, wr_per_c = 64, n_wr = 0;  // wave-rounds of plane queries, queries per wave-round of either kind, wave-rounds
     if (LANES == 1) {
-      const int ws = kSpreadSurf, wc = LINS_SPREAD_C > 0 && BLOCK == 512 ? LINS_SPREAD_C : kWaves - ws;
+      // (the tail kernel's four waves walk the HEAD's eight wave-rounds, two each — the same lanes in the same reduction
+      // tree: the same bits — or, tail_dense, wave-rounds of 64)
+      constexpr int ws = kTail ? LINS_SPREAD_S : kSpreadSurf;
+      constexpr int wc = kTail ? LINS_SPREAD_C : (LINS_SPREAD_C > 0 && BLOCK == 512 ? LINS_SPREAD_C : kWaves - ws);
       const int ps = (sd.n_surf_q + ws - 1) / ws, pc = wc > 0 ? (sd.n_corner_q + wc - 1) / wc : 65;
-      if (ws < kWaves && ps <= 64 && pc <= 64) spread_s = ps, spread_c = pc, surf_waves = ws;
+      if ((kTail || ws < kWaves) && ps <= 64 && pc <= 64 && !(kTail && ka.tail_dense))
+        wr_ns = ws, wr_per_s = ps, wr_per_c = pc, n_wr = ws + wc;
+      else
+        wr_ns = (sd.n_surf_q + 63) >> 6, n_wr = wr_ns + ((sd.n_corner_q + 63) >> 6);
     }
-    const bool spread = LANES == 1 && (spread_s | spread_c) != 0;
-    const int span = spread ? kQPerRound : (aligned ? surf_waves * kQPerWave + sd.n_corner_q : total);  // row slots in use
+    const int span = LANES == 1 ? ((n_wr + kWaves - 1) / kWaves) * kQPerRound
+                                : (aligned ? surf_waves * kQPerWave + sd.n_corner_q : total);  // row slots in use
     int4 held = make_int4(0, 0, 0, -1);  // (ICP, ICP_FREQ > 1, single round) a corner triplet waiting for the plane-row count
     for (int base = 0; base < span; base += kQPerRound) {
       const int vslot = base + wave * kQPerWave + q_in_wave;  // position in the (padded) layout
       int slot = vslot;                                        // query index: surf first, then corner
       bool active = lane_used && vslot < span;
-      if (spread) {
-        if (wave < surf_waves)
-          slot = wave * spread_s + lane, active = lane < spread_s && slot < sd.n_surf_q;
-        else
-          slot = sd.n_surf_q + (wave - surf_waves) * spread_c + lane, active = lane < spread_c && slot < total;
+      bool kind_s = true;  // (LANES == 1) this wave-round's kind, wave-uniform
+      int wr_k = 0;        // (LANES == 1) this wave's wave-round
+      if (LANES == 1) {
+        const int k = wr_k = (base / kQPerRound) * kWaves + wave;
+        if (kTail && k >= n_wr) continue;  // (wave-uniform; nothing below synchronises the workgroup)
+        kind_s = k < wr_ns;
+        const int q0 = kind_s ? k * wr_per_s : (k - wr_ns) * wr_per_c;
+        const int left = (kind_s ? sd.n_surf_q : sd.n_corner_q) - q0, per = kind_s ? wr_per_s : wr_per_c;
+        slot = (kind_s ? 0 : sd.n_surf_q) + q0 + lane, active = lane < (left < per ? left : per);
       } else if (aligned) {
         if (wave < surf_waves)
           active = active && vslot < sd.n_surf_q;
@@ -1124,7 +1405,11 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           slot = vslot - surf_waves * kQPerWave + sd.n_surf_q;
       }
       double row[7] = {0, 0, 0, 0, 0, 0, 0};
-      if (span > kQPerRound) {  // several rounds: the lane <-> query mapping changes, nothing carries over
+      if constexpr (kTail) {  // the carried state of this wave-round's queries lives in LDS between the rounds
+#if LINS_LDS_TAIL
+        if (active) carry_unpack(CarryWords{L.cw0[slot], L.cw1[slot], L.cw2[slot], L.cw3[slot]});
+#endif
+      } else if (span > kQPerRound) {  // several rounds: the lane <-> query mapping changes, nothing carries over
         a1 = b1c = ra1 = rb1 = a2 = b2c = a3 = b3c = sel1 = -1, have_cert = false;
         lb1 = lb2 = lb3 = 0.f;
       }
@@ -1134,14 +1419,14 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         // search are then served several lanes at a time (inputs and results travel by bpermute, no LDS
         // and no barrier): a wave's search time follows the number of searches it really has to run, not
         // the union of 64 independent control flows.
-        const bool is_surf = slot < sd.n_surf_q;
+        const bool is_surf = kind_s;  // (wave-uniform)
         const int qi = is_surf ? slot : slot - sd.n_surf_q;
         const LCloud& c = is_surf ? cs : cc;
         const float thr = prm.nearest_f;
-        const bool single_round = span <= kQPerRound;  // (the lane <-> query mapping is fixed)
-        const bool warm_iter = single_round && searched;  // certificates / warm candidates exist (uniform)
+        const bool single_round = kTail || span <= kQPerRound;  // (the lane <-> query mapping is fixed, or the state travels with the query)
+        const bool warm_iter = kTail || (single_round && searched);  // certificates / warm candidates exist (uniform)
         const float margin = warm_iter ? prm.margin_warm : prm.margin_cold;
-        const bool verify = (prm.pad & 8) != 0;  // test aid: search anyway and count disagreements
+        const bool verify = (pad & 8) != 0;  // test aid: search anyway and count disagreements
         // the cold iteration searches for every query: one lane each (more lanes per wave cost more than the shorter
         // chains give back — measured); afterwards only the uncertified queries search, up to kCoopMaxLanes lanes each
         const int coop_cap = warm_iter ? kCoopMaxLanes : LINS_COOP_COLD;
@@ -1155,13 +1440,28 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         QueryPolar qp = {0.f, 0.f, 0.f, 0.f, 0};
         int p1 = -1, p2 = -1, p3 = -1;
         long long s0 = prof ? clock64() : 0, s1 = s0, s2 = s0;
+        // (tail kernel) R[k]: the record (x, y, z, index bits) of the k-th tracked candidate {a1, b1c, a2, b2c, a3, b3c},
+        // fetched from the index's sorted copy in ONE round trip at the top of the wave-round — in flight under the
+        // de-skew — and kept in step with the six positions below (swapped with them, re-read after a search).  Through
+        // the generic accessors every one of these reads was a branch (LDS or global?) and a dependent L2 round trip of
+        // its own: a dozen in a row per wave-round, what the late iterations of a scan without resident points cost most.
+        float4 R[6];
         if (active) {
-          if (prm.pad & 0x400000)  // (counting aid: no query load)
+          if (pad & 0x400000)  // (counting aid: no query load)
             q = make_float4(1.f + lane, 2.f, 0.5f, 3.25f);
           else
             q = arena[(is_surf ? sd.off_surf_q : sd.off_corner_q) + qi];
+          if constexpr (kTail) {
+#if LINS_TAIL_STAGED
+            R[0] = c.gs[a1 < 0 ? 0 : a1], R[1] = c.gs[b1c < 0 ? 0 : b1c];  // (the other four: behind the nearest neighbour's stage)
+#else
+            const int cp[6] = {a1, b1c, a2, b2c, a3, b3c};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) R[k] = c.gs[cp[k] < 0 ? 0 : cp[k]];
+#endif
+          }
           V3 t{L.ic.lin[0], L.ic.lin[1], L.ic.lin[2]};
-          if (prm.pad & 0x100000)  // (counting aid: no de-skew)
+          if (pad & 0x100000)  // (counting aid: no de-skew)
             o.sel[0] = q.x, o.sel[1] = q.y, o.sel[2] = q.z;
           else
             transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2], g_lds.trig);
@@ -1173,6 +1473,46 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #endif
         }
         auto dist_to = [&](int pos) { return pt_sqdist(L, c, pos, o.sel[0], o.sel[1], o.sel[2]); };
+        // distance to / original index of tracked candidate `pos`, whose record is r in the tail kernel
+        auto dist_r = [&](const float4& r, int pos) {
+          if constexpr (kTail)
+            return sqdist3(r.x, r.y, r.z, o.sel[0], o.sel[1], o.sel[2]);
+          else
+            return dist_to(pos);
+        };
+        auto idx_r = [&](const float4& r, int pos) {
+          if constexpr (kTail)
+            return __float_as_int(r.w);
+          else
+            return pt_idx(L, c, pos);
+        };
+        auto reload_r = [&](float4& r, int pos) {
+          if constexpr (kTail) r = c.gs[pos < 0 ? 0 : pos];
+        };
+        auto swap_r = [&](float4& x, float4& y) {
+          if constexpr (kTail) {
+            const float4 t = x;
+            x = y, y = t;
+          }
+        };
+        auto tail_park = [&]() {
+#if LINS_LDS_TAIL
+          if (active) {
+            const CarryWords cw = carry_pack();
+            L.cw0[slot] = cw.w0, L.cw1[slot] = cw.w1, L.cw2[slot] = cw.w2, L.cw3[slot] = cw.w3;
+          }
+#endif
+        };
+        auto tail_unpark = [&]() {
+#if LINS_LDS_TAIL
+          if (active) {
+            carry_unpack(CarryWords{L.cw0[slot], L.cw1[slot], L.cw2[slot], L.cw3[slot]});
+            const int cp[6] = {a1, b1c, a2, b2c, a3, b3c};
+#pragma unroll
+            for (int k = 0; k < 6; ++k) R[k] = c.gs[cp[k] < 0 ? 0 : cp[k]];
+          }
+#endif
+        };
         auto drift_from = [&](const float* cp) {
           float ex = o.sel[0] - cp[0], ey = o.sel[1] - cp[1], ez = o.sel[2] - cp[2];
           return bound_sqrtf(ex * ex + ey * ey + ez * ez);
@@ -1187,19 +1527,19 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           // (distance, key) order as the search); otherwise the search runs again, warm-started from A.
           bool need_nn = false, said = false, flip = false;
           int pred = -1;
-          if (active && (prm.pad & 0x80000) && warm_iter) {  // (counting aid: every certificate holds, unchecked)
+          if (active && (pad & 0x80000) && warm_iter) {  // (counting aid: every certificate holds, unchecked)
             pred = a1, said = true;
           } else if (active) {
-            if (!(prm.pad & 0x200000)) {
+            if (!(pad & 0x200000) && !(kTail && LINS_TAIL_OOL)) {  // (the tail kernel's searches make it for themselves: coop_nn_ool)
               qp.rho = sqrtf(o.sel[0] * o.sel[0] + o.sel[1] * o.sel[1]);
               qp.qn3 = sqrtf(qp.rho * qp.rho + o.sel[2] * o.sel[2]);
               qp.el = atan2f(o.sel[2], qp.rho);
               qp.a0_surf_or_corner = az_bin_lds(o.sel[0], o.sel[1], c.naz);
             }
-            const float da = a1 >= 0 ? dist_to(a1) : INFINITY, db = b1c >= 0 ? dist_to(b1c) : INFINITY;
-            bool ok = warm_iter && !(prm.pad & 16) && certified(fminf(fminf(da, db), thr), lb1, drift_from(certA));
-            const unsigned long long ka = da < thr ? pack_key(da, pt_idx(L, c, a1)) : kNone;
-            const unsigned long long kb = db < thr ? pack_key(db, pt_idx(L, c, b1c)) : kNone;
+            const float da = a1 >= 0 ? dist_r(R[0], a1) : INFINITY, db = b1c >= 0 ? dist_r(R[1], b1c) : INFINITY;
+            bool ok = warm_iter && !(pad & 16) && certified(fminf(fminf(da, db), thr), lb1, drift_from(certA));
+            const unsigned long long ka = da < thr ? pack_key(da, idx_r(R[0], a1)) : kNone;
+            const unsigned long long kb = db < thr ? pack_key(db, idx_r(R[1], b1c)) : kNone;
             flip = kb < ka;
             pred = (flip ? kb : ka) == kNone ? -1 : (flip ? b1c : a1);
             said = ok;
@@ -1212,31 +1552,19 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
             int r_pos = -1, r_ring = -1, r_pos2 = -1, r_ring2 = -1;
             float r_lb = 0.f;
             if (cm.n) {  // (wave-uniform)
-              // lanes per search: as many as the wave can give each of its cm.n searches, a power of two
-              const int ln = coop_lanes(cm.n, coop_cap);
-              const int wrole = lane & (ln - 1), wbase = lane - wrole, item = lane / ln;
-              bool valid = need_nn;
-              float isx = o.sel[0], isy = o.sel[1], isz = o.sel[2];
-              QueryPolar iq = qp;
-              int i_surf = is_surf, i_rq = ring_of(q.w), i_a1 = a1, i_ra1 = ra1;
-              if (ln > 1) {  // the inputs of search `item` travel from its owner to the ln lanes that serve it
-                valid = item < cm.n;
-                const int owner = __shfl(cm.owner_map, valid ? item : 0);
-                isx = __shfl(o.sel[0], owner), isy = __shfl(o.sel[1], owner), isz = __shfl(o.sel[2], owner);
-                iq.rho = __shfl(qp.rho, owner), iq.qn3 = __shfl(qp.qn3, owner), iq.el = __shfl(qp.el, owner);
-                iq.a0_surf_or_corner = __shfl(qp.a0_surf_or_corner, owner);
-                i_surf = __shfl((int)is_surf, owner), i_rq = __shfl(i_rq, owner);
-                i_a1 = __shfl(a1, owner), i_ra1 = __shfl(ra1, owner);
+              NnOut r;
+              if constexpr (kTail && LINS_TAIL_OOL) {
+                // (a call keeps only a third of the registers: what the loop carries — the query's state and its six
+                // records — would be spilled around it, on the path of the waves that do NOT search too.  So the state
+                // waits in its LDS slot and the records are fetched again: paid by the waves that search.)
+                tail_park();
+                r = coop_nn_ool(is_surf, gs, sd.n_corner_t, sd.n_surf_t, n_lds, cm.n, cm.rank, cm.owner_map, coop_cap, need_nn, lane, o.sel[0],
+                                o.sel[1], o.sel[2], ring_of(q.w), a1, ra1, thr, margin, (pad & 2) != 0);
+                tail_unpark();
+              } else {
+                r = coop_nn(L, c, cm, coop_cap, need_nn, lane, o.sel[0], o.sel[1], o.sel[2], qp, ring_of(q.w), a1, ra1, thr, margin, (pad & 2) != 0);
               }
-              Best bb = best_init(thr);
-              if (valid && !(prm.pad & 2))  // (profiling aid: LINS_DEBUG_SKIP=2 skips the search, 1 skips the walk)
-                bb = nn_lds<0>(L, i_surf ? cs : cc, isx, isy, isz, iq, thr, margin, i_rq, ln, wrole, wbase, i_a1, i_ra1);
-              r_pos = bb.pos, r_ring = bb.ring, r_pos2 = bb.pos2, r_ring2 = bb.ring2, r_lb = cert_lb(bb, thr, margin);
-              if (ln > 1) {  // hand back: the owner of rank r reads the first lane of group r
-                const int src = (cm.rank * ln) & 63;
-                r_pos = __shfl(r_pos, src), r_ring = __shfl(r_ring, src);
-                r_pos2 = __shfl(r_pos2, src), r_ring2 = __shfl(r_ring2, src), r_lb = __shfl(r_lb, src);
-              }
+              r_pos = r.pos, r_ring = r.ring, r_pos2 = r.pos2, r_ring2 = r.ring2, r_lb = r.lb;
             }
             if (need_nn) {
               p1 = r_pos;  // (a winner beat the threshold sentinel, so its distance is < thr, SE:851)
@@ -1244,17 +1572,25 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
               a1 = r_pos, ra1 = r_ring, b1c = r_pos2, rb1 = r_ring2;
               lb1 = r_lb;
               certA[0] = o.sel[0], certA[1] = o.sel[1], certA[2] = o.sel[2];
+              reload_r(R[0], a1), reload_r(R[1], b1c);
             } else if (active) {
               p1 = pred;
               if (flip) {  // the runner-up took over: swap the two tracked candidates
                 const int tp = a1, tr = ra1;
                 a1 = b1c, ra1 = rb1, b1c = tp, rb1 = tr;
+                swap_r(R[0], R[1]);
               }
               atomicAdd(&L.dbg[1], 1);
             }
           }
           const bool nn_changed = p1 != sel1;
           if (active) sel1 = p1;
+#if LINS_LDS_TAIL && LINS_TAIL_STAGED
+          if (active) {
+            R[2] = c.gs[a2 < 0 ? 0 : a2], R[3] = c.gs[b2c < 0 ? 0 : b2c];
+            if (is_surf) R[4] = c.gs[a3 < 0 ? 0 : a3], R[5] = c.gs[b3c < 0 ? 0 : b3c];
+          }
+#endif
           if (prof) {
             s2 = clock64();
 #ifndef LINS_PROF_WAVES
@@ -1265,26 +1601,26 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           bool need_walk = false, flip2 = false, flip3 = false, said23 = false;
           int pred2 = -1, pred3 = -1, j1 = -1;
           if (active && p1 >= 0) {
-            j1 = pt_idx(L, c, p1);  // (p1 >= 0 => p1 is candidate A, on ring ra1)
+            j1 = idx_r(R[0], p1);  // (p1 >= 0 => p1 is candidate A, on ring ra1)
             need_walk = nn_changed || !warm_iter;
-            if (!need_walk && (prm.pad & 0x80000)) {
+            if (!need_walk && (pad & 0x80000)) {
               pred2 = a2, pred3 = a3, said23 = true;
             } else if (!need_walk) {
               const WalkCtx w = make_walk_ctx(c, is_surf ? sd.n_surf_q : sd.n_corner_q, j1, ra1);
               const float dB = drift_from(certB);
-              auto judge = [&](int pa, int pb, float lb, int& pd, bool& fl) {
-                const float da = pa >= 0 ? dist_to(pa) : INFINITY, db = pb >= 0 ? dist_to(pb) : INFINITY;
+              auto judge = [&](int pa, int pb, const float4& ra, const float4& rb, float lb, int& pd, bool& fl) {
+                const float da = pa >= 0 ? dist_r(ra, pa) : INFINITY, db = pb >= 0 ? dist_r(rb, pb) : INFINITY;
                 int rka = 0, rkb = 0;
-                if (pa >= 0) walk_rank(w, pt_idx(L, c, pa), rka);
-                if (pb >= 0) walk_rank(w, pt_idx(L, c, pb), rkb);
+                if (pa >= 0) walk_rank(w, idx_r(ra, pa), rka);
+                if (pb >= 0) walk_rank(w, idx_r(rb, pb), rkb);
                 const unsigned long long ka = da < thr ? pack_key(da, rka) : kNone;
                 const unsigned long long kb = db < thr ? pack_key(db, rkb) : kNone;
                 fl = kb < ka;
                 pd = (fl ? kb : ka) == kNone ? -1 : (fl ? pb : pa);
                 return certified(fminf(fminf(da, db), thr), lb, dB);
               };
-              bool ok23 = judge(a2, b2c, lb2, pred2, flip2);
-              if (is_surf) ok23 = judge(a3, b3c, lb3, pred3, flip3) && ok23;
+              bool ok23 = judge(a2, b2c, R[2], R[3], lb2, pred2, flip2);
+              if (is_surf) ok23 = judge(a3, b3c, R[4], R[5], lb3, pred3, flip3) && ok23;
               said23 = ok23;
               need_walk = !ok23 || verify;
             }
@@ -1295,32 +1631,18 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
             int r2 = -1, r2b = -1, r3 = -1, r3b = -1;
             float r_lb2 = 0.f, r_lb3 = 0.f;
             if (cm.n) {
-              const int ln = coop_lanes(cm.n, coop_cap);
-              const int wrole = lane & (ln - 1), wbase = lane - wrole, item = lane / ln;
-              bool valid = need_walk;
-              float isx = o.sel[0], isy = o.sel[1], isz = o.sel[2];
-              QueryPolar iq = qp;
-              int i_surf = is_surf, i_j1 = j1, i_rho1 = ra1, i_w2 = a2, i_w3 = a3, i_chk = nn_changed;
-              if (ln > 1) {
-                valid = item < cm.n;
-                const int owner = __shfl(cm.owner_map, valid ? item : 0);
-                isx = __shfl(o.sel[0], owner), isy = __shfl(o.sel[1], owner), isz = __shfl(o.sel[2], owner);
-                iq.rho = __shfl(qp.rho, owner), iq.qn3 = __shfl(qp.qn3, owner), iq.el = __shfl(qp.el, owner);
-                iq.a0_surf_or_corner = __shfl(qp.a0_surf_or_corner, owner);
-                i_surf = __shfl((int)is_surf, owner), i_j1 = __shfl(j1, owner), i_rho1 = __shfl(ra1, owner);
-                i_w2 = __shfl(a2, owner), i_w3 = __shfl(a3, owner), i_chk = __shfl((int)nn_changed, owner);
+              const int nq = is_surf ? sd.n_surf_q : sd.n_corner_q;
+              WalkOut r;
+              if constexpr (kTail && LINS_TAIL_OOL) {
+                tail_park();
+                r = coop_walk_ool(is_surf, gs, sd.n_corner_t, sd.n_surf_t, n_lds, nq, cm.n, cm.rank, cm.owner_map, coop_cap, need_walk, lane,
+                                  o.sel[0], o.sel[1], o.sel[2], j1, ra1, a2, a3, nn_changed, thr, margin, (pad & 1) != 0);
+                tail_unpark();
+              } else {
+                r = coop_walk(L, c, is_surf, nq, cm, coop_cap, need_walk, lane, o.sel[0], o.sel[1], o.sel[2], qp, j1, ra1, a2, a3, nn_changed, thr,
+                              margin, (pad & 1) != 0);
               }
-              Best c2 = best_init(thr), c3 = c2;
-              if (valid && !(prm.pad & 1))
-                walk_lds<0>(L, i_surf ? cs : cc, i_surf != 0, i_surf ? sd.n_surf_q : sd.n_corner_q, thr, i_j1, i_rho1, isx, isy, isz,
-                            iq, margin, ln, wrole, wbase, i_w2, i_w3, i_chk != 0, c2, c3);
-              r2 = c2.pos, r2b = c2.pos2, r3 = c3.pos, r3b = c3.pos2;
-              r_lb2 = cert_lb(c2, thr, margin), r_lb3 = cert_lb(c3, thr, margin);
-              if (ln > 1) {
-                const int src = (cm.rank * ln) & 63;
-                r2 = __shfl(r2, src), r2b = __shfl(r2b, src), r3 = __shfl(r3, src), r3b = __shfl(r3b, src);
-                r_lb2 = __shfl(r_lb2, src), r_lb3 = __shfl(r_lb3, src);
-              }
+              r2 = r.r2, r2b = r.r2b, r3 = r.r3, r3b = r.r3b, r_lb2 = r.lb2, r_lb3 = r.lb3;
             }
             if (need_walk) {
               if (said23 && (r2 != pred2 || (is_surf && r3 != pred3))) atomicAdd(&L.dbg[0], 1);
@@ -1328,15 +1650,18 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
               a2 = r2, b2c = r2b, a3 = r3, b3c = r3b;
               lb2 = r_lb2, lb3 = r_lb3;
               certB[0] = o.sel[0], certB[1] = o.sel[1], certB[2] = o.sel[2];
+              reload_r(R[2], a2), reload_r(R[3], b2c), reload_r(R[4], a3), reload_r(R[5], b3c);
             } else if (active && p1 >= 0) {
               p2 = pred2, p3 = pred3;
               if (flip2) {
                 const int tp = a2;
                 a2 = b2c, b2c = tp;
+                swap_r(R[2], R[3]);
               }
               if (flip3) {
                 const int tp = a3;
                 a3 = b3c, b3c = tp;
+                swap_r(R[4], R[5]);
               }
               atomicAdd(&L.dbg[2], 1);
             }
@@ -1356,22 +1681,31 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           int4 s = idx_store[sd.slot_base + slot];
           p1 = s.x, p2 = s.y, p3 = s.z;
         }
+#if LINS_LDS_TAIL
+        if (active) {  // the carried state goes back to its query's slot HERE: its eighteen registers are free for the rows
+          const CarryWords cw = carry_pack();
+          L.cw0[slot] = cw.w0, L.cw1[slot] = cw.w1, L.cw2[slot] = cw.w2, L.cw3[slot] = cw.w3;
+        }
+#endif
         long long s3 = prof ? clock64() : 0;
         // The iteration constants the rows need (R^T, G^T: 36 registers' worth, the same for every lane) are read from
         // LDS HERE.  Without the fence the compiler hoists those reads to the top of the iteration, finds no
         // registers for them across the search code, and moves them through scratch: ~12 scratch stores and as many
         // waited-for scratch loads per wave and iteration — the bulk of a late iteration's time.
         asm volatile("" ::: "memory");
-        if (active && !(prm.pad & 0x20000)) {  // (counting aid: LINS_DEBUG_SKIP bit 0x20000 drops the rows)
-          auto pt4 = [&](int pos) {
+        if (active && !(pad & 0x20000)) {  // (counting aid: LINS_DEBUG_SKIP bit 0x20000 drops the rows)
+          // (a selected point is the first of its two tracked candidates: p1 == a1, p2 == a2, p3 == a3 when they exist)
+          auto pt4 = [&](int pos, const float4& r) {
+            if constexpr (kTail) return r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             pt_xyz(L, c, pos, v.x, v.y, v.z);
             return v;
           };
           if (is_surf) {
-            if (p1 >= 0 && p2 >= 0 && p3 >= 0) surf_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], pt4(p1), pt4(p2), pt4(p3), o);
+            if (p1 >= 0 && p2 >= 0 && p3 >= 0)
+              surf_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], pt4(p1, R[0]), pt4(p2, R[2]), pt4(p3, R[4]), o);
           } else if (p1 >= 0 && p2 >= 0) {
-            corner_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], pt4(p1), pt4(p2), o);
+            corner_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], pt4(p1, R[0]), pt4(p2, R[2]), o);
           }
           if (o.accepted) {
             if (ICP) {  // Gauss-Newton row of the fallback (SE:1246-1257): [c^T(-R(s phi)[p]x), c^T | -0.05 res]
@@ -1446,11 +1780,11 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           // (same strict (distance, key) order as the search); otherwise the search runs again,
           // warm-started from A.
           const unsigned long long kNone = ~0ull;
-          const bool verify = (prm.pad & 8) != 0;  // test aid: search anyway and count disagreements
+          const bool verify = (pad & 8) != 0;  // test aid: search anyway and count disagreements
           // --- nearest neighbour -----------------------------------------------------------------------
           {
             const float da = a1 >= 0 ? dist_to(a1) : INFINITY, db = b1c >= 0 ? dist_to(b1c) : INFINITY;
-            bool ok = have_cert && !(prm.pad & 16) && certified(fminf(fminf(da, db), thr), lb1, drift_from(certA));
+            bool ok = have_cert && !(pad & 16) && certified(fminf(fminf(da, db), thr), lb1, drift_from(certA));
             const unsigned long long ka = da < thr ? pack_key(da, pt_idx(L, c, a1)) : kNone;
             const unsigned long long kb = db < thr ? pack_key(db, pt_idx(L, c, b1c)) : kNone;
             const bool flip = kb < ka;
@@ -1458,9 +1792,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
             const bool said = ok;
             if (verify) ok = false;
             if (!ok) {
-              if ((prm.pad & 32) && __ffsll(__ballot(1)) - 1 == lane) atomicAdd(&L.dbg[3], 1 + (iter >= 3 ? 1000 : 0));
+              if ((pad & 32) && __ffsll(__ballot(1)) - 1 == lane) atomicAdd(&L.dbg[3], 1 + (iter >= 3 ? 1000 : 0));
               Best bb = best_init(thr);
-              if (!(prm.pad & 2))  // (profiling aid: LINS_DEBUG_SKIP=2 skips the search, 1 skips the walk)
+              if (!(pad & 2))  // (profiling aid: LINS_DEBUG_SKIP=2 skips the search, 1 skips the walk)
                 bb = nn_lds<LANES>(L, c, o.sel[0], o.sel[1], o.sel[2], qp, thr, margin, ring_of(q.w), LANES, role, lane_base,
                                    a1, ra1);
               p1 = bb.pos;  // (a winner beat the threshold sentinel, so its distance is < thr, SE:851)
@@ -1511,9 +1845,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
               need_walk = !ok23 || verify;
             }
             if (need_walk) {
-              if ((prm.pad & 32) && __ffsll(__ballot(1)) - 1 == lane) atomicAdd(&L.dbg[0], 1 + (iter >= 3 ? 1000 : 0));
+              if ((pad & 32) && __ffsll(__ballot(1)) - 1 == lane) atomicAdd(&L.dbg[0], 1 + (iter >= 3 ? 1000 : 0));
               Best c2 = best_init(thr), c3 = c2;
-              if (!(prm.pad & 1))
+              if (!(pad & 1))
                 walk_lds<LANES>(L, c, is_surf, is_surf ? sd.n_surf_q : sd.n_corner_q, thr, j1, rho1, o.sel[0], o.sel[1],
                                 o.sel[2], qp, margin, LANES, role, lane_base, a2, a3, nn_changed, c2, c3);
               if (said23 && (c2.pos != pred2 || (is_surf && c3.pos != pred3)) && role == 0) atomicAdd(&L.dbg[0], 1);
@@ -1599,10 +1933,20 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #ifdef LINS_PROF_WAVES  // (experiment: per-wave correspondence time of the late iterations in slots 6..13)
       if (prof && lane == 0 && iter >= LINS_PROF_WAVES) L.prof_acc[6 + wave] += t1 - t0;
 #endif
-      if (!(prm.pad & 0x40000)) acc += wave_reduce_rows(row, lane);  // no LDS, no barrier: the rows never leave registers
+      if (!(pad & 0x40000)) {  // no LDS, no barrier: the rows never leave registers
+        const double red = wave_reduce_rows(row, lane);
+        if constexpr (kTail) {  // one partial per wave-round, in the slot of the head wave that would have held it
+#if LINS_LDS_TAIL
+          const int si = reduce_sum_index(lane);
+          if (si >= 0) L.partial[wr_k * 28 + si] = red;
+#endif
+        } else {
+          acc += red;
+        }
+      }
     }
     if (do_search) searched = true;
-    {
+    if (!kTail) {
       const int sidx28 = reduce_sum_index(lane);
       if (sidx28 >= 0) L.partial[wave * 28 + sidx28] = acc;
     }
@@ -1612,12 +1956,12 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     if (tid < 28) {
       double sacc = 0;
 #pragma unroll
-      for (int g = 0; g < BLOCK / 64; ++g) sacc += L.partial[g * 28 + tid];
+      for (int g = 0; g < (kTail ? kMaxLWaves : BLOCK / 64); ++g) sacc += L.partial[g * 28 + tid];
       L.sums[tid] = sacc;
     }
     __syncthreads();
     if (prof) t2 = clock64();
-    if (PASS_ONLY && (prm.pad & 4) && !L.conv) {
+    if (PASS_ONLY && (pad & 4) && !L.conv) {
       // test aid: repeat the pass with the warm start fed by the first one — a warm search at
       // the same state must return the very same triplets (exercises the tightest bounds)
       __syncthreads();
@@ -1625,8 +1969,8 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       continue;
     }
     if (PASS_ONLY) {
-      if (sums_out && tid < 28) sums_out[(size_t)scan * 28 + tid] = L.sums[tid];
-      if (counts_out && tid == 0) counts_out[scan * 2] = L.m_surf, counts_out[scan * 2 + 1] = L.m_corner;
+      if (ka.sums_out && tid < 28) ka.sums_out[(size_t)scan * 28 + tid] = L.sums[tid];
+      if (ka.counts_out && tid == 0) ka.counts_out[scan * 2] = L.m_surf, ka.counts_out[scan * 2 + 1] = L.m_corner;
       return;
     }
 
@@ -1635,7 +1979,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       if (tid < 64) icp_solve_and_update(tid, iter);
       __syncthreads();
     } else
-      t3 = solve_and_update(prm.r2, prm.fixed_iters, prm.pad, tid, iter, prof);
+      t3 = solve_and_update(prm.r2, prm.fixed_iters, pad, tid, iter, prof);
     if (prof) {
       long long t4 = clock64();
       if (tid == 0) {
@@ -1646,8 +1990,14 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       }
     }
   }
+#if LINS_COLD_ARGS
+  const ColdArgs kp = cold_args();  // (what only the epilogue needs is loaded here, not kept in SGPRs across the loop)
+#define KP(f) kp->f
+#else
+#define KP(f) ka.f
+#endif
   if (prof && tid == 0) {
-    long long* prof_out = prof_buf;
+    long long* prof_out = KP(prof_buf);
     L.prof_acc[5] = clock64() - t_begin;
     // residency probe: [13] = HW_ID | XCC_ID << 32, [14] / [15] = start / end on the 100 MHz wall clock
 #ifndef LINS_PROF_WAVES
@@ -1659,58 +2009,56 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   }
 
   if (kRelay && relay_out) {  // the second part of this scan's update continues from here (see relay_in)
-    double* h = relay_hdr + (size_t)scan * kRelayHdr;
+    double* h = KP(relay_hdr) + (size_t)scan * kRelayHdr;
     if (tid < 58) relay_st(h + tid, reinterpret_cast<const double*>(&L.ic)[tid]);
     if (tid == 64) relay_st(h + 58, L.res_prev), relay_st(h + 59, L.res_last), relay_st(h + 60, L.upd_norm);
     if (tid == 65) {
       int* hi = reinterpret_cast<int*>(h + 61);
       relay_st(hi, L.iter), relay_st(hi + 1, L.dbg[0]), relay_st(hi + 2, L.dbg[1]), relay_st(hi + 3, L.dbg[2]), relay_st(hi + 4, L.dbg[3]);
     }
-    int* ln = relay_lane + (size_t)scan * 18 * BLOCK + tid;
-    const int w[18] = {a1, b1c, ra1, rb1, a2, b2c, a3, b3c, sel1, __float_as_int(lb1), __float_as_int(lb2), __float_as_int(lb3),
-                       __float_as_int(certA[0]), __float_as_int(certA[1]), __float_as_int(certA[2]),
-                       __float_as_int(certB[0]), __float_as_int(certB[1]), __float_as_int(certB[2])};
-#pragma unroll
-    for (int k = 0; k < 18; ++k) relay_st(ln + k * BLOCK, w[k]);
-    // every store of this thread has completed (device-coherent stores: at the memory side) before the barrier, the
-    // flag after it: whoever sees the flag sees the hand-over
+    relay_out_carry(KP(relay_lane) + (size_t)scan * kRelayLaneInts, tid, a1, b1c, ra1, rb1, a2, b2c, a3, b3c, sel1, lb1, lb2, lb3, certA[0],
+                    certA[1], certA[2], certB[0], certB[1], certB[2]);
+    // every store of this wave has completed — write-through stores: at the memory side — before the barrier, the flag
+    // after it: whoever sees the flag sees the hand-over
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) relay_st(relay_flag + scan, relay_gen * 16 + part + 1);
+    if (tid == 0) relay_raise(KP(relay_flag) + scan, KP(relay_gen) * 16 + part + 1);
     return;
   }
-  if (kRelay && relay_n > 0 && part + 1 < relay_parts && tid == 0)  // this part finished the scan: the later parts have nothing to do
-    relay_st(relay_flag + scan, relay_gen * 16 + 15);
+  if (kRelay && relay_n > 0 && (solo || part + 1 < relay_parts) && tid == 0)  // this part finished the scan: the others have nothing to do
+    relay_raise(KP(relay_flag) + scan, KP(relay_gen) * 16 + 15);
 
   // ---- hand-off to the Joseph kernel / the caller (SE:585-598) ---------------
   const int div = L.div;
   if (ICP) {  // filterState with rn_, qbn_ replaced (SE:590-592); the covariance is the caller's, un-updated
-    if (tid < 19) state_out[(size_t)scan * 19 + tid] = (tid < 3 || (tid >= 6 && tid < 10)) ? L.ic.lin[tid] : L.filt[tid];
+    if (tid < 19) KP(state_out)[(size_t)scan * 19 + tid] = (tid < 3 || (tid >= 6 && tid < 10)) ? L.ic.lin[tid] : L.filt[tid];
   } else {
-    if (tid < 19) state_out[(size_t)scan * 19 + tid] = div ? L.filt[tid] : L.ic.lin[tid];
-    if (a6_out && tid < 21) a6_out[(size_t)scan * 21 + tid] = L.sums[tid];
+    if (tid < 19) KP(state_out)[(size_t)scan * 19 + tid] = div ? L.filt[tid] : L.ic.lin[tid];
+    if (KP(a6_out) && tid < 21) KP(a6_out)[(size_t)scan * 21 + tid] = L.sums[tid];
   }
   if (tid == 0) {
     OutRec r;
     r.residual_norm = L.res_last, r.update_norm = L.upd_norm;
     r.iters = L.iter, r.converged = L.conv, r.diverged = div;
     r.m_surf = L.m_surf, r.m_corner = L.m_corner;
-    r.pad[0] = L.dbg[0], r.pad[1] = (prm.pad & 32) ? L.dbg[3] : L.dbg[1], r.pad[2] = L.dbg[2];
-    out[scan] = r;
+    r.pad[0] = L.dbg[0], r.pad[1] = (pad & 32) ? L.dbg[3] : L.dbg[1], r.pad[2] = L.dbg[2];
+    KP(out)[scan] = r;
   }
-  if (poses && tid < 32) {
-    lins_pose_record* pr = poses + scan;
+  if (KP(poses) && tid < 32) {
+    lins_pose_record* pr = KP(poses) + scan;
     const double* st = div ? L.filt : L.ic.lin;
     if (tid < 19) pr->state[tid] = st[tid];
     if (tid == 19) pr->residual_norm = L.res_last;
     if (tid == 20) {
       pr->iters = L.iter, pr->converged = L.conv, pr->diverged = div;
-      pr->m_surf = L.m_surf, pr->m_corner = L.m_corner, pr->scan_id = scan_id_base + scan;
+      pr->m_surf = L.m_surf, pr->m_corner = L.m_corner, pr->scan_id = KP(scan_id_base) + scan;
       pr->pad[0] = pr->pad[1] = 0;
     }
   }
-  if (!ICP && cov_out) joseph_epilogue<BLOCK>(prm.r2, div, cov_out + (size_t)scan * 324, tid);
+  if (!ICP && KP(cov_out)) joseph_epilogue<BLOCK>(KP(prm).r2, div, KP(cov_out) + (size_t)scan * 324, tid);
 }
 
+#undef KP
 }  // namespace LINS_LDS_NS
 }  // namespace lins

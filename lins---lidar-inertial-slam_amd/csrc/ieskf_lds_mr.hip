@@ -41,48 +41,61 @@
 
 namespace lins {
 
-#define LINS_LAUNCH(NS, B, LN, PR)                                                                                  \
-  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, false, PR>), dim3(grid), dim3(B), 0, stream, prm, descs, order, arena, sorted, tabs, \
-                     state_in, cov_in, (const double*)nullptr, 0, state_out, a6, cov_out, (NS::OutRec*)out, idx_store, poses,  \
-                     scan_id_base, (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, prof, RELAY_ARGS)
-#define LINS_LAUNCH_PASS(NS, B, LN)                                                                                    \
-  hipLaunchKernelGGL((NS::ieskf_lds_kernel<B, LN, true, false>), dim3(n), dim3(B), 0, stream, prm, descs, order, arena, sorted, tabs, \
-                     filt_state, (const double*)nullptr, lin_state, iter, (double*)nullptr, (double*)nullptr,           \
-                     (double*)nullptr, (NS::OutRec*)nullptr, idx_store, (lins_pose_record*)nullptr, 0, dump, sums_out, counts_out,        \
-                     (long long*)nullptr, 0, 0, 0, 0, (double*)nullptr, (int*)nullptr, (int*)nullptr)
+// one KernelArgs by value (ieskf_lds_impl.h): fields not named by a launcher are zero
+template <class K>
+static void launch_args(K kernel, int grid, int block, hipStream_t stream, const lds_mr::KernelArgs& ka, const float4* arena, const float4* sorted,
+                        int4* idx_store, lins_corr* dump = nullptr) {
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, ka, arena, sorted, idx_store, dump);
+}
 
 int lds_mr_np_cap() { return lds_mr::kNpMax; }
 
-// relay_hdr != nullptr: every update is cut every relay_at iterations into relay_parts workgroups of the launch, see
-// the kernel; relay_gen numbers the launch (the per-scan flags are never reset: a flag of an earlier launch is smaller)
+// relay != nullptr: every update is cut every relay->at iterations into parts, relay->launched of them workgroups of this
+// launch, see the kernel; relay->gen numbers the launch (the per-scan flags are never reset: a flag of an earlier launch is
+// smaller)
 void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const int* order, const float4* arena,
                    const float4* sorted, const GridTables* tabs, const double* state_in, const double* cov_in, double* state_out, double* a6,
                    double* cov_out, void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof,
-                   int relay_at, int relay_parts, int relay_gen, double* relay_hdr, int* relay_lane, int* relay_flag) {
-  const int relay_n = relay_hdr ? n : 0, grid = relay_n ? relay_parts * n : n;
-#define RELAY_ARGS relay_n, relay_at, relay_parts, relay_gen, relay_hdr, relay_lane, relay_flag
+                   const RelayArgs* relay) {
+  lds_mr::KernelArgs ka{};
+  ka.prm = prm, ka.descs = descs, ka.order = order, ka.tabs = tabs;
+  ka.state_in = state_in, ka.cov_in = cov_in, ka.state_out = state_out, ka.a6_out = a6, ka.cov_out = cov_out;
+  ka.out = (lds_mr::OutRec*)out, ka.poses = poses, ka.scan_id_base = scan_id_base, ka.prof_buf = prof;
+  int grid = n;
+  if (relay) {
+    ka.relay_n = n, ka.relay_at = relay->at, ka.relay_parts = relay->parts, ka.relay_gen = relay->gen, ka.relay_spins = relay->spins;
+    ka.relay_hdr = relay->hdr, ka.relay_lane = relay->lane, ka.relay_flag = relay->flag, ka.relay_err = relay->err;
+    grid = relay->launched * n;
+  }
   if (prof)
-    LINS_LAUNCH(lds_mr, LINS_MR_BLOCK, 1, true);
-  else
-    LINS_LAUNCH(lds_mr, LINS_MR_BLOCK, 1, false);
+    launch_args(lds_mr::ieskf_lds_kernel<LINS_MR_BLOCK, 1, false, true>, grid, LINS_MR_BLOCK, stream, ka, arena, sorted, idx_store);
+  else {
+    if (prm.pad)  // (counting aids / test modes asked for: the instantiation that has them)
+      launch_args(lds_mr::ieskf_lds_kernel<LINS_MR_BLOCK, 1, false, false, false, true>, grid, LINS_MR_BLOCK, stream, ka, arena, sorted, idx_store);
+    else
+      launch_args(lds_mr::ieskf_lds_kernel<LINS_MR_BLOCK, 1, false, false, false, false>, grid, LINS_MR_BLOCK, stream, ka, arena, sorted, idx_store);
+  }
 }
 
 // ICP / Gauss-Newton fallback (estimateTransform, SE:1163-1320) on the same grid and searches:
 // state_in = the pose to start from (the filter's), state_out = that state with rn_, qbn_ replaced
 void launch_lds_mr_icp(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
                        const float4* sorted, const GridTables* tabs, const double* state_in, double* state_out, void* out, int4* idx_store) {
-  hipLaunchKernelGGL((lds_mr::ieskf_lds_kernel<512, 1, false, false, true>), dim3(n), dim3(512), 0, stream, prm, descs,
-                     (const int*)nullptr, arena, sorted, tabs, state_in, state_in /*unused: no covariance on this path*/, (const double*)nullptr, 0,
-                     state_out, (double*)nullptr, (double*)nullptr, (lds_mr::OutRec*)out, idx_store, (lins_pose_record*)nullptr, 0,
-                     (lins_corr*)nullptr, (double*)nullptr, (int*)nullptr, (long long*)nullptr, 0, 0, 0, 0, (double*)nullptr,
-                     (int*)nullptr, (int*)nullptr);
+  lds_mr::KernelArgs ka{};
+  ka.prm = prm, ka.descs = descs, ka.tabs = tabs;
+  ka.state_in = state_in, ka.cov_in = state_in /*unused: no covariance on this path*/, ka.state_out = state_out;
+  ka.out = (lds_mr::OutRec*)out;
+  launch_args(lds_mr::ieskf_lds_kernel<512, 1, false, false, true>, n, 512, stream, ka, arena, sorted, idx_store);
 }
 
 void launch_lds_mr_pass(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
                         const float4* sorted, const GridTables* tabs, const double* lin_state, const double* filt_state, int iter,
                         int4* idx_store, lins_corr* dump, double* sums_out, int* counts_out) {
-  const int* order = nullptr;
-  LINS_LAUNCH_PASS(lds_mr, 512, 1);
+  lds_mr::KernelArgs ka{};
+  ka.prm = prm, ka.descs = descs, ka.tabs = tabs;
+  ka.state_in = filt_state, ka.lin_in = lin_state, ka.iter_arg = iter;
+  ka.sums_out = sums_out, ka.counts_out = counts_out;
+  launch_args(lds_mr::ieskf_lds_kernel<512, 1, true, false>, n, 512, stream, ka, arena, sorted, idx_store, dump);
 }
 
 }  // namespace lins

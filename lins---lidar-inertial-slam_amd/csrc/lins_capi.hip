@@ -40,7 +40,10 @@ void launch_lds_pass(hipStream_t, int, const DevParams&, int, const ScanDesc*, c
                      const double*, int, int4*, lins_corr*, double*, int*);
 int lds_np_cap();
 void launch_lds_mr(hipStream_t, int, const DevParams&, const ScanDesc*, const int*, const float4*, const float4*, const GridTables*, const double*,
-                   const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*, int, int, int, double*, int*, int*);
+                   const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*, const RelayArgs*);
+void launch_lds_tail(hipStream_t, int, const DevParams&, const ScanDesc*, const int*, const float4*, const float4*, const GridTables*, const double*,
+                     const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, const RelayArgs&, int);
+int lds_tail_max_queries();
 void launch_lds_mr_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const float4*, const GridTables*, const double*,
                         const double*, int, int4*, lins_corr*, double*, int*);
 int lds_mr_np_cap();
@@ -128,6 +131,15 @@ struct lins_ctx {
   int relay_list_parts = 0;         // parts of the launch list that is on the device (0 = none yet for this upload)
   double* d_relay_hdr = nullptr;
   int *d_relay_lane = nullptr, *d_relay_flag = nullptr;
+  int* h_relay_err = nullptr;       // (pinned, device-visible) hand-over protocol violations seen by the tail kernel: checked at lins_sync
+  int relay_spins = 1 << 14;        // polls (~1 us) a part waits for its hand-over before it runs the whole update alone
+  int relay_scramble = 0;           // debug (LINS_RELAY_SCRAMBLE): launch list in an order that violates "a part behind the part before it"
+  // the tail kernel (ieskf_lds_tail.hip): the iterations from tail_at on as a launch of their own, four scans per CU
+  int tail_at = 0;                  // (0 = off: the batch kernel's own last part runs to the end.  Off by default: measured
+                                    // slower than the batch kernel's own parts; LINS_TAIL_AT with the debug gate)
+  int tail_dense = 0;               // wave-rounds of 64 queries instead of the head's layout (sums in another order)
+  bool tail_ok = false;             // every uploaded scan has a query set the tail kernel takes (set at upload)
+  int last_parts = 0, last_tail = 0;  // how the last run was cut (lins_last_cut)
   ScanDesc* d_desc = nullptr;
   bool use_order = true;  // (LINS_LAUNCH_ORDER=0 with the debug gate: index order, for A/B timing)
   int *h_order = nullptr, *d_order = nullptr;  // launch order of the uploaded batch (longest-expected-first), see launch_order()
@@ -426,6 +438,7 @@ struct CallTrace {
 
 struct RangeFlags {  // which kernel families the scans of a range can take
   bool lds_ok = true, mr_ok = true, lds3_ok = true;
+  bool tail_ok = true;  // the batch kernel lays the queries out in its one-round "spread" form and the tail kernel has a slot for each
 };
 
 // pass 1 (serial, cheap): argument checks and the arena layout of the whole batch
@@ -496,6 +509,8 @@ RangeFlags range_flags(const lins_ctx* ctx, int lo, int hi) {
     if (!grid || d.n_surf_t + d.n_corner_t > lds_np_cap()) fl.lds_ok = false;
     if (!grid || d.n_surf_t + d.n_corner_t > lds_mr_np_cap()) fl.mr_ok = false;
     if (d.n_surf_q + d.n_corner_q > 336) fl.lds3_ok = false;  // (16 waves x 21 query slots = the VLP-16 caps, 144 flat + 192 sharp)
+    // (ieskf_lds_impl.h: plane queries over 5 waves, line queries over 3, at most 64 a wave)
+    if (d.n_surf_q > 5 * 64 || d.n_corner_q > 3 * 64 || d.n_surf_q + d.n_corner_q > lds_tail_max_queries()) fl.tail_ok = false;
   }
   return fl;
 }
@@ -523,7 +538,7 @@ int h2d_range(lins_ctx* ctx, int lo, int hi, size_t arena_end, hipStream_t st) {
 
 void set_batch_state(lins_ctx* ctx, int n, const RangeFlags& fl, size_t slots, uint64_t bytes) {
   ctx->n_uploaded = n;
-  ctx->lds_ok = fl.lds_ok, ctx->mr_ok = fl.mr_ok, ctx->lds3_ok = fl.lds3_ok;
+  ctx->lds_ok = fl.lds_ok, ctx->mr_ok = fl.mr_ok, ctx->lds3_ok = fl.lds3_ok, ctx->tail_ok = fl.tail_ok;
   ctx->slots_uploaded = slots;
   ctx->ran = false;
   ctx->bytes_per_iter = bytes;
@@ -594,7 +609,7 @@ int run_range(lins_ctx* ctx, int lo, int cnt, int n_total, const RangeFlags& fl,
   if (use_mr || use_lds) {
     if (use_mr)
       launch_lds_mr(ctx->stream, cnt, ctx->dprm, desc, nullptr, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out, ctx->d_idx, ps,
-                    scan_id_base + lo, nullptr, 0, 0, 0, nullptr, nullptr, nullptr);
+                    scan_id_base + lo, nullptr, nullptr);
     else
       launch_lds(ctx->stream, cnt, ctx->dprm, s == SEARCH_LDS3 ? 3 : 1, desc, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out,
                  ctx->d_idx, ps, scan_id_base + lo, nullptr);  // (the Joseph update is the kernels' epilogue)
@@ -643,6 +658,10 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
     if (g[0] == '1') {
       if (const char* e = std::getenv("LINS_LAUNCH_ORDER")) ctx->use_order = e[0] != '0';
       if (const char* e = std::getenv("LINS_RELAY_AT")) ctx->relay_at = std::max(0, std::atoi(e));  // (0: whole updates)
+      if (const char* e = std::getenv("LINS_TAIL_AT")) ctx->tail_at = std::max(0, std::atoi(e));    // (0: no tail kernel)
+      if (const char* e = std::getenv("LINS_TAIL_DENSE")) ctx->tail_dense = e[0] != '0';
+      if (const char* e = std::getenv("LINS_RELAY_SPINS")) ctx->relay_spins = std::max(1, std::atoi(e));
+      if (const char* e = std::getenv("LINS_RELAY_SCRAMBLE")) ctx->relay_scramble = std::atoi(e);
     }
   ctx->max_batch = max_batch;
   ctx->max_targets = max_targets;
@@ -688,11 +707,13 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   CREATE_TRY(hipMalloc((void**)&ctx->d_gridtab, (size_t)ctx->max_batch * sizeof(GridTables)));
   if (ctx->max_batch > 2 * ctx->n_cu) {  // (only batches beyond the device's workgroup slots are cut into parts)
     CREATE_TRY(hipMalloc((void**)&ctx->d_relay_hdr, (size_t)ctx->max_batch * 64 * sizeof(double)));
-    CREATE_TRY(hipMalloc((void**)&ctx->d_relay_lane, (size_t)ctx->max_batch * 18 * 512 * sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_relay_lane, (size_t)ctx->max_batch * 4 * 512 * 16));  // (CarryWords: 4 x 16 B per head lane)
+    CREATE_TRY(hipHostMalloc((void**)&ctx->h_relay_err, sizeof(int)));
+    *ctx->h_relay_err = 0;
     CREATE_TRY(hipMalloc((void**)&ctx->d_relay_flag, (size_t)ctx->max_batch * sizeof(int)));
     CREATE_TRY(hipMemset(ctx->d_relay_flag, 0, (size_t)ctx->max_batch * sizeof(int)));
   } else {
-    ctx->relay_at = 0;
+    ctx->relay_at = 0, ctx->tail_at = 0;
   }
   CREATE_TRY(hipEventCreate(&ctx->ev_idx0));
   CREATE_TRY(hipEventCreate(&ctx->ev_idx1));
@@ -728,7 +749,7 @@ void lins_destroy(lins_ctx* ctx) {
   (void)hipFree(ctx->d_binned);
   (void)hipFree(ctx->d_gsorted);
   (void)hipFree(ctx->d_gridtab);
-  (void)hipFree(ctx->d_relay_hdr), (void)hipFree(ctx->d_relay_lane), (void)hipFree(ctx->d_relay_flag);
+  (void)hipFree(ctx->d_relay_hdr), (void)hipFree(ctx->d_relay_lane), (void)hipFree(ctx->d_relay_flag), (void)hipHostFree(ctx->h_relay_err);
   if (ctx->ev_idx0) (void)hipEventDestroy(ctx->ev_idx0);
   if (ctx->ev_idx1) (void)hipEventDestroy(ctx->ev_idx1);
   (void)hipFree(ctx->d_desc);
@@ -799,6 +820,13 @@ const char* lins_last_search(const lins_ctx* ctx) {
 
 int lins_batch_upload(lins_ctx* ctx, int n, const lins_scan_pair* in) { return upload(ctx, n, in); }
 
+int lins_last_cut(const lins_ctx* ctx, int* parts, int* tail_kernel) {
+  if (!ctx || !parts || !tail_kernel) return LINS_E_ARG;
+  if (!ctx->ran) return LINS_E_STATE;
+  *parts = ctx->last_parts, *tail_kernel = ctx->last_tail;
+  return LINS_OK;
+}
+
 /* HIP-event time (ms) of the search-index build of the last upload (grid_index_kernel over every scan of the batch:
  * the device counterpart of the reference's kd-tree build, setInputCloud in updatePointCloud, SE:1156-1160); 0 when
  * the batch cannot take the grid kernels (nothing was built).                                                       */
@@ -832,33 +860,57 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   // Several-part updates (the kernel's relay): when the batch has more scans than the device has workgroup slots (two
   // per CU), the launch ends with slots idle while the last whole updates finish; cut every relay_at iterations the
   // same work is several times as many shorter jobs and that end shrinks.  Not with the phase profile (one record per
-  // scan).
-  const bool relay = use_mr && ctx->relay_at > 0 && ctx->n_uploaded > 2 * ctx->n_cu && !ctx->d_prof && ctx->relay_at < ctx->prm.num_iter;
-  // (parts: one per relay_at iterations the update may run, at most kRelayMaxParts — the last part runs to the end)
-  const int relay_parts = relay ? std::min(kRelayMaxParts, (ctx->prm.num_iter + ctx->relay_at - 1) / ctx->relay_at) : 1;
+  // scan), and only with ICP_FREQ 1: with a larger one the iterations in between read the triplets an earlier part of
+  // the scan left in idx_store — plain stores of another workgroup, possibly on another XCD.
+  // The iterations from tail_at on run in the tail kernel (ieskf_lds_tail.hip: four scans per CU) as a second launch
+  // behind this one — the last "part", handed over the same way, ordered by the stream instead of a flag wait.
+  const bool cut_ok = use_mr && ctx->n_uploaded > 2 * ctx->n_cu && !ctx->d_prof && ctx->prm.icp_freq == 1 && ctx->d_relay_hdr;
+  const bool tail = cut_ok && ctx->tail_at > 0 && ctx->tail_at < ctx->prm.num_iter && ctx->tail_ok;
+  RelayArgs ra;
+  if (tail) {  // head parts of relay_at iterations when that divides tail_at, else one head part; then the tail
+    const bool sub = ctx->relay_at > 0 && ctx->relay_at < ctx->tail_at && ctx->tail_at % ctx->relay_at == 0 && ctx->tail_at / ctx->relay_at < kRelayMaxParts;
+    ra.at = sub ? ctx->relay_at : ctx->tail_at;
+    ra.launched = ctx->tail_at / ra.at, ra.parts = ra.launched + 1;
+  } else if (cut_ok && ctx->relay_at > 0 && ctx->relay_at < ctx->prm.num_iter) {
+    ra.at = ctx->relay_at;
+    ra.parts = ra.launched = std::min(kRelayMaxParts, (ctx->prm.num_iter + ctx->relay_at - 1) / ctx->relay_at);
+  }
+  const bool relay = ra.parts > 1;
+  ctx->last_parts = relay ? ra.parts : 1, ctx->last_tail = tail ? 1 : 0;
   if (relay && ctx->relay_gen >= (1 << 26)) {  // (flags are 16 gen + part: start over long before the int runs out)
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_relay_flag, 0, (size_t)ctx->max_batch * sizeof(int), ctx->stream));
     ctx->relay_gen = 0;
   }
-  if (relay && ctx->relay_list_parts != relay_parts) {  // the launch list of this many parts: every part 0, then every part 1, ...
+  if (relay && ctx->relay_list_parts != ra.launched) {  // the launch list of this many parts: every part 0, then every part 1, ...
     int* list = ctx->h_order + ctx->n_uploaded;
-    for (int p = 0; p < relay_parts; ++p)
-      for (int k = 0; k < ctx->n_uploaded; ++k) list[p * ctx->n_uploaded + k] = (ctx->use_order ? ctx->h_order[k] : k) | (p << 27);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order + ctx->n_uploaded, list, (size_t)relay_parts * ctx->n_uploaded * sizeof(int), hipMemcpyHostToDevice,
-                                ctx->stream));
-    ctx->relay_list_parts = relay_parts;
+    const int np = ra.launched, n = ctx->n_uploaded;
+    for (int p = 0; p < np; ++p)
+      for (int k = 0; k < n; ++k) {
+        // (debug: 1 = parts in reverse order — every workgroup that waits is handed out before the part it waits for)
+        const int at = ctx->relay_scramble == 1 ? (np - 1 - p) * n + k : p * n + k;
+        list[at] = (ctx->use_order ? ctx->h_order[k] : k) | (p << 27);
+      }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order + n, list, (size_t)np * n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    ctx->relay_list_parts = np;
+  }
+  if (relay) {
+    ra.gen = ++ctx->relay_gen, ra.spins = ctx->relay_spins;
+    ra.hdr = ctx->d_relay_hdr, ra.lane = ctx->d_relay_lane, ra.flag = ctx->d_relay_flag, ra.err = ctx->h_relay_err;
   }
   if (use_mr || use_lds) {
     if (use_mr)
       launch_lds_mr(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc,
                     relay ? ctx->d_order + ctx->n_uploaded : (ctx->use_order ? ctx->d_order : nullptr), ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in,
                     ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx, (lins_pose_record*)d_poses,
-                    scan_id_base, ctx->d_prof, ctx->relay_at, relay_parts, relay ? ++ctx->relay_gen : 0, relay ? ctx->d_relay_hdr : nullptr,
-                    ctx->d_relay_lane, ctx->d_relay_flag);
+                    scan_id_base, ctx->d_prof, relay ? &ra : nullptr);
     else
       launch_lds(ctx->stream, ctx->n_uploaded, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc,
                  ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx,
                  (lins_pose_record*)d_poses, scan_id_base, ctx->d_prof);
+    if (tail)
+      launch_lds_tail(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->use_order ? ctx->d_order : nullptr, ctx->d_arena, ctx->d_gsorted,
+                      ctx->d_gridtab, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx,
+                      (lins_pose_record*)d_poses, scan_id_base, ra, ctx->tail_dense);
     HIP_TRY(ctx, hipEventRecord(ctx->hist1[h], ctx->stream));
     if (q.on) HIP_TRY(ctx, hipEventRecord(q.ev_main[set], ctx->stream));  // (the pose records of this run are complete)
     // (The Joseph update, SE:594-598, is the update kernel's epilogue since round 3: ieskf_lds_impl.h joseph_epilogue.
@@ -1506,8 +1558,7 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
       launch_grid_index(ctx->stream, n, t.d_desc, t.d_arena, t.d_gsorted, t.d_gridtab);
       if (use_mr)
         launch_lds_mr(ctx->stream, n, ctx->dprm, t.d_desc, nullptr, t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in, ctx->d_cov_in,
-                      ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr, 0, 0, 0, nullptr, nullptr,
-                      nullptr);
+                      ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr, nullptr);
       else
         launch_lds(ctx->stream, n, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, t.d_desc, t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in,
                    ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr);
@@ -1685,6 +1736,11 @@ int lins_sync(lins_ctx* ctx) {
   int rc = pipe_join(ctx);  // (side streams of the pipelined mode: ordered before the wait below)
   if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->h_relay_err && *ctx->h_relay_err) {  // (the tail kernel met a scan that was neither handed over nor finished)
+    ctx->hip_err = "several-part update: a scan reached the tail kernel without its hand-over";
+    *ctx->h_relay_err = 0;
+    return LINS_E_HIP;
+  }
   return LINS_OK;
 }
 

@@ -24,7 +24,7 @@ EXPORTS = [
     "lins_streams_init", "lins_streams_step", "lins_streams_stats", "lins_streams_peek", "lins_segment_batch",
     "lins_last_segment_ms", "lins_streams_step_raw", "lins_map_correspondences", "lins_scan2map_batch",
     "lins_last_map_stats", "lins_last_search", "lins_kernel_ms_history", "lins_set_pipelined",
-    "lins_rccl_unique_id", "lins_rccl_init", "lins_pose_allgather", "lins_rccl_destroy", "lins_last_index_ms",
+    "lins_rccl_unique_id", "lins_rccl_init", "lins_pose_allgather", "lins_rccl_destroy", "lins_last_index_ms", "lins_last_cut",
 ]
 
 
@@ -354,6 +354,12 @@ class IeskfContext:
         ms = C.c_float(0)
         self._check(lib().lins_last_index_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def last_cut(self):
+        """(parts, tail_kernel) of the last run(): pieces every update was cut into, and whether the last ran as the tail kernel."""
+        parts, tail = C.c_int(0), C.c_int(0)
+        self._check(lib().lins_last_cut(self._h, C.byref(parts), C.byref(tail)))
+        return parts.value, tail.value
 
     def kernel_ms_history(self, n):
         """HIP-event times (ms) of the update kernels of the last n run() calls, oldest first."""

@@ -232,31 +232,134 @@ def test_search_index_of_an_upload_serves_every_later_run(pkg, ieskf, host):
             c.last_index_ms()
 
 
+def _same_bits(a, b):
+    assert (a.iters, a.converged, a.diverged, a.m_surf, a.m_corner) == (b.iters, b.converged, b.diverged, b.m_surf, b.m_corner)
+    assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov)
+    assert a.residual_norm == b.residual_norm and a.update_norm == b.update_norm
+
+
+def _run_cut(ieskf, monkeypatch, prm, batch, relay_at, tail_at, runs=2, **knobs):
+    """One context with the given cut settings (debug knobs): results + (parts, tail_kernel) of the last run."""
+    monkeypatch.setenv("LINS_ENABLE_DEBUG_KNOBS", "1")
+    monkeypatch.setenv("LINS_RELAY_AT", str(relay_at))
+    monkeypatch.setenv("LINS_TAIL_AT", str(tail_at))
+    for k in ("LINS_TAIL_DENSE", "LINS_RELAY_SCRAMBLE", "LINS_RELAY_SPINS"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, str(v))
+    with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384, search="mr") as c:
+        c.upload(batch)
+        for _ in range(runs):
+            c.run()
+        c.sync()
+        assert c.last_search() == "mr"
+        return c.download(), c.last_cut()
+
+
 @pytest.mark.parametrize("stop_rule", [False, True])
 def test_two_part_updates_return_the_whole_updates_bits(pkg, ieskf, host, monkeypatch, stop_rule):
-    """Batches beyond the device's workgroup slots run every update as consecutive workgroups of one launch (the kernel's
-    relay: each takes the loop state over from the one before, LINS_RELAY_AT iterations per part, default 4).  Same arithmetic in the same order: the
-    results are the whole updates' (LINS_RELAY_AT=0) bit for bit — with fixed iterations and with the reference's stop
-    rule (updates that end before the cut never start a second part), run twice per context (the per-scan flags are
-    numbered by launch, never reset)."""
+    """Batches beyond the device's workgroup slots run every update in parts that hand the loop state over through
+    global memory: consecutive workgroups of the batch kernel's launch (LINS_RELAY_AT iterations each) and / or the TAIL
+    kernel — the iterations from LINS_TAIL_AT on as a second launch, 256-thread workgroups that keep the carried state
+    of every query in LDS and walk the head's wave-rounds two per wave.  Same arithmetic in the same order: the
+    results are the whole updates' (both knobs 0) bit for bit — with fixed iterations and with the reference's stop
+    rule (updates that end before a cut never start the next part), run twice per context (the per-scan flags are
+    numbered by launch, never reset).  601 scans: consecutive parts of a scan sit on different XCDs."""
     prm = pkg.default_params(num_iter=30) if stop_rule else pkg.default_params(num_iter=10, fixed_iters=1)
-    batch = host.synth_batch(600, start=9000)
-    monkeypatch.setenv("LINS_ENABLE_DEBUG_KNOBS", "1")
-    out = {}
-    for at in ("0", "5", "2", "9"):
-        monkeypatch.setenv("LINS_RELAY_AT", at)
-        with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384, search="mr") as c:
-            c.upload(batch)
-            for _ in range(2):
-                c.run()
-            c.sync()
-            out[at] = c.download()
-            assert c.last_search() == "mr"
-    for at in ("5", "2", "9"):
-        for a, b in zip(out["0"], out[at]):
-            assert (a.iters, a.converged, a.diverged, a.m_surf, a.m_corner) == (b.iters, b.converged, b.diverged, b.m_surf, b.m_corner)
-            assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov)
-            assert a.residual_norm == b.residual_norm and a.update_norm == b.update_norm
+    batch = host.synth_batch(601, start=9000)
+    whole, cut0 = _run_cut(ieskf, monkeypatch, prm, batch, 0, 0)
+    assert cut0 == (1, 0)
+    #            relay_at, tail_at -> (parts, tail kernel)
+    for at, tail_at, want in ((5, 0, None), (2, 0, None), (9, 0, None),  # parts of the batch kernel's launch only
+                              (4, 4, (2, 1)), (2, 4, (3, 1)), (3, 6, (3, 1)), (0, 5, (2, 1)), (4, 7, (2, 1))):
+        got, cut = _run_cut(ieskf, monkeypatch, prm, batch, at, tail_at)
+        if want is not None:
+            assert cut == want, (at, tail_at, cut)
+        else:
+            assert cut[0] > 1 and cut[1] == 0
+        for a, b in zip(whole, got):
+            _same_bits(a, b)
+
+
+def test_default_cut_of_a_large_batch(pkg, ieskf, host):
+    """What a caller gets without any knob: parts of four iterations inside the batch kernel's launch, no tail kernel
+    (measured slower); a batch within the device's workgroup slots: whole updates."""
+    prm = pkg.default_params(num_iter=10, fixed_iters=1)
+    batch = host.synth_batch(520, start=12000)
+    with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384) as c:
+        c.upload(batch)
+        c.run()
+        c.sync()
+        assert c.last_search() == "mr" and c.last_cut() == (3, 0)
+        r = c.download()
+        c.upload(batch[:300])
+        c.run()
+        c.sync()
+        assert c.last_cut() == (1, 0)
+    assert all(x.iters == 10 for x in r)
+
+
+def test_tail_kernel_with_dense_wave_rounds_agrees_to_rounding(pkg, ieskf, host, monkeypatch):
+    """LINS_TAIL_DENSE packs the tail's wave-rounds to 64 queries: the 28 sums are added in another order, so the results
+    agree with the whole updates' to rounding, not bit for bit (flags and row counts equal)."""
+    prm = pkg.default_params(num_iter=10, fixed_iters=1)
+    batch = host.synth_batch(601, start=9000)
+    whole, _ = _run_cut(ieskf, monkeypatch, prm, batch, 0, 0, runs=1)
+    dense, cut = _run_cut(ieskf, monkeypatch, prm, batch, 4, 4, runs=1, LINS_TAIL_DENSE=1)
+    assert cut == (2, 1)
+    for a, b in zip(whole, dense):
+        assert (a.iters, a.converged, a.diverged) == (b.iters, b.converged, b.diverged)
+        assert abs(a.m_surf - b.m_surf) + abs(a.m_corner - b.m_corner) <= 1  # (a row on the s > 0.1 edge may flip)
+        assert np.max(np.abs(a.state - b.state)) < 1e-9 and np.max(np.abs(a.cov - b.cov)) <= 1e-9 * np.max(np.abs(a.cov))
+
+
+def test_parts_handed_out_in_the_wrong_order_degrade_to_whole_updates(pkg, ieskf, host, monkeypatch):
+    """HIP promises nothing about the order workgroups are handed out in.  LINS_RELAY_SCRAMBLE=1 lists every part in
+    front of the part it waits for — the worst case: the waiting workgroups fill the device before any first part is
+    resident.  Each gives up after its bounded wait (LINS_RELAY_SPINS, shortened here) and runs the whole update alone:
+    the launch ends, the results are the whole updates' bits (round 3 ended such a wait in __builtin_trap())."""
+    prm = pkg.default_params(num_iter=10, fixed_iters=1)
+    batch = host.synth_batch(601, start=9000)
+    whole, _ = _run_cut(ieskf, monkeypatch, prm, batch, 0, 0, runs=1)
+    for at, tail_at in ((2, 0), (2, 4)):
+        got, cut = _run_cut(ieskf, monkeypatch, prm, batch, at, tail_at, runs=2, LINS_RELAY_SCRAMBLE=1, LINS_RELAY_SPINS=64)
+        assert cut[0] > 1
+        for a, b in zip(whole, got):
+            _same_bits(a, b)
+
+
+def test_certificates_in_the_tail_kernel_never_disagree_with_a_real_search(pkg, ieskf, host, monkeypatch):
+    """LINS_DEBUG_SKIP=8 (search anyway, count disagreements on device) through head + tail: the KNOBS instantiations of
+    both kernels, the counters travelling in the hand-over."""
+    prm = pkg.default_params(num_iter=10, fixed_iters=1)
+    batch = host.synth_batch(601, start=9000)
+    plain, _ = _run_cut(ieskf, monkeypatch, prm, batch, 4, 4, runs=1)
+    monkeypatch.setenv("LINS_DEBUG_SKIP", "8")
+    got, cut = _run_cut(ieskf, monkeypatch, prm, batch, 4, 4, runs=1)
+    monkeypatch.delenv("LINS_DEBUG_SKIP")
+    assert cut == (2, 1)
+    for a, b in zip(plain, got):
+        assert b.reserved[0] == 0, f"{b.reserved[0]} certificate disagreements"
+        assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov)
+    # (the certificates did speak in the plain run: ~2 decisions per query and late iteration, counted across the cut)
+    assert sum(a.reserved[1] + a.reserved[2] for a in plain) > 100 * len(batch)
+
+
+def test_icp_freq_above_one_is_never_cut(pkg, ieskf, host, monkeypatch):
+    """With ICP_FREQ > 1 the iterations between two searches read the triplets an earlier iteration stored — plain
+    stores that another workgroup (another XCD) need not see: such batches run whole updates whatever their size
+    (ADVICE round 3), and return what a small batch of the same scans returns."""
+    prm = pkg.default_params(num_iter=9, fixed_iters=1, icp_freq=2)
+    batch = host.synth_batch(603, start=9000)
+    got, cut = _run_cut(ieskf, monkeypatch, prm, batch, 2, 4, runs=1)
+    assert cut == (1, 0)
+    with ieskf.IeskfContext(prm, max_batch=64, max_targets=16384, search="mr") as c:
+        c.upload(batch[:64])
+        c.run()
+        c.sync()
+        small = c.download()
+    for a, b in zip(small, got[:64]):
+        _same_bits(a, b)
 
 
 def test_pipelined_staged_mode_returns_the_same_bits(pkg, ieskf, host):
