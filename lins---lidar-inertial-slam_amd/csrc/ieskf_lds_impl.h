@@ -70,8 +70,14 @@
 #ifndef LINS_TAIL_STAGED
 #define LINS_TAIL_STAGED 0
 #endif
+#ifndef LINS_WALK_CACHE
+#define LINS_WALK_CACHE 1  // (the second / third points of a query's previous nearest neighbour kept for its return: see the kernel)
+#endif
 #ifndef LINS_TAIL_OOL
-#define LINS_TAIL_OOL 1
+#define LINS_TAIL_OOL 0  // (the tail kernel's searches out of line)
+#endif
+#ifndef LINS_TAIL_PREFETCH
+#define LINS_TAIL_PREFETCH 0  // (the tail kernel's six candidate records in one round trip: measured slower — the registers)
 #endif
 #ifndef LINS_SPREAD_S
 // waves the plane / line queries of a 512-thread workgroup are spread over.  Measured on the batch workload (91 plane
@@ -115,10 +121,11 @@ struct KernelArgs {
   int* relay_lane;
   int* relay_flag;
   int* relay_err;  // one word per context: raised when a hand-over protocol violation was seen (checked at lins_batch_sync)
+  unsigned* walk_cache;  // per query slot 8 words: the second / third points of the nearest neighbour the query had BEFORE (walk cache below); may be null
+  int run_gen;           // number of this launch (tags of the walk cache: an entry of an earlier launch does not count)
   int iter_arg, scan_id_base, relay_n, relay_at, relay_parts, relay_gen;
   int relay_spins;  // polls of ~1 us a part waits for its hand-over before it runs the whole update on its own
   int tail_part;    // (tail kernel) the part this launch continues: the head handed over at iteration tail_part x relay_at
-  int tail_dense;   // (tail kernel) 1: dense wave-rounds of 64 queries, 0: the head's own query <-> lane layout (same bits)
 };
 typedef const KernelArgs __attribute__((address_space(4))) * ColdArgs;
 __device__ __forceinline__ ColdArgs cold_args() {
@@ -138,6 +145,7 @@ static_assert(kNpMax >= kNpCap && kNpMax <= kGridNpMax, "positions are u16, indi
 #define LINS_LDS_TAIL 0
 #endif
 constexpr bool kTail = LINS_LDS_TAIL != 0;
+constexpr bool kTailR = kTail && LINS_TAIL_PREFETCH != 0;
 constexpr int kTailSlots = 384;  // queries of a scan the tail kernel takes (the VLP-16 caps: 144 + 192, SE:727-793)
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 struct LdsStore {
@@ -157,6 +165,10 @@ struct LdsStore {
   int scan_tmp[kMaxLWaves + 4];
   int m_surf, m_corner, iter, conv, div, pad;
   long long prof_acc[16];  // phase profile accumulators of the PROF variant (written by thread 0)
+#ifdef LINS_PROF2
+  int prof2[64];  // per wave x phase ticks of the iterations >= LINS_PROF2 (lane 0 of each wave; lins_debug_wave_phases)
+  int prof3[32];  // per wave: [0] wave-iterations with a nearest-neighbour search [1] ... with a walk [2] searches [3] walks
+#endif
   int dbg[4];  // [0] certificate disagreements (verify mode) [1] NN searches skipped [2] walks skipped
 #if LINS_LDS_TAIL
   // tail kernel: the carried per-query state (CarryWords) of every query of the scan, by query index — a wave takes a
@@ -1119,10 +1131,11 @@ struct CarryWords {
   v4u w0, w1, w2;
   unsigned w3;
 };
-constexpr int kRelayLanes = 512;                    // lanes of the head kernel: the hand-over is indexed by head lane
-constexpr int kRelayLaneInts = 4 * kRelayLanes * 4;  // ints per scan in relay_lane
+constexpr int kRelayLanes = 512;                    // query slots of a scan (the batch kernel's one-round layouts hold at most 320 + 192)
+constexpr int kRelayRegionInts = 4 * kRelayLanes * 4;  // ints per scan in relay_lane: [4][512] 16-byte words, by QUERY slot
+constexpr int kRelayLaneInts = kRelayRegionInts;
 __device__ __forceinline__ void relay_st_carry(int* scan_base /*wave-uniform*/, int head_lane, const CarryWords& c) {
-  const auto rs = __builtin_amdgcn_make_buffer_rsrc(scan_base, 0, kRelayLaneInts * 4, 0x00020000);
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(scan_base, 0, kRelayRegionInts * 4, 0x00020000);
   __builtin_amdgcn_raw_buffer_store_b128(c.w0, rs, (0 * kRelayLanes + head_lane) * 16, 0, 16);  // (aux 16 = sc1)
   __builtin_amdgcn_raw_buffer_store_b128(c.w1, rs, (1 * kRelayLanes + head_lane) * 16, 0, 16);
   __builtin_amdgcn_raw_buffer_store_b128(c.w2, rs, (2 * kRelayLanes + head_lane) * 16, 0, 16);
@@ -1143,7 +1156,7 @@ __device__ __noinline__ void relay_out_carry(int* scan_base, int head_lane, int 
   relay_st_carry(scan_base, head_lane, c);
 }
 __device__ __forceinline__ CarryWords relay_ld_carry(const int* scan_base /*wave-uniform*/, int head_lane) {
-  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(scan_base), 0, kRelayLaneInts * 4, 0x00020000);
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(scan_base), 0, kRelayRegionInts * 4, 0x00020000);
   CarryWords c;
   c.w0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (0 * kRelayLanes + head_lane) * 16, 0, 16);
   c.w1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (1 * kRelayLanes + head_lane) * 16, 0, 16);
@@ -1179,6 +1192,18 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   // allocation of the production one: [0] setup [1] corr [2] reduce [3] solve [4] update [5] total
   // [6..9] thread 0's own de-skew / NN / walk / geometry  [10..15] per-iteration time of iterations 0..5
   if (prof && threadIdx.x < 16) g_lds.prof_acc[threadIdx.x] = 0;
+#ifdef LINS_PROF2
+  if (prof && threadIdx.x < 64) g_lds.prof2[threadIdx.x] = 0;
+  if (prof && threadIdx.x < 32) g_lds.prof3[threadIdx.x] = 0;
+#define PROF2_ADD(ph, dt)                                                                   \
+  do {                                                                                      \
+    if (prof && lane == 0 && iter >= LINS_PROF2 && wave < 8) g_lds.prof2[wave * 8 + (ph)] += (int)(dt); \
+  } while (0)
+#else
+#define PROF2_ADD(ph, dt) \
+  do {                    \
+  } while (0)
+#endif
   const long long t_begin = prof ? clock64() : 0, t_wall_begin = prof ? wall_clock64() : 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave: a scalar)
   // Launch order: workgroup b takes scan order[b] — the host lists the scans longest-expected-first (lins_capi.hip
@@ -1274,6 +1299,45 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
                   gs, n_lds};
   const int role = lane % LANES, lane_base = lane - role, q_in_wave = lane / LANES;
   const bool lane_used = lane < kQPerWave * LANES;
+  // ---- query -> lane layout of the one-lane-per-query shapes: WAVE-ROUNDS -------------------------------------------------
+  // A wave takes, per round, up to 64 queries of ONE kind (plane or line), so that the kind, the target cloud's grid
+  // (LCloud) and every branch on them are wave-uniform: scalar selects and branches instead of per-lane selects with both
+  // clouds' parameters live across the search code.  Two layouts:
+  //   spread  the plane queries (the costlier kind: two walks over five rings) evenly over the first kSpreadSurf waves,
+  //           the line queries over the rest, one round — a wave runs the union of its lanes' search paths, so the
+  //           queries are spread as thin as the waves allow; the lane <-> query mapping is fixed for the whole update;
+  //   rounds  query sets that do not fit one round: wave-rounds of 64 dealt to the waves round after round (nothing is
+  //           carried between iterations then).
+  // (Round 4 measured a third one for the late iterations — as few wave-rounds as hold the queries, 2 + 3 instead of 5 + 3,
+  // the extra waves placed so that the two scans of a CU double different SIMDs, the change of layout through the
+  // hand-over words: +1.9 % kernel time from iteration 4 on, +9 % from iteration 1)
+  struct WrLay {
+    int n_wr, k;  // wave-rounds of the scan, this wave's wave-round (>= n_wr: none)
+    bool kind_s;  // its kind
+    int slot;     // this lane's query: plane queries first, then line queries
+    bool active;
+  };
+  constexpr int kWaves = BLOCK / 64, kSpreadSurf = LINS_SPREAD_S > 0 && BLOCK == 512 ? LINS_SPREAD_S : (kWaves * 5 + 4) / 8;
+  constexpr int kWs = kTail ? LINS_SPREAD_S : kSpreadSurf;
+  constexpr int kWc = kTail ? LINS_SPREAD_C : (LINS_SPREAD_C > 0 && BLOCK == 512 ? LINS_SPREAD_C : kWaves - kWs);
+  const int lay_ps = (sd.n_surf_q + kWs - 1) / kWs, lay_pc = kWc > 0 ? (sd.n_corner_q + kWc - 1) / kWc : 65;
+  const bool spread_ok = (kTail || kWs < kWaves) && lay_ps <= 64 && lay_pc <= 64;  // the one-round spread layout holds the scan
+  auto wr_layout = [&](int rnd) {
+    WrLay y;
+    int nws, per_s, per_c;
+    if (spread_ok) {
+      nws = kWs, per_s = lay_ps, per_c = lay_pc, y.n_wr = kWs + kWc;
+    } else {
+      nws = (sd.n_surf_q + 63) >> 6, per_s = per_c = 64, y.n_wr = nws + ((sd.n_corner_q + 63) >> 6);
+    }
+    y.k = rnd * kWaves + wave;
+    y.kind_s = y.k < nws;
+    const int q0 = y.kind_s ? y.k * per_s : (y.k - nws) * per_c;
+    const int left = (y.kind_s ? sd.n_surf_q : sd.n_corner_q) - q0, per = y.kind_s ? per_s : per_c;
+    y.slot = (y.kind_s ? 0 : sd.n_surf_q) + q0 + lane, y.active = y.k < y.n_wr && lane < (left < per ? left : per);
+    return y;
+  };
+
   // last iteration's triplet of this lane's query (grid positions) for the warm start; only
   // meaningful when the scan needs a single round (the lane <-> query mapping is then fixed)
   int a1 = -1, b1c = -1, ra1 = -1, rb1 = -1;  // nearest neighbour: tracked winner / runner-up (+ their rings)
@@ -1307,6 +1371,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     certB[0] = __uint_as_float(c.w2.z), certB[1] = __uint_as_float(c.w2.w), certB[2] = __uint_as_float(c.w3);
   };
   static_assert(kGridNpMax < 32768, "grid positions travel as signed 16-bit words");
+  (void)carry_pack, (void)carry_unpack;
   if ((kRelay && part) || kTail) {  // take-over: the loop state the part before left (the barrier of the grid load has passed)
     const double* h = ka.relay_hdr + (size_t)scan * kRelayHdr;
     if (tid < 58) reinterpret_cast<double*>(&L.ic)[tid] = relay_ld(h + tid);
@@ -1318,29 +1383,23 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     const int* ln = ka.relay_lane + (size_t)scan * kRelayLaneInts;
     if constexpr (kTail) {
 #if LINS_LDS_TAIL
-      // every head lane's words go to the LDS slot of its query (the head's layout: plane queries spread over its first
-      // LINS_SPREAD_S waves, line queries over the other LINS_SPREAD_C — the host only sends scans laid out that way)
-      const int ps = (sd.n_surf_q + LINS_SPREAD_S - 1) / LINS_SPREAD_S, pc = (sd.n_corner_q + LINS_SPREAD_C - 1) / LINS_SPREAD_C;
-#pragma unroll
-      for (int hl = tid; hl < kRelayLanes; hl += BLOCK) {
-        const int w = hl >> 6, l = hl & 63;
-        const bool ks = w < LINS_SPREAD_S;
-        const int q = ks ? w * ps + l : (w - LINS_SPREAD_S) * pc + l;
-        if (l < (ks ? ps : pc) && q < (ks ? sd.n_surf_q : sd.n_corner_q)) {
-          const CarryWords c = relay_ld_carry(ln, hl);
-          const int slot = (ks ? 0 : sd.n_surf_q) + q;
-          L.cw0[slot] = c.w0, L.cw1[slot] = c.w1, L.cw2[slot] = c.w2, L.cw3[slot] = c.w3;
-        }
+      for (int slot = tid; slot < total; slot += BLOCK) {  // every query's words into its LDS slot
+        const CarryWords c = relay_ld_carry(ln, slot);
+        L.cw0[slot] = c.w0, L.cw1[slot] = c.w1, L.cw2[slot] = c.w2, L.cw3[slot] = c.w3;
       }
       for (int k = tid; k < kMaxLWaves * 28; k += BLOCK) L.partial[k] = 0.0;  // (wave-rounds a scan does not have stay 0)
 #endif
     } else {
-      carry_unpack(relay_ld_carry(ln, tid));
+      const WrLay y = wr_layout(0);
+      if (y.active) carry_unpack(relay_ld_carry(ln, y.slot));
     }
     searched = true;
     __syncthreads();
   }
   bool relay_out = false;
+#ifdef LINS_PROF2
+  int dbg_nn = 0, dbg_walk = 0, dbg_walk_mask = 0, dbg_slot = -1;  // this lane's query: searches / walks in the iterations >= LINS_PROF2
+#endif
 
   for (;;) {
     const int iter = L.iter;
@@ -1356,35 +1415,15 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     double acc = 0;
     int ms = 0, mc = 0;
     long long t0 = prof ? clock64() : 0, t1 = t0, t2 = t0, t3 = t0;
-    // Query -> lane layout.
-    // LANES == 1: WAVE-ROUNDS — a wave takes, per round, up to 64 queries of ONE kind (plane or line), so that the kind, the
-    // target cloud's grid (LCloud) and every branch on them are wave-uniform: scalar selects and scalar branches instead of
-    // per-lane selects with both clouds' parameters live across the search code (the round-3 kernel sat at the 106-SGPR
-    // limit with ~280 v_readlane / v_writelane in the per-iteration path for it).  One lane per query means a wave runs
-    // the union of its lanes' search paths, so its time grows with the number of active lanes: when they fit, the plane
-    // queries (the costlier kind: two walks over five rings) are spread evenly over the first kSpreadSurf waves and the
-    // line queries over the rest — one round, the lane <-> query mapping fixed for the whole update.  Larger query sets:
-    // dense wave-rounds of 64, dealt to the waves round after round (nothing carries over between iterations then).
-    // LANES == 3: when both kinds fit one round with the corner queries starting on a wave boundary, do that: no wave
-    // then mixes plane and line code paths.
+    // Query -> lane layout.  LANES == 1: wave-rounds (wr_layout above).  LANES == 3: when both kinds fit one round with the
+    // corner queries starting on a wave boundary, do that: no wave then mixes plane and line code paths.
     int surf_waves = (sd.n_surf_q + kQPerWave - 1) / kQPerWave;
     const bool aligned = surf_waves * kQPerWave + sd.n_corner_q <= kQPerRound;
-    constexpr int kWaves = BLOCK / 64, kSpreadSurf = LINS_SPREAD_S > 0 && BLOCK == 512 ? LINS_SPREAD_S : (kWaves * 5 + 4) / 8;
-    int wr_ns = 0, wr_per_s = 64, wr_per_c = 64, n_wr = 0;  // wave-rounds of plane queries, queries per wave-round of either kind, wave-rounds
-    if (LANES == 1) {
-      // (the tail kernel's four waves walk the HEAD's eight wave-rounds, two each — the same lanes in the same reduction
-      // tree: the same bits — or, tail_dense, wave-rounds of 64)
-      constexpr int ws = kTail ? LINS_SPREAD_S : kSpreadSurf;
-      constexpr int wc = kTail ? LINS_SPREAD_C : (LINS_SPREAD_C > 0 && BLOCK == 512 ? LINS_SPREAD_C : kWaves - ws);
-      const int ps = (sd.n_surf_q + ws - 1) / ws, pc = wc > 0 ? (sd.n_corner_q + wc - 1) / wc : 65;
-      if ((kTail || ws < kWaves) && ps <= 64 && pc <= 64 && !(kTail && ka.tail_dense))
-        wr_ns = ws, wr_per_s = ps, wr_per_c = pc, n_wr = ws + wc;
-      else
-        wr_ns = (sd.n_surf_q + 63) >> 6, n_wr = wr_ns + ((sd.n_corner_q + 63) >> 6);
-    }
+    const int n_wr = LANES == 1 ? wr_layout(0).n_wr : 0;
     const int span = LANES == 1 ? ((n_wr + kWaves - 1) / kWaves) * kQPerRound
                                 : (aligned ? surf_waves * kQPerWave + sd.n_corner_q : total);  // row slots in use
     int4 held = make_int4(0, 0, 0, -1);  // (ICP, ICP_FREQ > 1, single round) a corner triplet waiting for the plane-row count
+    int part_k = wave;  // the slot of this wave's partial sums: its wave-round
     for (int base = 0; base < span; base += kQPerRound) {
       const int vslot = base + wave * kQPerWave + q_in_wave;  // position in the (padded) layout
       int slot = vslot;                                        // query index: surf first, then corner
@@ -1392,12 +1431,10 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       bool kind_s = true;  // (LANES == 1) this wave-round's kind, wave-uniform
       int wr_k = 0;        // (LANES == 1) this wave's wave-round
       if (LANES == 1) {
-        const int k = wr_k = (base / kQPerRound) * kWaves + wave;
-        if (kTail && k >= n_wr) continue;  // (wave-uniform; nothing below synchronises the workgroup)
-        kind_s = k < wr_ns;
-        const int q0 = kind_s ? k * wr_per_s : (k - wr_ns) * wr_per_c;
-        const int left = (kind_s ? sd.n_surf_q : sd.n_corner_q) - q0, per = kind_s ? wr_per_s : wr_per_c;
-        slot = (kind_s ? 0 : sd.n_surf_q) + q0 + lane, active = lane < (left < per ? left : per);
+        const WrLay y = wr_layout(base / kQPerRound);
+        wr_k = y.k, kind_s = y.kind_s, slot = y.slot, active = y.active;
+        if (base == 0) part_k = y.k & (kMaxLWaves - 1);
+        if (kTail && y.k >= n_wr) continue;  // (wave-uniform; nothing below synchronises the workgroup)
       } else if (aligned) {
         if (wave < surf_waves)
           active = active && vslot < sd.n_surf_q;
@@ -1451,7 +1488,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
             q = make_float4(1.f + lane, 2.f, 0.5f, 3.25f);
           else
             q = arena[(is_surf ? sd.off_surf_q : sd.off_corner_q) + qi];
-          if constexpr (kTail) {
+          if constexpr (kTailR) {
 #if LINS_TAIL_STAGED
             R[0] = c.gs[a1 < 0 ? 0 : a1], R[1] = c.gs[b1c < 0 ? 0 : b1c];  // (the other four: behind the nearest neighbour's stage)
 #else
@@ -1471,26 +1508,27 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #ifndef LINS_PROF_WAVES
           if (tid == 0) L.prof_acc[6] += s1 - s0;
 #endif
+          PROF2_ADD(0, s1 - s0);
         }
         auto dist_to = [&](int pos) { return pt_sqdist(L, c, pos, o.sel[0], o.sel[1], o.sel[2]); };
         // distance to / original index of tracked candidate `pos`, whose record is r in the tail kernel
         auto dist_r = [&](const float4& r, int pos) {
-          if constexpr (kTail)
+          if constexpr (kTailR)
             return sqdist3(r.x, r.y, r.z, o.sel[0], o.sel[1], o.sel[2]);
           else
             return dist_to(pos);
         };
         auto idx_r = [&](const float4& r, int pos) {
-          if constexpr (kTail)
+          if constexpr (kTailR)
             return __float_as_int(r.w);
           else
             return pt_idx(L, c, pos);
         };
         auto reload_r = [&](float4& r, int pos) {
-          if constexpr (kTail) r = c.gs[pos < 0 ? 0 : pos];
+          if constexpr (kTailR) r = c.gs[pos < 0 ? 0 : pos];
         };
         auto swap_r = [&](float4& x, float4& y) {
-          if constexpr (kTail) {
+          if constexpr (kTailR) {
             const float4 t = x;
             x = y, y = t;
           }
@@ -1507,9 +1545,11 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #if LINS_LDS_TAIL
           if (active) {
             carry_unpack(CarryWords{L.cw0[slot], L.cw1[slot], L.cw2[slot], L.cw3[slot]});
-            const int cp[6] = {a1, b1c, a2, b2c, a3, b3c};
+            if constexpr (kTailR) {
+              const int cp[6] = {a1, b1c, a2, b2c, a3, b3c};
 #pragma unroll
-            for (int k = 0; k < 6; ++k) R[k] = c.gs[cp[k] < 0 ? 0 : cp[k]];
+              for (int k = 0; k < 6; ++k) R[k] = c.gs[cp[k] < 0 ? 0 : cp[k]];
+            }
           }
 #endif
         };
@@ -1549,6 +1589,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           // --- nearest neighbour: the searches of this wave, coop_lanes() lanes each ---------------------------
           {
             const CoopMap cm = coop_map(need_nn, lane);
+#ifdef LINS_PROF2
+            if (prof && lane == 0 && iter >= LINS_PROF2 && cm.n) g_lds.prof3[wave * 4 + 0] += 1, g_lds.prof3[wave * 4 + 2] += cm.n;
+#endif
             int r_pos = -1, r_ring = -1, r_pos2 = -1, r_ring2 = -1;
             float r_lb = 0.f;
             if (cm.n) {  // (wave-uniform)
@@ -1584,8 +1627,41 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
             }
           }
           const bool nn_changed = p1 != sel1;
+          // Walk cache.  A query that sits on the bisector of two target points changes its nearest neighbour back and
+          // forth — the ICP flip-flop: the correspondence flips, the row with it, the state moves by a micron, the
+          // correspondence flips back — and every change asks for the walk again, because the candidate sets of the second /
+          // third point hang on the nearest neighbour (its index and ring, SE:859-910).  Round 4 measured it: 0.8 % of the
+          // plane queries walk in EVERY late iteration and account for 60 % of the late walks, each ~20 k ticks on the
+          // critical path of its workgroup (tools/wave_phases.py).  So the tracked candidates and certificates of the walk
+          // are kept PER NEAREST NEIGHBOUR: on a change, the outgoing neighbour's set goes to the query's entry in global
+          // memory and, if the entry holds the set of the incoming one, that set comes back and is judged like any other —
+          // it was established by an exact walk for exactly this neighbour over the same clouds, so its certificate says
+          // what it said then.  (Tags carry the launch number: nothing survives a run; device-coherent accesses: the parts
+          // of a cut update may sit on different XCDs.)
+          bool set_ok = !nn_changed;  // the carried second / third points belong to this nearest neighbour
+          // (not a workgroup that runs a scan alone: a slow part of the same scan may be reading and writing the entries)
+          if (LINS_WALK_CACHE && !PASS_ONLY && warm_iter && nn_changed && active && ka.walk_cache && !solo && !(pad & 0x800000)) {  // (LINS_DEBUG_SKIP bit 0x800000: no walk cache)
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(ka.walk_cache + (size_t)sd.slot_base * 8, 0, total * 32, 0x00020000);
+            const unsigned gen16 = (unsigned)ka.run_gen << 16;
+            const v4u e0 = __builtin_amdgcn_raw_buffer_load_b128(rs, slot * 32, 0, 16);
+            const v4u e1 = __builtin_amdgcn_raw_buffer_load_b128(rs, slot * 32 + 16, 0, 16);
+            if (sel1 >= 0) {  // (the carried set is sel1's: a walk or a judged set stood behind every selected neighbour)
+              __builtin_amdgcn_raw_buffer_store_b128(v4u{gen16 | (unsigned)sel1, ((unsigned)a2 & 0xFFFFu) | ((unsigned)b2c << 16),
+                                                         ((unsigned)a3 & 0xFFFFu) | ((unsigned)b3c << 16), __float_as_uint(lb2)},
+                                                     rs, slot * 32, 0, 16);
+              __builtin_amdgcn_raw_buffer_store_b128(v4u{__float_as_uint(lb3), __float_as_uint(certB[0]), __float_as_uint(certB[1]),
+                                                         __float_as_uint(certB[2])},
+                                                     rs, slot * 32 + 16, 0, 16);
+            }
+            if (p1 >= 0 && e0.x == (gen16 | (unsigned)p1)) {
+              a2 = (int)(short)(e0.y & 0xFFFFu), b2c = (int)e0.y >> 16, a3 = (int)(short)(e0.z & 0xFFFFu), b3c = (int)e0.z >> 16;
+              lb2 = __uint_as_float(e0.w), lb3 = __uint_as_float(e1.x);
+              certB[0] = __uint_as_float(e1.y), certB[1] = __uint_as_float(e1.z), certB[2] = __uint_as_float(e1.w);
+              set_ok = true;
+            }
+          }
           if (active) sel1 = p1;
-#if LINS_LDS_TAIL && LINS_TAIL_STAGED
+#if LINS_LDS_TAIL && LINS_TAIL_STAGED && LINS_TAIL_PREFETCH
           if (active) {
             R[2] = c.gs[a2 < 0 ? 0 : a2], R[3] = c.gs[b2c < 0 ? 0 : b2c];
             if (is_surf) R[4] = c.gs[a3 < 0 ? 0 : a3], R[5] = c.gs[b3c < 0 ? 0 : b3c];
@@ -1596,13 +1672,14 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #ifndef LINS_PROF_WAVES
             if (tid == 0) L.prof_acc[7] += s2 - s1;
 #endif
+            PROF2_ADD(1, s2 - s1);
           }
           // --- second / third point: certificate (owner) --------------------------------------------------
           bool need_walk = false, flip2 = false, flip3 = false, said23 = false;
           int pred2 = -1, pred3 = -1, j1 = -1;
           if (active && p1 >= 0) {
             j1 = idx_r(R[0], p1);  // (p1 >= 0 => p1 is candidate A, on ring ra1)
-            need_walk = nn_changed || !warm_iter;
+            need_walk = !set_ok || !warm_iter;
             if (!need_walk && (pad & 0x80000)) {
               pred2 = a2, pred3 = a3, said23 = true;
             } else if (!need_walk) {
@@ -1628,6 +1705,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           // --- second / third point: the walks of this wave --------------------------------------------------
           {
             const CoopMap cm = coop_map(need_walk, lane);
+#ifdef LINS_PROF2
+            if (prof && lane == 0 && iter >= LINS_PROF2 && cm.n) g_lds.prof3[wave * 4 + 1] += 1, g_lds.prof3[wave * 4 + 3] += cm.n;
+#endif
             int r2 = -1, r2b = -1, r3 = -1, r3b = -1;
             float r_lb2 = 0.f, r_lb3 = 0.f;
             if (cm.n) {
@@ -1636,14 +1716,17 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
               if constexpr (kTail && LINS_TAIL_OOL) {
                 tail_park();
                 r = coop_walk_ool(is_surf, gs, sd.n_corner_t, sd.n_surf_t, n_lds, nq, cm.n, cm.rank, cm.owner_map, coop_cap, need_walk, lane,
-                                  o.sel[0], o.sel[1], o.sel[2], j1, ra1, a2, a3, nn_changed, thr, margin, (pad & 1) != 0);
+                                  o.sel[0], o.sel[1], o.sel[2], j1, ra1, a2, a3, !set_ok, thr, margin, (pad & 1) != 0);
                 tail_unpark();
               } else {
-                r = coop_walk(L, c, is_surf, nq, cm, coop_cap, need_walk, lane, o.sel[0], o.sel[1], o.sel[2], qp, j1, ra1, a2, a3, nn_changed, thr,
+                r = coop_walk(L, c, is_surf, nq, cm, coop_cap, need_walk, lane, o.sel[0], o.sel[1], o.sel[2], qp, j1, ra1, a2, a3, !set_ok, thr,
                               margin, (pad & 1) != 0);
               }
               r2 = r.r2, r2b = r.r2b, r3 = r.r3, r3b = r.r3b, r_lb2 = r.lb2, r_lb3 = r.lb3;
             }
+#ifdef LINS_PROF2
+            if (prof && iter >= LINS_PROF2 && active) dbg_slot = sd.slot_base + slot, dbg_walk += need_walk, dbg_nn += need_nn, dbg_walk_mask |= (need_walk ? 1 : 0) << iter | (nn_changed ? 1 : 0) << (16 + iter);
+#endif
             if (need_walk) {
               if (said23 && (r2 != pred2 || (is_surf && r3 != pred3))) atomicAdd(&L.dbg[0], 1);
               p2 = r2, p3 = r3;
@@ -1688,6 +1771,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         }
 #endif
         long long s3 = prof ? clock64() : 0;
+        if (prof && do_search) PROF2_ADD(2, s3 - s2);
         // The iteration constants the rows need (R^T, G^T: 36 registers' worth, the same for every lane) are read from
         // LDS HERE.  Without the fence the compiler hoists those reads to the top of the iteration, finds no
         // registers for them across the search code, and moves them through scratch: ~12 scratch stores and as many
@@ -1696,7 +1780,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         if (active && !(pad & 0x20000)) {  // (counting aid: LINS_DEBUG_SKIP bit 0x20000 drops the rows)
           // (a selected point is the first of its two tracked candidates: p1 == a1, p2 == a2, p3 == a3 when they exist)
           auto pt4 = [&](int pos, const float4& r) {
-            if constexpr (kTail) return r;
+            if constexpr (kTailR) return r;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             pt_xyz(L, c, pos, v.x, v.y, v.z);
             return v;
@@ -1738,6 +1822,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #ifndef LINS_PROF_WAVES
         if (prof && tid == 0) L.prof_acc[9] += clock64() - s3;
 #endif
+        if (prof) PROF2_ADD(3, clock64() - s3);
       } else if (active) {
         const bool is_surf = slot < sd.n_surf_q;
         const int qi = is_surf ? slot : slot - sd.n_surf_q;
@@ -1934,7 +2019,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       if (prof && lane == 0 && iter >= LINS_PROF_WAVES) L.prof_acc[6 + wave] += t1 - t0;
 #endif
       if (!(pad & 0x40000)) {  // no LDS, no barrier: the rows never leave registers
+        const long long r0 = prof ? clock64() : 0;
         const double red = wave_reduce_rows(row, lane);
+        if (prof) PROF2_ADD(4, clock64() - r0);
         if constexpr (kTail) {  // one partial per wave-round, in the slot of the head wave that would have held it
 #if LINS_LDS_TAIL
           const int si = reduce_sum_index(lane);
@@ -1948,11 +2035,14 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     if (do_search) searched = true;
     if (!kTail) {
       const int sidx28 = reduce_sum_index(lane);
-      if (sidx28 >= 0) L.partial[wave * 28 + sidx28] = acc;
+      if (sidx28 >= 0) L.partial[part_k * 28 + sidx28] = acc;
     }
     if (ms) atomicAdd(&L.m_surf, ms);
     if (mc) atomicAdd(&L.m_corner, mc);
+    const long long b0 = prof ? clock64() : 0;
     __syncthreads();
+    const long long b1 = prof ? clock64() : 0;
+    PROF2_ADD(5, b1 - b0);
     if (tid < 28) {
       double sacc = 0;
 #pragma unroll
@@ -1961,6 +2051,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     }
     __syncthreads();
     if (prof) t2 = clock64();
+    PROF2_ADD(6, t2 - b1);
     if (PASS_ONLY && (pad & 4) && !L.conv) {
       // test aid: repeat the pass with the warm start fed by the first one — a warm search at
       // the same state must return the very same triplets (exercises the tightest bounds)
@@ -1982,6 +2073,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       t3 = solve_and_update(prm.r2, prm.fixed_iters, pad, tid, iter, prof);
     if (prof) {
       long long t4 = clock64();
+      PROF2_ADD(7, t4 - t2);
       if (tid == 0) {
         L.prof_acc[1] += t1 - t0, L.prof_acc[2] += t2 - t1, L.prof_acc[3] += t3 - t2, L.prof_acc[4] += t4 - t3;
 #ifndef LINS_PROF_WAVES
@@ -1996,6 +2088,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #else
 #define KP(f) ka.f
 #endif
+#ifdef LINS_PROF2
+  if (prof && dbg_slot >= 0) idx_store[dbg_slot] = make_int4(dbg_nn, dbg_walk, dbg_walk_mask, ra1 | (a3 >= 0 ? 0x100 : 0));
+#endif
   if (prof && tid == 0) {
     long long* prof_out = KP(prof_buf);
     L.prof_acc[5] = clock64() - t_begin;
@@ -2006,6 +2101,13 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #endif
     L.prof_acc[14] = t_wall_begin, L.prof_acc[15] = wall_clock64();
     for (int k = 0; k < 16; ++k) prof_out[(size_t)scan * 16 + k] = L.prof_acc[k];
+#ifdef LINS_PROF2
+    int* ext = reinterpret_cast<int*>(prof_out + (size_t)gridDim.x * 16) + (size_t)scan * 64;  // (whole updates: one workgroup per scan)
+    // (the reduction phase, ~230 ticks a wave, gives its slot to the search counts: [w][4] = wave-iterations with a
+    // nearest-neighbour search | with a walk, both << 16 ... kept simple: phase 4 of wave w = walks << 16 | wave-iterations with a walk,
+    // phase 4 is re-read by tools/wave_phases.py)
+    for (int k = 0; k < 64; ++k) ext[k] = (k & 7) == 4 ? (L.prof3[(k >> 3) * 4 + 1] | (L.prof3[(k >> 3) * 4 + 3] << 12) | (L.prof3[(k >> 3) * 4 + 0] << 20) | (L.prof3[(k >> 3) * 4 + 2] << 26)) : L.prof2[k];
+#endif
   }
 
   if (kRelay && relay_out) {  // the second part of this scan's update continues from here (see relay_in)
@@ -2016,8 +2118,12 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       int* hi = reinterpret_cast<int*>(h + 61);
       relay_st(hi, L.iter), relay_st(hi + 1, L.dbg[0]), relay_st(hi + 2, L.dbg[1]), relay_st(hi + 3, L.dbg[2]), relay_st(hi + 4, L.dbg[3]);
     }
-    relay_out_carry(KP(relay_lane) + (size_t)scan * kRelayLaneInts, tid, a1, b1c, ra1, rb1, a2, b2c, a3, b3c, sel1, lb1, lb2, lb3, certA[0],
-                    certA[1], certA[2], certB[0], certB[1], certB[2]);
+    {
+      const WrLay y = wr_layout(0);
+      if (y.active)
+        relay_out_carry(KP(relay_lane) + (size_t)scan * kRelayLaneInts, y.slot, a1, b1c, ra1, rb1, a2, b2c, a3, b3c, sel1, lb1, lb2, lb3,
+                        certA[0], certA[1], certA[2], certB[0], certB[1], certB[2]);
+    }
     // every store of this wave has completed — write-through stores: at the memory side — before the barrier, the flag
     // after it: whoever sees the flag sees the hand-over
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2060,5 +2166,6 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 }
 
 #undef KP
+#undef PROF2_ADD
 }  // namespace LINS_LDS_NS
 }  // namespace lins

@@ -56,12 +56,13 @@ int lds_mr_np_cap() { return lds_mr::kNpMax; }
 void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const int* order, const float4* arena,
                    const float4* sorted, const GridTables* tabs, const double* state_in, const double* cov_in, double* state_out, double* a6,
                    double* cov_out, void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof,
-                   const RelayArgs* relay) {
+                   const RelayArgs* relay, unsigned* walk_cache, int run_gen) {
   lds_mr::KernelArgs ka{};
   ka.prm = prm, ka.descs = descs, ka.order = order, ka.tabs = tabs;
   ka.state_in = state_in, ka.cov_in = cov_in, ka.state_out = state_out, ka.a6_out = a6, ka.cov_out = cov_out;
   ka.out = (lds_mr::OutRec*)out, ka.poses = poses, ka.scan_id_base = scan_id_base, ka.prof_buf = prof;
   int grid = n;
+  ka.walk_cache = walk_cache, ka.run_gen = run_gen;
   if (relay) {
     ka.relay_n = n, ka.relay_at = relay->at, ka.relay_parts = relay->parts, ka.relay_gen = relay->gen, ka.relay_spins = relay->spins;
     ka.relay_hdr = relay->hdr, ka.relay_lane = relay->lane, ka.relay_flag = relay->flag, ka.relay_err = relay->err;

@@ -10,8 +10,7 @@
 // runs through the same loops with (almost) no resident positions — the hybrid fall-through to the sorted copy.
 //
 // Same code as the head (one template), same query -> lane layout inside a wave-round, same reduction tree and fold
-// order: the results are the head's bits (tests/test_gpu_parity.py); `tail_dense` packs the wave-rounds to 64 queries
-// instead (fewer instructions, sums in another order: equal to rounding).
+// order: the results are the head's bits (tests/test_gpu_parity.py).
 #define LINS_LDS_NS lds_tail
 #define LINS_LDS_TAIL 1
 #ifndef LINS_TAIL_CAP
@@ -41,14 +40,14 @@ int lds_tail_max_queries() { return lds_tail::kTailSlots; }
 void launch_lds_tail(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const int* order, const float4* arena,
                      const float4* sorted, const GridTables* tabs, const double* state_in, const double* cov_in, double* state_out, double* a6,
                      double* cov_out, void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, const RelayArgs& relay,
-                     int tail_dense) {
+                     unsigned* walk_cache, int run_gen) {
   lds_tail::KernelArgs ka{};
   ka.prm = prm, ka.descs = descs, ka.order = order, ka.tabs = tabs;
   ka.state_in = state_in, ka.cov_in = cov_in, ka.state_out = state_out, ka.a6_out = a6, ka.cov_out = cov_out;
   ka.out = (lds_tail::OutRec*)out, ka.poses = poses, ka.scan_id_base = scan_id_base;
   ka.relay_n = n, ka.relay_at = relay.at, ka.relay_parts = relay.parts, ka.relay_gen = relay.gen, ka.relay_spins = relay.spins;
   ka.relay_hdr = relay.hdr, ka.relay_lane = relay.lane, ka.relay_flag = relay.flag, ka.relay_err = relay.err;
-  ka.tail_part = relay.launched, ka.tail_dense = tail_dense;
+  ka.tail_part = relay.launched, ka.walk_cache = walk_cache, ka.run_gen = run_gen;
   if (prm.pad)
     hipLaunchKernelGGL((lds_tail::ieskf_lds_kernel<256, 1, false, false, false, true>), dim3(n), dim3(256), 0, stream, ka, arena, sorted,
                        idx_store, (lins_corr*)nullptr);

@@ -40,9 +40,9 @@ void launch_lds_pass(hipStream_t, int, const DevParams&, int, const ScanDesc*, c
                      const double*, int, int4*, lins_corr*, double*, int*);
 int lds_np_cap();
 void launch_lds_mr(hipStream_t, int, const DevParams&, const ScanDesc*, const int*, const float4*, const float4*, const GridTables*, const double*,
-                   const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*, const RelayArgs*);
+                   const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*, const RelayArgs*, unsigned*, int);
 void launch_lds_tail(hipStream_t, int, const DevParams&, const ScanDesc*, const int*, const float4*, const float4*, const GridTables*, const double*,
-                     const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, const RelayArgs&, int);
+                     const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, const RelayArgs&, unsigned*, int);
 int lds_tail_max_queries();
 void launch_lds_mr_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const float4*, const GridTables*, const double*,
                         const double*, int, int4*, lins_corr*, double*, int*);
@@ -131,13 +131,16 @@ struct lins_ctx {
   int relay_list_parts = 0;         // parts of the launch list that is on the device (0 = none yet for this upload)
   double* d_relay_hdr = nullptr;
   int *d_relay_lane = nullptr, *d_relay_flag = nullptr;
+  // walk cache of the one-lane-per-query kernels (ieskf_lds_impl.h): per query slot 32 B — the second / third points of the
+  // nearest neighbour a query had before; cleared wherever new target clouds arrive, tagged with the launch number
+  unsigned* d_walk_cache = nullptr;
+  int run_gen = 0;
   int* h_relay_err = nullptr;       // (pinned, device-visible) hand-over protocol violations seen by the tail kernel: checked at lins_sync
   int relay_spins = 1 << 14;        // polls (~1 us) a part waits for its hand-over before it runs the whole update alone
   int relay_scramble = 0;           // debug (LINS_RELAY_SCRAMBLE): launch list in an order that violates "a part behind the part before it"
   // the tail kernel (ieskf_lds_tail.hip): the iterations from tail_at on as a launch of their own, four scans per CU
   int tail_at = 0;                  // (0 = off: the batch kernel's own last part runs to the end.  Off by default: measured
                                     // slower than the batch kernel's own parts; LINS_TAIL_AT with the debug gate)
-  int tail_dense = 0;               // wave-rounds of 64 queries instead of the head's layout (sums in another order)
   bool tail_ok = false;             // every uploaded scan has a query set the tail kernel takes (set at upload)
   int last_parts = 0, last_tail = 0;  // how the last run was cut (lins_last_cut)
   ScanDesc* d_desc = nullptr;
@@ -250,6 +253,7 @@ const lins_params* ctx_params(const lins_ctx* ctx) { return &ctx->prm; }
 namespace {
 
 constexpr int kRelayMaxParts = 8;  // (flag values 16 gen + part: parts < 15)
+constexpr size_t kLaneIntsPerScan = 4 * 512 * 4;  // ieskf_lds_impl.h kRelayLaneInts: [4][512] 16-byte words per scan
 
 int fail_hip(lins_ctx* ctx, hipError_t e, const char* what) {
   if (ctx) ctx->hip_err = std::string(what) + ": " + hipGetErrorString(e);
@@ -519,6 +523,10 @@ RangeFlags range_flags(const lins_ctx* ctx, int lo, int hi) {
 // that cannot take them run the any-size kernel, which bins for itself)
 int build_index_range(lins_ctx* ctx, int lo, int cnt, const RangeFlags& fl) {
   if (cnt <= 0 || !(fl.lds_ok || fl.mr_ok)) return LINS_OK;
+  {  // new target clouds: what the walk cache holds for these scans' query slots is about other clouds
+    const size_t s0 = (size_t)ctx->h_desc[lo].slot_base, s1 = (size_t)ctx->h_desc[lo + cnt - 1].slot_base + ctx->h_desc[lo + cnt - 1].n_surf_q + ctx->h_desc[lo + cnt - 1].n_corner_q;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_walk_cache + s0 * 8, 0xFF, (s1 - s0) * 32, ctx->stream));
+  }
   launch_grid_index(ctx->stream, cnt, ctx->d_desc + lo, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo);
   HIP_TRY(ctx, hipGetLastError());
   return LINS_OK;
@@ -609,7 +617,7 @@ int run_range(lins_ctx* ctx, int lo, int cnt, int n_total, const RangeFlags& fl,
   if (use_mr || use_lds) {
     if (use_mr)
       launch_lds_mr(ctx->stream, cnt, ctx->dprm, desc, nullptr, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out, ctx->d_idx, ps,
-                    scan_id_base + lo, nullptr, nullptr);
+                    scan_id_base + lo, nullptr, nullptr, ctx->d_walk_cache, ++ctx->run_gen);
     else
       launch_lds(ctx->stream, cnt, ctx->dprm, s == SEARCH_LDS3 ? 3 : 1, desc, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out,
                  ctx->d_idx, ps, scan_id_base + lo, nullptr);  // (the Joseph update is the kernels' epilogue)
@@ -659,7 +667,6 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
       if (const char* e = std::getenv("LINS_LAUNCH_ORDER")) ctx->use_order = e[0] != '0';
       if (const char* e = std::getenv("LINS_RELAY_AT")) ctx->relay_at = std::max(0, std::atoi(e));  // (0: whole updates)
       if (const char* e = std::getenv("LINS_TAIL_AT")) ctx->tail_at = std::max(0, std::atoi(e));    // (0: no tail kernel)
-      if (const char* e = std::getenv("LINS_TAIL_DENSE")) ctx->tail_dense = e[0] != '0';
       if (const char* e = std::getenv("LINS_RELAY_SPINS")) ctx->relay_spins = std::max(1, std::atoi(e));
       if (const char* e = std::getenv("LINS_RELAY_SCRAMBLE")) ctx->relay_scramble = std::atoi(e);
     }
@@ -706,8 +713,8 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   CREATE_TRY(hipMalloc((void**)&ctx->d_gsorted, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_gridtab, (size_t)ctx->max_batch * sizeof(GridTables)));
   if (ctx->max_batch > 2 * ctx->n_cu) {  // (only batches beyond the device's workgroup slots are cut into parts)
+    CREATE_TRY(hipMalloc((void**)&ctx->d_relay_lane, (size_t)ctx->max_batch * kLaneIntsPerScan * sizeof(int)));  // (CarryWords by query)
     CREATE_TRY(hipMalloc((void**)&ctx->d_relay_hdr, (size_t)ctx->max_batch * 64 * sizeof(double)));
-    CREATE_TRY(hipMalloc((void**)&ctx->d_relay_lane, (size_t)ctx->max_batch * 4 * 512 * 16));  // (CarryWords: 4 x 16 B per head lane)
     CREATE_TRY(hipHostMalloc((void**)&ctx->h_relay_err, sizeof(int)));
     *ctx->h_relay_err = 0;
     CREATE_TRY(hipMalloc((void**)&ctx->d_relay_flag, (size_t)ctx->max_batch * sizeof(int)));
@@ -726,6 +733,8 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   CREATE_TRY(hipMalloc((void**)&ctx->d_a6, nb * 21 * 8));
   CREATE_TRY(hipMalloc((void**)&ctx->d_out, nb * out_rec_size()));
   CREATE_TRY(hipMalloc((void**)&ctx->d_idx, ctx->slot_cap * sizeof(int4)));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_walk_cache, ctx->slot_cap * 32));
+  CREATE_TRY(hipMemset(ctx->d_walk_cache, 0xFF, ctx->slot_cap * 32));
   CREATE_TRY(hipMalloc((void**)&ctx->d_dump, 2 * LINS_MAX_QUERY * sizeof(lins_corr)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_sums, nb * 28 * 8));
   CREATE_TRY(hipMalloc((void**)&ctx->d_counts, nb * 2 * sizeof(int)));
@@ -767,6 +776,7 @@ void lins_destroy(lins_ctx* ctx) {
   if (ctx->map_state && ctx->map_state_free) ctx->map_state_free(ctx->map_state);
   (void)hipFree(ctx->d_out);
   (void)hipFree(ctx->d_idx);
+  (void)hipFree(ctx->d_walk_cache);
   (void)hipFree(ctx->d_dump);
   (void)hipFree(ctx->d_sums);
   (void)hipFree(ctx->d_counts);
@@ -865,7 +875,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   // The iterations from tail_at on run in the tail kernel (ieskf_lds_tail.hip: four scans per CU) as a second launch
   // behind this one — the last "part", handed over the same way, ordered by the stream instead of a flag wait.
   const bool cut_ok = use_mr && ctx->n_uploaded > 2 * ctx->n_cu && !ctx->d_prof && ctx->prm.icp_freq == 1 && ctx->d_relay_hdr;
-  const bool tail = cut_ok && ctx->tail_at > 0 && ctx->tail_at < ctx->prm.num_iter && ctx->tail_ok;
+  const bool tail = cut_ok && ctx->tail_at > 0 && ctx->tail_at < ctx->prm.num_iter && ctx->tail_ok;  // (the tail follows the head's schedule of layouts)
   RelayArgs ra;
   if (tail) {  // head parts of relay_at iterations when that divides tail_at, else one head part; then the tail
     const bool sub = ctx->relay_at > 0 && ctx->relay_at < ctx->tail_at && ctx->tail_at % ctx->relay_at == 0 && ctx->tail_at / ctx->relay_at < kRelayMaxParts;
@@ -902,7 +912,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
       launch_lds_mr(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc,
                     relay ? ctx->d_order + ctx->n_uploaded : (ctx->use_order ? ctx->d_order : nullptr), ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in,
                     ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx, (lins_pose_record*)d_poses,
-                    scan_id_base, ctx->d_prof, relay ? &ra : nullptr);
+                    scan_id_base, ctx->d_prof, relay ? &ra : nullptr, ctx->d_walk_cache, ++ctx->run_gen);
     else
       launch_lds(ctx->stream, ctx->n_uploaded, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc,
                  ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx,
@@ -910,7 +920,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
     if (tail)
       launch_lds_tail(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->use_order ? ctx->d_order : nullptr, ctx->d_arena, ctx->d_gsorted,
                       ctx->d_gridtab, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx,
-                      (lins_pose_record*)d_poses, scan_id_base, ra, ctx->tail_dense);
+                      (lins_pose_record*)d_poses, scan_id_base, ra, ctx->d_walk_cache, ctx->run_gen);
     HIP_TRY(ctx, hipEventRecord(ctx->hist1[h], ctx->stream));
     if (q.on) HIP_TRY(ctx, hipEventRecord(q.ev_main[set], ctx->stream));  // (the pose records of this run are complete)
     // (The Joseph update, SE:594-598, is the update kernel's epilogue since round 3: ieskf_lds_impl.h joseph_epilogue.
@@ -1124,8 +1134,10 @@ int lins_debug_phase_profile(lins_ctx* ctx, int enable, long long* out, int n_sc
   if (!ctx) return LINS_E_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (enable && !ctx->d_prof) {
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_prof, (size_t)ctx->max_batch * 16 * sizeof(long long)));
-    HIP_TRY(ctx, hipMemset(ctx->d_prof, 0, (size_t)ctx->max_batch * 16 * sizeof(long long)));
+    // (16 words per scan, then — behind the records of the launch — 32 words per scan of per-wave phase ticks, written by
+    // libraries built with -DLINS_PROF2=k: lins_debug_wave_phases)
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_prof, (size_t)ctx->max_batch * 48 * sizeof(long long)));
+    HIP_TRY(ctx, hipMemset(ctx->d_prof, 0, (size_t)ctx->max_batch * 48 * sizeof(long long)));
   }
   if (out && ctx->d_prof) {
     if (n_scans > ctx->max_batch) return LINS_E_CAPACITY;
@@ -1136,6 +1148,29 @@ int lins_debug_phase_profile(lins_ctx* ctx, int enable, long long* out, int n_sc
     (void)hipFree(ctx->d_prof);
     ctx->d_prof = nullptr;
   }
+  return LINS_OK;
+}
+
+/* Debug aid (libraries built with -DLINS_PROF2=k, profile enabled, whole updates of the batch kernel): per scan 8 waves x
+ * 8 phases of 32-bit shader-clock ticks summed over the iterations >= k — [0] query load + de-skew [1] nearest
+ * neighbour: certificates + searches [2] second / third point [3] rows [4] row reduction [5] wait at the barrier behind
+ * it [6] fold + barrier [7] solve / update (the waves that do not solve wait here).  n_scans = the scans of the last run. */
+int lins_debug_wave_phases(lins_ctx* ctx, int* out, int n_scans) {
+  if (!ctx || !out) return LINS_E_ARG;
+  if (!ctx->d_prof || n_scans != ctx->n_uploaded) return LINS_E_STATE;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpy(out, ctx->d_prof + (size_t)n_scans * 16, (size_t)n_scans * 64 * sizeof(int), hipMemcpyDeviceToHost));
+  return LINS_OK;
+}
+
+/* Debug aid (LINS_PROF2 builds): the per-query slots of the uploaded batch (int4 each), where the profiled batch kernel
+ * leaves (searches, walks, walk mask by iteration, ring) of every query. */
+int lins_debug_query_slots(lins_ctx* ctx, int* out, int n_slots) {
+  if (!ctx || !out || n_slots < 0 || (size_t)n_slots > ctx->slot_cap) return LINS_E_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpy(out, ctx->d_idx, (size_t)n_slots * sizeof(int4), hipMemcpyDeviceToHost));
   return LINS_OK;
 }
 
@@ -1556,9 +1591,10 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
       idx_ready = true;
       // the search index of the last scan's clouds (they were re-projected in place at the end of the previous step)
       launch_grid_index(ctx->stream, n, t.d_desc, t.d_arena, t.d_gsorted, t.d_gridtab);
+      HIP_TRY(ctx, hipMemsetAsync(ctx->d_walk_cache, 0xFF, (size_t)n * LINS_MAX_QUERY * 32, ctx->stream));  // (slot_base = k * LINS_MAX_QUERY)
       if (use_mr)
         launch_lds_mr(ctx->stream, n, ctx->dprm, t.d_desc, nullptr, t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in, ctx->d_cov_in,
-                      ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr, nullptr);
+                      ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr, nullptr, ctx->d_walk_cache, ++ctx->run_gen);
       else
         launch_lds(ctx->stream, n, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, t.d_desc, t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in,
                    ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr);

@@ -243,7 +243,7 @@ def _run_cut(ieskf, monkeypatch, prm, batch, relay_at, tail_at, runs=2, **knobs)
     monkeypatch.setenv("LINS_ENABLE_DEBUG_KNOBS", "1")
     monkeypatch.setenv("LINS_RELAY_AT", str(relay_at))
     monkeypatch.setenv("LINS_TAIL_AT", str(tail_at))
-    for k in ("LINS_TAIL_DENSE", "LINS_RELAY_SCRAMBLE", "LINS_RELAY_SPINS"):
+    for k in ("LINS_RELAY_SCRAMBLE", "LINS_RELAY_SPINS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in knobs.items():
         monkeypatch.setenv(k, str(v))
@@ -299,20 +299,6 @@ def test_default_cut_of_a_large_batch(pkg, ieskf, host):
     assert all(x.iters == 10 for x in r)
 
 
-def test_tail_kernel_with_dense_wave_rounds_agrees_to_rounding(pkg, ieskf, host, monkeypatch):
-    """LINS_TAIL_DENSE packs the tail's wave-rounds to 64 queries: the 28 sums are added in another order, so the results
-    agree with the whole updates' to rounding, not bit for bit (flags and row counts equal)."""
-    prm = pkg.default_params(num_iter=10, fixed_iters=1)
-    batch = host.synth_batch(601, start=9000)
-    whole, _ = _run_cut(ieskf, monkeypatch, prm, batch, 0, 0, runs=1)
-    dense, cut = _run_cut(ieskf, monkeypatch, prm, batch, 4, 4, runs=1, LINS_TAIL_DENSE=1)
-    assert cut == (2, 1)
-    for a, b in zip(whole, dense):
-        assert (a.iters, a.converged, a.diverged) == (b.iters, b.converged, b.diverged)
-        assert abs(a.m_surf - b.m_surf) + abs(a.m_corner - b.m_corner) <= 1  # (a row on the s > 0.1 edge may flip)
-        assert np.max(np.abs(a.state - b.state)) < 1e-9 and np.max(np.abs(a.cov - b.cov)) <= 1e-9 * np.max(np.abs(a.cov))
-
-
 def test_parts_handed_out_in_the_wrong_order_degrade_to_whole_updates(pkg, ieskf, host, monkeypatch):
     """HIP promises nothing about the order workgroups are handed out in.  LINS_RELAY_SCRAMBLE=1 lists every part in
     front of the part it waits for — the worst case: the waiting workgroups fill the device before any first part is
@@ -343,6 +329,35 @@ def test_certificates_in_the_tail_kernel_never_disagree_with_a_real_search(pkg, 
         assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov)
     # (the certificates did speak in the plain run: ~2 decisions per query and late iteration, counted across the cut)
     assert sum(a.reserved[1] + a.reserved[2] for a in plain) > 100 * len(batch)
+
+
+@pytest.mark.parametrize("search,n", [("mr", 601), ("mr", 96), ("lds1", 24)])
+def test_walk_cache_never_changes_a_bit_and_saves_walks(pkg, ieskf, host, monkeypatch, search, n):
+    """The one-lane-per-query kernels keep, per query, the second / third points (and their certificates) of the nearest
+    neighbour the query had BEFORE: a query on the bisector of two target points flips between them from iteration to
+    iteration, and every flip used to cost the full index walk again.  A set that comes back from the cache was
+    established by an exact walk for exactly that neighbour, so it is judged like any other: results are bit-identical
+    with the cache off (LINS_DEBUG_SKIP bit 0x800000), under the stop rule too, and the kernels run fewer walks."""
+    for prm in (pkg.default_params(num_iter=10, fixed_iters=1), pkg.default_params(num_iter=30)):
+        batch = host.synth_batch(n, start=9000)
+        monkeypatch.setenv("LINS_ENABLE_DEBUG_KNOBS", "1")
+        out = {}
+        for knob in ("0", str(0x800000)):
+            monkeypatch.setenv("LINS_DEBUG_SKIP", knob)
+            with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384, search=search) as c:
+                c.upload(batch)
+                for _ in range(2):  # (the second run must not profit from the first: tags carry the launch number)
+                    c.run()
+                c.sync()
+                out[knob] = c.download()
+        monkeypatch.delenv("LINS_DEBUG_SKIP")
+        on, off = out["0"], out[str(0x800000)]
+        for a, b in zip(on, off):
+            _same_bits(a, b)
+        skipped_on, skipped_off = sum(r.reserved[2] for r in on), sum(r.reserved[2] for r in off)
+        assert skipped_on >= skipped_off  # (reserved[2]: walks the certificates skipped)
+        if n > 90:
+            assert skipped_on > skipped_off
 
 
 def test_icp_freq_above_one_is_never_cut(pkg, ieskf, host, monkeypatch):
