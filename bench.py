@@ -134,9 +134,16 @@ def single_scan_latency(pkg, ieskf, pair):
             c.update(pair)
             if k >= 5:
                 e2e.append((time.perf_counter() - t0) * 1e3)
-    return {"kernel": "lds_full::ieskf_lds_kernel<1024,3>", "kernel_ms": float(np.median(ks)), "iterations": int(its),
-            "us_per_iteration": float(np.median(ks)) * 1e3 / max(int(its), 1), "update_call_ms_incl_pcie": float(np.median(e2e)),
-            "stop_rule": "|dx| <= 1e-2 (SE:575-578), NUM_ITER 30"}
+    k_ms = float(np.median(ks))
+    alg = float(pair.bytes_per_iter()) * int(its)  # B_iter of this pair x the iterations it ran
+    return {"kernel": "lds_full::ieskf_lds_kernel<1024,3>", "kernel_ms": k_ms, "iterations": int(its),
+            "us_per_iteration": k_ms * 1e3 / max(int(its), 1), "update_call_ms_incl_pcie": float(np.median(e2e)),
+            "stop_rule": "|dx| <= 1e-2 (SE:575-578), NUM_ITER 30",
+            # BASELINE.json configs[2]: "rocprof HBM GB/s" of the single-scan kernel — one workgroup on one CU of 256: a
+            # latency figure, the fraction says how far ONE scan is from streaming its clouds at the whole device's rate
+            "roofline": {"bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg,
+                         "note": "one scan = one workgroup = one of 256 CUs; kernel_ms by HIP events (profiles/: the kernel's row in the with-extras trace)"}}
 
 
 def cpu_leg(pkg, args, prm, pairs, gpu_results):
@@ -161,6 +168,9 @@ def cpu_leg(pkg, args, prm, pairs, gpu_results):
             "all_cores": {"value": itn / secn, "cores": ncpu},
             "reduced_6x6_form_1core": {"value": itr / secr, "cores": 1},
             "reduced_all_cores": {"value": itrn / secrn, "cores": ncpu}}
+    if os.environ.get("LINS_REQUIRE_REF") == "1" and not ref.available():
+        raise SystemExit("bench.py: LINS_REQUIRE_REF=1 and oracle/_ref/liblins_ref.so is not here (it is built where /root/reference "
+                         "exists and travels with the snapshot): refusing to fall back to cpu_baseline kind \"port\"")
     if ref.available():
         stop = pkg.default_params(num_iter=30, fixed_iters=0)
         rs1, ri1 = ref.bench(stop, sample, threads=1)
@@ -168,8 +178,10 @@ def cpu_leg(pkg, args, prm, pairs, gpu_results):
         out["cpu_baseline"] = {
             "value": ri1 / rs1, "unit": "iterations/s", "cores": 1, "kind": "reference",
             "sample": f"first {len(sample)} scan pairs of the same batch through the reference's own performIESKF "
-                      "(StateEstimator.hpp compiled verbatim against stand-in Eigen / PCL headers, g++ -O3 no FMA, exact "
-                      f"kd-tree): its own stop rule, NUM_ITER 30, {ri1} iterations executed",
+                      "(the reference's TEXT — StateEstimator.hpp compiled verbatim — on stand-in Eigen / PCL headers: plain loops, "
+                      "no vectorised Eigen kernels, so the real library would be somewhat faster; g++ -O3 no FMA, exact "
+                      f"kd-tree): its own stop rule, NUM_ITER 30, {ri1} iterations executed.  `port` (the restated oracle, reduced "
+                      "6 x 6 algebra, all cores) is the stronger CPU figure to compare against",
             "all_cores": {"value": rin / rsn, "cores": ncpu},
             "port": port}
     else:
@@ -244,6 +256,12 @@ def e2e_rates(pkg, ieskf, host, pairs, args):
         out["streams_scans_s"] = ns / float(np.min(ts[1:]))
         out["streams_scans_s_on_device"] = ns / ((fe + up + rp) * 1e-3)
         out["streams"] = ns
+        # the device-resident chain stage by stage (HIP events of the last step): what a pipeline that keeps the clouds in
+        # HBM runs per scan — feature front-end (SE:619-827), IESKF update + search index, re-projection (SE:1083-1161)
+        out["chain"] = {"streams": ns, "frontend_ms": fe, "update_ms": up, "reprojection_ms": rp, "device_ms": fe + up + rp,
+                        "scans_per_s_on_device": ns / ((fe + up + rp) * 1e-3),
+                        "ms_per_1024_streams": {"frontend": fe * 1024 / ns, "update": up * 1024 / ns, "reprojection": rp * 1024 / ns},
+                        "longest_stage": max((fe, "frontend"), (up, "update"), (rp, "reprojection"))[1]}
     out["note"] = "the C calls as a C++ caller sees them: host buffers in and out (update_batch) / segmented clouds uploaded per scan (streams): PCIe-bound"
     return out
 
@@ -427,6 +445,27 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = ctx.kernel_ms_history(min(args.steps, 64))  # HIP events on the context's stream, the timed steps
+    # N > 1: what a scaling curve needs to explain itself — every rank's own kernel time and step time, and the cost of the
+    # exchange step alone (the same flat all-gather, back to back with one wait, outside the timed region)
+    per_rank = None
+    if use_dist:
+        gather_us = None
+        if c_abi_gather:
+            reps = 20
+            ctx.sync()
+            tg = time.perf_counter()
+            for k in range(reps):
+                ctx.pose_allgather(poses[k & 1].data_ptr(), max_n, gathered[k & 1].data_ptr())
+            ctx.sync()
+            gather_us = (time.perf_counter() - tg) / reps * 1e6
+        mine = torch.tensor([float(np.mean(kernel_ms)), elapsed / args.steps * 1e3, gather_us if gather_us is not None else -1.0],
+                            dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"kernel_ms": [float(t[0]) for t in allr], "ms_per_step": [float(t[1]) for t in allr],
+                    "gather_us": [float(t[2]) if float(t[2]) >= 0 else None for t in allr],
+                    "note": "kernel_ms: HIP events of the update kernel on each rank's stream (mean of the timed steps); gather_us: the "
+                            "all-gather of the pose records alone, 20 back to back, one wait"}
 
     # device-copy ceiling of this box: a streaming float4 copy inside the context's arenas,
     # measured after the timed region (it overwrites the uploaded clouds)
@@ -485,7 +524,8 @@ def main():
             "config": {
                 "workload": f"configs[3]: batch of {args.batch} independent scan pairs per GPU, "
                             f"{args.iters} IESKF iterations each (fixed), 2 scans resident per CU, an update = consecutive workgroups of "
-                            "one launch handing the loop state over every four iterations when the batch exceeds the 512 slots; "
+                            "one launch handing the loop state over (13 words per query, by query) every four iterations when the batch "
+                            "exceeds the 512 slots; "
                             "inputs resident in HBM before the timed region (PCIe-inclusive rates: see e2e), the target clouds' search "
                             "index built with them (see search_index)",
                 "scans_per_gpu": len(pairs),
@@ -503,6 +543,7 @@ def main():
                                                            else ", RCCL all-gather of 192 B pose records through torch.distributed (fallback)") if use_dist else ""),
                 "gen_seconds": round(gen_s, 2),
             },
+            "per_rank": per_rank,
             "roofline": {
                 "bound": "hbm",
                 "kernel": {"auto": "lds_mr::ieskf_lds_kernel<512,1>" if len(pairs) > 256 else "lds_full::ieskf_lds_kernel<1024,3>",
@@ -563,6 +604,12 @@ def main():
     if out is not None and out.get("parity_checked") and not out["parity_checked"]["ok"]:
         print(json.dumps(out), flush=True)
         raise SystemExit("bench.py: the GPU results of the timed batch do not match the CPU checker (parity_checked)")
+    if use_dist and world > 1 and not c_abi_gather:
+        # A run whose exchange step fell back to torch.distributed (a host wait per step) is not a scaling point of THIS
+        # path: the line is printed for diagnosis, the exit code says so.
+        if out is not None:
+            print(json.dumps(out), flush=True)
+        raise SystemExit(3)
     if out is not None:
         # RCCL writes its version banner to the C stdout buffer, which would otherwise be flushed at exit — after a
         # line printed from Python.  Drain it first: the JSON line is the last thing on stdout.

@@ -1475,6 +1475,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         o.c[0] = o.c[1] = o.c[2] = o.c[3] = 0.f;
         o.sel[0] = o.sel[1] = o.sel[2] = 0.f;
         QueryPolar qp = {0.f, 0.f, 0.f, 0.f, 0};
+        bool qp_ready = false;  // (wave-uniform)
         int p1 = -1, p2 = -1, p3 = -1;
         long long s0 = prof ? clock64() : 0, s1 = s0, s2 = s0;
         // (tail kernel) R[k]: the record (x, y, z, index bits) of the k-th tracked candidate {a1, b1c, a2, b2c, a3, b3c},
@@ -1570,12 +1571,6 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           if (active && (pad & 0x80000) && warm_iter) {  // (counting aid: every certificate holds, unchecked)
             pred = a1, said = true;
           } else if (active) {
-            if (!(pad & 0x200000) && !(kTail && LINS_TAIL_OOL)) {  // (the tail kernel's searches make it for themselves: coop_nn_ool)
-              qp.rho = sqrtf(o.sel[0] * o.sel[0] + o.sel[1] * o.sel[1]);
-              qp.qn3 = sqrtf(qp.rho * qp.rho + o.sel[2] * o.sel[2]);
-              qp.el = atan2f(o.sel[2], qp.rho);
-              qp.a0_surf_or_corner = az_bin_lds(o.sel[0], o.sel[1], c.naz);
-            }
             const float da = a1 >= 0 ? dist_r(R[0], a1) : INFINITY, db = b1c >= 0 ? dist_r(R[1], b1c) : INFINITY;
             bool ok = warm_iter && !(pad & 16) && certified(fminf(fminf(da, db), thr), lb1, drift_from(certA));
             const unsigned long long ka = da < thr ? pack_key(da, idx_r(R[0], a1)) : kNone;
@@ -1595,6 +1590,10 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
             int r_pos = -1, r_ring = -1, r_pos2 = -1, r_ring2 = -1;
             float r_lb = 0.f;
             if (cm.n) {  // (wave-uniform)
+              // The polar view of the query (two square roots, an atan2f, the column) only feeds the searches: made here,
+              // by every lane of a wave that searches — wave-uniform, so no lane waits for another's branch; a wave
+              // whose selections are all certified (nearly every wave of a late iteration) never computes it.
+              if (!(pad & 0x200000) && !(kTail && LINS_TAIL_OOL)) qp = polar_of(o.sel[0], o.sel[1], o.sel[2], c.naz), qp_ready = true;
               NnOut r;
               if constexpr (kTail && LINS_TAIL_OOL) {
                 // (a call keeps only a third of the registers: what the loop carries — the query's state and its six
@@ -1711,6 +1710,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
             int r2 = -1, r2b = -1, r3 = -1, r3b = -1;
             float r_lb2 = 0.f, r_lb3 = 0.f;
             if (cm.n) {
+              if (!qp_ready && !(pad & 0x200000) && !(kTail && LINS_TAIL_OOL)) qp = polar_of(o.sel[0], o.sel[1], o.sel[2], c.naz);
               const int nq = is_surf ? sd.n_surf_q : sd.n_corner_q;
               WalkOut r;
               if constexpr (kTail && LINS_TAIL_OOL) {
