@@ -784,7 +784,16 @@ __device__ __noinline__ WalkOut coop_walk_ool(bool is_surf, const float4* gs, in
 // traced to its root (ROCm 7.2 clang).  As a separate function nothing of it is scheduled into the kernel body; the
 // GPU suite (golden pairs, adversarial clouds, reference parity, every search mode) is the guard.
 template <int BLOCK>
-__device__ __noinline__ void load_lds_grid(const GridTables* __restrict__ tab, const float4* __restrict__ gs, int n_lds, int tid) {
+#ifndef LINS_GRID_INLINE
+#define LINS_GRID_INLINE 0
+#endif
+#if LINS_GRID_INLINE
+__device__ __forceinline__
+#else
+__device__ __noinline__
+#endif
+    void
+    load_lds_grid(const GridTables* __restrict__ tab, const float4* __restrict__ gs, int n_lds, int tid) {
   LdsStore& L = g_lds;
   constexpr int kTabPer = (kGridTableWords + BLOCK - 1) / BLOCK, kPtPer = (kNpCap + BLOCK - 1) / BLOCK;
   constexpr int kChunk = kPtPer < 12 ? kPtPer : 12;
