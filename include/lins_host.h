@@ -179,6 +179,13 @@ int lins_synth_generate(uint32_t seed, uint32_t scan_index, lins_synth_pair* out
 int lins_synth_raw_scan(uint32_t seed, uint32_t scan_index, int k, lins_point* out,
                         int cap);
 
+/* A SEQUENCE of scans along one seeded trajectory (a circle inside the synthetic room) with its IMU: what a
+ * lins_fusion_node would receive over any number of consecutive sweeps — the input of the in-situ test of the drop-in
+ * boundary (tests/test_gpu_sequence.py).  Sweep k covers [0.1 k, 0.1 (k + 1)) s; 40 IMU samples per sweep.       */
+int lins_synth_seq_raw_scan(uint32_t seed, int k, lins_point* out, int cap);
+int lins_synth_seq_imu(uint32_t seed, int k, double* acc /* 40 x 3 */, double* gyr /* 40 x 3 */);
+int lins_synth_seq_truth(uint32_t seed, double tau, double* xyyaw, double* speed, double* yaw_rate);
+
 /* ---- performIESKF as the node sees it -------------------------------------- */
 int lins_host_perform_ieskf(lins_ctx* ctx, const lins_params* prm,
                             const lins_scan_pair* in, lins_result* out,

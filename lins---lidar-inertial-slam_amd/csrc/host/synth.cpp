@@ -186,6 +186,34 @@ int raw_scan(const Scene& s, uint32_t seed, uint32_t scan_index, int k, lins_poi
   return n;
 }
 
+// ---- a SEQUENCE of scans along one trajectory (the in-situ test of the drop-in boundary: tests/test_gpu_sequence.py) ----
+// The same scene model; the sensor drives a circle of radius 3 .. 5 m around the scene's start point at 1 .. 3 m/s, so
+// that any number of consecutive 0.1 s sweeps stays inside the room; poles and boxes keep 2.5 m off the circle.
+constexpr uint32_t kSeqTag = 0x5E9u;
+Scene make_seq_scene(uint32_t seed) {
+  Rng r(((uint64_t)seed << 32) ^ 0x5E95E95E9ull);
+  Scene s;
+  s.x0 = r.uni(-4, 4), s.y0 = r.uni(-3, 3), s.yaw0 = r.uni(-M_PI, M_PI);
+  s.speed = r.uni(1, 3);
+  const double radius = r.uni(3, 5);
+  s.yaw_rate = (r.uni() < 0.5 ? -1.0 : 1.0) * s.speed / radius;
+  // centre of the circle: to the left (yaw_rate > 0) or right of the start heading
+  const double sg = s.yaw_rate > 0 ? 1.0 : -1.0;
+  const double cx = s.x0 - sg * radius * std::sin(s.yaw0), cy = s.y0 + sg * radius * std::cos(s.yaw0);
+  auto place = [&](double* xy, double margin) {
+    for (;;) {
+      double x = r.uni(-kHalfX + margin, kHalfX - margin), y = r.uni(-kHalfY + margin, kHalfY - margin);
+      double d = std::sqrt((x - cx) * (x - cx) + (y - cy) * (y - cy));
+      if (std::fabs(d - radius) < 2.5 + margin) continue;  // keep the path clear
+      xy[0] = x, xy[1] = y;
+      return;
+    }
+  };
+  for (auto& p : s.pole) place(p, 0.5);
+  for (auto& b : s.box) place(b, 1.5);
+  return s;
+}
+
 struct FeatBuf {
   std::vector<lins_point> cs, cls, sf, slf;
   lins_features f;
@@ -219,6 +247,43 @@ int lins_synth_raw_scan(uint32_t seed, uint32_t scan_index, int k, lins_point* o
   Scene s = make_scene(seed, scan_index);
   int n = raw_scan(s, seed, scan_index, k, out, cap);
   return n < 0 ? LINS_E_CAPACITY : n;
+}
+
+/* scan k (k = 0, 1, ...: the k-th 0.1 s sweep) of sequence `seed`: raw distorted cloud, firing order */
+int lins_synth_seq_raw_scan(uint32_t seed, int k, lins_point* out, int cap) {
+  if (!out || k < 0) return LINS_E_ARG;
+  Scene s = make_seq_scene(seed);
+  int n = raw_scan(s, seed, kSeqTag, k, out, cap);
+  return n < 0 ? LINS_E_CAPACITY : n;
+}
+
+/* the 40 IMU samples (400 Hz) of sweep k: specific force and angular rate of the planar constant-twist motion in the
+ * sensor frame + constant biases (INIT_BA / INIT_BW + a seeded offset) + white noise; acc, gyr: 40 x 3 */
+int lins_synth_seq_imu(uint32_t seed, int k, double* acc, double* gyr) {
+  if (!acc || !gyr || k < 0) return LINS_E_ARG;
+  Scene s = make_seq_scene(seed);
+  Rng rb(((uint64_t)seed << 32) ^ 0xB1A5ull);
+  const double ba0[3] = {-0.015774, 0.143237, -0.0263845}, bw0[3] = {-0.00275058, -0.000165954, 0.00262913};
+  double ba[3], bw[3];
+  for (int i = 0; i < 3; ++i) ba[i] = ba0[i] + 0.01 * rb.gauss(), bw[i] = bw0[i] + 0.0005 * rb.gauss();
+  Rng r(((uint64_t)seed << 32) ^ ((uint64_t)(k + 1) * 0x9E3779B97F4A7C15ull));
+  for (int i = 0; i < kImuPerScan; ++i) {
+    acc[i * 3 + 0] = ba[0] + 0.05 * r.gauss(), acc[i * 3 + 1] = s.speed * s.yaw_rate + ba[1] + 0.05 * r.gauss();
+    acc[i * 3 + 2] = 9.81 + ba[2] + 0.05 * r.gauss();
+    gyr[i * 3 + 0] = bw[0] + 0.002 * r.gauss(), gyr[i * 3 + 1] = bw[1] + 0.002 * r.gauss();
+    gyr[i * 3 + 2] = s.yaw_rate + bw[2] + 0.002 * r.gauss();
+  }
+  return kImuPerScan;
+}
+
+/* ground truth: planar pose (x, y, yaw) of the sensor at time tau since the start of sweep 0, speed, yaw rate */
+int lins_synth_seq_truth(uint32_t seed, double tau, double* xyyaw, double* speed, double* yaw_rate) {
+  if (!xyyaw) return LINS_E_ARG;
+  Scene s = make_seq_scene(seed);
+  pose_at(s, tau, xyyaw[0], xyyaw[1], xyyaw[2]);
+  if (speed) *speed = s.speed;
+  if (yaw_rate) *yaw_rate = s.yaw_rate;
+  return LINS_OK;
 }
 
 int lins_synth_generate(uint32_t seed, uint32_t scan_index, lins_synth_pair* out) {

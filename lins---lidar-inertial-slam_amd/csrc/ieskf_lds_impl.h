@@ -1211,6 +1211,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #else
 #define PROF2_ADD(ph, dt) \
   do {                    \
+    (void)sizeof(dt);     \
   } while (0)
 #endif
   const long long t_begin = prof ? clock64() : 0, t_wall_begin = prof ? wall_clock64() : 0;

@@ -158,6 +158,12 @@ def lib():
         L.lins_synth_generate.restype = C.c_int
         L.lins_synth_raw_scan.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(Point), C.c_int]
         L.lins_synth_raw_scan.restype = C.c_int
+        dp = C.POINTER(C.c_double)
+        L.lins_synth_seq_raw_scan.argtypes = [C.c_uint32, C.c_int, C.POINTER(Point), C.c_int]
+        L.lins_synth_seq_imu.argtypes = [C.c_uint32, C.c_int, dp, dp]
+        L.lins_synth_seq_truth.argtypes = [C.c_uint32, C.c_double, dp, dp, dp]
+        for f in (L.lins_synth_seq_raw_scan, L.lins_synth_seq_imu, L.lins_synth_seq_truth):
+            f.restype = C.c_int
         L.lins_frontend_extract.argtypes = [C.POINTER(Point), C.c_int, C.c_double, C.POINTER(Features)]
         L.lins_frontend_extract.restype = C.c_int
         L.lins_transform_to_end.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double,
@@ -205,6 +211,34 @@ def synth_raw_scan(index, k, seed=SYNTH_SEED):
     if n < 0:
         raise RuntimeError(f"lins_synth_raw_scan failed: {n}")
     return a[:n].copy()
+
+
+def synth_seq_raw_scan(seq, k):
+    """Raw cloud (firing order) of sweep k of the seeded scan SEQUENCE `seq` (one trajectory: lins_synth_seq_raw_scan)."""
+    a, p = _buf(CLOUD_MAX)
+    n = lib().lins_synth_seq_raw_scan(seq, k, p, CLOUD_MAX)
+    if n < 0:
+        raise RuntimeError(f"lins_synth_seq_raw_scan failed: {n}")
+    return a[:n].copy()
+
+
+def synth_seq_imu(seq, k):
+    """(acc, gyr): the 40 IMU samples (400 Hz) of sweep k of sequence `seq`, each 40 x 3."""
+    acc, gyr = np.zeros((40, 3)), np.zeros((40, 3))
+    dp = C.POINTER(C.c_double)
+    n = lib().lins_synth_seq_imu(seq, k, acc.ctypes.data_as(dp), gyr.ctypes.data_as(dp))
+    if n != 40:
+        raise RuntimeError(f"lins_synth_seq_imu failed: {n}")
+    return acc, gyr
+
+
+def synth_seq_truth(seq, tau):
+    """(x, y, yaw, speed, yaw_rate) of the sensor at time tau [s] since the start of sweep 0."""
+    xyy, v, w = np.zeros(3), C.c_double(0), C.c_double(0)
+    rc = lib().lins_synth_seq_truth(seq, tau, xyy.ctypes.data_as(C.POINTER(C.c_double)), C.byref(v), C.byref(w))
+    if rc != 0:
+        raise RuntimeError(f"lins_synth_seq_truth failed: {rc}")
+    return xyy[0], xyy[1], xyy[2], v.value, w.value
 
 
 def frontend_extract(raw, scan_period=0.1):

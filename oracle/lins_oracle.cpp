@@ -1097,6 +1097,15 @@ int oracle_perform_ieskf(const lins_params* prm, const lins_scan_pair* in, int f
   return rc;
 }
 
+// oracle_perform_ieskf behind the signature of lins_host_perform_ieskf (a context pointer first): what the CPU test of
+// the in-situ checker hands to oracle/ref_seq_driver.cpp's hook instead of the GPU path (dense M x M form, kd-tree)
+int oracle_perform_ieskf_hook(void* /*user*/, const lins_params* prm, const lins_scan_pair* in, lins_result* out,
+                              int32_t* used_icp) {
+  const int rc = oracle_perform_ieskf(prm, in, ORACLE_FORM_DENSE, ORACLE_NN_KDTREE, out);
+  if (used_icp) *used_icp = (rc == LINS_OK && out->diverged) ? 1 : 0;
+  return rc;
+}
+
 int oracle_nn(const lins_point* targets, int n_targets, const lins_point* queries, int n_queries,
               int nn_mode, int32_t* idx, float* sqd) {
   KdTree tree;

@@ -63,6 +63,8 @@ int oracle_perform_ieskf(const lins_params* prm, const lins_scan_pair* in,
                          int form, int nn_mode, lins_result* out);
 
 /* Exact 1-NN (lowest index wins ties), f32 L2_Simple order ((dx²+dy²)+dz²).    */
+int oracle_perform_ieskf_hook(void* user, const lins_params* prm, const lins_scan_pair* in, lins_result* out,
+                              int32_t* used_icp);
 int oracle_nn(const lins_point* targets, int n_targets, const lins_point* queries,
               int n_queries, int nn_mode, int32_t* idx, float* sqdist);
 

@@ -28,42 +28,7 @@
 #include "../include/lins_ieskf.h"
 #include <lins_ref_shim/events.h>
 
-// ---- definitions the reference keeps in translation units we do not compile ------------------------------------
-int fusion::Scan::scan_counter_ = 0;  // lins/src/lib/Estimator.cpp:22
-
-namespace parameter {  // lins/src/lib/parameters.cpp:22-69 declares these; values: config/exp_config/exp_port.yaml
-int CALIBARTE_IMU = 0;
-int SHOW_CONFIGURATION = 0;
-int AVERAGE_NUMS = 100;
-double IMU_LIDAR_EXTRINSIC_ANGLE = 0.0;
-double IMU_MISALIGN_ANGLE = 3.0;
-int LINE_NUM = 16;
-int SCAN_NUM = 1800;
-double SCAN_PERIOD = 0.1;
-double EDGE_THRESHOLD = 0.5;
-double SURF_THRESHOLD = 0.5;
-double NEAREST_FEATURE_SEARCH_SQ_DIST = 25;
-int VERBOSE = 0;
-int ICP_FREQ = 1;
-int MAX_LIDAR_NUMS = 200000;
-int NUM_ITER = 30;
-double LIDAR_SCALE = 1;
-double LIDAR_STD = 0.01;
-std::string IMU_TOPIC, LIDAR_TOPIC, LIDAR_ODOMETRY_TOPIC, LIDAR_MAPPING_TOPIC;
-double ACC_N = 70000;
-double ACC_W = 500;
-double GYR_N = 0.1;
-double GYR_W = 0.05;
-V3D INIT_POS_STD(0.0, 0.0, 0.0);
-V3D INIT_VEL_STD(0.0, 0.0, 0.0);
-V3D INIT_ATT_STD(0.0, 0.0, 0.0);
-V3D INIT_ACC_STD(0.01, 0.01, 0.02);
-V3D INIT_GYR_STD(0.002, 0.002, 0.002);
-V3D INIT_BA(-0.015774, 0.143237, -0.0263845);
-V3D INIT_BW(-0.00275058, -0.000165954, 0.00262913);
-V3D INIT_TBL(0.0, 0.0, 0.0);
-Q4D INIT_RBL(1.0, 0.0, 0.0, 0.0);
-}  // namespace parameter
+#include "ref_params.inc"
 
 namespace {
 
