@@ -325,8 +325,15 @@ __device__ __forceinline__ bool certified(float d_now, float lb, float drift) {
 // All lanes of a wave run the SAME code on different (ring, column-range) data: every
 // scan goes through scan_cols(), whose point loop exists once per call site, so splitting
 // a query's ring windows over three lanes is real parallelism, not serialised branches.
-template <class F>
-__device__ __forceinline__ void scan_cols(const LdsStore& L, const LCloud& c, int r, int lo, int hi, F f) {
+#ifndef LINS_GLOB_BATCH
+#define LINS_GLOB_BATCH 1
+#endif
+constexpr int kGlobBatch = LINS_GLOB_BATCH;
+struct Spans {  // the grid positions of a column window: [s0, e0) and, when the window wraps past the last column, [s1, e1)
+  int s0, e0, s1, e1, spans;
+  __device__ __forceinline__ int count() const { return (e0 - s0) + (e1 - s1); }
+};
+__device__ __forceinline__ Spans spans_of(const LCloud& c, int r, int lo, int hi) {
   int s0 = 0, e0 = 0, s1 = 0, e1 = 0, spans = 1;  // (a window that wraps past the last column has a second span)
   if (lo <= hi) {
     const int naz = c.naz, row = r * naz;
@@ -343,9 +350,13 @@ __device__ __forceinline__ void scan_cols(const LdsStore& L, const LCloud& c, in
       e1 = (int)c.cell_end[row + hi - naz];
     }
   }
+  return Spans{s0, e0, s1, e1, spans};
+}
+template <class F>
+__device__ __forceinline__ void scan_spans(const LdsStore& L, const LCloud& c, const Spans& w, F f) {
 #pragma unroll 1
-  for (int k = 0; k < spans; ++k) {
-    const int s = k ? s1 : s0, e = k ? e1 : e0;
+  for (int k = 0; k < w.spans; ++k) {
+    const int s = k ? w.s1 : w.s0, e = k ? w.e1 : w.e0;
     const int el = kHybrid ? (e < c.n_lds ? e : c.n_lds) : e;
     // kScanBatch points per trip, all their LDS reads issued before the first is consumed (the
     // loop is latency bound: one dependent LDS round trip per trip instead of per point); the last
@@ -364,13 +375,25 @@ __device__ __forceinline__ void scan_cols(const LdsStore& L, const LCloud& c, in
       for (int u = 0; u < kScanBatch; ++u) f(x[u], y[u], z[u], j[u], p + u, p + u < el);
     }
     if (kHybrid) {
+      // the positions past the resident ones, from the sorted global copy (L2).  One record per trip (kGlobBatch = 1):
+      // four in flight like the LDS loop above measured +2.0 % on the batch kernel (round 4, 0.5876 against 0.5761 ms in
+      // one call: four more spilled registers, and these scans are short — the searches of the upper rings end in a
+      // few columns).
 #pragma unroll 1
-      for (int p = s > c.n_lds ? s : c.n_lds; p < e; ++p) {
-        const float4 g = c.gs[p];
-        f(g.x, g.y, g.z, __float_as_int(g.w), p, true);
+      for (int p = s > c.n_lds ? s : c.n_lds; p < e; p += kGlobBatch) {
+        float4 g[kGlobBatch];
+#pragma unroll
+        for (int u = 0; u < kGlobBatch; ++u) g[u] = c.gs[p + u < e ? p + u : e - 1];
+#pragma unroll
+        for (int u = 0; u < kGlobBatch; ++u) f(g[u].x, g[u].y, g[u].z, __float_as_int(g[u].w), p + u, p + u < e);
       }
     }
   }
+}
+
+template <class F>
+__device__ __forceinline__ void scan_cols(const LdsStore& L, const LCloud& c, int r, int lo, int hi, F f) {
+  scan_spans(L, c, spans_of(c, r, lo, hi), f);
 }
 
 // How many columns either side of a0 can hold a point within sqrt(bound) of the query:
@@ -582,6 +605,9 @@ __device__ __forceinline__ void walk_task(const LdsStore& L, const LCloud& c, co
   // candidate shows up, instead of one sweep over the whole search radius.
   int kk = done ? 1 : -1;  // columns a0-kk..a0+kk are covered (-1: nothing yet)
   const int half = c.naz / 2;
+  // (Round 4 tried, one GPU call each: ONE scan per round over the whole window a0-nk..a0+nk, re-seeing the covered
+  // columns: +6.8 % kernel time — the points are paid for; the whole window of the current bound at once when it holds at
+  // most 96 / 256 / any number of points, decided from two cell_end reads: +0.1 / +0.4 / -0.8 % — not the rounds either.)
 #pragma unroll 1
   for (int round = 0; round < 8 && go; ++round) {
     const int K = reach(c, rho_q, bound_sqrtf(cur.d()) + margin);
@@ -784,6 +810,9 @@ __device__ __noinline__ WalkOut coop_walk_ool(bool is_surf, const float4* gs, in
 // traced to its root (ROCm 7.2 clang).  As a separate function nothing of it is scheduled into the kernel body; the
 // GPU suite (golden pairs, adversarial clouds, reference parity, every search mode) is the guard.
 template <int BLOCK>
+#ifndef LINS_INTERLEAVE
+#define LINS_INTERLEAVE 0
+#endif
 #ifndef LINS_GRID_INLINE
 #define LINS_GRID_INLINE 0
 #endif
@@ -1342,6 +1371,19 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     }
     y.k = rnd * kWaves + wave;
     y.kind_s = y.k < nws;
+#if LINS_INTERLEAVE
+    if (spread_ok) {
+      // INTERLEAVED (off): query q of a kind on wave q mod (waves of the kind), lane q div that.  The queries come
+      // sorted by ring and what a search costs goes with the ring (tools/wave_phases.py, cold iteration: the fifth plane
+      // wave walks for 62.9 k ticks, the first for 25.0 k), so contiguous blocks leave one wave with all the long ones —
+      // and that is the better deal: a wave runs as long as its longest lane, dealt out EVERY wave has long lanes.
+      // Measured (round 4, one call): +2.5 % kernel time.
+      const int kw = y.kind_s ? y.k : y.k - nws, nwk = y.kind_s ? kWs : kWc, q = lane * nwk + kw;
+      y.slot = (y.kind_s ? 0 : sd.n_surf_q) + q;
+      y.active = y.k < y.n_wr && q < (y.kind_s ? sd.n_surf_q : sd.n_corner_q);
+      return y;
+    }
+#endif
     const int q0 = y.kind_s ? y.k * per_s : (y.k - nws) * per_c;
     const int left = (y.kind_s ? sd.n_surf_q : sd.n_corner_q) - q0, per = y.kind_s ? per_s : per_c;
     y.slot = (y.kind_s ? 0 : sd.n_surf_q) + q0 + lane, y.active = y.k < y.n_wr && lane < (left < per ? left : per);
