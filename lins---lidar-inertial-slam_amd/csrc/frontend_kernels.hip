@@ -45,7 +45,7 @@ struct FeLds {
       unsigned char flags[kFeMaxN + 16];  // bit 0 picked (cloudNeighborPicked); bits 1-2 cloudLabel: 0 = 0, 1 = 1 (less
                                           // sharp), 2 = 2 (sharp), 3 = -1 (flat); bit 3 ground
       unsigned short col[kFeMaxN + 16];
-      unsigned long long skey[kFeRows][kSectorCap];  // per wave: (|diffRange| bits << 32) | index
+      unsigned long long skey[kFeRows][kSectorCap];  // per wave: 4 KB of work space (the less-flat stage's index lists; rounds 1-3: the sector sort's keys)
     } a;                                              // stencils, masks, sector picks
     unsigned short vso[kFeRows][kRingCap];            // VoxelGrid: per ring, sorted (run start << 15) | order
   };
@@ -227,7 +227,6 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   // ---- extractFeatures: one wave per ring, sectors in order (marks of one sector reach the next) ---
   {
     const int ring = __builtin_amdgcn_readfirstlane(wave);
-    unsigned long long* key = L.a.skey[ring];
     for (int j = 0; j < 6; ++j) {
       const int sp = (sc.start_ring[ring] * (6 - j) + sc.end_ring[ring] * j) / 6;
       const int ep = (sc.start_ring[ring] * (5 - j) + sc.end_ring[ring] * (j + 1)) / 6 - 1;
@@ -238,53 +237,44 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
         continue;
       }
       int pick_entry = 0;  // lane k < 29 carries entry k of the sector's pick list: one 116-byte store at the end
-      const int m = ep - sp;  // the sort covers [sp, ep) — ep itself keeps its place (SE:739-740)
+      const int m = ep - sp;  // [sp, ep) is visited in curvature order — ep itself keeps its place (SE:739-740)
       // cloudSmoothness[i].ind is i only where the stencil ran, [5, n - 5); elsewhere the value-initialised 0
       auto smooth_ind = [&](int i) { return (i >= 5 && i < n - 5) ? i : 0; };
-      bool ground_here = false;  // does any candidate of the plane loop exist at all?
-      // the sort network is sized to the sector: 64 x kP keys, the smallest that holds [sp, ep] (a VLP-16 sector
-      // of a segmented ring has ~150 points: two or four keys per lane instead of eight)
-      auto sort_sector = [&](auto tag) {
-        constexpr int kP = decltype(tag)::value;
-        unsigned long long kv[kP];
+      // Round 4: NO SORT.  The reference sorts the sector by curvature and walks the order from the top (edges) and from
+      // the bottom (planes), taking the first candidate that is still eligible; flags only gain bits, so "the first
+      // eligible candidate in descending order" is the eligible candidate with the LARGEST key — an arg-max over the
+      // wave per pick (at most 20 + 4 picks a sector; 6.4 on the bench scans) instead of a 128 / 256 / 512-key bitonic
+      // network per sector (rounds 1-3: ~1.7 k of the ~2.3 k instructions a sector cost, 168 LDS-crossbar shuffles).
+      // Keys as before: (|diffRange| bits, index) — the index breaks the ties std::sort leaves open, the host restatement
+      // sorts by the same total order.  Element e = u * 64 + lane of the sector lives in this lane's u-th register
+      // (coalesced stencil reads); per lane a bit mask of its edge candidates (curvature > 0.5, not ground) and of its
+      // plane candidates (curvature < 0.5, ground), from which a candidate drops for good once it is found picked.
+      constexpr int kPmax = kSectorCap / 64;
+      unsigned dbits[kPmax];
+      unsigned ecand = 0, pcand = 0;
 #pragma unroll
-        for (int u = 0; u < kP; ++u) {
-          const int e = lane * kP + u;
-          kv[u] = e < m ? ((unsigned long long)__float_as_uint(fabsf(diff_at(sp + e))) << 32) | (unsigned)smooth_ind(sp + e) : ~0ull;
-          ground_here = ground_here || (e <= m && (g_fe.a.flags[smooth_ind(sp + e)] & 8));
+      for (int u = 0; u < kPmax; ++u) {
+        dbits[u] = 0;
+        if (u * 64 < m) {  // (wave-uniform)
+          const int e = u * 64 + lane;
+          if (e < m) {
+            const float d = fabsf(diff_at(sp + e));
+            const double c = (double)d * (double)d;  // cloudCurvature (SE:668), compared as the reference compares it
+            const unsigned char f = L.a.flags[smooth_ind(sp + e)];
+            dbits[u] = __float_as_uint(d);
+            ecand |= (c > 0.5 && !(f & 8)) ? 1u << u : 0u;
+            pcand |= (c < 0.5 && (f & 8)) ? 1u << u : 0u;
+          }
         }
-        wave_bitonic_sort<kP, unsigned long long>(kv, lane);  // ascending
-#pragma unroll
-        for (int u = 0; u < kP; ++u) key[lane * kP + u] = kv[u];
-      };
-      static_assert(kSectorCap == 512, "sort sizes below");
-      if (m < 128)
-        sort_sector(FeInt<2>{});
-      else if (m < 256)
-        sort_sector(FeInt<4>{});
-      else
-        sort_sector(FeInt<8>{});
-      const bool any_ground = __any(ground_here);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      const int ind_ep = smooth_ind(ep);
+      const float d_ep = fabsf(diff_at(ep));
+      const double c_ep = (double)d_ep * (double)d_ep;
       {
-        // The greedy picks (SE:743-813) with the whole wave: 64 candidates at a time in visiting order
-        // (lane 0 first); the first lane that is still eligible under the CURRENT flags takes its pick
-        // and marks its neighbours, the lanes after it re-read their flags and the search resumes
-        // behind it — the sequential loop's outcome, one wave round per pick instead of one loop
-        // trip per candidate.  (A candidate that was not eligible when it was passed never becomes
-        // eligible: flags only gain bits.)
         auto wave_sync = [&] {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        };
-        auto sorted_ind = [&](int k) { return k == ep ? smooth_ind(ep) : (int)(unsigned)key[k - sp]; };
-        const float d_ep = fabsf(diff_at(ep));
-        auto curv_at = [&](int k) {  // cloudCurvature of the k-th element = the square of the sort key's value
-          const double d = (double)(k == ep ? d_ep : __uint_as_float((unsigned)(key[k - sp] >> 32)));
-          return d * d;
         };
         auto col_gap = [&](int a, int b) {
           if (a < 0 || b < 0 || a >= n || b >= n) return 1000;
@@ -303,72 +293,74 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           if (fwd && lane < reach_f) L.a.flags[ind + l] |= 1;
           if (bwd && lane - 5 < reach_b) L.a.flags[ind + l] |= 1;
         };
-        int n_sharp = 0, n_ls = 0, n_flat = 0;
-        // edges: largest curvature first, at most 2 sharp + 18 less sharp
-        bool stop = false;
-        for (int top = ep; top >= sp && !stop; top -= 64) {
-          const int k = top - lane;
-          const bool valid = k >= sp;
-          const int ind = valid ? sorted_ind(k) : 0;
-          const bool curv_ok = valid && curv_at(k) > 0.5;
-          // ascending order below ep: a failed curvature test fails for every later candidate too
-          if (__any(valid && k < ep && !curv_ok)) stop = true;
-          unsigned long long passed = 0;  // lanes at or before the last pick
-          for (;;) {
-            const unsigned char f = valid ? L.a.flags[ind] : (unsigned char)1;
-            const unsigned long long elig = __ballot(curv_ok && !(f & 1) && !(f & 8)) & ~passed;
-            if (!elig) break;
-            const int who = __ffsll((long long)elig) - 1;
-            const int pind = __shfl(ind, who);
-            if (lane == who) {
-              if (n_ls < 2) {
-                L.a.flags[ind] = (unsigned char)((f & ~6) | (2 << 1) | 1);  // cloudLabel 2, picked
+        // the best key among this lane's candidates that are still unpicked (kMax: largest, else smallest), then over the wave
+        auto best_of = [&](unsigned& cand, auto is_max) {
+          constexpr bool kMax = decltype(is_max)::value != 0;
+          unsigned long long best = kMax ? 0ull : ~0ull;
+#pragma unroll
+          for (int u = 0; u < kPmax; ++u) {
+            if (u * 64 < m && ((cand >> u) & 1u)) {
+              const int ind = smooth_ind(sp + u * 64 + lane);
+              if (g_fe.a.flags[ind] & 1) {
+                cand &= ~(1u << u);
               } else {
-                L.a.flags[ind] = (unsigned char)((f & ~6) | (1 << 1) | 1);  // cloudLabel 1, picked
+                const unsigned long long k = ((unsigned long long)dbits[u] << 32) | (unsigned)ind;
+                best = kMax ? (k > best ? k : best) : (k < best ? k : best);
               }
             }
-            if ((n_ls < 2 && lane == n_sharp) || lane == 2 + n_ls) pick_entry = pind;
-            n_sharp += n_ls < 2 ? 1 : 0;
-            ++n_ls;
-            wave_sync();
-            mark_nbrs(pind);
-            wave_sync();
-            passed = (2ull << who) - 1ull;
-            if (n_ls >= 20) {  // the 21st eligible candidate would only end the loop (SE:757-759)
-              stop = true;
-              break;
-            }
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long w = fe_shfl_xor(best, o);
+            best = kMax ? (w > best ? w : best) : (w < best ? w : best);
+          }
+          return best;
+        };
+        int n_sharp = 0, n_ls = 0, n_flat = 0;
+        // edges: largest curvature first, at most 2 sharp + 18 less sharp (SE:743-780)
+        auto edge_pick = [&](int pind) {
+          const unsigned char f = L.a.flags[pind];
+          wave_sync();  // (every lane has read the flag before lane 0 rewrites it)
+          if (lane == 0) L.a.flags[pind] = (unsigned char)((f & ~6) | ((n_ls < 2 ? 2 : 1) << 1) | 1);  // cloudLabel 2 / 1, picked
+          if ((n_ls < 2 && lane == n_sharp) || lane == 2 + n_ls) pick_entry = pind;
+          n_sharp += n_ls < 2 ? 1 : 0;
+          ++n_ls;
+          wave_sync();
+          mark_nbrs(pind);
+          wave_sync();
+        };
+        if (c_ep > 0.5 && !(L.a.flags[ind_ep] & 9)) edge_pick(ind_ep);  // position ep comes first whatever its curvature
+        if (__any(ecand != 0)) {
+          while (n_ls < 20) {  // the 21st eligible candidate would only end the loop (SE:757-759)
+            const unsigned long long best = best_of(ecand, FeInt<1>{});
+            if (!best) break;  // (an edge candidate's key is > 0: its |diffRange| is)
+            edge_pick((int)(unsigned)best);
           }
         }
         // planes: smallest curvature first, ground points only, at most 4; the 4th is not marked (SE:782-813)
-        stop = !any_ground;
-        for (int bot = sp; bot <= ep && !stop; bot += 64) {
-          const int k = bot + lane;
-          const bool valid = k <= ep;
-          const int ind = valid ? sorted_ind(k) : 0;
-          const bool curv_ok = valid && curv_at(k) < 0.5;
-          unsigned long long passed = 0;
-          for (;;) {
-            const unsigned char f = valid ? L.a.flags[ind] : (unsigned char)1;
-            const unsigned long long elig = __ballot(curv_ok && !(f & 1) && (f & 8)) & ~passed;
-            if (!elig) break;
-            const int who = __ffsll((long long)elig) - 1;
-            const int pind = __shfl(ind, who);
-            const bool last = n_flat + 1 >= 4;
-            if (lane == who) {
-              L.a.flags[ind] = (unsigned char)(f | (3 << 1) | (last ? 0 : 1));  // cloudLabel -1 (+ picked unless the 4th)
-            }
-            if (lane == 22 + n_flat) pick_entry = pind;
-            ++n_flat;
-            wave_sync();
-            if (last) {
-              stop = true;
-              break;
-            }
+        auto plane_pick = [&](int pind) {
+          const bool last = n_flat + 1 >= 4;
+          const unsigned char f = L.a.flags[pind];
+          wave_sync();
+          if (lane == 0) L.a.flags[pind] = (unsigned char)(f | (3 << 1) | (last ? 0 : 1));  // cloudLabel -1 (+ picked unless the 4th)
+          if (lane == 22 + n_flat) pick_entry = pind;
+          ++n_flat;
+          wave_sync();
+          if (!last) {
             mark_nbrs(pind);
             wave_sync();
-            passed = (2ull << who) - 1ull;
           }
+        };
+        if (__any(pcand != 0)) {
+          while (n_flat < 4) {
+            const unsigned long long best = best_of(pcand, FeInt<0>{});
+            if (best == ~0ull) break;
+            plane_pick((int)(unsigned)best);
+          }
+        }
+        if (n_flat < 4 && c_ep < 0.5) {  // position ep comes last
+          const unsigned char f = L.a.flags[ind_ep];
+          if ((f & 8) && !(f & 1)) plane_pick(ind_ep);
         }
         if (lane == 26) pick_entry = n_sharp;
         if (lane == 27) pick_entry = n_ls;
