@@ -81,6 +81,40 @@ __device__ __forceinline__ unsigned long long fe_shfl_xor(unsigned long long v, 
 }
 __device__ __forceinline__ unsigned fe_shfl_xor(unsigned v, int m) { return __shfl_xor(v, m); }
 
+// The largest (kMax) or smallest 64-bit key of a wave, in every lane, without the LDS crossbar: four DPP butterflies inside a
+// row of 16 lanes (quad swaps, then the two mirrors), then the row swaps of gfx950 (v_permlane16_swap / v_permlane32_swap
+// with both operands the same value: each lane sees its partner row's).  ~30 VALU instructions; the six ds_bpermute pairs
+// it replaces each waited for an LDS round trip.
+typedef unsigned fe_v2u __attribute__((ext_vector_type(2)));
+template <bool kMax>
+__device__ __forceinline__ unsigned long long fe_pick64(unsigned long long a, unsigned long long b) {
+  return kMax ? (a > b ? a : b) : (a < b ? a : b);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long fe_dpp64(unsigned long long v) {
+  const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)v, CTRL, 0xF, 0xF, true);
+  const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(v >> 32), CTRL, 0xF, 0xF, true);
+  return ((unsigned long long)hi << 32) | lo;
+}
+template <bool kMax>
+__device__ __forceinline__ unsigned long long wave_best64(unsigned long long v) {
+  v = fe_pick64<kMax>(v, fe_dpp64<0xB1>(v));   // quad_perm [1, 0, 3, 2]
+  v = fe_pick64<kMax>(v, fe_dpp64<0x4E>(v));   // quad_perm [2, 3, 0, 1]
+  v = fe_pick64<kMax>(v, fe_dpp64<0x141>(v));  // row_half_mirror
+  v = fe_pick64<kMax>(v, fe_dpp64<0x140>(v));  // row_mirror
+  {
+    const fe_v2u l = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    const fe_v2u h = __builtin_amdgcn_permlane16_swap((unsigned)(v >> 32), (unsigned)(v >> 32), false, false);
+    v = fe_pick64<kMax>(((unsigned long long)h.x << 32) | l.x, ((unsigned long long)h.y << 32) | l.y);
+  }
+  {
+    const fe_v2u l = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    const fe_v2u h = __builtin_amdgcn_permlane32_swap((unsigned)(v >> 32), (unsigned)(v >> 32), false, false);
+    v = fe_pick64<kMax>(((unsigned long long)h.x << 32) | l.x, ((unsigned long long)h.y << 32) | l.y);
+  }
+  return v;
+}
+
 template <int P, class K>
 __device__ __forceinline__ void wave_bitonic_sort(K (&v)[P], int lane) {
 #pragma unroll
@@ -271,11 +305,14 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
       const float d_ep = fabsf(diff_at(ep));
       const double c_ep = (double)d_ep * (double)d_ep;
       {
+        // Flags change by 32-bit LDS atomic ORs with no return value (`mark`, above) and are read as bytes: the LDS unit
+        // takes a wave's instructions in order, so a flag read issued after an OR sees it — nothing to wait for; what
+        // is needed is that the COMPILER keeps the order (it does for accesses that may alias; the barrier makes it plain).
         auto wave_sync = [&] {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          asm volatile("" ::: "memory");
           __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         };
+        auto set_bits = [&](int i, unsigned bits) { atomicOr(&fw[i >> 2], bits << ((i & 3) * 8)); };
         auto col_gap = [&](int a, int b) {
           if (a < 0 || b < 0 || a >= n || b >= n) return 1000;
           const int g = (int)L.a.col[a] - (int)L.a.col[b];
@@ -290,8 +327,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           const unsigned long long gm = __ballot(gap);
           const int stop_f = __ffsll((long long)(gm & 0x1Full)), stop_b = __ffsll((long long)((gm >> 5) & 0x1Full));
           const int reach_f = stop_f ? stop_f - 1 : 5, reach_b = stop_b ? stop_b - 1 : 5;  // neighbours marked per side
-          if (fwd && lane < reach_f) L.a.flags[ind + l] |= 1;
-          if (bwd && lane - 5 < reach_b) L.a.flags[ind + l] |= 1;
+          if ((fwd && lane < reach_f) || (bwd && lane - 5 < reach_b)) set_bits(ind + l, 1u);
         };
         // the best key among this lane's candidates that are still unpicked (kMax: largest, else smallest), then over the wave
         auto best_of = [&](unsigned& cand, auto is_max) {
@@ -309,19 +345,13 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
               }
             }
           }
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) {
-            const unsigned long long w = fe_shfl_xor(best, o);
-            best = kMax ? (w > best ? w : best) : (w < best ? w : best);
-          }
-          return best;
+          return wave_best64<kMax>(best);
         };
         int n_sharp = 0, n_ls = 0, n_flat = 0;
         // edges: largest curvature first, at most 2 sharp + 18 less sharp (SE:743-780)
         auto edge_pick = [&](int pind) {
-          const unsigned char f = L.a.flags[pind];
-          wave_sync();  // (every lane has read the flag before lane 0 rewrites it)
-          if (lane == 0) L.a.flags[pind] = (unsigned char)((f & ~6) | ((n_ls < 2 ? 2 : 1) << 1) | 1);  // cloudLabel 2 / 1, picked
+          // cloudLabel 2 / 1, picked: ORed in — an eligible edge candidate (not ground, not picked) carries no label yet
+          if (lane == 0) set_bits(pind, ((n_ls < 2 ? 2u : 1u) << 1) | 1u);
           if ((n_ls < 2 && lane == n_sharp) || lane == 2 + n_ls) pick_entry = pind;
           n_sharp += n_ls < 2 ? 1 : 0;
           ++n_ls;
@@ -340,9 +370,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
         // planes: smallest curvature first, ground points only, at most 4; the 4th is not marked (SE:782-813)
         auto plane_pick = [&](int pind) {
           const bool last = n_flat + 1 >= 4;
-          const unsigned char f = L.a.flags[pind];
-          wave_sync();
-          if (lane == 0) L.a.flags[pind] = (unsigned char)(f | (3 << 1) | (last ? 0 : 1));  // cloudLabel -1 (+ picked unless the 4th)
+          if (lane == 0) set_bits(pind, (3u << 1) | (last ? 0u : 1u));  // cloudLabel -1 (+ picked unless the 4th)
           if (lane == 22 + n_flat) pick_entry = pind;
           ++n_flat;
           wave_sync();
