@@ -54,6 +54,7 @@ struct FeLds {
   int ring_base[kFeRows];  // the ring's first sector's start: what its kept-point list is relative to
   int ring_out[kFeRows];   // voxels (= output points) of each ring
   int ring_off[kFeRows + 1];
+  int chunk_off[kFeRows + 1];  // D2: 64-position chunks of the rings' sorted lists, prefix sum
   int bad;
 };
 static_assert(sizeof(FeLds) <= 160 * 1024, "LDS budget");
@@ -239,20 +240,35 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   };
   unsigned* fw = reinterpret_cast<unsigned*>(L.a.flags);  // (marks are idempotent bit sets: 32-bit LDS atomics)
   auto mark = [&](int i) { atomicOr(&fw[i >> 2], 1u << ((i & 3) * 8)); };
-  for (int i = tid; i < n; i += kFeBlock) {
-    if (i >= 5 && i < n - 6) {  // markOccludedPoints (SE:680-713)
-      const float d1 = rg[i], d2 = rg[i + 1];
-      int cd = (int)L.a.col[i + 1] - (int)L.a.col[i];
-      cd = cd < 0 ? -cd : cd;
-      if (cd < 10) {
-        if (d1 - d2 > 0.3) {
-          for (int k = 0; k <= 5; ++k) mark(i - k);
-        } else if (d2 - d1 > 0.3) {
-          for (int k = 1; k <= 6; ++k) mark(i + k);
+  {
+    constexpr int kIn = 4;  // points per thread whose range reads are in flight together (one at a time until round 4:
+                            // eighteen dependent trips to L2 per thread)
+    for (int i0 = tid; i0 < n; i0 += kIn * kFeBlock) {
+      float rm[kIn], r0[kIn], rp[kIn];
+#pragma unroll
+      for (int u = 0; u < kIn; ++u) {
+        const int i = i0 + u * kFeBlock, ic = i < 1 ? 1 : (i > n - 2 ? n - 2 : i);  // (clamped: n >= 12 wherever a value is used)
+        rm[u] = r0[u] = rp[u] = 0.f;
+        if (n >= 3) rm[u] = rg[ic - 1], r0[u] = rg[ic], rp[u] = rg[ic + 1];
+      }
+#pragma unroll
+      for (int u = 0; u < kIn; ++u) {
+        const int i = i0 + u * kFeBlock;
+        if (i >= 5 && i < n - 6) {  // markOccludedPoints (SE:680-713)
+          const float d1 = r0[u], d2 = rp[u];
+          int cd = (int)L.a.col[i + 1] - (int)L.a.col[i];
+          cd = cd < 0 ? -cd : cd;
+          if (cd < 10) {
+            if (d1 - d2 > 0.3) {
+              for (int k = 0; k <= 5; ++k) mark(i - k);
+            } else if (d2 - d1 > 0.3) {
+              for (int k = 1; k <= 6; ++k) mark(i + k);
+            }
+          }
+          const float f1 = fabsf(rm[u] - r0[u]), f2 = fabsf(rp[u] - r0[u]);
+          if (f1 > 0.02 * r0[u] && f2 > 0.02 * r0[u]) mark(i);
         }
       }
-      const float f1 = fabsf(rg[i - 1] - rg[i]), f2 = fabsf(rg[i + 1] - rg[i]);
-      if (f1 > 0.02 * rg[i] && f2 > 0.02 * rg[i]) mark(i);
     }
   }
   __syncthreads();
@@ -418,13 +434,18 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
       cnt[tid] = spk[26], cnt[kSec + tid] = spk[27], cnt[2 * kSec + tid] = spk[28];
     }
     __syncthreads();
-    if (tid < 3) {
-      int run = 0;
-      for (int s2 = 0; s2 < kSec; ++s2) {
-        cnt[(3 + tid) * kSec + s2] = run;
-        run += cnt[tid * kSec + s2];
+    if (wave < 3) {  // exclusive offsets of the 96 sectors' counts: a wave per kind, two sectors per lane (48 lanes)
+      static_assert(kSec <= 128, "two sectors per lane");
+      const int a = 2 * lane < kSec ? cnt[wave * kSec + 2 * lane] : 0, b = 2 * lane + 1 < kSec ? cnt[wave * kSec + 2 * lane + 1] : 0;
+      int incl = a + b;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int nb = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += nb;
       }
-      out_counts[scan * 4 + tid] = run;
+      if (2 * lane < kSec) cnt[(3 + wave) * kSec + 2 * lane] = incl - a - b;
+      if (2 * lane + 1 < kSec) cnt[(3 + wave) * kSec + 2 * lane + 1] = incl - b;
+      if (lane == 63) out_counts[scan * 4 + wave] = incl;
     }
     __syncthreads();
     auto und_pt = [&](int i) {  // the de-skewed point: coordinates as they came, the relative-time tag as intensity (SE:649-650)
@@ -611,6 +632,9 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     for (int r = 0; r < kFeRows; ++r) L.ring_off[r] = run, run += L.ring_out[r];
     L.ring_off[kFeRows] = run;
     out_counts[scan * 4 + 3] = run;
+    int ch = 0;
+    for (int r = 0; r < kFeRows; ++r) L.chunk_off[r] = ch, ch += (L.ring_m[r] + 63) >> 6;
+    L.chunk_off[kFeRows] = ch;
   }
   __syncthreads();
   // D2: one centroid per run start — f32 sums of all four fields in stable (original) order — at the ring's final
@@ -618,7 +642,16 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   // wave per ring before): a thread per sorted position, so the gathers of all sixteen waves fall into ONE ring's points
   // at a time (they stay in the caches between the first touch of a line and the last) and neighbouring threads write
   // neighbouring centroids.
-  for (int ring = 0; ring < kFeRows; ++ring) {
+  // (Round 4: the 64-position chunks of all rings are dealt to the waves as ONE list — ring after ring, a ring's last
+  // chunks together with the next ring's first — instead of a pass of the workgroup per ring, whose second step kept
+  // 1024 threads for the ~200 positions a ring has beyond the first 1024: 32 steps a wave -> ~19.)
+#ifdef LINS_FE_PROF
+  long long d2_t[4] = {0, 0, 0, 0};
+#endif
+  const int n_chunks = L.chunk_off[kFeRows];
+  for (int ch = wave; ch < n_chunks; ch += kFeBlock / 64) {
+    // the chunk's ring: lane r < 16 tests ring r's first chunk, the ballot counts (chunk_off is non-decreasing)
+    const int ring = __popcll(__ballot(lane >= 1 && lane < kFeRows && L.chunk_off[lane] <= ch));
     const int m = L.ring_m[ring], base = L.ring_base[ring];
     const unsigned short* vs = L.vso[ring];
     const unsigned short* slot = reinterpret_cast<const unsigned short*>(L.a.skey[ring]);
@@ -628,7 +661,8 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     // others' values left to right with shuffles — the sums in the order VoxelGrid adds them (ascending original
     // index).  Only a run that crosses the step's last lane is finished by its first lane alone.  (Issuing the next
     // step's gather before working on the current one was measured: no faster — the other waves cover the latency.)
-    for (int e0 = wave * 64; e0 < m; e0 += kFeBlock) {
+    {
+      const int e0 = (ch - L.chunk_off[ring]) * 64;
       const int e = e0 + lane;
       const bool valid = e < m;
       const unsigned v = valid ? (unsigned)vs[e] : 0x8000u;
@@ -636,7 +670,21 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
       const int i = base + (int)(v & 2047u);
       float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
       float tg = 0.f;
-      if (valid) p = pts[i], tg = tag_of(i, p);
+#ifdef LINS_FE_PROF
+      long long d2a = clock64();
+#endif
+      if (valid) p = pts[i];
+#ifdef LINS_FE_PROF
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      long long d2b = clock64();
+      d2_t[0] += d2b - d2a;
+#endif
+      if (valid) tg = tag_of(i, p);
+#ifdef LINS_FE_PROF
+      asm volatile("" ::"v"(tg) : "memory");
+      long long d2c = clock64();
+      d2_t[1] += d2c - d2b;
+#endif
       const unsigned long long bounds = __ballot(start || !valid);  // where a run ends: the next start, or the end of the ring
       const unsigned long long above = lane < 63 ? bounds & ~((2ull << lane) - 1ull) : 0ull;
       const int nxt = above ? __ffsll((long long)above) - 1 : 64;
@@ -646,6 +694,12 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
         const float ax = __shfl_down(p.x, d), ay = __shfl_down(p.y, d), az = __shfl_down(p.z, d), at = __shfl_down(tg, d);
         if (start && d < len_in) sx += ax, sy += ay, sz += az, si += at;
       }
+#ifdef LINS_FE_PROF
+      asm volatile("" ::"v"(sx) : "memory");
+      long long d2d = clock64();
+      d2_t[2] += d2d - d2c;
+      d2_t[3] += 1;
+#endif
       if (start) {
         int total = len_in;
         if (nxt == 64) {  // the run may go on beyond this step
@@ -666,8 +720,8 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
 #ifdef LINS_FE_PROF
   FE_MARK(7)
   if (tid == 0 && (scan & 255) == 0)
-    printf("FE scan %d: load %lld flip %lld tags+stencil+masks %lld sort+picks %lld labels %lld compact %lld voxel grid %lld gaps %lld\n", scan, fe_t[0],
-           fe_t[1], fe_t[2], fe_t[3], fe_t[4], fe_t[5], fe_t[6], fe_t[7]);
+    printf("FE scan %d: load %lld flip %lld tags+stencil+masks %lld sort+picks %lld labels %lld compact %lld voxel grid %lld gaps %lld | D2 wave 0: gather %lld tag %lld sums %lld chunks %lld\n", scan, fe_t[0],
+           fe_t[1], fe_t[2], fe_t[3], fe_t[4], fe_t[5], fe_t[6], fe_t[7], d2_t[0], d2_t[1], d2_t[2], d2_t[3]);
 #endif
 }
 
