@@ -67,10 +67,6 @@ __device__ __forceinline__ int fe_ordered_int(float f) {
 }
 __device__ __forceinline__ float fe_ordered_float(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 
-// Bitonic sort of 64 * P keys by one wave, the keys in registers (lane l owns positions l P .. l P + P - 1):
-// compare-exchanges whose partner lies inside the lane's own block are register selects, the others
-// one wave shuffle per key (both lanes of a pair evaluate it and keep the min or the max) — no LDS
-// round trips, no fences.  Fully unrolled: every register index is a compile-time constant.
 template <int N>
 struct FeInt {
   static constexpr int value = N;
@@ -116,34 +112,70 @@ __device__ __forceinline__ unsigned long long wave_best64(unsigned long long v) 
   return v;
 }
 
-template <int P, class K>
-__device__ __forceinline__ void wave_bitonic_sort(K (&v)[P], int lane) {
+// v of lane (l ^ LM), LM a power of two below 64, as VALU moves: DPP inside a row of 16 (quad swaps; xor 4 as two
+// bank-masked row shifts; xor 8 as a row rotation), the row swaps of gfx950 beyond.  (__shfl_xor is a ds_bpermute: an LDS
+// instruction and a wait each — the 2048-key network of the VoxelGrid stage issues 672 of them per ring.)
+template <int LM>
+__device__ __forceinline__ unsigned fe_xor_lane(unsigned v, int lane) {
+  if constexpr (LM == 1) {
+    return __builtin_amdgcn_update_dpp(0u, v, 0xB1, 0xF, 0xF, true);
+  } else if constexpr (LM == 2) {
+    return __builtin_amdgcn_update_dpp(0u, v, 0x4E, 0xF, 0xF, true);
+  } else if constexpr (LM == 4) {
+    unsigned r = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);  // row_shl:4 into banks 0, 2: lane i <- i + 4
+    r = __builtin_amdgcn_update_dpp(r, v, 0x114, 0xF, 0xA, false);           // row_shr:4 into banks 1, 3: lane i <- i - 4
+    return r;
+  } else if constexpr (LM == 8) {
+    return __builtin_amdgcn_update_dpp(0u, v, 0x128, 0xF, 0xF, true);  // row_ror:8
+  } else if constexpr (LM == 16) {
+    const fe_v2u s = __builtin_amdgcn_permlane16_swap(v, v, false, false);  // x: rows (0, 0, 2, 2), y: rows (1, 1, 3, 3)
+    return (lane & 16) ? s.x : s.y;
+  } else {
+    static_assert(LM == 32, "lane distance");
+    const fe_v2u s = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // x: halves (lo, lo), y: (hi, hi)
+    return (lane & 32) ? s.x : s.y;
+  }
+}
+template <int LM>
+__device__ __forceinline__ unsigned long long fe_xor_lane(unsigned long long v, int lane) {
+  return ((unsigned long long)fe_xor_lane<LM>((unsigned)(v >> 32), lane) << 32) | fe_xor_lane<LM>((unsigned)v, lane);
+}
+// Bitonic sort of 64 * P keys by one wave, the keys in registers (lane l owns positions l P .. l P + P - 1):
+// compare-exchanges whose partner lies inside the lane's own block are register selects, the others one lane-xor move
+// per key (both lanes of a pair evaluate it and keep the min or the max) — no LDS round trips, no fences.  The network
+// is unrolled by template recursion: every register index and every lane distance is a compile-time constant.
+template <int P, int K2, int J2, class K>
+__device__ __forceinline__ void bitonic_step(K (&v)[P], int lane) {
+  if constexpr (J2 < P) {
 #pragma unroll
-  for (int k2 = 2; k2 <= 64 * P; k2 <<= 1) {
-#pragma unroll
-    for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
-      if (j2 < P) {
-#pragma unroll
-        for (int u = 0; u < P; ++u)
-          if ((u & j2) == 0) {
-            const bool up = ((lane * P + u) & k2) == 0;
-            const K a = v[u], b = v[u | j2];
-            const bool sw = (a > b) == up;
-            v[u] = sw ? b : a, v[u | j2] = sw ? a : b;
-          }
-      } else {
-        const int lm = j2 / P;
-        const bool lower = (lane & lm) == 0;
-#pragma unroll
-        for (int u = 0; u < P; ++u) {
-          const bool up = ((lane * P + u) & k2) == 0;
-          const K w = fe_shfl_xor(v[u], lm);
-          const bool keep_min = lower == up;
-          v[u] = keep_min ? (w < v[u] ? w : v[u]) : (w > v[u] ? w : v[u]);
-        }
+    for (int u = 0; u < P; ++u)
+      if ((u & J2) == 0) {
+        const bool up = ((lane * P + u) & K2) == 0;
+        const K a = v[u], b = v[u | J2];
+        const bool sw = (a > b) == up;
+        v[u] = sw ? b : a, v[u | J2] = sw ? a : b;
       }
+  } else {
+    constexpr int kLm = J2 / P;
+    const bool lower = (lane & kLm) == 0;
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const bool up = ((lane * P + u) & K2) == 0;
+      const K w = fe_xor_lane<kLm>(v[u], lane);
+      const bool keep_min = lower == up;
+      v[u] = keep_min ? (w < v[u] ? w : v[u]) : (w > v[u] ? w : v[u]);
     }
   }
+  if constexpr (J2 > 1) bitonic_step<P, K2, J2 / 2, K>(v, lane);
+}
+template <int P, int K2, class K>
+__device__ __forceinline__ void bitonic_merge(K (&v)[P], int lane) {
+  bitonic_step<P, K2, K2 / 2, K>(v, lane);
+  if constexpr (K2 < 64 * P) bitonic_merge<P, K2 * 2, K>(v, lane);
+}
+template <int P, class K>
+__device__ __forceinline__ void wave_bitonic_sort(K (&v)[P], int lane) {
+  bitonic_merge<P, 2, K>(v, lane);
 }
 
 __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
