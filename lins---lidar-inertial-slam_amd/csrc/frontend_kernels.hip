@@ -60,6 +60,9 @@ struct FeLds {
 static_assert(sizeof(FeLds) <= 160 * 1024, "LDS budget");
 
 __shared__ FeLds g_fe;
+#ifdef LINS_FE_PROF
+__device__ long long g_fe_prof[16 * 8];
+#endif
 
 __device__ __forceinline__ int fe_ordered_int(float f) {
   int i = __float_as_int(f);
@@ -309,6 +312,10 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   // ---- extractFeatures: one wave per ring, sectors in order (marks of one sector reach the next) ---
   {
     const int ring = __builtin_amdgcn_readfirstlane(wave);
+#ifdef LINS_FE_PROF
+    long long p3_t[5] = {0, 0, 0, 0, 0};
+    const long long p3_begin = clock64();
+#endif
     for (int j = 0; j < 6; ++j) {
       const int sp = (sc.start_ring[ring] * (6 - j) + sc.end_ring[ring] * j) / 6;
       const int ep = (sc.start_ring[ring] * (5 - j) + sc.end_ring[ring] * (j + 1)) / 6 - 1;
@@ -329,9 +336,15 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
       // network per sector (rounds 1-3: ~1.7 k of the ~2.3 k instructions a sector cost, 168 LDS-crossbar shuffles).
       // Keys as before: (|diffRange| bits, index) — the index breaks the ties std::sort leaves open, the host restatement
       // sorts by the same total order.  Element e = u * 64 + lane of the sector lives in this lane's u-th register
-      // (coalesced stencil reads); per lane a bit mask of its edge candidates (curvature > 0.5, not ground) and of its
-      // plane candidates (curvature < 0.5, ground), from which a candidate drops for good once it is found picked.
+      // (coalesced stencil reads); per lane a bit mask of its edge candidates (curvature > 0.5, not ground, not picked
+      // when the sector begins) and of its plane candidates (curvature < 0.5, ground, not picked).  While the sector is
+      // worked on, cloudNeighborPicked changes only through this wave's own picks — the picked index and the run of
+      // neighbours it marks — so the masks are kept up to date in registers (drop_range) and a round reads no flag at
+      // all: local best (registers), wave arg-max (VALU), the pick's column-gap test (the one LDS round trip), marks.
       constexpr int kPmax = kSectorCap / 64;
+#ifdef LINS_FE_PROF
+      long long p3a = clock64();
+#endif
       unsigned dbits[kPmax];
       unsigned ecand = 0, pcand = 0;
 #pragma unroll
@@ -344,14 +357,19 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
             const double c = (double)d * (double)d;  // cloudCurvature (SE:668), compared as the reference compares it
             const unsigned char f = L.a.flags[smooth_ind(sp + e)];
             dbits[u] = __float_as_uint(d);
-            ecand |= (c > 0.5 && !(f & 8)) ? 1u << u : 0u;
-            pcand |= (c < 0.5 && (f & 8)) ? 1u << u : 0u;
+            ecand |= (c > 0.5 && !(f & 9)) ? 1u << u : 0u;
+            pcand |= (c < 0.5 && (f & 9) == 8) ? 1u << u : 0u;
           }
         }
       }
       const int ind_ep = smooth_ind(ep);
       const float d_ep = fabsf(diff_at(ep));
       const double c_ep = (double)d_ep * (double)d_ep;
+#ifdef LINS_FE_PROF
+      asm volatile("" ::"v"(ecand), "v"(pcand), "v"(d_ep) : "memory");
+      long long p3b = clock64();
+      p3_t[0] += p3b - p3a;
+#endif
       {
         // Flags change by 32-bit LDS atomic ORs with no return value (`mark`, above) and are read as bytes: the LDS unit
         // takes a wave's instructions in order, so a flag read issued after an OR sees it — nothing to wait for; what
@@ -368,6 +386,17 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
         };
         // cloudNeighborPicked of the +-5 neighbours up to the first column gap > 10 (SE:764-779): lanes 0-4
         // look forward, 5-9 backward, the break position comes from a ballot
+        // this lane's candidates whose point index lies in [lo, hi] are picked now: out of both masks
+        auto drop_range = [&](int lo, int hi) {
+#pragma unroll
+          for (int u = 0; u < kPmax; ++u) {
+            if (u * 64 < m) {
+              const int ind = smooth_ind(sp + u * 64 + lane);
+              const unsigned keep = (ind >= lo && ind <= hi) ? ~(1u << u) : ~0u;
+              ecand &= keep, pcand &= keep;
+            }
+          }
+        };
         auto mark_nbrs = [&](int ind) {
           const bool fwd = lane < 5, bwd = lane >= 5 && lane < 10;
           const int l = fwd ? lane + 1 : -(lane - 5 + 1);
@@ -376,21 +405,17 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           const int stop_f = __ffsll((long long)(gm & 0x1Full)), stop_b = __ffsll((long long)((gm >> 5) & 0x1Full));
           const int reach_f = stop_f ? stop_f - 1 : 5, reach_b = stop_b ? stop_b - 1 : 5;  // neighbours marked per side
           if ((fwd && lane < reach_f) || (bwd && lane - 5 < reach_b)) set_bits(ind + l, 1u);
+          drop_range(ind - reach_b, ind + reach_f);
         };
-        // the best key among this lane's candidates that are still unpicked (kMax: largest, else smallest), then over the wave
-        auto best_of = [&](unsigned& cand, auto is_max) {
+        // the best key among this lane's candidates (kMax: largest, else smallest), then over the wave
+        auto best_of = [&](unsigned cand, auto is_max) {
           constexpr bool kMax = decltype(is_max)::value != 0;
           unsigned long long best = kMax ? 0ull : ~0ull;
 #pragma unroll
           for (int u = 0; u < kPmax; ++u) {
-            if (u * 64 < m && ((cand >> u) & 1u)) {
-              const int ind = smooth_ind(sp + u * 64 + lane);
-              if (g_fe.a.flags[ind] & 1) {
-                cand &= ~(1u << u);
-              } else {
-                const unsigned long long k = ((unsigned long long)dbits[u] << 32) | (unsigned)ind;
-                best = kMax ? (k > best ? k : best) : (k < best ? k : best);
-              }
+            if (u * 64 < m) {
+              const unsigned long long k = ((unsigned long long)dbits[u] << 32) | (unsigned)smooth_ind(sp + u * 64 + lane);
+              if ((cand >> u) & 1u) best = fe_pick64<kMax>(best, k);
             }
           }
           return wave_best64<kMax>(best);
@@ -415,6 +440,11 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
             edge_pick((int)(unsigned)best);
           }
         }
+#ifdef LINS_FE_PROF
+        long long p3c = clock64();
+        p3_t[1] += p3c - p3b;
+        p3_t[3] += n_ls;
+#endif
         // planes: smallest curvature first, ground points only, at most 4; the 4th is not marked (SE:782-813)
         auto plane_pick = [&](int pind) {
           const bool last = n_flat + 1 >= 4;
@@ -438,6 +468,10 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           const unsigned char f = L.a.flags[ind_ep];
           if ((f & 8) && !(f & 1)) plane_pick(ind_ep);
         }
+#ifdef LINS_FE_PROF
+        p3_t[2] += clock64() - p3c;
+        p3_t[4] += n_flat;
+#endif
         if (lane == 26) pick_entry = n_sharp;
         if (lane == 27) pick_entry = n_ls;
         if (lane == 28) pick_entry = n_flat;
@@ -447,6 +481,12 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+#ifdef LINS_FE_PROF
+    if (lane == 0 && scan == 0) {
+      long long* o = g_fe_prof + ring * 8;
+      o[0] = p3_t[0], o[1] = p3_t[1], o[2] = p3_t[2], o[3] = p3_t[3], o[4] = p3_t[4], o[5] = sc.end_ring[ring] - sc.start_ring[ring], o[6] = clock64() - p3_begin;
+    }
+#endif
   }
   __threadfence_block();
   __syncthreads();
@@ -751,6 +791,9 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   }
 #ifdef LINS_FE_PROF
   FE_MARK(7)
+  if (tid < 16 && scan == 0)
+    printf("FE scan 0 ring %d: keys %lld edges %lld (%lld picks) planes %lld (%lld picks), n %lld, whole %lld\n", tid, g_fe_prof[tid * 8], g_fe_prof[tid * 8 + 1], g_fe_prof[tid * 8 + 3],
+           g_fe_prof[tid * 8 + 2], g_fe_prof[tid * 8 + 4], g_fe_prof[tid * 8 + 5], g_fe_prof[tid * 8 + 6]);
   if (tid == 0 && (scan & 255) == 0)
     printf("FE scan %d: load %lld flip %lld tags+stencil+masks %lld sort+picks %lld labels %lld compact %lld voxel grid %lld gaps %lld | D2 wave 0: gather %lld tag %lld sums %lld chunks %lld\n", scan, fe_t[0],
            fe_t[1], fe_t[2], fe_t[3], fe_t[4], fe_t[5], fe_t[6], fe_t[7], d2_t[0], d2_t[1], d2_t[2], d2_t[3]);
