@@ -23,6 +23,9 @@
 
 namespace lins {
 
+#ifndef LINS_FE_COMPACT_MAX
+#define LINS_FE_COMPACT_MAX 64  // edge candidates of a sector up to which they are dealt one per lane
+#endif
 constexpr int kFeRows = LINS_LINE_NUM;
 constexpr int kFeMaxN = LINS_CLOUD_MAX;  // 28 800 cells
 constexpr int kFeBlock = 1024;
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
             const unsigned char f = L.a.flags[smooth_ind(sp + e)];
             dbits[u] = __float_as_uint(d);
             ecand |= (c > 0.5 && !(f & 9)) ? 1u << u : 0u;
-            pcand |= (c < 0.5 && (f & 9) == 8) ? 1u << u : 0u;
+            pcand |= (c < 0.5 && (f & 8)) ? 1u << u : 0u;  // (picked or not is looked up when the edges are done)
           }
         }
       }
@@ -386,17 +389,19 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
         };
         // cloudNeighborPicked of the +-5 neighbours up to the first column gap > 10 (SE:764-779): lanes 0-4
         // look forward, 5-9 backward, the break position comes from a ballot
-        // this lane's candidates whose point index lies in [lo, hi] are picked now: out of both masks
-        auto drop_range = [&](int lo, int hi) {
+        // this lane's candidates whose point index lies in [lo, hi] are picked now: out of the mask.  Only the blocks
+        // of 64 elements the range touches are looked at (wave-uniform test; a range that reaches index 0 — where the
+        // elements outside the stencil's reach point, smooth_ind — looks at all).
+        auto drop_range = [&](unsigned& cand, int lo, int hi) {
 #pragma unroll
           for (int u = 0; u < kPmax; ++u) {
-            if (u * 64 < m) {
+            if (u * 64 < m && (lo <= 0 || (sp + u * 64 <= hi && sp + u * 64 + 63 >= lo))) {
               const int ind = smooth_ind(sp + u * 64 + lane);
-              const unsigned keep = (ind >= lo && ind <= hi) ? ~(1u << u) : ~0u;
-              ecand &= keep, pcand &= keep;
+              cand &= (ind >= lo && ind <= hi) ? ~(1u << u) : ~0u;
             }
           }
         };
+        int mk_lo = 0, mk_hi = -1;  // the run of indices the last pick marked (itself included)
         auto mark_nbrs = [&](int ind) {
           const bool fwd = lane < 5, bwd = lane >= 5 && lane < 10;
           const int l = fwd ? lane + 1 : -(lane - 5 + 1);
@@ -405,7 +410,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           const int stop_f = __ffsll((long long)(gm & 0x1Full)), stop_b = __ffsll((long long)((gm >> 5) & 0x1Full));
           const int reach_f = stop_f ? stop_f - 1 : 5, reach_b = stop_b ? stop_b - 1 : 5;  // neighbours marked per side
           if ((fwd && lane < reach_f) || (bwd && lane - 5 < reach_b)) set_bits(ind + l, 1u);
-          drop_range(ind - reach_b, ind + reach_f);
+          mk_lo = ind - reach_b, mk_hi = ind + reach_f;
         };
         // the best key among this lane's candidates (kMax: largest, else smallest), then over the wave
         auto best_of = [&](unsigned cand, auto is_max) {
@@ -432,12 +437,44 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           mark_nbrs(pind);
           wave_sync();
         };
-        if (c_ep > 0.5 && !(L.a.flags[ind_ep] & 9)) edge_pick(ind_ep);  // position ep comes first whatever its curvature
-        if (__any(ecand != 0)) {
+        if (c_ep > 0.5 && !(L.a.flags[ind_ep] & 9)) {  // position ep comes first whatever its curvature
+          edge_pick(ind_ep);
+          drop_range(ecand, mk_lo, mk_hi);
+        }
+        // how many edge candidates the sector has (wave-uniform), and this lane's first one's rank among them
+        int n_ec = 0, my_rank[kPmax];
+#pragma unroll
+        for (int u = 0; u < kPmax; ++u) {
+          my_rank[u] = 0;
+          if (u * 64 < m) {
+            const unsigned long long bm = __ballot((ecand >> u) & 1u);
+            my_rank[u] = n_ec + __popcll(bm & ((1ull << lane) - 1ull));
+            n_ec += __popcll(bm);
+          }
+        }
+        if (n_ec > 0 && n_ec <= LINS_FE_COMPACT_MAX) {
+          // ONE candidate per lane (the usual case: a sector has a few dozen points of curvature > 0.5): through the
+          // wave's 4 KB of LDS work space into lane order; a round is then the wave arg-max of one register, the pick, and
+          // a three-instruction range test — the block masks are not touched again.
+          unsigned long long* sk = L.a.skey[ring];
+#pragma unroll
+          for (int u = 0; u < kPmax; ++u)
+            if (u * 64 < m && ((ecand >> u) & 1u)) sk[my_rank[u]] = ((unsigned long long)dbits[u] << 32) | (unsigned)smooth_ind(sp + u * 64 + lane);
+          wave_sync();
+          unsigned long long ck = lane < n_ec ? sk[lane] : 0ull;
           while (n_ls < 20) {  // the 21st eligible candidate would only end the loop (SE:757-759)
-            const unsigned long long best = best_of(ecand, FeInt<1>{});
+            const unsigned long long best = wave_best64<true>(ck);
             if (!best) break;  // (an edge candidate's key is > 0: its |diffRange| is)
             edge_pick((int)(unsigned)best);
+            const int ci = (int)(unsigned)ck;
+            ck = (ci >= mk_lo && ci <= mk_hi) ? 0ull : ck;
+          }
+        } else if (n_ec > 0) {
+          while (n_ls < 20) {
+            const unsigned long long best = best_of(ecand, FeInt<1>{});
+            if (!best) break;
+            edge_pick((int)(unsigned)best);
+            drop_range(ecand, mk_lo, mk_hi);
           }
         }
 #ifdef LINS_FE_PROF
@@ -458,10 +495,18 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           }
         };
         if (__any(pcand != 0)) {
+          {  // the plane candidates the edge picks (and everything before this sector) have left unpicked
+            unsigned char fl[kPmax];
+#pragma unroll
+            for (int u = 0; u < kPmax; ++u) fl[u] = u * 64 < m ? L.a.flags[smooth_ind(sp + u * 64 + lane)] : (unsigned char)1;
+#pragma unroll
+            for (int u = 0; u < kPmax; ++u) pcand &= (fl[u] & 1) ? ~(1u << u) : ~0u;
+          }
           while (n_flat < 4) {
             const unsigned long long best = best_of(pcand, FeInt<0>{});
             if (best == ~0ull) break;
             plane_pick((int)(unsigned)best);
+            drop_range(pcand, mk_lo, mk_hi);
           }
         }
         if (n_flat < 4 && c_ep < 0.5) {  // position ep comes last
