@@ -61,6 +61,10 @@ __device__ __forceinline__ int az_bin_lds(float x, float y, int naz) {
 
 // the build of scans [0, n) of `descs` on `stream`: sorted copy into gsorted (same offsets as the targets in the
 // arena: positions 0 .. n_all - 1 at off_surf_t), tables into tab[scan]
+// updatePointCloud in one kernel: the clouds `descs` name as targets are re-projected in place with states[scan] (19
+// doubles each: t at 0, q at 6) and indexed as re-projected (ieskf_grid.hip grid_index_kernel<true>)
+void launch_reproject_and_index(hipStream_t stream, int n, const ScanDesc* descs, float4* arena, float4* gsorted, GridTables* tab,
+                                const double* states, double inv_period);
 void launch_grid_index(hipStream_t stream, int n, const ScanDesc* descs, const float4* arena, float4* gsorted,
                        GridTables* tab);
 

@@ -29,11 +29,23 @@ struct GridLds {
   int scan_tmp[kGBlock / 64 + 4];
 };
 
-__global__ __launch_bounds__(kGBlock) void grid_index_kernel(const ScanDesc* __restrict__ descs, const float4* __restrict__ arena,
-                                                             float4* __restrict__ sorted, GridTables* __restrict__ tab) {
+// REPROJECT (round 4, the reference's updatePointCloud as ONE pass: SE:1116-1161): the clouds are the scan's less-sharp /
+// less-flat clouds as the front-end left them; every point is taken to the scan end with the stream's final state
+// (transformToEnd, SE:1083-1101) where the histogram pass reads it, written back in place — the next update's rows and
+// the any-size kernels read the arena — and binned as what it has become.  One read of the new clouds instead of two
+// kernels' two (lins_streams_step ran reproject_in_place_kernel, then this kernel at the start of the next step).
+template <bool REPROJECT>
+__global__ __launch_bounds__(kGBlock) void grid_index_kernel(const ScanDesc* __restrict__ descs, const float4* arena, float4* arena_rw,
+                                                             float4* __restrict__ sorted, GridTables* __restrict__ tab,
+                                                             const double* __restrict__ states, double inv_period) {
   __shared__ GridLds L;
   const int tid = threadIdx.x;
   const ScanDesc sd = descs[blockIdx.x];
+  ToEnd te;
+  if (REPROJECT) {
+    const double* st = states + (size_t)blockIdx.x * 19;
+    te = make_to_end(V3{st[0], st[1], st[2]}, Q4{st[6], st[7], st[8], st[9]}, inv_period);
+  }
   float4* const gsorted = sorted + sd.off_surf_t;
   // cell c's counter is the u16 half (c & 1) of word c >> 1 of cell_end: counts and positions stay
   // below 2^16, so a half never carries into its neighbour
@@ -104,7 +116,12 @@ __global__ __launch_bounds__(kGBlock) void grid_index_kernel(const ScanDesc* __r
         int eb = 0, ek = -1;  // elevation bits, (cloud, ring) key of this lane's point
         if (j < n_all) {
           const bool is_s = j < sd.n_surf_t;
-          const float4 p = pbuf[u];
+          float4 p = pbuf[u];
+          if (REPROJECT) {
+            const V3 e = to_end_point(te, (double)p.x, (double)p.y, (double)p.z, p.w);
+            p.x = (float)e.x, p.y = (float)e.y, p.z = (float)e.z;
+            (is_s ? arena_rw + sd.off_surf_t : arena_rw + sd.off_corner_t - sd.n_surf_t)[j] = p;
+          }
           const int r = ring_of(p.w), naz = is_s ? kAzSurf : kAzCorner;
           const int cell = (is_s ? kCellsCorner : 0) + r * naz + az_bin_lds(p.x, p.y, naz);
           cell_of[k] = cell;
@@ -202,7 +219,12 @@ __global__ __launch_bounds__(kGBlock) void grid_index_kernel(const ScanDesc* __r
 void launch_grid_index(hipStream_t stream, int n, const ScanDesc* descs, const float4* arena, float4* gsorted,
                        GridTables* tab) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(grid_index_kernel, dim3(n), dim3(kGBlock), 0, stream, descs, arena, gsorted, tab);
+  hipLaunchKernelGGL(grid_index_kernel<false>, dim3(n), dim3(kGBlock), 0, stream, descs, arena, nullptr, gsorted, tab, nullptr, 0.0);
+}
+void launch_reproject_and_index(hipStream_t stream, int n, const ScanDesc* descs, float4* arena, float4* gsorted, GridTables* tab,
+                                const double* states, double inv_period) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(grid_index_kernel<true>, dim3(n), dim3(kGBlock), 0, stream, descs, arena, arena, gsorted, tab, states, inv_period);
 }
 
 }  // namespace lins

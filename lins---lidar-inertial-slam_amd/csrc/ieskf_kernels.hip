@@ -539,30 +539,37 @@ struct ReprojectJob {
   double inv_period;
 };
 
+constexpr int kToEndPts = 8;
 __global__ __launch_bounds__(256) void transform_to_end_kernel(const ReprojectJob* __restrict__ jobs,
                                                                const float4* __restrict__ in,
                                                                float4* __restrict__ out_xyz,
                                                                float4* __restrict__ out_yzx) {
   const ReprojectJob jb = jobs[blockIdx.y];
-  const V3 t{jb.t[0], jb.t[1], jb.t[2]};
-  const Q4 q{jb.q[0], jb.q[1], jb.q[2], jb.q[3]};
-  const V3 phi = quat2axis(q);
-  const Q4 qinv = qinverse(q);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += gridDim.x * blockDim.x) {
-    const float4 pi = in[jb.off + i];
-    const float frac = pi.w - (float)(int)pi.w;
-    const double s = jb.inv_period * (double)frac;
-    const V3 p1 = qrot(axis2quat(s * phi), V3{(double)pi.x, (double)pi.y, (double)pi.z}) + s * t;
-    const V3 p2 = qrot(qinv, p1 - t);
-    const float x = (float)p2.x, y = (float)p2.y, z = (float)p2.z;
-    out_xyz[jb.off + i] = make_float4(x, y, z, pi.w);
-    if (jb.has_yzx) out_yzx[jb.off + i] = make_float4(y, z, x, pi.w);
+  const ToEnd te = make_to_end(V3{jb.t[0], jb.t[1], jb.t[2]}, Q4{jb.q[0], jb.q[1], jb.q[2], jb.q[3]}, jb.inv_period);
+  // kToEndPts points per thread, their reads in flight together: the per-cloud constants (a libm quat2axis, a matrix)
+  // cost as much as a dozen points, and with one point per thread (rounds 1-3) they were the kernel
+  for (int i0 = blockIdx.x * blockDim.x * kToEndPts + threadIdx.x; i0 < jb.n; i0 += gridDim.x * blockDim.x * kToEndPts) {
+    float4 pi[kToEndPts];
+#pragma unroll
+    for (int u = 0; u < kToEndPts; ++u) {
+      const int i = i0 + u * (int)blockDim.x;
+      pi[u] = in[jb.off + (i < jb.n ? i : jb.n - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < kToEndPts; ++u) {
+      const int i = i0 + u * (int)blockDim.x;
+      if (i >= jb.n) break;
+      const V3 p2 = to_end_point(te, (double)pi[u].x, (double)pi[u].y, (double)pi[u].z, pi[u].w);
+      const float x = (float)p2.x, y = (float)p2.y, z = (float)p2.z;
+      out_xyz[jb.off + i] = make_float4(x, y, z, pi[u].w);
+      if (jb.has_yzx) out_yzx[jb.off + i] = make_float4(y, z, x, pi[u].w);
+    }
   }
 }
 
 void launch_transform_to_end(hipStream_t stream, int n_jobs, int max_n, const void* jobs, const float4* in,
                              float4* out_xyz, float4* out_yzx) {
-  int gx = (max_n + 255) / 256;
+  int gx = (max_n + 256 * kToEndPts - 1) / (256 * kToEndPts);
   if (gx < 1) gx = 1;
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(transform_to_end_kernel, dim3(gx, n_jobs), dim3(256), 0, stream, (const ReprojectJob*)jobs, in,
@@ -581,22 +588,26 @@ __global__ __launch_bounds__(256) void reproject_in_place_kernel(const StreamClo
                                                                  double inv_period) {
   const StreamCloud jb = jobs[blockIdx.y];
   const double* st = states + (size_t)jb.stream * 19;
-  const V3 t{st[0], st[1], st[2]};
-  const Q4 q{st[6], st[7], st[8], st[9]};
-  const V3 phi = quat2axis(q);
-  const Q4 qinv = qinverse(q);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < jb.n; i += gridDim.x * blockDim.x) {
-    const float4 pi = arena[jb.off + i];
-    const float frac = pi.w - (float)(int)pi.w;
-    const double s = inv_period * (double)frac;
-    const V3 p1 = qrot(axis2quat(s * phi), V3{(double)pi.x, (double)pi.y, (double)pi.z}) + s * t;
-    const V3 p2 = qrot(qinv, p1 - t);
-    arena[jb.off + i] = make_float4((float)p2.x, (float)p2.y, (float)p2.z, pi.w);
+  const ToEnd te = make_to_end(V3{st[0], st[1], st[2]}, Q4{st[6], st[7], st[8], st[9]}, inv_period);
+  for (int i0 = blockIdx.x * blockDim.x * kToEndPts + threadIdx.x; i0 < jb.n; i0 += gridDim.x * blockDim.x * kToEndPts) {
+    float4 pi[kToEndPts];
+#pragma unroll
+    for (int u = 0; u < kToEndPts; ++u) {
+      const int i = i0 + u * (int)blockDim.x;
+      pi[u] = arena[jb.off + (i < jb.n ? i : jb.n - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < kToEndPts; ++u) {
+      const int i = i0 + u * (int)blockDim.x;
+      if (i >= jb.n) break;
+      const V3 p2 = to_end_point(te, (double)pi[u].x, (double)pi[u].y, (double)pi[u].z, pi[u].w);
+      arena[jb.off + i] = make_float4((float)p2.x, (float)p2.y, (float)p2.z, pi[u].w);
+    }
   }
 }
 void launch_reproject_in_place(hipStream_t stream, int n_jobs, int max_n, const void* jobs, const double* states,
                                float4* arena, double inv_period) {
-  int gx = (max_n + 255) / 256;
+  int gx = (max_n + 256 * kToEndPts - 1) / (256 * kToEndPts);
   gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
   hipLaunchKernelGGL(reproject_in_place_kernel, dim3(gx, n_jobs), dim3(256), 0, stream, (const StreamCloud*)jobs, states,
                      arena, inv_period);

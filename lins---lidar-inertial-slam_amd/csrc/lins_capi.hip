@@ -185,6 +185,8 @@ struct lins_ctx {
     float4 *d_arena = nullptr, *d_sorted = nullptr, *d_gsorted = nullptr;
     GridTables* d_gridtab = nullptr;
     ScanDesc* d_desc = nullptr;
+    ScanDesc* d_desc_next = nullptr;  // the clouds of the scan just taken in as the NEXT step's targets (fused re-projection + index)
+    bool index_ready = false;         // d_gsorted / d_gridtab hold the index of the resident last scans (built by the step before)
     void* d_jobs = nullptr;
     std::vector<int> last_counts;  // per stream: less sharp, less flat of the resident last scan (-1: none yet)
     bool failed = false;           // a step stopped half way (HIP error): the resident clouds are not trustworthy any more
@@ -351,7 +353,8 @@ int effective_search(const lins_ctx* ctx, int n) {
 
 void streams_free(lins_ctx* ctx) {
   auto& t = ctx->st;
-  (void)hipFree(t.d_arena), (void)hipFree(t.d_sorted), (void)hipFree(t.d_desc), (void)hipFree(t.d_jobs);
+  (void)hipFree(t.d_arena), (void)hipFree(t.d_sorted), (void)hipFree(t.d_desc), (void)hipFree(t.d_jobs), (void)hipFree(t.d_desc_next);
+  t.d_desc_next = nullptr, t.index_ready = false;
   (void)hipFree(t.d_gsorted), (void)hipFree(t.d_gridtab);
   t = lins_ctx::Streams{};
 }
@@ -1487,6 +1490,8 @@ int lins_streams_init(lins_ctx* ctx, int n_streams) {
   HIP_TRY(ctx, hipMalloc((void**)&t.d_gsorted, pts * sizeof(float4)));
   HIP_TRY(ctx, hipMalloc((void**)&t.d_gridtab, (size_t)n_streams * sizeof(GridTables)));
   HIP_TRY(ctx, hipMalloc((void**)&t.d_desc, (size_t)n_streams * sizeof(ScanDesc)));
+  HIP_TRY(ctx, hipMalloc((void**)&t.d_desc_next, (size_t)n_streams * sizeof(ScanDesc)));
+  t.index_ready = false;
   HIP_TRY(ctx, hipMalloc(&t.d_jobs, (size_t)n_streams * 2 * sizeof(StreamCloudHost)));
   t.n = n_streams, t.cur = 0;
   t.last_counts.assign((size_t)n_streams * 2, -1);
@@ -1589,13 +1594,36 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
     const bool use_mr = want_mr && mr_ok, use_lds = want_lds && !want_mr && lds_ok;
     if (use_mr || use_lds) {
       idx_ready = true;
-      // the search index of the last scan's clouds (they were re-projected in place at the end of the previous step)
-      launch_grid_index(ctx->stream, n, t.d_desc, t.d_arena, t.d_gsorted, t.d_gridtab);
+      // the search index of the last scan's clouds: left by the step before, which re-projected and indexed them in one
+      // kernel (step 3 below) — built here only when that step could not (its first scan, another search mode)
+      if (!t.index_ready) launch_grid_index(ctx->stream, n, t.d_desc, t.d_arena, t.d_gsorted, t.d_gridtab);
       HIP_TRY(ctx, hipMemsetAsync(ctx->d_walk_cache, 0xFF, (size_t)n * LINS_MAX_QUERY * 32, ctx->stream));  // (slot_base = k * LINS_MAX_QUERY)
-      if (use_mr)
-        launch_lds_mr(ctx->stream, n, ctx->dprm, t.d_desc, nullptr, t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in, ctx->d_cov_in,
-                      ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr, nullptr, ctx->d_walk_cache, ++ctx->run_gen);
-      else
+      if (use_mr) {
+        // several-part updates as in lins_batch_run (the relay): more streams than workgroup slots
+        RelayArgs ra;
+        const bool cut_ok = n > 2 * ctx->n_cu && ctx->prm.icp_freq == 1 && ctx->d_relay_hdr && ctx->relay_at > 0 && ctx->relay_at < ctx->prm.num_iter;
+        if (cut_ok) {
+          ra.at = ctx->relay_at;
+          ra.parts = ra.launched = std::min(kRelayMaxParts, (ctx->prm.num_iter + ctx->relay_at - 1) / ctx->relay_at);
+        }
+        const bool relay = ra.parts > 1;
+        if (relay) {
+          if (ctx->relay_gen >= (1 << 26)) {
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_relay_flag, 0, (size_t)ctx->max_batch * sizeof(int), ctx->stream));
+            ctx->relay_gen = 0;
+          }
+          int* list = ctx->h_order + n;  // the launch list: every part 0, then every part 1, ... (the batch calls rebuild theirs)
+          for (int p = 0; p < ra.launched; ++p)
+            for (int k = 0; k < n; ++k) list[p * n + k] = k | (p << 27);
+          HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order + n, list, (size_t)ra.launched * n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+          ctx->relay_list_parts = -1;
+          ra.gen = ++ctx->relay_gen, ra.spins = ctx->relay_spins;
+          ra.hdr = ctx->d_relay_hdr, ra.lane = ctx->d_relay_lane, ra.flag = ctx->d_relay_flag, ra.err = ctx->h_relay_err;
+        }
+        launch_lds_mr(ctx->stream, n, ctx->dprm, t.d_desc, relay ? ctx->d_order + n : nullptr, t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in,
+                      ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr, relay ? &ra : nullptr,
+                      ctx->d_walk_cache, ++ctx->run_gen);
+      } else
         launch_lds(ctx->stream, n, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, t.d_desc, t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in,
                    ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr);
     } else {
@@ -1663,10 +1691,32 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
     t.last_counts[(size_t)k * 2] = c[1], t.last_counts[(size_t)k * 2 + 1] = c[3];
     if (feature_counts) std::memcpy(feature_counts + (size_t)k * 4, c, 4 * sizeof(int));
   }
-  HIP_TRY(ctx, hipMemcpyAsync(t.d_jobs, jobs.data(), jobs.size() * sizeof(StreamCloudHost), hipMemcpyHostToDevice, ctx->stream));
+  // ... and, when the next step's update will search through the LDS grid, their search index in the same pass
+  // (grid_index_kernel<true>: one read of the new clouds for the re-projected arena copy, the grid-sorted copy and the
+  // tables; SURVEY f-2 "re-projection + target binning build")
+  bool fuse = effective_search(ctx, n) >= SEARCH_LDS;
+  for (int k = 0; k < n && fuse; ++k) {
+    const int* c = &counts[(size_t)k * 4];
+    if (c[1] + c[3] > kGridNpMax || c[1] + c[3] > (effective_search(ctx, n) == SEARCH_MR ? lds_mr_np_cap() : lds_np_cap())) fuse = false;
+  }
+  if (fuse) {
+    for (int k = 0; k < n; ++k) {
+      const int* c = &counts[(size_t)k * 4];
+      ScanDesc& d = ctx->h_desc[k];  // (the update's descriptors have been consumed: its kernel has finished)
+      const long long b = slot_base(k, cur);
+      d.off_surf_t = (int)(b + kSlotLessFlat), d.n_surf_t = c[3];
+      d.off_corner_t = (int)(b + kSlotLessSharp), d.n_corner_t = c[1];
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(t.d_desc_next, ctx->h_desc, (size_t)n * sizeof(ScanDesc), hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    HIP_TRY(ctx, hipMemcpyAsync(t.d_jobs, jobs.data(), jobs.size() * sizeof(StreamCloudHost), hipMemcpyHostToDevice, ctx->stream));
+  }
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  launch_reproject_in_place(ctx->stream, 2 * n, max_n, t.d_jobs, ctx->d_state_out, t.d_arena,
-                            (double)(1.f / (float)scan_period));
+  if (fuse)
+    launch_reproject_and_index(ctx->stream, n, t.d_desc_next, t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_out, (double)(1.f / (float)scan_period));
+  else
+    launch_reproject_in_place(ctx->stream, 2 * n, max_n, t.d_jobs, ctx->d_state_out, t.d_arena, (double)(1.f / (float)scan_period));
+  t.index_ready = fuse;
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
