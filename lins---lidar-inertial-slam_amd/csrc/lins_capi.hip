@@ -137,6 +137,7 @@ struct lins_ctx {
   int run_gen = 0;
   int* h_relay_err = nullptr;       // (pinned, device-visible) hand-over protocol violations seen by the tail kernel: checked at lins_sync
   int relay_spins = 1 << 14;        // polls (~1 us) a part waits for its hand-over before it runs the whole update alone
+  bool streams_fuse = true;         // lins_streams_step: updatePointCloud as one kernel (re-projection + index); debug knob LINS_STREAMS_FUSE
   int relay_scramble = 0;           // debug (LINS_RELAY_SCRAMBLE): launch list in an order that violates "a part behind the part before it"
   // the tail kernel (ieskf_lds_tail.hip): the iterations from tail_at on as a launch of their own, four scans per CU
   int tail_at = 0;                  // (0 = off: the batch kernel's own last part runs to the end.  Off by default: measured
@@ -672,6 +673,7 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
       if (const char* e = std::getenv("LINS_TAIL_AT")) ctx->tail_at = std::max(0, std::atoi(e));    // (0: no tail kernel)
       if (const char* e = std::getenv("LINS_RELAY_SPINS")) ctx->relay_spins = std::max(1, std::atoi(e));
       if (const char* e = std::getenv("LINS_RELAY_SCRAMBLE")) ctx->relay_scramble = std::atoi(e);
+      if (const char* e = std::getenv("LINS_STREAMS_FUSE")) ctx->streams_fuse = e[0] != '0';  // (0: re-projection and index build as two kernels)
     }
   ctx->max_batch = max_batch;
   ctx->max_targets = max_targets;
@@ -1694,7 +1696,7 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
   // ... and, when the next step's update will search through the LDS grid, their search index in the same pass
   // (grid_index_kernel<true>: one read of the new clouds for the re-projected arena copy, the grid-sorted copy and the
   // tables; SURVEY f-2 "re-projection + target binning build")
-  bool fuse = effective_search(ctx, n) >= SEARCH_LDS;
+  bool fuse = ctx->streams_fuse && effective_search(ctx, n) >= SEARCH_LDS;
   for (int k = 0; k < n && fuse; ++k) {
     const int* c = &counts[(size_t)k * 4];
     if (c[1] + c[3] > kGridNpMax || c[1] + c[3] > (effective_search(ctx, n) == SEARCH_MR ? lds_mr_np_cap() : lds_np_cap())) fuse = false;

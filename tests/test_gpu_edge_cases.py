@@ -427,6 +427,75 @@ def test_device_resident_streams_reproduce_the_staged_path(pkg, ieskf, host):
         assert all(np.isfinite(r.state).all() for r in r2)
 
 
+def test_update_point_cloud_as_one_kernel_leaves_the_same_bits(pkg, ieskf, host, monkeypatch):
+    """lins_streams_step re-projects a scan's clouds and builds their search index in ONE kernel (grid_index_kernel<true>);
+    with the debug knob LINS_STREAMS_FUSE=0 the two run as the two kernels they were: same resident clouds, same states
+    and covariances, bit for bit, over three steps (the slots swap twice)."""
+    n = 5
+    segs = [[host.frontend_segment(host.synth_raw_scan(60 + i, k)) for i in range(n)] for k in (0, 1)]
+    pairs = host.synth_batch(n, start=60)
+    boot = np.zeros((n, 19))
+    for i, p in enumerate(pairs):
+        boot[i, 0:3], boot[i, 6:10] = p.meta["true_t"], p.meta["true_q"]
+    cov0 = np.tile(np.eye(18)[None] * 1e-4, (n, 1, 1))
+    st = np.stack([p.state for p in pairs]); cv = np.stack([p.cov for p in pairs])
+
+    def run(fuse):
+        monkeypatch.setenv("LINS_ENABLE_DEBUG_KNOBS", "1")
+        monkeypatch.setenv("LINS_STREAMS_FUSE", "1" if fuse else "0")
+        out = []
+        with ieskf.IeskfContext(pkg.default_params(num_iter=12), max_batch=n, max_targets=16384) as c:
+            c.streams_init(n)
+            c.streams_step(segs[0], boot, cov0)
+            out.append([c.streams_peek(i, w) for i in range(n) for w in (0, 1)])
+            for k in (1, 0):
+                r, _ = c.streams_step(segs[k], st, cv)
+                out.append([(x.state.copy(), x.cov.copy(), x.iters) for x in r])
+                out.append([c.streams_peek(i, w) for i in range(n) for w in (0, 1)])
+        return out
+
+    a, b = run(True), run(False)
+    for x, y in zip(a, b):
+        for u, v in zip(x, y):
+            if isinstance(u, tuple):
+                assert np.array_equal(u[0], v[0]) and np.array_equal(u[1], v[1]) and u[2] == v[2]
+            else:
+                assert np.array_equal(u, v)
+    assert any(t[2] > 0 for t in a[1])  # (the second step really matched something)
+
+
+def test_streams_step_in_several_parts_leaves_the_same_bits(pkg, ieskf, host, monkeypatch):
+    """More streams than the device has workgroup slots (two per CU): the update of a step runs as several parts that hand
+    the loop state over (the relay, as in lins_batch_run).  Same states, covariances and iteration counts as whole
+    updates (LINS_RELAY_AT=0), bit for bit."""
+    n_dist = 8
+    n = 2 * 256 + 9  # (an MI355X has 256 CUs; an odd count, so that parts land on different XCDs)
+    segs = [[host.frontend_segment(host.synth_raw_scan(70 + i, k)) for i in range(n_dist)] for k in (0, 1)]
+    pairs = host.synth_batch(n_dist, start=70)
+    tile = lambda xs: [xs[i % n_dist] for i in range(n)]
+    boot = np.zeros((n, 19))
+    for i in range(n):
+        boot[i, 0:3], boot[i, 6:10] = pairs[i % n_dist].meta["true_t"], pairs[i % n_dist].meta["true_q"]
+    cov0 = np.tile(np.eye(18)[None] * 1e-4, (n, 1, 1))
+    st = np.stack([p.state for p in tile(pairs)]); cv = np.stack([p.cov for p in tile(pairs)])
+
+    def run(relay_at):
+        monkeypatch.setenv("LINS_ENABLE_DEBUG_KNOBS", "1")
+        monkeypatch.setenv("LINS_RELAY_AT", str(relay_at))
+        with ieskf.IeskfContext(pkg.default_params(num_iter=10, fixed_iters=1), max_batch=n, max_targets=16384) as c:
+            c.streams_init(n)
+            c.streams_step(tile(segs[0]), boot, cov0)
+            r, _ = c.streams_step(tile(segs[1]), st, cv)
+            return [(x.state.copy(), x.cov.copy(), x.iters) for x in r]
+
+    a, b = run(4), run(0)
+    assert all(t[2] == 10 for t in a)
+    for u, v in zip(a, b):
+        assert np.array_equal(u[0], v[0]) and np.array_equal(u[1], v[1]) and u[2] == v[2]
+    for i in range(n_dist, n):  # (the same scan on another stream: the same bits)
+        assert np.array_equal(a[i][0], a[i % n_dist][0])
+
+
 def test_device_segmentation_matches_the_host_restatement(pkg, ieskf, host):
     """image_projection_node (IP:191-415) on the device == the host restatement, bit for bit: projection
     (last point owns a cell), ground flags, the BFS labelling restated as a min-label propagation over the
