@@ -21,7 +21,18 @@
 #include <vector>
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>  // types only: the library is dlopen()ed on first use (lins_rccl_*), never linked
+// RCCL: types only — the library is dlopen()ed on first use (lins_rccl_*), never linked.  Without its header (a ROCm
+// install with no rccl-dev; -DLINS_NO_RCCL_HEADER to check) the four types the entry points need are declared here:
+// their ABI (an opaque communicator pointer, the 128-byte id, int enums with ncclSuccess = ncclChar = 0) has not changed
+// since NCCL 2.0, and a box without the library answers LINS_E_UNSUPPORTED at run time as before.
+#if __has_include(<rccl/rccl.h>) && !defined(LINS_NO_RCCL_HEADER)
+#include <rccl/rccl.h>
+#else
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0 } ncclDataType_t;
+#endif
 
 #include "../../include/lins_host.h"
 #include "ieskf_device.h"
