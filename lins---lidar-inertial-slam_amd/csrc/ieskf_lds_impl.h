@@ -851,12 +851,14 @@ __device__ __noinline__
 // registers, the 19-state) are allocated on their own instead of inflating — and spilling —
 // the search loop it would otherwise be fused with.  Called by every thread (barriers inside).
 // ---------------------------------------------------------------------------
-// (Scalars by value, the profile stamp returned: a reference to the kernel's parameter struct or to a local would
-// force them into scratch for the whole kernel — every later read of a parameter a scratch load.)
-__device__ __noinline__ long long solve_and_update(double prm_r2, int prm_fixed_iters, int prm_pad, int tid, int iter, bool prof) {
+// Round 4: the out-of-line bodies are entered by the waves that work in them only — solve_wave0 by wave 0,
+// next_iter_consts by waves 0-2 — and the barriers between them are the caller's.  As one function called by all eight
+// waves (rounds 2-3) every wave ran its prologue and epilogue, nine callee-saved registers to scratch and back per wave
+// and iteration: ~190 MB of scratch stores per launch of 1024 scans, most of the 208 MB WRITE_SIZE counted (the
+// hand-over of the several-part updates is 35 MB of it).
+__device__ __noinline__ long long solve_wave0(double prm_r2, int prm_fixed_iters, int lane, bool prof) {
   long long t3 = 0;
   LdsStore& L = g_lds;
-  const int lane = tid & 63, wave = tid >> 6;
   // ---- wave 0: (sigma^2 I + A P_SS) w = g + A d_S  (push-through form of SE:542-549) solved across the wave
   // (wave_gj_solve6: Gauss-Jordan, one element per lane, no back-substitution), dx = d - P[:,S] w, NaN / divergence /
   // convergence tests and boxPlus (SE:552-580).  This wave walks a chain of dependent f64 operations while the other
@@ -869,14 +871,9 @@ __device__ __noinline__ long long solve_and_update(double prm_r2, int prm_fixed_
   // iteration: wave 0 -> linState_, R^T;  wave 1 -> phi, Rinvleft(-phi)^T;  wave 2 -> x_filter (-) x_lin.
   // (Until round 2 the first three waves each ran the whole solve redundantly to save the staging: 2 x ~2.5 k
   // issued instructions per iteration for nothing.)
-  if (prm_pad & 0x10000) {  // counting aid (LINS_DEBUG_SKIP bit 0x10000): no solve, no update — the state stands still
-    if (tid == 0) L.iter = iter + 1;
-    __syncthreads();
-    return t3;
-  }
   double* const stage = &L.aug[0][0];  // 22 doubles: linState_ (19), |r|, |r| kept, |dx|
   int* const stage_flags = reinterpret_cast<int*>(&L.aug[1][0]);  // diverged, converged
-  if (wave == 0) {
+  {
     double v = 0.0;
     if (lane < 42) {
       const int i = lane / 7, j = lane % 7;
@@ -944,9 +941,14 @@ __device__ __noinline__ long long solve_and_update(double prm_r2, int prm_fixed_
       stage_flags[0] = div, stage_flags[1] = conv;
     }
   }
-  __syncthreads();  // every reader of the old linearisation state is done; the staged one is visible
-  const int div = stage_flags[0];
-  if (wave < 3 && !div) {
+  return t3;
+}
+// the constants of the next iteration from the staged linearisation state: wave 0 -> linState_, R^T; wave 1 -> phi,
+// Rinvleft(-phi)^T; wave 2 -> x_filter (-) x_lin
+__device__ __noinline__ void next_iter_consts(int wave, int lane) {
+  LdsStore& L = g_lds;
+  const double* const stage = &L.aug[0][0];
+  {
     const Q4 q{stage[6], stage[7], stage[8], stage[9]};
     // (static indices only: a lane-indexed register array would be spilled to scratch)
     if (wave == 0) {
@@ -978,6 +980,24 @@ __device__ __noinline__ long long solve_and_update(double prm_r2, int prm_fixed_
       }
     }
   }
+}
+// (Scalars by value, the profile stamp returned: a reference to the kernel's parameter struct or to a local would
+// force them into scratch for the whole kernel — every later read of a parameter a scratch load.)
+__device__ __forceinline__ long long solve_and_update(double prm_r2, int prm_fixed_iters, int prm_pad, int tid, int iter, bool prof) {
+  long long t3 = 0;
+  LdsStore& L = g_lds;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (prm_pad & 0x10000) {  // counting aid (LINS_DEBUG_SKIP bit 0x10000): no solve, no update — the state stands still
+    if (tid == 0) L.iter = iter + 1;
+    __syncthreads();
+    return t3;
+  }
+  const double* const stage = &L.aug[0][0];  // 22 doubles: linState_ (19), |r|, |r| kept, |dx|
+  const int* const stage_flags = reinterpret_cast<const int*>(&L.aug[1][0]);  // diverged, converged
+  if (wave == 0) t3 = solve_wave0(prm_r2, prm_fixed_iters, lane, prof);
+  __syncthreads();  // every reader of the old linearisation state is done; the staged one is visible
+  const int div = stage_flags[0];
+  if (wave < 3 && !div) next_iter_consts(wave, lane);
   if (tid == 0) {
     L.res_last = stage[19], L.res_prev = stage[20], L.upd_norm = stage[21];
     L.conv = stage_flags[1], L.div = div;
