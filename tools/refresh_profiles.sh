@@ -2,7 +2,7 @@
 # Regenerates the line-of-record artifacts for round $1 (default r03) on the GPU box into gpurun_out/; copy what is
 # to be judged into profiles/ afterwards (tools/README.md).  PMC passes are separate rocprofv3 runs with
 # --kernel-trace only (never combined with other trace domains).
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out
@@ -38,6 +38,21 @@ cat $out/${tag}_aux_rates.txt
   python tools/wg_cost_model.py 1024 mr 2>&1 | tail -3
   echo "== tools/step_modes.py  (host sync per step / back to back / pipelined gather mode)"
   python tools/step_modes.py 2>&1 | tail -3
+  echo "== tools/relay_sweep.py 1024 0 3 4 5 6  (iterations per part of the several-part updates; 0 = whole updates)"
+  python tools/relay_sweep.py 1024 0 3 4 5 6 2>&1 | tail -5
+  echo "== RS_ITERS=30 RS_FIXED=0 tools/relay_sweep.py 1024 0 4  (the reference's stop rule)"
+  RS_ITERS=30 RS_FIXED=0 python tools/relay_sweep.py 1024 0 4 2>&1 | tail -2
+  echo "== tools/index_time.py 1024  (grid_index_kernel at lins_batch_upload)"
+  python tools/index_time.py 1024 2>&1 | tail -1
+  if [ -f ab/prof2.so ]; then
+    echo "== LINS_IESKF_LIB=ab/prof2.so tools/wave_phases.py 5 10  (per-wave phases of the late iterations; -DLINS_PROF2=5 build)"
+    LINS_IESKF_LIB=$PWD/ab/prof2.so python tools/wave_phases.py 5 10 2>&1 | head -14
+  fi
+  if [ -f ab/prof0.so ]; then
+    echo "== LINS_IESKF_LIB=ab/prof0.so tools/wave_phases.py 0 1 / 0 4  (the cold iteration; iterations 0-3; -DLINS_PROF2=0 build)"
+    LINS_IESKF_LIB=$PWD/ab/prof0.so python tools/wave_phases.py 0 1 2>&1 | head -11
+    LINS_IESKF_LIB=$PWD/ab/prof0.so python tools/wave_phases.py 0 4 2>&1 | head -11
+  fi
 } > $out/${tag}_kernel_anatomy.txt 2>&1
 cat $out/${tag}_kernel_anatomy.txt
 bash tools/aux_profiles.sh > /dev/null 2>&1; cp $out/aux_kernel_stats.csv $out/${tag}_rocprofv3_kernel_stats_aux.csv; cat $out/${tag}_rocprofv3_kernel_stats_aux.csv
