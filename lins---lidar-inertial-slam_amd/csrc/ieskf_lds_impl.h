@@ -167,6 +167,14 @@ struct LdsStore {
   long long prof_acc[16];  // phase profile accumulators of the PROF variant (written by thread 0)
 #ifdef LINS_PROF2
   int prof2[64];  // per wave x phase ticks of the iterations >= LINS_PROF2 (lane 0 of each wave; lins_debug_wave_phases)
+#if !LINS_LDS_TAIL
+#define LINS_PROF2_ARR 1
+#ifndef LINS_PROF2_NNPH
+#define LINS_PROF2_CNT 1  // (LINS_PROF2_NNPH: prof4 takes the sub-phase ticks of nn_lds instead of the scan counts)
+#endif
+  int cnt_calls[512], cnt_pts[512];  // per lane: scan_spans() calls and grid positions scanned since the last fold
+  int prof4[64];  // per wave: nn phase (max calls, max points over the lanes, sum calls, sum points), walk phase (the same)
+#endif
   int prof3[32];  // per wave: [0] wave-iterations with a nearest-neighbour search [1] ... with a walk [2] searches [3] walks
 #endif
   int dbg[4];  // [0] certificate disagreements (verify mode) [1] NN searches skipped [2] walks skipped
@@ -262,6 +270,9 @@ __device__ __forceinline__ void consider(Best& b, float d, int key, int pos, int
 // runner-up and only lowers `omin` — one compare and a select, no branch; the 64-bit key logic runs
 // for the few that can enter the top two (ties on the runner-up's distance included).  `ok` masks
 // points that are not candidates at all (walk rank filter, batch padding).
+// (Round 4 measured the insertion WITHOUT a branch — four 64-bit compares and a dozen selects at every point instead of
+// insert_key() under a saved exec mask where a lane has a candidate: + 11 % kernel time, 0.6219 against 0.5598 ms in one
+// call.  Candidates are rare after a scan's first points; the compare-and-min below is what nearly every point costs.)
 __device__ __forceinline__ void consider_scan(Best& b, bool ok, float d, int key, int pos, int ring) {
   const bool cand = ok && d <= __uint_as_float((unsigned)(b.k2 >> 32));
   b.omin = (ok && !cand) ? fminf(b.omin, d) : b.omin;
@@ -354,6 +365,9 @@ __device__ __forceinline__ Spans spans_of(const LCloud& c, int r, int lo, int hi
 }
 template <class F>
 __device__ __forceinline__ void scan_spans(const LdsStore& L, const LCloud& c, const Spans& w, F f) {
+#ifdef LINS_PROF2_CNT
+  g_lds.cnt_calls[threadIdx.x & 511] += 1, g_lds.cnt_pts[threadIdx.x & 511] += w.count();
+#endif
 #pragma unroll 1
   for (int k = 0; k < w.spans; ++k) {
     const int s = k ? w.s1 : w.s0, e = k ? w.e1 : w.e0;
@@ -440,6 +454,12 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
   // distance to the re-de-skewed query bounds the search from the start — the seed scan is skipped
   // and the windows are minimal.  It only tightens bounds; the exact arg-min is still taken over
   // every cell that could beat it, so the result is the same as a cold search.
+#if defined(LINS_PROF2_NNPH) && defined(LINS_PROF2_ARR)
+  long long np0 = clock64();
+#define NNPH(k) { long long t_ = clock64(); if ((threadIdx.x & 63) == 0) g_lds.prof4[(threadIdx.x >> 6) * 8 + (k)] += (int)(t_ - np0); np0 = t_; }
+#else
+#define NNPH(k)
+#endif
   const bool warm = warm_pos >= 0;
   if (warm)
     consider(b, pt_sqdist(L, c, warm_pos, sx, sy, sz), pt_idx(L, c, warm_pos), warm_pos, warm_ring);
@@ -471,6 +491,7 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
     }
     rcur = rq;
   }
+  NNPH(1)
   const int cin = warm ? 0 : 2;  // first column either side that the seed has not covered
   const float B = b.d();  // fixed bound for everything below (conservative: >= the final best)
   const float sqrtB = bound_sqrtf(B) + margin;  // pruning bound inflated by the certificate margin
@@ -496,6 +517,8 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
       if (LANES == 0 && t >= kTasks) break;
       const int k = t - 2, off = (k >> 1) + 1;
       const int r = t < 2 ? rq : rq + ((k & 1) ? -off : off);
+      // (Round 4: these thirty tests take 8 k of the cold search's 44 k ticks — tools/r04_call21.sh; issuing the ring
+      // reads unconditionally instead of behind the && chain: + 0.75 % kernel time, not kept)
       bool go;
       if (t < 2)
         go = own && K >= cin;
@@ -504,6 +527,7 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
       todo |= go ? (1u << i) : 0u;
     }
   }
+  NNPH(2)
 #pragma unroll 1
   while (todo) {
     const int i = __ffs(todo) - 1;
@@ -515,7 +539,9 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
     // own ring: right part (with the centre column when warm) / left part; other rings: whole window
     scan_cols(L, c, r, t == 0 ? a0 + cin : a0 - K, t == 1 ? a0 - (warm ? 1 : 2) : a0 + K, f);
   }
+  NNPH(3)
   merge_query_lanes<LANES>(b, lane_base, role, ln);
+  NNPH(4)
   return b;
 }
 
@@ -731,8 +757,15 @@ __device__ __forceinline__ NnOut coop_nn(const LdsStore& L, const LCloud& c, con
     i_a1 = __shfl(a1, owner), i_ra1 = __shfl(ra1, owner);
   }
   Best bb = best_init(thr);
+#if defined(LINS_PROF2_NNPH) && defined(LINS_PROF2_ARR)
+  long long cp0 = clock64();
+  if ((threadIdx.x & 63) == 0) g_lds.prof4[(threadIdx.x >> 6) * 8 + 7] += 1;
+#endif
   if (valid && !skip)  // (profiling aid: LINS_DEBUG_SKIP=2 skips the search, 1 skips the walk)
     bb = nn_lds<0>(L, c, isx, isy, isz, iq, thr, margin, i_rq, ln, wrole, wbase, i_a1, i_ra1);
+#if defined(LINS_PROF2_NNPH) && defined(LINS_PROF2_ARR)
+  if ((threadIdx.x & 63) == 0) g_lds.prof4[(threadIdx.x >> 6) * 8 + 5] += (int)(clock64() - cp0);
+#endif
   NnOut r{bb.pos, bb.ring, bb.pos2, bb.ring2, cert_lb(bb, thr, margin)};
   if (ln > 1) {  // hand back: the owner of rank r reads the first lane of group r
     const int src = (cm.rank * ln) & 63;
@@ -1253,6 +1286,10 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #ifdef LINS_PROF2
   if (prof && threadIdx.x < 64) g_lds.prof2[threadIdx.x] = 0;
   if (prof && threadIdx.x < 32) g_lds.prof3[threadIdx.x] = 0;
+#ifdef LINS_PROF2_ARR
+  if (threadIdx.x < 64) g_lds.prof4[threadIdx.x] = 0;
+  g_lds.cnt_calls[threadIdx.x & 511] = 0, g_lds.cnt_pts[threadIdx.x & 511] = 0;
+#endif
 #define PROF2_ADD(ph, dt)                                                                   \
   do {                                                                                      \
     if (prof && lane == 0 && iter >= LINS_PROF2 && wave < 8) g_lds.prof2[wave * 8 + (ph)] += (int)(dt); \
@@ -1661,6 +1698,20 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #endif
             int r_pos = -1, r_ring = -1, r_pos2 = -1, r_ring2 = -1;
             float r_lb = 0.f;
+#ifdef LINS_PROF2_CNT
+            auto fold_counts = [&](int base) {  // the lanes' scan counts since the last fold -> prof4[wave][base ..]
+              int ca = g_lds.cnt_calls[tid & 511], pa = g_lds.cnt_pts[tid & 511];
+              g_lds.cnt_calls[tid & 511] = 0, g_lds.cnt_pts[tid & 511] = 0;
+              int cm_ = ca, pm_ = pa, cs_ = ca, ps_ = pa;
+              for (int o = 32; o > 0; o >>= 1) {
+                cm_ = max(cm_, __shfl_xor(cm_, o)), pm_ = max(pm_, __shfl_xor(pm_, o));
+                cs_ += __shfl_xor(cs_, o), ps_ += __shfl_xor(ps_, o);
+              }
+              if (prof && lane == 0 && iter >= LINS_PROF2 && wave < 8)
+                g_lds.prof4[wave * 8 + base] += cm_, g_lds.prof4[wave * 8 + base + 1] += pm_, g_lds.prof4[wave * 8 + base + 2] += cs_, g_lds.prof4[wave * 8 + base + 3] += ps_;
+            };
+            fold_counts(4);  // (what the walk phase of the iteration before left, and anything in between)
+#endif
             if (cm.n) {  // (wave-uniform)
               // The polar view of the query (two square roots, an atan2f, the column) only feeds the searches: made here,
               // by every lane of a wave that searches — wave-uniform, so no lane waits for another's branch; a wave
@@ -1781,6 +1832,19 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #endif
             int r2 = -1, r2b = -1, r3 = -1, r3b = -1;
             float r_lb2 = 0.f, r_lb3 = 0.f;
+#ifdef LINS_PROF2_CNT
+            {  // the nearest-neighbour phase's counts
+              int ca = g_lds.cnt_calls[tid & 511], pa = g_lds.cnt_pts[tid & 511];
+              g_lds.cnt_calls[tid & 511] = 0, g_lds.cnt_pts[tid & 511] = 0;
+              int cm_ = ca, pm_ = pa, cs_ = ca, ps_ = pa;
+              for (int o = 32; o > 0; o >>= 1) {
+                cm_ = max(cm_, __shfl_xor(cm_, o)), pm_ = max(pm_, __shfl_xor(pm_, o));
+                cs_ += __shfl_xor(cs_, o), ps_ += __shfl_xor(ps_, o);
+              }
+              if (prof && lane == 0 && iter >= LINS_PROF2 && wave < 8)
+                g_lds.prof4[wave * 8 + 0] += cm_, g_lds.prof4[wave * 8 + 1] += pm_, g_lds.prof4[wave * 8 + 2] += cs_, g_lds.prof4[wave * 8 + 3] += ps_;
+            }
+#endif
             if (cm.n) {
               if (!qp_ready && !(pad & 0x200000) && !(kTail && LINS_TAIL_OOL)) qp = polar_of(o.sel[0], o.sel[1], o.sel[2], c.naz);
               const int nq = is_surf ? sd.n_surf_q : sd.n_corner_q;
@@ -2160,6 +2224,19 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #else
 #define KP(f) ka.f
 #endif
+#ifdef LINS_PROF2_CNT
+  if (LANES == 1) {  // the last iteration's walk phase is still in the lanes' counters
+    int ca = g_lds.cnt_calls[tid & 511], pa = g_lds.cnt_pts[tid & 511];
+    int cm_ = ca, pm_ = pa, cs_ = ca, ps_ = pa;
+    for (int o = 32; o > 0; o >>= 1) {
+      cm_ = max(cm_, __shfl_xor(cm_, o)), pm_ = max(pm_, __shfl_xor(pm_, o));
+      cs_ += __shfl_xor(cs_, o), ps_ += __shfl_xor(ps_, o);
+    }
+    if (prof && lane == 0 && wave < 8)
+      g_lds.prof4[wave * 8 + 4] += cm_, g_lds.prof4[wave * 8 + 5] += pm_, g_lds.prof4[wave * 8 + 6] += cs_, g_lds.prof4[wave * 8 + 7] += ps_;
+    __syncthreads();
+  }
+#endif
 #ifdef LINS_PROF2
   if (prof && dbg_slot >= 0) idx_store[dbg_slot] = make_int4(dbg_nn, dbg_walk, dbg_walk_mask, ra1 | (a3 >= 0 ? 0x100 : 0));
 #endif
@@ -2178,6 +2255,12 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     // (the reduction phase, ~230 ticks a wave, gives its slot to the search counts: [w][4] = wave-iterations with a
     // nearest-neighbour search | with a walk, both << 16 ... kept simple: phase 4 of wave w = walks << 16 | wave-iterations with a walk,
     // phase 4 is re-read by tools/wave_phases.py)
+#ifdef LINS_PROF2_ARR
+    {  // the scan counts (walk phase of the last iteration still in the lanes' counters: left out — the cold profile runs two iterations)
+      int* ext2 = reinterpret_cast<int*>(prof_out + (size_t)gridDim.x * 48) + (size_t)scan * 64;
+      for (int k = 0; k < 64; ++k) ext2[k] = L.prof4[k];
+    }
+#endif
     for (int k = 0; k < 64; ++k) ext[k] = (k & 7) == 4 ? (L.prof3[(k >> 3) * 4 + 1] | (L.prof3[(k >> 3) * 4 + 3] << 12) | (L.prof3[(k >> 3) * 4 + 0] << 20) | (L.prof3[(k >> 3) * 4 + 2] << 26)) : L.prof2[k];
 #endif
   }

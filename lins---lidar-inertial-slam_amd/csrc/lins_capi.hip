@@ -1152,8 +1152,8 @@ int lins_debug_phase_profile(lins_ctx* ctx, int enable, long long* out, int n_sc
   if (enable && !ctx->d_prof) {
     // (16 words per scan, then — behind the records of the launch — 32 words per scan of per-wave phase ticks, written by
     // libraries built with -DLINS_PROF2=k: lins_debug_wave_phases)
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_prof, (size_t)ctx->max_batch * 48 * sizeof(long long)));
-    HIP_TRY(ctx, hipMemset(ctx->d_prof, 0, (size_t)ctx->max_batch * 48 * sizeof(long long)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_prof, (size_t)ctx->max_batch * 80 * sizeof(long long)));
+    HIP_TRY(ctx, hipMemset(ctx->d_prof, 0, (size_t)ctx->max_batch * 80 * sizeof(long long)));
   }
   if (out && ctx->d_prof) {
     if (n_scans > ctx->max_batch) return LINS_E_CAPACITY;
@@ -1177,6 +1177,18 @@ int lins_debug_wave_phases(lins_ctx* ctx, int* out, int n_scans) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipMemcpy(out, ctx->d_prof + (size_t)n_scans * 16, (size_t)n_scans * 64 * sizeof(int), hipMemcpyDeviceToHost));
+  return LINS_OK;
+}
+
+/* Debug aid (LINS_PROF2 builds): per scan 8 waves x 8 counts over the iterations >= k — nearest-neighbour phase: max over
+ * the lanes of the window scans (scan_spans calls) and of the grid positions they cover, the sums of both over the lanes;
+ * then the same four for the walk phase. */
+int lins_debug_wave_counts(lins_ctx* ctx, int* out, int n_scans) {
+  if (!ctx || !out) return LINS_E_ARG;
+  if (!ctx->d_prof || n_scans != ctx->n_uploaded) return LINS_E_STATE;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpy(out, ctx->d_prof + (size_t)n_scans * 48, (size_t)n_scans * 64 * sizeof(int), hipMemcpyDeviceToHost));
   return LINS_OK;
 }
 
