@@ -213,18 +213,30 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   // index and the flip position; the few consumers (the picked points, the kept points of the less-flat cloud: each
   // point at most once) evaluate it where they read the point — rounds 1-2 stored a de-skewed copy of the whole cloud.
   const double s_ori = (double)sc.start_ori, e_ori = (double)sc.end_ori;
+  // Round 4: ONE pass over the cloud does what two did (where halfPassed flips; flags and columns into LDS; then, behind a
+  // barrier, the occlusion / parallel-beam masks of SE:680-713 from a second read of the ranges): the masks need a
+  // point's own column and its successor's — both read from global memory here — and their marks are 32-bit LDS atomic
+  // ORs, as is the ground bit, so that nothing orders a point's own initialisation against its neighbours' marks: the
+  // flag words are zeroed first (LDS only), then everything is an OR.
+  unsigned* fw = reinterpret_cast<unsigned*>(L.a.flags);  // (marks are idempotent bit sets: 32-bit LDS atomics)
+  auto mark = [&](int i) { atomicOr(&fw[i >> 2], 1u << ((i & 3) * 8)); };
+  for (int w = tid; w < (n + 16 + 3) / 4; w += kFeBlock) fw[w] = 0u;
+  if (tid < 16) L.a.col[n + tid] = 0;
+  __syncthreads();
   {
     int first = n;
     constexpr int kIn = 4;  // points per thread whose reads are in flight together
-    for (int i0 = tid; i0 < n + 16; i0 += kIn * kFeBlock) {
+    for (int i0 = tid; i0 < n; i0 += kIn * kFeBlock) {
       float4 p[kIn];
       unsigned char g[kIn];
-      unsigned c[kIn];
+      unsigned c[kIn], c1[kIn];
+      float rm[kIn], r0[kIn], rp[kIn];
 #pragma unroll
       for (int u = 0; u < kIn; ++u) {
-        const int i = i0 + u * kFeBlock, ic = i < n ? i : n - 1;  // (clamped reads; an empty scan reads nothing)
-        p[u] = make_float4(0.f, 0.f, 0.f, 0.f), g[u] = 0, c[u] = 0;
-        if (n > 0) p[u] = pts[ic], g[u] = gd[ic], c[u] = cl[ic];
+        const int i = i0 + u * kFeBlock, ic = i < n ? i : n - 1;  // (clamped reads; an empty scan does not get here)
+        const int im = ic > 0 ? ic - 1 : 0, ip = ic < n - 1 ? ic + 1 : n - 1;
+        p[u] = pts[ic], g[u] = gd[ic], c[u] = cl[ic], c1[u] = cl[ip];
+        rm[u] = rg[im], r0[u] = rg[ic], rp[u] = rg[ip];
       }
 #pragma unroll
       for (int u = 0; u < kIn; ++u) {
@@ -236,10 +248,22 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           else if (ori > s_ori + kPi * 3 / 2)
             ori -= 2 * kPi;
           if (ori - s_ori > kPi && i < first) first = i;
-          L.a.flags[i] = g[u] ? 8 : 0;
+          if (g[u]) atomicOr(&fw[i >> 2], 8u << ((i & 3) * 8));
           L.a.col[i] = (unsigned short)c[u];
-        } else if (i < n + 16) {
-          L.a.flags[i] = 0, L.a.col[i] = 0;
+          if (i >= 5 && i < n - 6) {  // markOccludedPoints (SE:680-713)
+            const float d1 = r0[u], d2 = rp[u];
+            int cd = (int)c1[u] - (int)c[u];
+            cd = cd < 0 ? -cd : cd;
+            if (cd < 10) {
+              if (d1 - d2 > 0.3) {
+                for (int k = 0; k <= 5; ++k) mark(i - k);
+              } else if (d2 - d1 > 0.3) {
+                for (int k = 1; k <= 6; ++k) mark(i + k);
+              }
+            }
+            const float f1 = fabsf(rm[u] - r0[u]), f2 = fabsf(rp[u] - r0[u]);
+            if (f1 > 0.02 * r0[u] && f2 > 0.02 * r0[u]) mark(i);
+          }
         }
       }
     }
@@ -276,41 +300,6 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           rg[i + 4] + rg[i + 5];
     return d;
   };
-  unsigned* fw = reinterpret_cast<unsigned*>(L.a.flags);  // (marks are idempotent bit sets: 32-bit LDS atomics)
-  auto mark = [&](int i) { atomicOr(&fw[i >> 2], 1u << ((i & 3) * 8)); };
-  {
-    constexpr int kIn = 4;  // points per thread whose range reads are in flight together (one at a time until round 4:
-                            // eighteen dependent trips to L2 per thread)
-    for (int i0 = tid; i0 < n; i0 += kIn * kFeBlock) {
-      float rm[kIn], r0[kIn], rp[kIn];
-#pragma unroll
-      for (int u = 0; u < kIn; ++u) {
-        const int i = i0 + u * kFeBlock, ic = i < 1 ? 1 : (i > n - 2 ? n - 2 : i);  // (clamped: n >= 12 wherever a value is used)
-        rm[u] = r0[u] = rp[u] = 0.f;
-        if (n >= 3) rm[u] = rg[ic - 1], r0[u] = rg[ic], rp[u] = rg[ic + 1];
-      }
-#pragma unroll
-      for (int u = 0; u < kIn; ++u) {
-        const int i = i0 + u * kFeBlock;
-        if (i >= 5 && i < n - 6) {  // markOccludedPoints (SE:680-713)
-          const float d1 = r0[u], d2 = rp[u];
-          int cd = (int)L.a.col[i + 1] - (int)L.a.col[i];
-          cd = cd < 0 ? -cd : cd;
-          if (cd < 10) {
-            if (d1 - d2 > 0.3) {
-              for (int k = 0; k <= 5; ++k) mark(i - k);
-            } else if (d2 - d1 > 0.3) {
-              for (int k = 1; k <= 6; ++k) mark(i + k);
-            }
-          }
-          const float f1 = fabsf(rm[u] - r0[u]), f2 = fabsf(rp[u] - r0[u]);
-          if (f1 > 0.02 * r0[u] && f2 > 0.02 * r0[u]) mark(i);
-        }
-      }
-    }
-  }
-  __syncthreads();
-
   FE_MARK(2)
   // ---- extractFeatures: one wave per ring, sectors in order (marks of one sector reach the next) ---
   {
