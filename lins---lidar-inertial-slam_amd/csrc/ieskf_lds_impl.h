@@ -1027,10 +1027,18 @@ __device__ __forceinline__ long long solve_and_update(double prm_r2, int prm_fix
   }
   const double* const stage = &L.aug[0][0];  // 22 doubles: linState_ (19), |r|, |r| kept, |dx|
   const int* const stage_flags = reinterpret_cast<const int*>(&L.aug[1][0]);  // diverged, converged
+#if defined(LINS_PROF2_NNPH) && defined(LINS_PROF2_ARR)
+  long long sp0 = clock64();
+#define SOLVEPH(k) { long long t_ = clock64(); if (lane == 0 && wave < 3) g_lds.prof4[wave * 8 + (k)] += (int)(t_ - sp0); sp0 = t_; }
+#else
+#define SOLVEPH(k)
+#endif
   if (wave == 0) t3 = solve_wave0(prm_r2, prm_fixed_iters, lane, prof);
+  SOLVEPH(0)
   __syncthreads();  // every reader of the old linearisation state is done; the staged one is visible
   const int div = stage_flags[0];
   if (wave < 3 && !div) next_iter_consts(wave, lane);
+  SOLVEPH(6)
   if (tid == 0) {
     L.res_last = stage[19], L.res_prev = stage[20], L.upd_norm = stage[21];
     L.conv = stage_flags[1], L.div = div;
