@@ -1632,6 +1632,11 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
           ra.parts = ra.launched = std::min(kRelayMaxParts, (ctx->prm.num_iter + ctx->relay_at - 1) / ctx->relay_at);
         }
         const bool relay = ra.parts > 1;
+        // launch order as in the batch calls: longest-expected-first by the prior's translation (launch_order above;
+        // h_state holds this step's priors)
+        const bool ordered = ctx->use_order && n > 2 * ctx->n_cu;
+        if (ordered) launch_order(ctx, n);
+        if (ordered && !relay) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->h_order, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         if (relay) {
           if (ctx->relay_gen >= (1 << 26)) {
             HIP_TRY(ctx, hipMemsetAsync(ctx->d_relay_flag, 0, (size_t)ctx->max_batch * sizeof(int), ctx->stream));
@@ -1639,13 +1644,13 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
           }
           int* list = ctx->h_order + n;  // the launch list: every part 0, then every part 1, ... (the batch calls rebuild theirs)
           for (int p = 0; p < ra.launched; ++p)
-            for (int k = 0; k < n; ++k) list[p * n + k] = k | (p << 27);
+            for (int k = 0; k < n; ++k) list[p * n + k] = (ordered ? ctx->h_order[k] : k) | (p << 27);
           HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order + n, list, (size_t)ra.launched * n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
           ctx->relay_list_parts = -1;
           ra.gen = ++ctx->relay_gen, ra.spins = ctx->relay_spins;
           ra.hdr = ctx->d_relay_hdr, ra.lane = ctx->d_relay_lane, ra.flag = ctx->d_relay_flag, ra.err = ctx->h_relay_err;
         }
-        launch_lds_mr(ctx->stream, n, ctx->dprm, t.d_desc, relay ? ctx->d_order + n : nullptr, t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in,
+        launch_lds_mr(ctx->stream, n, ctx->dprm, t.d_desc, relay ? ctx->d_order + n : (ordered ? ctx->d_order : nullptr), t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in,
                       ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr, relay ? &ra : nullptr,
                       ctx->d_walk_cache, ++ctx->run_gen);
       } else

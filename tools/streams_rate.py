@@ -32,12 +32,14 @@ with ieskf.IeskfContext(pkg.default_params(num_iter=10, fixed_iters=1), max_batc
     c.streams_init(n)
     c.streams_step(seg0, boot, np.tile(np.eye(18)[None] * 1e-4, (n, 1, 1)))
     best = None
-    for rep in range(5):
+    for rep in range(7):
         t0 = time.perf_counter()
         assert L.lins_streams_step(c._h, a1 if rep % 2 == 0 else a0, st.ctypes.data_as(dp), cvf.ctypes.data_as(dp), 0.1, res, cp) == 0
         wall = time.perf_counter() - t0
         fe, up, rp = c.streams_stats()
-        if rep and (best is None or wall < best[3]):  # (the first call allocates the pinned staging)
+        # (the first call allocates the pinned staging; only the steps that feed scan 1 after scan 0 count: the priors are
+        # those of that direction, and a step fed the other way round searches more)
+        if rep and rep % 2 == 0 and (best is None or wall < best[3]):
             best = (fe, up, rp, wall)
     fe, up, rp, wall = best
     its = sum(r.iters for r in res)
@@ -51,7 +53,7 @@ with ieskf.IeskfContext(pkg.default_params(num_iter=10, fixed_iters=1), max_batc
     c.streams_init(n)
     c.streams_step_raw(raw0, boot, np.tile(np.eye(18)[None] * 1e-4, (n, 1, 1)))
     best = None
-    for rep in range(5):
+    for rep in range(7):
         t0 = time.perf_counter()
         assert L.lins_streams_step_raw(c._h, p1 if rep % 2 == 0 else p0, cn1 if rep % 2 == 0 else cn0, st.ctypes.data_as(dp), cvf.ctypes.data_as(dp), 0.1, res, cp) == 0
         wall = time.perf_counter() - t0
