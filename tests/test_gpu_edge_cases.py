@@ -559,6 +559,45 @@ def test_front_end_on_a_wide_hall_takes_the_large_sort_paths(pkg, ieskf, host):
             assert np.array_equal(f[k], ref[k]), k
 
 
+def test_front_end_on_rough_ranges_takes_the_many_candidates_paths(pkg, ieskf, host):
+    """Round 4's front-end picks the edge candidates of a sector one per lane when there are at most 64 of them and from
+    per-lane bit masks otherwise, and the plane candidates always from the masks; ties between equal curvatures go by index.
+    Scans whose ranges are rough (ripples of 0.3 m: hundreds of points of curvature > 0.5 per sector, many of them ground), quantised (ranges rounded to 0.25 m: equal curvatures everywhere) and with ground everywhere
+    (every sector has plane candidates in all its 64-element blocks) still give the host restatement's feature clouds, bit
+    for bit."""
+    base = [host.frontend_segment(host.synth_raw_scan(90 + i, i % 2)) for i in range(3)]
+    rng = np.random.default_rng(5)
+    segs = []
+    for k, w in enumerate(base):
+        n = w.n
+        r = w.range[:n].copy(); g = w.ground[:n].copy()
+        if k == 0:
+            # (smooth ripples: curvature up to 8 without the range jumps of 0.3 m that mark a neighbourhood as occluded, SE:691-703)
+            r += (0.3 * np.sin(0.5 * np.arange(n) + rng.uniform(0, 6.28))).astype(np.float32)
+        elif k == 1:
+            r = (np.round(r * 4) / 4).astype(np.float32)
+        else:
+            g[:] = 1
+        d = np.zeros(n)
+        for o in range(-5, 6):
+            d[5:n - 5] += (r[5 + o:n - 5 + o] if o else -10 * r[5:n - 5])
+        if k == 0:
+            per_sector = [int(((d[s + (e - s) * j // 6:s + (e - s) * (j + 1) // 6] ** 2) > 0.5).sum())
+                          for s, e in zip(w.c.start_ring, w.c.end_ring) for j in range(6) if e > s]
+            assert max(per_sector) > 128  # (beyond one candidate per lane: the mask path)
+        segs.append(host.segmented_from_arrays(w.cloud[:n], r, w.col[:n], g, n, list(w.c.start_ring), list(w.c.end_ring),
+                                               (w.c.start_ori, w.c.end_ori, w.c.ori_diff), w.c.n_outlier))
+    with ieskf.IeskfContext(pkg.default_params(), max_batch=1, max_targets=1024) as c:
+        feats = c.extract_features_batch(segs)
+    for i, (f, w) in enumerate(zip(feats, segs)):
+        ref = host.frontend_extract_segmented(w)
+        # (with ground everywhere nothing is an edge, SE:753, and every sector yields its four planes)
+        counts = {k: len(v) for k, v in ref.items() if hasattr(v, "shape")}
+        assert (counts["corner_less_sharp"] > 50) if i < 2 else (counts["corner_less_sharp"] == 0 and counts["surf_flat"] > 50), (i, counts)
+        for k in ("corner_sharp", "corner_less_sharp", "surf_flat", "surf_less_flat"):
+            assert np.array_equal(f[k], ref[k]), (i, k)
+
+
 def test_segmentation_of_a_cloud_with_more_points_than_cells(pkg, ieskf, host):
     """more raw points than the 28 800 cells (a driver that repeats packets): later points take over their cells
     (IP:238-240), and the kernel's cell-by-cell path (clouds beyond 32 768 points) equals the host restatement"""
