@@ -56,6 +56,26 @@ def test_host_restatement_equals_the_independent_checker(host, oracle, idx):
         assert_same_features(oracle.fe_features(o), host.frontend_extract_segmented(hs))
 
 
+def test_host_restatement_equals_the_independent_checker_on_rippled_and_all_ground_ranges(host, oracle):
+    """The inputs of tests/test_gpu_edge_cases.py::test_front_end_on_rough_ranges_... (hundreds of edge candidates per
+    sector; plane candidates in every block) through the two CPU implementations: the host restatement the device is held
+    against and the independent checker pick the same points."""
+    rng = np.random.default_rng(5)
+    for k in range(2):
+        o = oracle.fe_segment(host.synth_raw_scan(90 + k, k % 2))
+        n = o["n"]
+        r = o["range"][:n].copy(); g = o["ground"][:n].copy()
+        if k == 0:
+            r += (0.3 * np.sin(0.5 * np.arange(n) + rng.uniform(0, 6.28))).astype(np.float32)
+        else:
+            g[:] = 1
+        o2 = dict(o, range=np.ascontiguousarray(r), ground=np.ascontiguousarray(g))
+        hs = host.segmented_from_arrays(o["cloud"][:n], r, o["col"][:n], g, n, o["start_ring"], o["end_ring"], o["orientation"], o["n_outlier"])
+        fo, fx = oracle.fe_features(o2), host.frontend_extract_segmented(hs)
+        assert (len(fx["corner_less_sharp"]) > 50) if k == 0 else (len(fx["corner_less_sharp"]) == 0 and len(fx["surf_flat"]) > 50)
+        assert_same_features(fo, fx)
+
+
 def test_stock_scans_are_off_the_column_edges_and_edge_aligned_clouds_are_not(host, oracle):
     """The generator's promise (no firing within 0.1 column of an edge) as the libm checker and the product's
     fixed-sequence atan2f see it: identical range images on stock scans; on a cloud snapped onto the edges the two
