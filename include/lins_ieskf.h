@@ -174,20 +174,21 @@ int lins_last_index_ms(lins_ctx* ctx, float* ms);
 /* Runs the full IESKF loop for the uploaded batch on the context's stream.
  * d_poses: optional DEVICE pointer to n lins_pose_record (e.g. a torch tensor
  * that RCCL gathers afterwards); may be NULL. Asynchronous; lins_sync() waits. */
-/* A batch with more scans than the device has workgroup slots (two per CU) runs every update in PARTS that hand the
- * loop state over through global memory: the first four iterations in the batch kernel, the rest in the tail kernel —
- * a second launch behind it on the same stream that keeps four scans on a CU instead of two — a shorter step,
- * bit-identical results (ICP_FREQ 1 and VLP-16 sized query sets; other batches run whole updates or the batch kernel's
- * own parts).  A part never blocks the device: one whose hand-over does not come within a bounded wait runs the whole
- * update itself.  lins_last_cut() reports how the last run was cut.                                                  */
+/* A batch with more scans than the device has workgroup slots runs every update in PARTS of a few iterations that hand
+ * the loop state over through global memory; as many persistent workgroups as the device holds at once pull the parts
+ * from a work queue inside the one launch (a part is queued by the workgroup that produced its input, and only while its
+ * scan has not met the stop rule) — a shorter step, bit-identical results (ICP_FREQ 1; other batches run whole
+ * updates).  Nothing in it depends on the order workgroups are dispatched in; a wait at the queue is bounded, and a
+ * launch in which one ran out is reported by lins_sync() (LINS_E_HIP).  lins_last_cut() reports how the last run was cut. */
 int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base);
-/* parts = pieces every update of the last lins_batch_run() was cut into (1 = whole updates); tail_kernel = 1 when the
- * last of them ran as the tail kernel's launch.                                                                      */
-int lins_last_cut(const lins_ctx* ctx, int* parts, int* tail_kernel);
+/* parts = pieces every update of the last lins_batch_run() was cut into (1 = whole updates); queue_timeouts = waits at
+ * the work queue that ran out over the life of the context (0 in a healthy process: the production counter of degraded
+ * launches).                                                                                                          */
+int lins_last_cut(const lins_ctx* ctx, int* parts, int* queue_timeouts);
 int lins_sync(lins_ctx* ctx);
 int lins_batch_download(lins_ctx* ctx, int n, lins_result* out);
 /* HIP-event time (ms), on the context's stream, of the update kernel(s) of the last lins_batch_run(): the persistent
- * IESKF kernel — batch kernel + tail kernel when the run was cut that way (lins_last_cut) — whose epilogue is the
+ * IESKF kernel — one launch, also when the run was cut into parts (lins_last_cut) — whose epilogue is the
  * Joseph covariance update in the "lds" / "mr" / "lds1" families; for "binned" / "brute" the update kernel and the
  * separate Joseph kernel.  After lins_ieskf_update_batch(): from the first chunk's kernels to the last chunk's, i.e.
  * including the index builds and the waits for the copies in between — the call's device time, not one kernel's.   */

@@ -53,16 +53,27 @@ struct DevParams {
   int pad2[2];
 };
 
-// Several-part updates of the batch kernel (ieskf_lds_impl.h "relay"): the update of every scan of a large batch is cut every
-// `at` iterations into `parts` parts; the first `launched` of them are workgroups of the batch kernel's launch, the last
-// one may be the tail kernel's launch behind it (launched == parts - 1) or the batch kernel's own last part.
+// The iterations an update is cut at: k x at for k = 1 .. max_cuts, none afterwards (the last part runs to the end).
+// Shared by the kernel (where an item ends) and the host (how many items a launch has).
+__host__ __device__ inline int relay_next_cut(int iter, int at, int max_cuts) {
+  const int k = iter / at + 1;
+  return k <= max_cuts ? k * at : 0x7FFFFFFF;
+}
+__host__ __device__ inline int relay_max_parts(int num_iter, int at, int max_cuts) {  // parts an update of num_iter iterations can have
+  int parts = 1;
+  for (int c = relay_next_cut(0, at, max_cuts); c < num_iter; c = relay_next_cut(c, at, max_cuts)) ++parts;
+  return parts;
+}
+
+// Several-part updates of the batch kernel (ieskf_lds_impl.h "relay" + "work items"): the update of every scan of a large batch
+// is cut (relay_next_cut) into `parts` parts; the launch has one workgroup per (scan, part), which draws its item by ticket.
 struct RelayArgs {
-  int at = 0, parts = 0, launched = 0, gen = 0;
-  int spins = 1 << 14;  // polls (~1 us each) a part waits for its hand-over before it runs the whole update alone
+  int at = 0, cuts = 0, parts = 0, gen = 0;
+  int spins = 1 << 21;    // polls (~1 us each) a part waits for its hand-over before it gives up (reported by lins_sync)
   double* hdr = nullptr;  // per scan: 64 doubles of loop state
   int* lane = nullptr;    // per scan: the carried state of every query lane (ieskf_lds_impl.h CarryWords)
-  int* flag = nullptr;    // per scan: 16 gen + next part, 16 gen + 15 = finished
-  int* err = nullptr;     // per context: protocol violations seen
+  int* queue = nullptr;   // ticket counters + one flag per scan (ieskf_lds_impl.h kQ*)
+  int* err = nullptr;     // per context: waits that ran out
 };
 
 struct IterConst {  // per-iteration constants, hoisted (the reference recomputes per point)

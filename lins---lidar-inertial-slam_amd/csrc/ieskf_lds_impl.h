@@ -64,20 +64,8 @@
 #include "icp_wave.h"
 #include "ieskf_rowsum.h"
 
-#ifndef LINS_COLD_ARGS
-#define LINS_COLD_ARGS 1
-#endif
-#ifndef LINS_TAIL_STAGED
-#define LINS_TAIL_STAGED 0
-#endif
 #ifndef LINS_WALK_CACHE
 #define LINS_WALK_CACHE 1  // (the second / third points of a query's previous nearest neighbour kept for its return: see the kernel)
-#endif
-#ifndef LINS_TAIL_OOL
-#define LINS_TAIL_OOL 0  // (the tail kernel's searches out of line)
-#endif
-#ifndef LINS_TAIL_PREFETCH
-#define LINS_TAIL_PREFETCH 0  // (the tail kernel's six candidate records in one round trip: measured slower — the registers)
 #endif
 #ifndef LINS_SPREAD_S
 // waves the plane / line queries of a 512-thread workgroup are spread over.  Measured on the batch workload (91 plane
@@ -119,13 +107,12 @@ struct KernelArgs {
   long long* prof_buf;
   double* relay_hdr;
   int* relay_lane;
-  int* relay_flag;
-  int* relay_err;  // one word per context: raised when a hand-over protocol violation was seen (checked at lins_batch_sync)
+  int* queue;      // the launch's ticket counters and per-scan flags (kQ* below)
+  int* relay_err;  // one word per context (pinned host memory): raised when a queue wait ran out (checked at lins_sync)
   unsigned* walk_cache;  // per query slot 8 words: the second / third points of the nearest neighbour the query had BEFORE (walk cache below); may be null
   int run_gen;           // number of this launch (tags of the walk cache: an entry of an earlier launch does not count)
-  int iter_arg, scan_id_base, relay_n, relay_at, relay_parts, relay_gen;
-  int relay_spins;  // polls of ~1 us a part waits for its hand-over before it runs the whole update on its own
-  int tail_part;    // (tail kernel) the part this launch continues: the head handed over at iteration tail_part x relay_at
+  int iter_arg, scan_id_base, relay_n, relay_at, relay_cuts, relay_gen;
+  int relay_spins;  // polls of ~1 us a part waits for its hand-over before it gives up (and the launch reports it)
 };
 typedef const KernelArgs __attribute__((address_space(4))) * ColdArgs;
 __device__ __forceinline__ ColdArgs cold_args() {
@@ -141,12 +128,6 @@ constexpr bool kHybrid = kNpMax > kNpCap;  // positions >= kNpCap live in the so
 constexpr int kScanBatch = LINS_LDS_SCANBATCH;  // points per trip of the scan loops
 static_assert(kNpMax >= kNpCap && kNpMax <= kGridNpMax, "positions are u16, indices u16; the index kernel's cap");
 
-#ifndef LINS_LDS_TAIL
-#define LINS_LDS_TAIL 0
-#endif
-constexpr bool kTail = LINS_LDS_TAIL != 0;
-constexpr bool kTailR = kTail && LINS_TAIL_PREFETCH != 0;
-constexpr int kTailSlots = 384;  // queries of a scan the tail kernel takes (the VLP-16 caps: 144 + 192, SE:727-793)
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 struct LdsStore {
   float4 pt[kNpCap];  // grid-sorted targets, one 16-byte record (x, y, z, original index bits) per position
@@ -167,23 +148,9 @@ struct LdsStore {
   long long prof_acc[16];  // phase profile accumulators of the PROF variant (written by thread 0)
 #ifdef LINS_PROF2
   int prof2[64];  // per wave x phase ticks of the iterations >= LINS_PROF2 (lane 0 of each wave; lins_debug_wave_phases)
-#if !LINS_LDS_TAIL
-#define LINS_PROF2_ARR 1
-#ifndef LINS_PROF2_NNPH
-#define LINS_PROF2_CNT 1  // (LINS_PROF2_NNPH: prof4 takes the sub-phase ticks of nn_lds instead of the scan counts)
-#endif
-  int cnt_calls[512], cnt_pts[512];  // per lane: scan_spans() calls and grid positions scanned since the last fold
-  int prof4[64];  // per wave: nn phase (max calls, max points over the lanes, sum calls, sum points), walk phase (the same)
-#endif
   int prof3[32];  // per wave: [0] wave-iterations with a nearest-neighbour search [1] ... with a walk [2] searches [3] walks
 #endif
   int dbg[4];  // [0] certificate disagreements (verify mode) [1] NN searches skipped [2] walks skipped
-#if LINS_LDS_TAIL
-  // tail kernel: the carried per-query state (CarryWords) of every query of the scan, by query index — a wave takes a
-  // wave-round's queries, loads their state from here and puts it back
-  v4u cw0[kTailSlots], cw1[kTailSlots], cw2[kTailSlots];
-  unsigned cw3[kTailSlots];
-#endif
 };
 static_assert(sizeof(LdsStore) <= LINS_LDS_BYTES, "LDS budget of one workgroup");
 
@@ -365,9 +332,6 @@ __device__ __forceinline__ Spans spans_of(const LCloud& c, int r, int lo, int hi
 }
 template <class F>
 __device__ __forceinline__ void scan_spans(const LdsStore& L, const LCloud& c, const Spans& w, F f) {
-#ifdef LINS_PROF2_CNT
-  g_lds.cnt_calls[threadIdx.x & 511] += 1, g_lds.cnt_pts[threadIdx.x & 511] += w.count();
-#endif
 #pragma unroll 1
   for (int k = 0; k < w.spans; ++k) {
     const int s = k ? w.s1 : w.s0, e = k ? w.e1 : w.e0;
@@ -454,12 +418,6 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
   // distance to the re-de-skewed query bounds the search from the start — the seed scan is skipped
   // and the windows are minimal.  It only tightens bounds; the exact arg-min is still taken over
   // every cell that could beat it, so the result is the same as a cold search.
-#if defined(LINS_PROF2_NNPH) && defined(LINS_PROF2_ARR)
-  long long np0 = clock64();
-#define NNPH(k) { long long t_ = clock64(); if ((threadIdx.x & 63) == 0) g_lds.prof4[(threadIdx.x >> 6) * 8 + (k)] += (int)(t_ - np0); np0 = t_; }
-#else
-#define NNPH(k)
-#endif
   const bool warm = warm_pos >= 0;
   if (warm)
     consider(b, pt_sqdist(L, c, warm_pos, sx, sy, sz), pt_idx(L, c, warm_pos), warm_pos, warm_ring);
@@ -491,7 +449,6 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
     }
     rcur = rq;
   }
-  NNPH(1)
   const int cin = warm ? 0 : 2;  // first column either side that the seed has not covered
   const float B = b.d();  // fixed bound for everything below (conservative: >= the final best)
   const float sqrtB = bound_sqrtf(B) + margin;  // pruning bound inflated by the certificate margin
@@ -527,7 +484,6 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
       todo |= go ? (1u << i) : 0u;
     }
   }
-  NNPH(2)
 #pragma unroll 1
   while (todo) {
     const int i = __ffs(todo) - 1;
@@ -539,9 +495,7 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
     // own ring: right part (with the centre column when warm) / left part; other rings: whole window
     scan_cols(L, c, r, t == 0 ? a0 + cin : a0 - K, t == 1 ? a0 - (warm ? 1 : 2) : a0 + K, f);
   }
-  NNPH(3)
   merge_query_lanes<LANES>(b, lane_base, role, ln);
-  NNPH(4)
   return b;
 }
 
@@ -757,15 +711,8 @@ __device__ __forceinline__ NnOut coop_nn(const LdsStore& L, const LCloud& c, con
     i_a1 = __shfl(a1, owner), i_ra1 = __shfl(ra1, owner);
   }
   Best bb = best_init(thr);
-#if defined(LINS_PROF2_NNPH) && defined(LINS_PROF2_ARR)
-  long long cp0 = clock64();
-  if ((threadIdx.x & 63) == 0) g_lds.prof4[(threadIdx.x >> 6) * 8 + 7] += 1;
-#endif
   if (valid && !skip)  // (profiling aid: LINS_DEBUG_SKIP=2 skips the search, 1 skips the walk)
     bb = nn_lds<0>(L, c, isx, isy, isz, iq, thr, margin, i_rq, ln, wrole, wbase, i_a1, i_ra1);
-#if defined(LINS_PROF2_NNPH) && defined(LINS_PROF2_ARR)
-  if ((threadIdx.x & 63) == 0) g_lds.prof4[(threadIdx.x >> 6) * 8 + 5] += (int)(clock64() - cp0);
-#endif
   NnOut r{bb.pos, bb.ring, bb.pos2, bb.ring2, cert_lb(bb, thr, margin)};
   if (ln > 1) {  // hand back: the owner of rank r reads the first lane of group r
     const int src = (cm.rank * ln) & 63;
@@ -808,27 +755,6 @@ __device__ __forceinline__ LCloud make_cloud(const LdsStore& L, bool is_surf, co
   return is_surf ? LCloud{L.gt.cell_end + kCellsCorner, L.gt.ring_start[0], &L.gt.el_ang[0][0], kAzSurf, 1, n_corner_t, n_surf_t, gs, n_lds}
                  : LCloud{L.gt.cell_end, L.gt.ring_start[1], &L.gt.el_ang[1][0], kAzCorner, kAzSurf / kAzCorner, 0, n_corner_t, gs, n_lds};
 }
-// The tail kernel's searches, OUT OF LINE: there they are rare (> 99 % of the late iterations' selections are certified),
-// and inlined their registers (three running bests, windows, the lane merges) are the loop's — which then has none left
-// for the six candidate records it keeps in flight.  As calls, a wave pays their register saves when it searches.
-// (the polar view of the query is only needed here: the tail's loop does not compute it)
-__device__ __noinline__ NnOut coop_nn_ool(bool is_surf, const float4* gs, int n_corner_t, int n_surf_t, int n_lds, int cm_n, int cm_rank,
-                                          int cm_owner_map, int coop_cap, bool need_nn, int lane, float sx, float sy, float sz, int rq,
-                                          int a1, int ra1, float thr, float margin, bool skip) {
-  const LdsStore& L = g_lds;
-  const LCloud c = make_cloud(L, is_surf, gs, n_corner_t, n_surf_t, n_lds);
-  return coop_nn(L, c, CoopMap{cm_n, cm_rank, cm_owner_map}, coop_cap, need_nn, lane, sx, sy, sz, polar_of(sx, sy, sz, c.naz), rq, a1, ra1, thr,
-                 margin, skip);
-}
-__device__ __noinline__ WalkOut coop_walk_ool(bool is_surf, const float4* gs, int n_corner_t, int n_surf_t, int n_lds, int nq, int cm_n,
-                                              int cm_rank, int cm_owner_map, int coop_cap, bool need_walk, int lane, float sx, float sy,
-                                              float sz, int j1, int rho1, int w2, int w3, bool nn_changed, float thr, float margin, bool skip) {
-  const LdsStore& L = g_lds;
-  const LCloud c = make_cloud(L, is_surf, gs, n_corner_t, n_surf_t, n_lds);
-  return coop_walk(L, c, is_surf, nq, CoopMap{cm_n, cm_rank, cm_owner_map}, coop_cap, need_walk, lane, sx, sy, sz, polar_of(sx, sy, sz, c.naz),
-                   j1, rho1, w2, w3, nn_changed, thr, margin, skip);
-}
-
 // ---- grid load: the scan's prebuilt index (grid_index_kernel, ieskf_grid.hip — the reference's setInputCloud,
 // SE:1156-1160, outside performIESKF) into LDS: the tables and the first n_lds records of the sorted copy as 16-byte
 // words, every read of a thread in flight before its first LDS write (~1 HBM round trip per scan).  Ends with a
@@ -843,9 +769,6 @@ __device__ __noinline__ WalkOut coop_walk_ool(bool is_surf, const float4* gs, in
 // traced to its root (ROCm 7.2 clang).  As a separate function nothing of it is scheduled into the kernel body; the
 // GPU suite (golden pairs, adversarial clouds, reference parity, every search mode) is the guard.
 template <int BLOCK>
-#ifndef LINS_INTERLEAVE
-#define LINS_INTERLEAVE 0
-#endif
 #ifndef LINS_GRID_INLINE
 #define LINS_GRID_INLINE 0
 #endif
@@ -1027,18 +950,10 @@ __device__ __forceinline__ long long solve_and_update(double prm_r2, int prm_fix
   }
   const double* const stage = &L.aug[0][0];  // 22 doubles: linState_ (19), |r|, |r| kept, |dx|
   const int* const stage_flags = reinterpret_cast<const int*>(&L.aug[1][0]);  // diverged, converged
-#if defined(LINS_PROF2_NNPH) && defined(LINS_PROF2_ARR)
-  long long sp0 = clock64();
-#define SOLVEPH(k) { long long t_ = clock64(); if (lane == 0 && wave < 3) g_lds.prof4[wave * 8 + (k)] += (int)(t_ - sp0); sp0 = t_; }
-#else
-#define SOLVEPH(k)
-#endif
   if (wave == 0) t3 = solve_wave0(prm_r2, prm_fixed_iters, lane, prof);
-  SOLVEPH(0)
   __syncthreads();  // every reader of the old linearisation state is done; the staged one is visible
   const int div = stage_flags[0];
   if (wave < 3 && !div) next_iter_consts(wave, lane);
-  SOLVEPH(6)
   if (tid == 0) {
     L.res_last = stage[19], L.res_prev = stage[20], L.upd_norm = stage[21];
     L.conv = stage_flags[1], L.div = div;
@@ -1216,11 +1131,38 @@ __device__ __forceinline__ void relay_st(double* p, double v) {
 __device__ __forceinline__ double relay_ld(const double* p) {
   return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
-// A scan's flag only ever rises within a launch (16 gen + next part ... 16 gen + 15 = finished): raised with an atomic
-// max, so that a part that hands over late cannot take back the "finished" of a workgroup that ran the update alone.
+__device__ __forceinline__ int relay_add(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// A scan's flag only ever rises within a launch (16 gen + next part ... 16 gen + 15 = finished): raised with an atomic max.
 __device__ __forceinline__ void relay_raise(int* p, int v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// The per-query loop state a part hands to the next (and the tail kernel keeps in LDS between its wave-rounds): the
+// ---- the work items of a batch launch: tickets (the batch shape only; KernelArgs::queue, relay_n > 0) ---------------------
+// A batch with more scans than the device has workgroup slots is launched with one workgroup per WORK ITEM — (scan, part):
+// "run scan s from cut p to cut p + 1" (relay_next_cut, ieskf_device.h) — and a LIST of the items (KernelArgs::order): every
+// part 0 in the host's longest-expected-first order, then every part 1 in that order, ...  A workgroup does not take the
+// item of its index: it DRAWS A TICKET when it starts (an atomic counter) and takes the item the list has there.  Part
+// p > 0 waits for the flag of its scan to say that part p - 1 has handed the loop state over (relay_out below), or that
+// the scan is finished (stop rule met in an earlier part: nothing to do).
+//   Why the wait cannot starve its producer, whatever order the dispatcher hands workgroups out in: the item a workgroup
+//   waits for has a smaller ticket (the list names a part behind the part before it), tickets are drawn by workgroups
+//   that have STARTED, so its holder is resident — running, or itself waiting for a still smaller ticket; the chain ends
+//   at a part 0, which never waits.  Rounds 3-4 took item blockIdx.x and relied on blocks being handed out in index
+//   order, with a bounded spin and a whole-update fallback ("solo") in case they were not; both are gone.  The bound on
+//   the wait stays as a safety net that REPORTS (relay_err -> lins_sync fails): a launch never spins for ever.
+//   Q[kQHead]        tickets drawn
+//   Q[kQExited]      workgroups that left: the last one out resets both counters for the next launch
+//   Q[kQFlags + s]   flag of scan s: 16 gen + p once part p - 1 has handed over, 16 gen + 15 once the update is finished;
+//                    gen numbers the launches of the context, so the flags are never reset (the host clears them when
+//                    gen would overflow)
+// All of these are device-scope atomics (the parts of a scan may sit on different XCDs); the hand-over data is complete at
+// the memory side before the flag rises, and the taker reads it with device-coherent loads.
+// (Round 5 also built the other obvious design — a FIFO of continuations pushed by the workgroup that produced them,
+// drawn in push order, persistent or not — and measured it slower: 0.602 against 0.567 ms per 1024 scans x 10
+// iterations, 1.014 against 0.988 ms under the stop rule, profiles/r05_batch_kernel_variants.md: push order is
+// shortest-part-first, which is the wrong way round for the end of the launch; the list keeps longest-expected-first.)
+constexpr int kQHead = 0, kQExited = 32, kQFlags = 64;  // (ints; the counters on lines of their own)
+
+// The per-query loop state a part hands to the next: the
 // tracked candidates of the three selections as 16-bit grid positions (< 12288; -1 = none), the rings of the nearest
 // neighbour's two candidates, the certificates' bounds and the query positions they were established at: 13 words
 // (round 3 stored 18 words as 18 four-byte device-scope stores per lane, each a fabric write of its own: 264 MB written
@@ -1264,22 +1206,15 @@ __device__ __forceinline__ CarryWords relay_ld_carry(const int* scan_base /*wave
   return c;
 }
 
-// KNOBS: the counting aids and test modes of LINS_DEBUG_SKIP (DevParams::pad) compiled in.  The production instantiations
-// of the update kernels are built without them — twenty-odd tests of a run-time word in the hottest code of a kernel that is
-// short of scalar registers; the launchers take the KNOBS twin whenever pad != 0 (tools/, the certificate tests).
-template <int BLOCK, int LANES, bool PASS_ONLY, bool PROF, bool ICP = false, bool KNOBS = true>
-#if LINS_LDS_MINW > 1
-// (second argument: waves per SIMD the register allocation must allow)
-__global__ __launch_bounds__(BLOCK, LINS_LDS_MINW) void ieskf_lds_kernel(
-#else
-__global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
-#endif
-    const KernelArgs ka, const float4* __restrict__ arena, const float4* __restrict__ sorted, int4* __restrict__ idx_store,
-    lins_corr* __restrict__ dump) {
-  // (the four pointers the loop reads and writes through stay parameters of their own: only a parameter carries
-  // `noalias`, and without it the register allocation of every instantiation got worse)
+// One work item: the update of scan `scan` — from its start (cont = false) or from the loop state another workgroup
+// handed over (cont = true: the batch shape under the work queue) — to its end or to the next cut.  Returns true when
+// the scan is finished (results written), false when it was handed over.
+template <int BLOCK, int LANES, bool PASS_ONLY, bool PROF, bool ICP, bool KNOBS>
+__device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const float4* __restrict__ arena, const float4* __restrict__ sorted,
+                                                 int4* __restrict__ idx_store, lins_corr* __restrict__ dump, const int scan, const int part) {
+  const bool cont = part > 0;
   const DevParams prm = ka.prm;
-  const int relay_n = ka.relay_n, relay_at = ka.relay_at, relay_parts = ka.relay_parts;
+  const int relay_n = ka.relay_n, relay_at = ka.relay_at;
   const int pad = KNOBS ? prm.pad : 0;  // (debug / counting flags: a constant 0 in the production instantiations)
   constexpr bool prof = PROF;  // phase profile compiled in only for the debug variant
   constexpr int kLBlock = BLOCK, kQPerWave = 64 / LANES, kQPerRound = (BLOCK / 64) * kQPerWave;
@@ -1294,10 +1229,6 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #ifdef LINS_PROF2
   if (prof && threadIdx.x < 64) g_lds.prof2[threadIdx.x] = 0;
   if (prof && threadIdx.x < 32) g_lds.prof3[threadIdx.x] = 0;
-#ifdef LINS_PROF2_ARR
-  if (threadIdx.x < 64) g_lds.prof4[threadIdx.x] = 0;
-  g_lds.cnt_calls[threadIdx.x & 511] = 0, g_lds.cnt_pts[threadIdx.x & 511] = 0;
-#endif
 #define PROF2_ADD(ph, dt)                                                                   \
   do {                                                                                      \
     if (prof && lane == 0 && iter >= LINS_PROF2 && wave < 8) g_lds.prof2[wave * 8 + (ph)] += (int)(dt); \
@@ -1310,59 +1241,15 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #endif
   const long long t_begin = prof ? clock64() : 0, t_wall_begin = prof ? wall_clock64() : 0;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave: a scalar)
-  // Launch order: workgroup b takes scan order[b] — the host lists the scans longest-expected-first (lins_capi.hip
-  // launch_order: by the prior's translation, the best predictor of a scan's search work the host has), so that the
-  // dispatcher, which hands workgroups out in index order as slots free up, ends the launch with the short ones.
-  // Relay (the batch shape only; relay_n = scans of the launch, 0 = off): the update of a scan is cut every relay_at
-  // iterations into parts that run as consecutive workgroups of one launch, so that a launch of 2 x (slots) scans is
-  // several rounds of shorter jobs instead of two rounds of whole updates: the end of the launch (slots idle while the
-  // last whole updates finish) shrinks with the job size — 0.665 -> 0.615 ms per 1024 scans x 10 iterations in parts of
-  // four iterations (tools/relay_sweep.py; parts of 2: 0.647, 3: 0.625, 5: 0.641, 6: 0.623, 7: 0.626, 8: 0.641).  The
-  // launch list (lins_batch_run) names every part 0, then every part 1, ...  A part takes over the loop state through
-  // global memory (relay_out / relay_in below) and waits for it on a per-scan flag; blocks are handed out in list order
-  // (per XCD), so the part a workgroup waits for is resident or done before the waiting one starts: the wait cannot
-  // starve its producer.  Same arithmetic in the same order: results do not depend on the cuts, bit for bit
-  // (tests/test_gpu_parity.py test_two_part_updates_return_the_whole_updates_bits).
-  constexpr bool kRelay = BLOCK == 512 && LANES == 1 && !PASS_ONLY && !ICP && !kTail;
-  static_assert(!kTail || (LANES == 1 && !PASS_ONLY && !ICP && BLOCK == 256), "the tail kernel's shape");
-  // (with the relay on, the launch list has relay_parts x relay_n entries: scan | part << 27 — a part anywhere behind
-  // the part before it; part p runs iterations [p relay_at, (p + 1) relay_at), the last one to the end.  Flag of a scan:
-  // 16 gen + p once part p - 1 has handed over, 16 gen + 15 once the update is finished; it only ever rises.)
-  // The TAIL kernel (ieskf_lds_tail.hip; kTail) is the last part as a launch of its own behind the head's on the same
-  // stream: stream order replaces the wait, the hand-over is the same.
-  const int entry = ka.order ? ka.order[blockIdx.x] : (int)blockIdx.x;
-  int part = kTail ? ka.tail_part : ((kRelay && relay_n > 0) ? entry >> 27 : 0);
-  const int scan = (kRelay && relay_n > 0) ? entry & 0x7FFFFFF : entry;
-  bool solo = false;  // (uniform) this workgroup runs the update from its start to its end, wherever the list put it
-  if ((kRelay && part) || kTail) {
-    // The wait is bounded (relay_spins polls of ~1 us).  Blocks are handed out in list order on the devices this was
-    // measured on, but nothing in HIP promises that: a hand-over that has not come by then — the part before not yet
-    // resident because another process, a debugger or a different dispatcher changed the order — makes THIS workgroup
-    // run the whole update on its own (part 0, no cuts; same arithmetic, same bits) and mark the scan finished; whoever
-    // else holds a part of that scan then finds nothing to do, or finds its own hand-over missing and does the same.
-    // Degraded, never stuck, never aborted (round 3 ended this wait in __builtin_trap()).
-    const int want = ka.relay_gen * 16 + part;
-    if (tid == 0) {
-      int f = relay_ld(ka.relay_flag + scan);
-      if (!kTail)
-        for (int spins = 0; f < want && spins < ka.relay_spins; ++spins) {
-          __builtin_amdgcn_s_sleep(32);
-          f = relay_ld(ka.relay_flag + scan);
-        }
-      L.scan_tmp[0] = f;
-    }
-    __syncthreads();
-    const int f = L.scan_tmp[0];
-    if (f > want) return;  // the scan is finished (stop rule, divergence, or somebody ran it alone)
-    if (f < want) {
-      if (kTail) {  // (cannot happen behind the head's launch: every scan was handed over or finished)
-        if (tid == 0) atomicAdd(ka.relay_err, 1);
-        return;
-      }
-      part = 0, solo = true;
-    }
-    __syncthreads();  // (scan_tmp is reused below)
-  }
+  // Several-part updates (the batch shape only; relay_n = scans of the launch, 0 = off): the update of a scan is cut every
+  // relay_at iterations into parts that run as separate work items of one launch (the tickets above), so that a launch of
+  // 2 x (slots) scans is several rounds of shorter jobs instead of two rounds of whole updates: the end of the launch (slots
+  // idle while the last whole updates finish) shrinks with the job size — 0.665 -> 0.615 ms per 1024 scans x 10 iterations in
+  // parts of four iterations (tools/relay_sweep.py; parts of 2: 0.647, 3: 0.625, 5: 0.641, 6: 0.623, 7: 0.626, 8: 0.641).
+  // A part takes over the loop state through global memory (relay_out / the take-over below).  Same arithmetic in the same
+  // order: results do not depend on the cuts, bit for bit (tests/test_gpu_parity.py
+  // test_two_part_updates_return_the_whole_updates_bits).
+  constexpr bool kRelay = BLOCK == 512 && LANES == 1 && !PASS_ONLY && !ICP;
   const ScanDesc sd = ka.descs[scan];
   const int total = sd.n_surf_q + sd.n_corner_q;
   // hybrid storage: this scan's slice of the sorted copy (same offsets as its targets in the arena:
@@ -1384,7 +1271,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     L.dbg[0] = L.dbg[1] = L.dbg[2] = L.dbg[3] = 0;
   }
   __syncthreads();
-  if (tid < 64 && !((kRelay && part) || kTail)) {  // wave 0, lane-redundant: constants of the first iteration (a later part takes them over)
+  if (tid < 64 && !(kRelay && cont)) {  // wave 0, lane-redundant: constants of the first iteration (a later part takes them over)
     IterConst ic;
     double filt[19];
     for (int k = 0; k < 19; ++k) ic.lin[k] = L.ic.lin[k], filt[k] = L.filt[k];
@@ -1422,10 +1309,10 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     bool active;
   };
   constexpr int kWaves = BLOCK / 64, kSpreadSurf = LINS_SPREAD_S > 0 && BLOCK == 512 ? LINS_SPREAD_S : (kWaves * 5 + 4) / 8;
-  constexpr int kWs = kTail ? LINS_SPREAD_S : kSpreadSurf;
-  constexpr int kWc = kTail ? LINS_SPREAD_C : (LINS_SPREAD_C > 0 && BLOCK == 512 ? LINS_SPREAD_C : kWaves - kWs);
+  constexpr int kWs = kSpreadSurf;
+  constexpr int kWc = LINS_SPREAD_C > 0 && BLOCK == 512 ? LINS_SPREAD_C : kWaves - kWs;
   const int lay_ps = (sd.n_surf_q + kWs - 1) / kWs, lay_pc = kWc > 0 ? (sd.n_corner_q + kWc - 1) / kWc : 65;
-  const bool spread_ok = (kTail || kWs < kWaves) && lay_ps <= 64 && lay_pc <= 64;  // the one-round spread layout holds the scan
+  const bool spread_ok = kWs < kWaves && lay_ps <= 64 && lay_pc <= 64;  // the one-round spread layout holds the scan
   auto wr_layout = [&](int rnd) {
     WrLay y;
     int nws, per_s, per_c;
@@ -1436,19 +1323,6 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     }
     y.k = rnd * kWaves + wave;
     y.kind_s = y.k < nws;
-#if LINS_INTERLEAVE
-    if (spread_ok) {
-      // INTERLEAVED (off): query q of a kind on wave q mod (waves of the kind), lane q div that.  The queries come
-      // sorted by ring and what a search costs goes with the ring (tools/wave_phases.py, cold iteration: the fifth plane
-      // wave walks for 62.9 k ticks, the first for 25.0 k), so contiguous blocks leave one wave with all the long ones —
-      // and that is the better deal: a wave runs as long as its longest lane, dealt out EVERY wave has long lanes.
-      // Measured (round 4, one call): +2.5 % kernel time.
-      const int kw = y.kind_s ? y.k : y.k - nws, nwk = y.kind_s ? kWs : kWc, q = lane * nwk + kw;
-      y.slot = (y.kind_s ? 0 : sd.n_surf_q) + q;
-      y.active = y.k < y.n_wr && q < (y.kind_s ? sd.n_surf_q : sd.n_corner_q);
-      return y;
-    }
-#endif
     const int q0 = y.kind_s ? y.k * per_s : (y.k - nws) * per_c;
     const int left = (y.kind_s ? sd.n_surf_q : sd.n_corner_q) - q0, per = y.kind_s ? per_s : per_c;
     y.slot = (y.kind_s ? 0 : sd.n_surf_q) + q0 + lane, y.active = y.k < y.n_wr && lane < (left < per ? left : per);
@@ -1489,7 +1363,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   };
   static_assert(kGridNpMax < 32768, "grid positions travel as signed 16-bit words");
   (void)carry_pack, (void)carry_unpack;
-  if ((kRelay && part) || kTail) {  // take-over: the loop state the part before left (the barrier of the grid load has passed)
+  if (kRelay && cont) {  // take-over: the loop state the part before left (the barrier of the grid load has passed)
     const double* h = ka.relay_hdr + (size_t)scan * kRelayHdr;
     if (tid < 58) reinterpret_cast<double*>(&L.ic)[tid] = relay_ld(h + tid);
     if (tid == 64) L.res_prev = relay_ld(h + 58), L.res_last = relay_ld(h + 59), L.upd_norm = relay_ld(h + 60);
@@ -1498,15 +1372,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       L.iter = relay_ld(hi), L.dbg[0] = relay_ld(hi + 1), L.dbg[1] = relay_ld(hi + 2), L.dbg[2] = relay_ld(hi + 3), L.dbg[3] = relay_ld(hi + 4);
     }
     const int* ln = ka.relay_lane + (size_t)scan * kRelayLaneInts;
-    if constexpr (kTail) {
-#if LINS_LDS_TAIL
-      for (int slot = tid; slot < total; slot += BLOCK) {  // every query's words into its LDS slot
-        const CarryWords c = relay_ld_carry(ln, slot);
-        L.cw0[slot] = c.w0, L.cw1[slot] = c.w1, L.cw2[slot] = c.w2, L.cw3[slot] = c.w3;
-      }
-      for (int k = tid; k < kMaxLWaves * 28; k += BLOCK) L.partial[k] = 0.0;  // (wave-rounds a scan does not have stay 0)
-#endif
-    } else {
+    {
       const WrLay y = wr_layout(0);
       if (y.active) carry_unpack(relay_ld_carry(ln, y.slot));
     }
@@ -1514,6 +1380,8 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     __syncthreads();
   }
   bool relay_out = false;
+  // (ticketed launch) this item ends at the scan's next cut
+  const int cut_at = (kRelay && relay_n > 0) ? relay_next_cut(L.iter, relay_at, ka.relay_cuts) : 0x7FFFFFFF;
 #ifdef LINS_PROF2
   int dbg_nn = 0, dbg_walk = 0, dbg_walk_mask = 0, dbg_slot = -1;  // this lane's query: searches / walks in the iterations >= LINS_PROF2
 #endif
@@ -1521,7 +1389,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   for (;;) {
     const int iter = L.iter;
     if (!PASS_ONLY && (iter >= prm.num_iter || L.conv || L.div)) break;
-    if (kRelay && relay_n > 0 && !solo && part + 1 < relay_parts && iter >= (part + 1) * relay_at) {
+    if (kRelay && iter >= cut_at) {
       relay_out = true;
       break;
     }
@@ -1551,7 +1419,6 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         const WrLay y = wr_layout(base / kQPerRound);
         wr_k = y.k, kind_s = y.kind_s, slot = y.slot, active = y.active;
         if (base == 0) part_k = y.k & (kMaxLWaves - 1);
-        if (kTail && y.k >= n_wr) continue;  // (wave-uniform; nothing below synchronises the workgroup)
       } else if (aligned) {
         if (wave < surf_waves)
           active = active && vslot < sd.n_surf_q;
@@ -1559,11 +1426,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           slot = vslot - surf_waves * kQPerWave + sd.n_surf_q;
       }
       double row[7] = {0, 0, 0, 0, 0, 0, 0};
-      if constexpr (kTail) {  // the carried state of this wave-round's queries lives in LDS between the rounds
-#if LINS_LDS_TAIL
-        if (active) carry_unpack(CarryWords{L.cw0[slot], L.cw1[slot], L.cw2[slot], L.cw3[slot]});
-#endif
-      } else if (span > kQPerRound) {  // several rounds: the lane <-> query mapping changes, nothing carries over
+      if (span > kQPerRound) {  // several rounds: the lane <-> query mapping changes, nothing carries over
         a1 = b1c = ra1 = rb1 = a2 = b2c = a3 = b3c = sel1 = -1, have_cert = false;
         lb1 = lb2 = lb3 = 0.f;
       }
@@ -1577,8 +1440,8 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         const int qi = is_surf ? slot : slot - sd.n_surf_q;
         const LCloud& c = is_surf ? cs : cc;
         const float thr = prm.nearest_f;
-        const bool single_round = kTail || span <= kQPerRound;  // (the lane <-> query mapping is fixed, or the state travels with the query)
-        const bool warm_iter = kTail || (single_round && searched);  // certificates / warm candidates exist (uniform)
+        const bool single_round = span <= kQPerRound;  // (the lane <-> query mapping is fixed)
+        const bool warm_iter = single_round && searched;  // certificates / warm candidates exist (uniform)
         const float margin = warm_iter ? prm.margin_warm : prm.margin_cold;
         const bool verify = (pad & 8) != 0;  // test aid: search anyway and count disagreements
         // the cold iteration searches for every query: one lane each (more lanes per wave cost more than the shorter
@@ -1595,26 +1458,11 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         bool qp_ready = false;  // (wave-uniform)
         int p1 = -1, p2 = -1, p3 = -1;
         long long s0 = prof ? clock64() : 0, s1 = s0, s2 = s0;
-        // (tail kernel) R[k]: the record (x, y, z, index bits) of the k-th tracked candidate {a1, b1c, a2, b2c, a3, b3c},
-        // fetched from the index's sorted copy in ONE round trip at the top of the wave-round — in flight under the
-        // de-skew — and kept in step with the six positions below (swapped with them, re-read after a search).  Through
-        // the generic accessors every one of these reads was a branch (LDS or global?) and a dependent L2 round trip of
-        // its own: a dozen in a row per wave-round, what the late iterations of a scan without resident points cost most.
-        float4 R[6];
         if (active) {
           if (pad & 0x400000)  // (counting aid: no query load)
             q = make_float4(1.f + lane, 2.f, 0.5f, 3.25f);
           else
             q = arena[(is_surf ? sd.off_surf_q : sd.off_corner_q) + qi];
-          if constexpr (kTailR) {
-#if LINS_TAIL_STAGED
-            R[0] = c.gs[a1 < 0 ? 0 : a1], R[1] = c.gs[b1c < 0 ? 0 : b1c];  // (the other four: behind the nearest neighbour's stage)
-#else
-            const int cp[6] = {a1, b1c, a2, b2c, a3, b3c};
-#pragma unroll
-            for (int k = 0; k < 6; ++k) R[k] = c.gs[cp[k] < 0 ? 0 : cp[k]];
-#endif
-          }
           V3 t{L.ic.lin[0], L.ic.lin[1], L.ic.lin[2]};
           if (pad & 0x100000)  // (counting aid: no de-skew)
             o.sel[0] = q.x, o.sel[1] = q.y, o.sel[2] = q.z;
@@ -1629,48 +1477,6 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           PROF2_ADD(0, s1 - s0);
         }
         auto dist_to = [&](int pos) { return pt_sqdist(L, c, pos, o.sel[0], o.sel[1], o.sel[2]); };
-        // distance to / original index of tracked candidate `pos`, whose record is r in the tail kernel
-        auto dist_r = [&](const float4& r, int pos) {
-          if constexpr (kTailR)
-            return sqdist3(r.x, r.y, r.z, o.sel[0], o.sel[1], o.sel[2]);
-          else
-            return dist_to(pos);
-        };
-        auto idx_r = [&](const float4& r, int pos) {
-          if constexpr (kTailR)
-            return __float_as_int(r.w);
-          else
-            return pt_idx(L, c, pos);
-        };
-        auto reload_r = [&](float4& r, int pos) {
-          if constexpr (kTailR) r = c.gs[pos < 0 ? 0 : pos];
-        };
-        auto swap_r = [&](float4& x, float4& y) {
-          if constexpr (kTailR) {
-            const float4 t = x;
-            x = y, y = t;
-          }
-        };
-        auto tail_park = [&]() {
-#if LINS_LDS_TAIL
-          if (active) {
-            const CarryWords cw = carry_pack();
-            L.cw0[slot] = cw.w0, L.cw1[slot] = cw.w1, L.cw2[slot] = cw.w2, L.cw3[slot] = cw.w3;
-          }
-#endif
-        };
-        auto tail_unpark = [&]() {
-#if LINS_LDS_TAIL
-          if (active) {
-            carry_unpack(CarryWords{L.cw0[slot], L.cw1[slot], L.cw2[slot], L.cw3[slot]});
-            if constexpr (kTailR) {
-              const int cp[6] = {a1, b1c, a2, b2c, a3, b3c};
-#pragma unroll
-              for (int k = 0; k < 6; ++k) R[k] = c.gs[cp[k] < 0 ? 0 : cp[k]];
-            }
-          }
-#endif
-        };
         auto drift_from = [&](const float* cp) {
           float ex = o.sel[0] - cp[0], ey = o.sel[1] - cp[1], ez = o.sel[2] - cp[2];
           return bound_sqrtf(ex * ex + ey * ey + ez * ez);
@@ -1688,10 +1494,10 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           if (active && (pad & 0x80000) && warm_iter) {  // (counting aid: every certificate holds, unchecked)
             pred = a1, said = true;
           } else if (active) {
-            const float da = a1 >= 0 ? dist_r(R[0], a1) : INFINITY, db = b1c >= 0 ? dist_r(R[1], b1c) : INFINITY;
+            const float da = a1 >= 0 ? dist_to(a1) : INFINITY, db = b1c >= 0 ? dist_to(b1c) : INFINITY;
             bool ok = warm_iter && !(pad & 16) && certified(fminf(fminf(da, db), thr), lb1, drift_from(certA));
-            const unsigned long long ka = da < thr ? pack_key(da, idx_r(R[0], a1)) : kNone;
-            const unsigned long long kb = db < thr ? pack_key(db, idx_r(R[1], b1c)) : kNone;
+            const unsigned long long ka = da < thr ? pack_key(da, pt_idx(L, c, a1)) : kNone;
+            const unsigned long long kb = db < thr ? pack_key(db, pt_idx(L, c, b1c)) : kNone;
             flip = kb < ka;
             pred = (flip ? kb : ka) == kNone ? -1 : (flip ? b1c : a1);
             said = ok;
@@ -1706,37 +1512,12 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #endif
             int r_pos = -1, r_ring = -1, r_pos2 = -1, r_ring2 = -1;
             float r_lb = 0.f;
-#ifdef LINS_PROF2_CNT
-            auto fold_counts = [&](int base) {  // the lanes' scan counts since the last fold -> prof4[wave][base ..]
-              int ca = g_lds.cnt_calls[tid & 511], pa = g_lds.cnt_pts[tid & 511];
-              g_lds.cnt_calls[tid & 511] = 0, g_lds.cnt_pts[tid & 511] = 0;
-              int cm_ = ca, pm_ = pa, cs_ = ca, ps_ = pa;
-              for (int o = 32; o > 0; o >>= 1) {
-                cm_ = max(cm_, __shfl_xor(cm_, o)), pm_ = max(pm_, __shfl_xor(pm_, o));
-                cs_ += __shfl_xor(cs_, o), ps_ += __shfl_xor(ps_, o);
-              }
-              if (prof && lane == 0 && iter >= LINS_PROF2 && wave < 8)
-                g_lds.prof4[wave * 8 + base] += cm_, g_lds.prof4[wave * 8 + base + 1] += pm_, g_lds.prof4[wave * 8 + base + 2] += cs_, g_lds.prof4[wave * 8 + base + 3] += ps_;
-            };
-            fold_counts(4);  // (what the walk phase of the iteration before left, and anything in between)
-#endif
             if (cm.n) {  // (wave-uniform)
               // The polar view of the query (two square roots, an atan2f, the column) only feeds the searches: made here,
               // by every lane of a wave that searches — wave-uniform, so no lane waits for another's branch; a wave
               // whose selections are all certified (nearly every wave of a late iteration) never computes it.
-              if (!(pad & 0x200000) && !(kTail && LINS_TAIL_OOL)) qp = polar_of(o.sel[0], o.sel[1], o.sel[2], c.naz), qp_ready = true;
-              NnOut r;
-              if constexpr (kTail && LINS_TAIL_OOL) {
-                // (a call keeps only a third of the registers: what the loop carries — the query's state and its six
-                // records — would be spilled around it, on the path of the waves that do NOT search too.  So the state
-                // waits in its LDS slot and the records are fetched again: paid by the waves that search.)
-                tail_park();
-                r = coop_nn_ool(is_surf, gs, sd.n_corner_t, sd.n_surf_t, n_lds, cm.n, cm.rank, cm.owner_map, coop_cap, need_nn, lane, o.sel[0],
-                                o.sel[1], o.sel[2], ring_of(q.w), a1, ra1, thr, margin, (pad & 2) != 0);
-                tail_unpark();
-              } else {
-                r = coop_nn(L, c, cm, coop_cap, need_nn, lane, o.sel[0], o.sel[1], o.sel[2], qp, ring_of(q.w), a1, ra1, thr, margin, (pad & 2) != 0);
-              }
+              if (!(pad & 0x200000)) qp = polar_of(o.sel[0], o.sel[1], o.sel[2], c.naz), qp_ready = true;
+              const NnOut r = coop_nn(L, c, cm, coop_cap, need_nn, lane, o.sel[0], o.sel[1], o.sel[2], qp, ring_of(q.w), a1, ra1, thr, margin, (pad & 2) != 0);
               r_pos = r.pos, r_ring = r.ring, r_pos2 = r.pos2, r_ring2 = r.ring2, r_lb = r.lb;
             }
             if (need_nn) {
@@ -1745,13 +1526,11 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
               a1 = r_pos, ra1 = r_ring, b1c = r_pos2, rb1 = r_ring2;
               lb1 = r_lb;
               certA[0] = o.sel[0], certA[1] = o.sel[1], certA[2] = o.sel[2];
-              reload_r(R[0], a1), reload_r(R[1], b1c);
             } else if (active) {
               p1 = pred;
               if (flip) {  // the runner-up took over: swap the two tracked candidates
                 const int tp = a1, tr = ra1;
                 a1 = b1c, ra1 = rb1, b1c = tp, rb1 = tr;
-                swap_r(R[0], R[1]);
               }
               atomicAdd(&L.dbg[1], 1);
             }
@@ -1769,8 +1548,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           // what it said then.  (Tags carry the launch number: nothing survives a run; device-coherent accesses: the parts
           // of a cut update may sit on different XCDs.)
           bool set_ok = !nn_changed;  // the carried second / third points belong to this nearest neighbour
-          // (not a workgroup that runs a scan alone: a slow part of the same scan may be reading and writing the entries)
-          if (LINS_WALK_CACHE && !PASS_ONLY && warm_iter && nn_changed && active && ka.walk_cache && !solo && !(pad & 0x800000)) {  // (LINS_DEBUG_SKIP bit 0x800000: no walk cache)
+          if (LINS_WALK_CACHE && !PASS_ONLY && warm_iter && nn_changed && active && ka.walk_cache && !(pad & 0x800000)) {  // (LINS_DEBUG_SKIP bit 0x800000: no walk cache)
             const auto rs = __builtin_amdgcn_make_buffer_rsrc(ka.walk_cache + (size_t)sd.slot_base * 8, 0, total * 32, 0x00020000);
             const unsigned gen16 = (unsigned)ka.run_gen << 16;
             const v4u e0 = __builtin_amdgcn_raw_buffer_load_b128(rs, slot * 32, 0, 16);
@@ -1791,12 +1569,6 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
             }
           }
           if (active) sel1 = p1;
-#if LINS_LDS_TAIL && LINS_TAIL_STAGED && LINS_TAIL_PREFETCH
-          if (active) {
-            R[2] = c.gs[a2 < 0 ? 0 : a2], R[3] = c.gs[b2c < 0 ? 0 : b2c];
-            if (is_surf) R[4] = c.gs[a3 < 0 ? 0 : a3], R[5] = c.gs[b3c < 0 ? 0 : b3c];
-          }
-#endif
           if (prof) {
             s2 = clock64();
 #ifndef LINS_PROF_WAVES
@@ -1808,26 +1580,26 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           bool need_walk = false, flip2 = false, flip3 = false, said23 = false;
           int pred2 = -1, pred3 = -1, j1 = -1;
           if (active && p1 >= 0) {
-            j1 = idx_r(R[0], p1);  // (p1 >= 0 => p1 is candidate A, on ring ra1)
+            j1 = pt_idx(L, c, p1);  // (p1 >= 0 => p1 is candidate A, on ring ra1)
             need_walk = !set_ok || !warm_iter;
             if (!need_walk && (pad & 0x80000)) {
               pred2 = a2, pred3 = a3, said23 = true;
             } else if (!need_walk) {
               const WalkCtx w = make_walk_ctx(c, is_surf ? sd.n_surf_q : sd.n_corner_q, j1, ra1);
               const float dB = drift_from(certB);
-              auto judge = [&](int pa, int pb, const float4& ra, const float4& rb, float lb, int& pd, bool& fl) {
-                const float da = pa >= 0 ? dist_r(ra, pa) : INFINITY, db = pb >= 0 ? dist_r(rb, pb) : INFINITY;
+              auto judge = [&](int pa, int pb, float lb, int& pd, bool& fl) {
+                const float da = pa >= 0 ? dist_to(pa) : INFINITY, db = pb >= 0 ? dist_to(pb) : INFINITY;
                 int rka = 0, rkb = 0;
-                if (pa >= 0) walk_rank(w, idx_r(ra, pa), rka);
-                if (pb >= 0) walk_rank(w, idx_r(rb, pb), rkb);
+                if (pa >= 0) walk_rank(w, pt_idx(L, c, pa), rka);
+                if (pb >= 0) walk_rank(w, pt_idx(L, c, pb), rkb);
                 const unsigned long long ka = da < thr ? pack_key(da, rka) : kNone;
                 const unsigned long long kb = db < thr ? pack_key(db, rkb) : kNone;
                 fl = kb < ka;
                 pd = (fl ? kb : ka) == kNone ? -1 : (fl ? pb : pa);
                 return certified(fminf(fminf(da, db), thr), lb, dB);
               };
-              bool ok23 = judge(a2, b2c, R[2], R[3], lb2, pred2, flip2);
-              if (is_surf) ok23 = judge(a3, b3c, R[4], R[5], lb3, pred3, flip3) && ok23;
+              bool ok23 = judge(a2, b2c, lb2, pred2, flip2);
+              if (is_surf) ok23 = judge(a3, b3c, lb3, pred3, flip3) && ok23;
               said23 = ok23;
               need_walk = !ok23 || verify;
             }
@@ -1840,32 +1612,11 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #endif
             int r2 = -1, r2b = -1, r3 = -1, r3b = -1;
             float r_lb2 = 0.f, r_lb3 = 0.f;
-#ifdef LINS_PROF2_CNT
-            {  // the nearest-neighbour phase's counts
-              int ca = g_lds.cnt_calls[tid & 511], pa = g_lds.cnt_pts[tid & 511];
-              g_lds.cnt_calls[tid & 511] = 0, g_lds.cnt_pts[tid & 511] = 0;
-              int cm_ = ca, pm_ = pa, cs_ = ca, ps_ = pa;
-              for (int o = 32; o > 0; o >>= 1) {
-                cm_ = max(cm_, __shfl_xor(cm_, o)), pm_ = max(pm_, __shfl_xor(pm_, o));
-                cs_ += __shfl_xor(cs_, o), ps_ += __shfl_xor(ps_, o);
-              }
-              if (prof && lane == 0 && iter >= LINS_PROF2 && wave < 8)
-                g_lds.prof4[wave * 8 + 0] += cm_, g_lds.prof4[wave * 8 + 1] += pm_, g_lds.prof4[wave * 8 + 2] += cs_, g_lds.prof4[wave * 8 + 3] += ps_;
-            }
-#endif
             if (cm.n) {
-              if (!qp_ready && !(pad & 0x200000) && !(kTail && LINS_TAIL_OOL)) qp = polar_of(o.sel[0], o.sel[1], o.sel[2], c.naz);
+              if (!qp_ready && !(pad & 0x200000)) qp = polar_of(o.sel[0], o.sel[1], o.sel[2], c.naz);
               const int nq = is_surf ? sd.n_surf_q : sd.n_corner_q;
-              WalkOut r;
-              if constexpr (kTail && LINS_TAIL_OOL) {
-                tail_park();
-                r = coop_walk_ool(is_surf, gs, sd.n_corner_t, sd.n_surf_t, n_lds, nq, cm.n, cm.rank, cm.owner_map, coop_cap, need_walk, lane,
-                                  o.sel[0], o.sel[1], o.sel[2], j1, ra1, a2, a3, !set_ok, thr, margin, (pad & 1) != 0);
-                tail_unpark();
-              } else {
-                r = coop_walk(L, c, is_surf, nq, cm, coop_cap, need_walk, lane, o.sel[0], o.sel[1], o.sel[2], qp, j1, ra1, a2, a3, !set_ok, thr,
-                              margin, (pad & 1) != 0);
-              }
+              const WalkOut r = coop_walk(L, c, is_surf, nq, cm, coop_cap, need_walk, lane, o.sel[0], o.sel[1], o.sel[2], qp, j1, ra1, a2, a3, !set_ok, thr,
+                                              margin, (pad & 1) != 0);
               r2 = r.r2, r2b = r.r2b, r3 = r.r3, r3b = r.r3b, r_lb2 = r.lb2, r_lb3 = r.lb3;
             }
 #ifdef LINS_PROF2
@@ -1877,18 +1628,15 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
               a2 = r2, b2c = r2b, a3 = r3, b3c = r3b;
               lb2 = r_lb2, lb3 = r_lb3;
               certB[0] = o.sel[0], certB[1] = o.sel[1], certB[2] = o.sel[2];
-              reload_r(R[2], a2), reload_r(R[3], b2c), reload_r(R[4], a3), reload_r(R[5], b3c);
             } else if (active && p1 >= 0) {
               p2 = pred2, p3 = pred3;
               if (flip2) {
                 const int tp = a2;
                 a2 = b2c, b2c = tp;
-                swap_r(R[2], R[3]);
               }
               if (flip3) {
                 const int tp = a3;
                 a3 = b3c, b3c = tp;
-                swap_r(R[4], R[5]);
               }
               atomicAdd(&L.dbg[2], 1);
             }
@@ -1908,12 +1656,6 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           int4 s = idx_store[sd.slot_base + slot];
           p1 = s.x, p2 = s.y, p3 = s.z;
         }
-#if LINS_LDS_TAIL
-        if (active) {  // the carried state goes back to its query's slot HERE: its eighteen registers are free for the rows
-          const CarryWords cw = carry_pack();
-          L.cw0[slot] = cw.w0, L.cw1[slot] = cw.w1, L.cw2[slot] = cw.w2, L.cw3[slot] = cw.w3;
-        }
-#endif
         long long s3 = prof ? clock64() : 0;
         if (prof && do_search) PROF2_ADD(2, s3 - s2);
         // The iteration constants the rows need (R^T, G^T: 36 registers' worth, the same for every lane) are read from
@@ -1923,17 +1665,16 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         asm volatile("" ::: "memory");
         if (active && !(pad & 0x20000)) {  // (counting aid: LINS_DEBUG_SKIP bit 0x20000 drops the rows)
           // (a selected point is the first of its two tracked candidates: p1 == a1, p2 == a2, p3 == a3 when they exist)
-          auto pt4 = [&](int pos, const float4& r) {
-            if constexpr (kTailR) return r;
+          auto pt4 = [&](int pos) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             pt_xyz(L, c, pos, v.x, v.y, v.z);
             return v;
           };
           if (is_surf) {
             if (p1 >= 0 && p2 >= 0 && p3 >= 0)
-              surf_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], pt4(p1, R[0]), pt4(p2, R[2]), pt4(p3, R[4]), o);
+              surf_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], pt4(p1), pt4(p2), pt4(p3), o);
           } else if (p1 >= 0 && p2 >= 0) {
-            corner_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], pt4(p1, R[0]), pt4(p2, R[2]), o);
+            corner_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], pt4(p1), pt4(p2), o);
           }
           if (o.accepted) {
             if (ICP) {  // Gauss-Newton row of the fallback (SE:1246-1257): [c^T(-R(s phi)[p]x), c^T | -0.05 res]
@@ -2166,18 +1907,11 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         const long long r0 = prof ? clock64() : 0;
         const double red = wave_reduce_rows(row, lane);
         if (prof) PROF2_ADD(4, clock64() - r0);
-        if constexpr (kTail) {  // one partial per wave-round, in the slot of the head wave that would have held it
-#if LINS_LDS_TAIL
-          const int si = reduce_sum_index(lane);
-          if (si >= 0) L.partial[wr_k * 28 + si] = red;
-#endif
-        } else {
-          acc += red;
-        }
+        acc += red;
       }
     }
     if (do_search) searched = true;
-    if (!kTail) {
+    {
       const int sidx28 = reduce_sum_index(lane);
       if (sidx28 >= 0) L.partial[part_k * 28 + sidx28] = acc;
     }
@@ -2190,7 +1924,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     if (tid < 28) {
       double sacc = 0;
 #pragma unroll
-      for (int g = 0; g < (kTail ? kMaxLWaves : BLOCK / 64); ++g) sacc += L.partial[g * 28 + tid];
+      for (int g = 0; g < BLOCK / 64; ++g) sacc += L.partial[g * 28 + tid];
       L.sums[tid] = sacc;
     }
     __syncthreads();
@@ -2206,7 +1940,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     if (PASS_ONLY) {
       if (ka.sums_out && tid < 28) ka.sums_out[(size_t)scan * 28 + tid] = L.sums[tid];
       if (ka.counts_out && tid == 0) ka.counts_out[scan * 2] = L.m_surf, ka.counts_out[scan * 2 + 1] = L.m_corner;
-      return;
+      return true;
     }
 
     if (ICP && held.w >= 0 && L.m_surf >= 10) idx_store[held.w] = make_int4(held.x, held.y, held.z, 0);
@@ -2226,25 +1960,8 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
       }
     }
   }
-#if LINS_COLD_ARGS
   const ColdArgs kp = cold_args();  // (what only the epilogue needs is loaded here, not kept in SGPRs across the loop)
 #define KP(f) kp->f
-#else
-#define KP(f) ka.f
-#endif
-#ifdef LINS_PROF2_CNT
-  if (LANES == 1) {  // the last iteration's walk phase is still in the lanes' counters
-    int ca = g_lds.cnt_calls[tid & 511], pa = g_lds.cnt_pts[tid & 511];
-    int cm_ = ca, pm_ = pa, cs_ = ca, ps_ = pa;
-    for (int o = 32; o > 0; o >>= 1) {
-      cm_ = max(cm_, __shfl_xor(cm_, o)), pm_ = max(pm_, __shfl_xor(pm_, o));
-      cs_ += __shfl_xor(cs_, o), ps_ += __shfl_xor(ps_, o);
-    }
-    if (prof && lane == 0 && wave < 8)
-      g_lds.prof4[wave * 8 + 4] += cm_, g_lds.prof4[wave * 8 + 5] += pm_, g_lds.prof4[wave * 8 + 6] += cs_, g_lds.prof4[wave * 8 + 7] += ps_;
-    __syncthreads();
-  }
-#endif
 #ifdef LINS_PROF2
   if (prof && dbg_slot >= 0) idx_store[dbg_slot] = make_int4(dbg_nn, dbg_walk, dbg_walk_mask, ra1 | (a3 >= 0 ? 0x100 : 0));
 #endif
@@ -2263,12 +1980,6 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     // (the reduction phase, ~230 ticks a wave, gives its slot to the search counts: [w][4] = wave-iterations with a
     // nearest-neighbour search | with a walk, both << 16 ... kept simple: phase 4 of wave w = walks << 16 | wave-iterations with a walk,
     // phase 4 is re-read by tools/wave_phases.py)
-#ifdef LINS_PROF2_ARR
-    {  // the scan counts (walk phase of the last iteration still in the lanes' counters: left out — the cold profile runs two iterations)
-      int* ext2 = reinterpret_cast<int*>(prof_out + (size_t)gridDim.x * 48) + (size_t)scan * 64;
-      for (int k = 0; k < 64; ++k) ext2[k] = L.prof4[k];
-    }
-#endif
     for (int k = 0; k < 64; ++k) ext[k] = (k & 7) == 4 ? (L.prof3[(k >> 3) * 4 + 1] | (L.prof3[(k >> 3) * 4 + 3] << 12) | (L.prof3[(k >> 3) * 4 + 0] << 20) | (L.prof3[(k >> 3) * 4 + 2] << 26)) : L.prof2[k];
 #endif
   }
@@ -2287,16 +1998,16 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         relay_out_carry(KP(relay_lane) + (size_t)scan * kRelayLaneInts, y.slot, a1, b1c, ra1, rb1, a2, b2c, a3, b3c, sel1, lb1, lb2, lb3,
                         certA[0], certA[1], certA[2], certB[0], certB[1], certB[2]);
     }
-    // every store of this wave has completed — write-through stores: at the memory side — before the barrier, the flag
-    // after it: whoever sees the flag sees the hand-over
+    // every store of this wave has completed — write-through stores: at the memory side — before the barrier, the queue
+    // slot after it: whoever pops the continuation sees the hand-over
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) relay_raise(KP(relay_flag) + scan, KP(relay_gen) * 16 + part + 1);
-    return;
+    if (tid == 0) relay_raise(KP(queue) + kQFlags + scan, KP(relay_gen) * 16 + part + 1);
+    return false;
   }
-  if (kRelay && relay_n > 0 && (solo || part + 1 < relay_parts) && tid == 0)  // this part finished the scan: the others have nothing to do
-    relay_raise(KP(relay_flag) + scan, KP(relay_gen) * 16 + 15);
+  if (kRelay && relay_n > 0 && tid == 0)  // this part finished the scan: the later ones have nothing to do
+    relay_raise(KP(queue) + kQFlags + scan, KP(relay_gen) * 16 + 15);
 
   // ---- hand-off to the Joseph kernel / the caller (SE:585-598) ---------------
   const int div = L.div;
@@ -2326,6 +2037,60 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     }
   }
   if (!ICP && KP(cov_out)) joseph_epilogue<BLOCK>(KP(prm).r2, div, KP(cov_out) + (size_t)scan * 324, tid);
+  return true;
+}
+
+// KNOBS: the counting aids and test modes of LINS_DEBUG_SKIP (DevParams::pad) compiled in.  The production instantiations
+// of the update kernels are built without them — twenty-odd tests of a run-time word in the hottest code of a kernel that is
+// short of scalar registers; the launchers take the KNOBS twin whenever pad != 0 (tools/, the certificate tests).
+template <int BLOCK, int LANES, bool PASS_ONLY, bool PROF, bool ICP = false, bool KNOBS = true>
+#if LINS_LDS_MINW > 1
+// (second argument: waves per SIMD the register allocation must allow)
+__global__ __launch_bounds__(BLOCK, LINS_LDS_MINW) void ieskf_lds_kernel(
+#else
+__global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
+#endif
+    const KernelArgs ka, const float4* __restrict__ arena, const float4* __restrict__ sorted, int4* __restrict__ idx_store,
+    lins_corr* __restrict__ dump) {
+  // (the four pointers the loop reads and writes through stay parameters of their own: only a parameter carries
+  // `noalias`, and without it the register allocation of every instantiation got worse)
+  constexpr bool kQueue = BLOCK == 512 && LANES == 1 && !PASS_ONLY && !ICP;  // (the shape that has the relay)
+  const bool queued = kQueue && ka.relay_n > 0;  // (uniform) a workgroup of a ticketed batch launch, see "work items" above
+  int item;  // scan | part << 27; -1: nothing to do
+  if (kQueue && queued) {
+    if (threadIdx.x == 0) {
+      int* const Q = ka.queue;
+      int it = ka.order[relay_add(Q + kQHead, 1)];
+      const int part = it >> 27, scan = it & 0x7FFFFFF;
+      if (part) {
+        const int want = ka.relay_gen * 16 + part;
+        int f = relay_ld(Q + kQFlags + scan);
+        for (int spins = 0; f < want; ++spins) {
+          if (spins >= ka.relay_spins) {  // (cannot happen on a healthy device, see above: reported, not worked around)
+            __hip_atomic_fetch_add(ka.relay_err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(32);
+          f = relay_ld(Q + kQFlags + scan);
+        }
+        if (f != want) it = -1;  // the scan is finished (stop rule, divergence) — or the wait ran out
+      }
+      g_lds.scan_tmp[0] = it;
+    }
+    __syncthreads();
+    item = g_lds.scan_tmp[0];
+    __syncthreads();  // (scan_tmp is the update's from here)
+  } else {
+    // one workgroup per scan, in the host's launch order (lins_capi.hip launch_order: longest-expected-first, so that
+    // the dispatcher, which hands workgroups out in index order as slots free up, ends the launch with the short ones)
+    item = ka.order ? ka.order[blockIdx.x] : (int)blockIdx.x;
+  }
+  if (item >= 0)
+    ieskf_lds_update<BLOCK, LANES, PASS_ONLY, PROF, ICP, KNOBS>(ka, arena, sorted, idx_store, dump, item & 0x7FFFFFF, kQueue ? item >> 27 : 0);
+  if (kQueue && queued && threadIdx.x == 0) {  // the last workgroup out leaves the counters at zero for the next launch
+    int* const Q = cold_args()->queue;
+    if (relay_add(Q + kQExited, 1) == (int)gridDim.x - 1) relay_st(Q + kQHead, 0), relay_st(Q + kQExited, 0);
+  }
 }
 
 #undef KP

@@ -5,7 +5,7 @@
 // LDS holds only the first 4208 grid positions of the scan's prebuilt search index (ieskf_grid.h) — the
 // corner cloud and the low surf rings, where nearly every search ends; the rest of the grid is read from
 // the index's sorted copy in global memory, which the same loops fall through to.  Batches beyond the
-// device's workgroup slots run every update as consecutive workgroups of the launch (the kernel's relay).  At < 80 KB of LDS and 128 VGPRs two independent scans are
+// device's workgroup slots run every update as several workgroups of the launch, which draw their parts by ticket (the kernel's relay).  At < 80 KB of LDS and 128 VGPRs two independent scans are
 // resident per CU and fill each other's barriers and serial tails (measured with the HW_ID /
 // wall-clock probe of the PROF variant, tools/residency.py).  Results are identical to the
 // full-residency kernel: the same loops run over the same grid, only the storage of a position
@@ -49,10 +49,20 @@ static void launch_args(K kernel, int grid, int block, hipStream_t stream, const
 }
 
 int lds_mr_np_cap() { return lds_mr::kNpMax; }
+int lds_mr_queue_flags_offset() { return lds_mr::kQFlags; }
 
-// relay != nullptr: every update is cut every relay->at iterations into parts, relay->launched of them workgroups of this
-// launch, see the kernel; relay->gen numbers the launch (the per-scan flags are never reset: a flag of an earlier launch is
-// smaller)
+// workgroups of the production batch kernel that are resident at once on the current device (larger batches are cut into parts)
+int lds_mr_resident_workgroups(int n_cu) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lds_mr::ieskf_lds_kernel<LINS_MR_BLOCK, 1, false, false, false, false>, LINS_MR_BLOCK, 0) != hipSuccess ||
+      per_cu < 1)
+    per_cu = 2;
+  return per_cu * n_cu;
+}
+
+// relay != nullptr: every update is cut (relay_next_cut) into relay->parts parts, the launch has one workgroup per (scan, part)
+// and `order` lists them (every part 0, then every part 1, ...: scan | part << 27); relay->gen numbers the launch (the
+// per-scan flags are never reset: a flag of an earlier launch is smaller)
 void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const int* order, const float4* arena,
                    const float4* sorted, const GridTables* tabs, const double* state_in, const double* cov_in, double* state_out, double* a6,
                    double* cov_out, void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof,
@@ -64,9 +74,9 @@ void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDe
   int grid = n;
   ka.walk_cache = walk_cache, ka.run_gen = run_gen;
   if (relay) {
-    ka.relay_n = n, ka.relay_at = relay->at, ka.relay_parts = relay->parts, ka.relay_gen = relay->gen, ka.relay_spins = relay->spins;
-    ka.relay_hdr = relay->hdr, ka.relay_lane = relay->lane, ka.relay_flag = relay->flag, ka.relay_err = relay->err;
-    grid = relay->launched * n;
+    ka.relay_n = n, ka.relay_at = relay->at, ka.relay_cuts = relay->cuts, ka.relay_gen = relay->gen, ka.relay_spins = relay->spins;
+    ka.relay_hdr = relay->hdr, ka.relay_lane = relay->lane, ka.queue = relay->queue, ka.relay_err = relay->err;
+    grid = relay->parts * n;
   }
   if (prof)
     launch_args(lds_mr::ieskf_lds_kernel<LINS_MR_BLOCK, 1, false, true>, grid, LINS_MR_BLOCK, stream, ka, arena, sorted, idx_store);

@@ -52,9 +52,8 @@ void launch_lds_pass(hipStream_t, int, const DevParams&, int, const ScanDesc*, c
 int lds_np_cap();
 void launch_lds_mr(hipStream_t, int, const DevParams&, const ScanDesc*, const int*, const float4*, const float4*, const GridTables*, const double*,
                    const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*, const RelayArgs*, unsigned*, int);
-void launch_lds_tail(hipStream_t, int, const DevParams&, const ScanDesc*, const int*, const float4*, const float4*, const GridTables*, const double*,
-                     const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, const RelayArgs&, unsigned*, int);
-int lds_tail_max_queries();
+int lds_mr_resident_workgroups(int n_cu);
+int lds_mr_queue_flags_offset();
 void launch_lds_mr_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const float4*, const GridTables*, const double*,
                         const double*, int, int4*, lins_corr*, double*, int*);
 int lds_mr_np_cap();
@@ -136,25 +135,23 @@ struct lins_ctx {
   GridTables* d_gridtab = nullptr;
   hipEvent_t ev_idx0 = nullptr, ev_idx1 = nullptr;
   bool idx_timed = false;
-  // several-part updates of the batch kernel (ieskf_lds_impl.h "relay"): hand-over buffers, one flag per scan, launch counter
+  // several-part updates of the batch kernel (ieskf_lds_impl.h "relay"): hand-over buffers, the work queue, launch counter
   int relay_at = 4, relay_gen = 0;  // (relay_at: iterations per part; 0 = whole updates.  1024 scans x 10 iterations: 2 -> 0.647 ms,
                                     // 3 -> 0.625, 4 -> 0.615, 5 -> 0.641, 6 -> 0.623, 7 -> 0.626, 8 -> 0.641; whole updates 0.665)
-  int relay_list_parts = 0;         // parts of the launch list that is on the device (0 = none yet for this upload)
+  int relay_cuts = 2;               // cuts an update gets at most: at relay_at, 2 relay_at, ... (the last part runs to the end)
+  int relay_list_parts = 0, relay_list_n = 0;  // the item list that is on the device (0 = none for this upload / order)
   double* d_relay_hdr = nullptr;
-  int *d_relay_lane = nullptr, *d_relay_flag = nullptr;
+  int *d_relay_lane = nullptr, *d_queue = nullptr;  // d_queue: ticket counters + one flag per scan (ieskf_lds_impl.h kQ*)
+  int queue_grid = 0;               // workgroups of the batch kernel resident at once on this device: larger batches are cut into parts
+  long long queue_timeouts = 0;     // hand-over waits that ran out, over the life of the context (lins_last_cut)
   // walk cache of the one-lane-per-query kernels (ieskf_lds_impl.h): per query slot 32 B — the second / third points of the
   // nearest neighbour a query had before; cleared wherever new target clouds arrive, tagged with the launch number
   unsigned* d_walk_cache = nullptr;
   int run_gen = 0;
-  int* h_relay_err = nullptr;       // (pinned, device-visible) hand-over protocol violations seen by the tail kernel: checked at lins_sync
-  int relay_spins = 1 << 14;        // polls (~1 us) a part waits for its hand-over before it runs the whole update alone
+  int* h_relay_err = nullptr;       // (pinned, device-visible) queue waits that ran out in a launch: checked at lins_sync
+  int relay_spins = 1 << 21;        // polls (~1 us) a workgroup waits at an empty queue slot before the launch gives up
   bool streams_fuse = true;         // lins_streams_step: updatePointCloud as one kernel (re-projection + index); debug knob LINS_STREAMS_FUSE
-  int relay_scramble = 0;           // debug (LINS_RELAY_SCRAMBLE): launch list in an order that violates "a part behind the part before it"
-  // the tail kernel (ieskf_lds_tail.hip): the iterations from tail_at on as a launch of their own, four scans per CU
-  int tail_at = 0;                  // (0 = off: the batch kernel's own last part runs to the end.  Off by default: measured
-                                    // slower than the batch kernel's own parts; LINS_TAIL_AT with the debug gate)
-  bool tail_ok = false;             // every uploaded scan has a query set the tail kernel takes (set at upload)
-  int last_parts = 0, last_tail = 0;  // how the last run was cut (lins_last_cut)
+  int last_parts = 0;  // how the last run was cut (lins_last_cut)
   ScanDesc* d_desc = nullptr;
   bool use_order = true;  // (LINS_LAUNCH_ORDER=0 with the debug gate: index order, for A/B timing)
   int *h_order = nullptr, *d_order = nullptr;  // launch order of the uploaded batch (longest-expected-first), see launch_order()
@@ -266,7 +263,6 @@ const lins_params* ctx_params(const lins_ctx* ctx) { return &ctx->prm; }
 
 namespace {
 
-constexpr int kRelayMaxParts = 8;  // (flag values 16 gen + part: parts < 15)
 constexpr size_t kLaneIntsPerScan = 4 * 512 * 4;  // ieskf_lds_impl.h kRelayLaneInts: [4][512] 16-byte words per scan
 
 int fail_hip(lins_ctx* ctx, hipError_t e, const char* what) {
@@ -457,7 +453,6 @@ struct CallTrace {
 
 struct RangeFlags {  // which kernel families the scans of a range can take
   bool lds_ok = true, mr_ok = true, lds3_ok = true;
-  bool tail_ok = true;  // the batch kernel lays the queries out in its one-round "spread" form and the tail kernel has a slot for each
 };
 
 // pass 1 (serial, cheap): argument checks and the arena layout of the whole batch
@@ -528,8 +523,6 @@ RangeFlags range_flags(const lins_ctx* ctx, int lo, int hi) {
     if (!grid || d.n_surf_t + d.n_corner_t > lds_np_cap()) fl.lds_ok = false;
     if (!grid || d.n_surf_t + d.n_corner_t > lds_mr_np_cap()) fl.mr_ok = false;
     if (d.n_surf_q + d.n_corner_q > 336) fl.lds3_ok = false;  // (16 waves x 21 query slots = the VLP-16 caps, 144 flat + 192 sharp)
-    // (ieskf_lds_impl.h: plane queries over 5 waves, line queries over 3, at most 64 a wave)
-    if (d.n_surf_q > 5 * 64 || d.n_corner_q > 3 * 64 || d.n_surf_q + d.n_corner_q > lds_tail_max_queries()) fl.tail_ok = false;
   }
   return fl;
 }
@@ -538,10 +531,6 @@ RangeFlags range_flags(const lins_ctx* ctx, int lo, int hi) {
 // that cannot take them run the any-size kernel, which bins for itself)
 int build_index_range(lins_ctx* ctx, int lo, int cnt, const RangeFlags& fl) {
   if (cnt <= 0 || !(fl.lds_ok || fl.mr_ok)) return LINS_OK;
-  {  // new target clouds: what the walk cache holds for these scans' query slots is about other clouds
-    const size_t s0 = (size_t)ctx->h_desc[lo].slot_base, s1 = (size_t)ctx->h_desc[lo + cnt - 1].slot_base + ctx->h_desc[lo + cnt - 1].n_surf_q + ctx->h_desc[lo + cnt - 1].n_corner_q;
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_walk_cache + s0 * 8, 0xFF, (s1 - s0) * 32, ctx->stream));
-  }
   launch_grid_index(ctx->stream, cnt, ctx->d_desc + lo, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo);
   HIP_TRY(ctx, hipGetLastError());
   return LINS_OK;
@@ -561,7 +550,7 @@ int h2d_range(lins_ctx* ctx, int lo, int hi, size_t arena_end, hipStream_t st) {
 
 void set_batch_state(lins_ctx* ctx, int n, const RangeFlags& fl, size_t slots, uint64_t bytes) {
   ctx->n_uploaded = n;
-  ctx->lds_ok = fl.lds_ok, ctx->mr_ok = fl.mr_ok, ctx->lds3_ok = fl.lds3_ok, ctx->tail_ok = fl.tail_ok;
+  ctx->lds_ok = fl.lds_ok, ctx->mr_ok = fl.mr_ok, ctx->lds3_ok = fl.lds3_ok;
   ctx->slots_uploaded = slots;
   ctx->ran = false;
   ctx->bytes_per_iter = bytes;
@@ -585,7 +574,38 @@ void launch_order(lins_ctx* ctx, int n) {
   }
   std::sort(key.begin(), key.end());
   for (int s = 0; s < n; ++s) ctx->h_order[s] = key[s].second;
-  ctx->relay_list_parts = 0;  // (the list of the several-part updates is built by the first run that needs it)
+  ctx->relay_list_parts = 0;  // (the item list of the several-part updates is rebuilt by the next run that needs it)
+}
+
+// The number of the next launch of an update kernel.  It tags the entries of the walk cache (16 bits of it: an entry of
+// any earlier launch — other clouds, other priors — never matches), so the cache is cleared when those 16 bits come round
+// again, not per upload or per step (the per-step clear of lins_streams_step was 33 MB per 1024 streams).
+int next_run_gen(lins_ctx* ctx) {
+  ++ctx->run_gen;
+  if ((ctx->run_gen & 0xFFFF) == 0 && ctx->d_walk_cache) (void)hipMemsetAsync(ctx->d_walk_cache, 0xFF, ctx->slot_cap * 32, ctx->stream);
+  return ctx->run_gen;
+}
+
+// Several-part updates of a launch of n scans on the batch kernel: the cuts, the launch's number, the list of its
+// (scan, part) items on the device — every part 0 in launch order, then every part 1, ... — and the ticket counters and
+// flags (RelayArgs; ieskf_lds_impl.h "work items").  `listed`: the launch order of these n scans is on the device.
+int relay_prepare(lins_ctx* ctx, int n, bool ordered, RelayArgs& ra) {
+  ra.at = ctx->relay_at, ra.cuts = ctx->relay_cuts;
+  ra.parts = relay_max_parts(ctx->prm.num_iter, ra.at, ra.cuts);
+  if (ctx->relay_gen >= (1 << 26)) {  // (flags are 16 gen + part: start over long before the int runs out)
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, (lds_mr_queue_flags_offset() + (size_t)ctx->max_batch) * sizeof(int), ctx->stream));
+    ctx->relay_gen = 0;
+  }
+  if (ctx->relay_list_parts != ra.parts || ctx->relay_list_n != n) {
+    int* list = ctx->h_order + ctx->max_batch;
+    for (int p = 0; p < ra.parts; ++p)
+      for (int k = 0; k < n; ++k) list[p * n + k] = (ordered ? ctx->h_order[k] : k) | (p << 27);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order + ctx->max_batch, list, (size_t)ra.parts * n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    ctx->relay_list_parts = ra.parts, ctx->relay_list_n = n;
+  }
+  ra.gen = ++ctx->relay_gen, ra.spins = ctx->relay_spins;
+  ra.hdr = ctx->d_relay_hdr, ra.lane = ctx->d_relay_lane, ra.queue = ctx->d_queue, ra.err = ctx->h_relay_err;
+  return LINS_OK;
 }
 
 int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
@@ -632,7 +652,7 @@ int run_range(lins_ctx* ctx, int lo, int cnt, int n_total, const RangeFlags& fl,
   if (use_mr || use_lds) {
     if (use_mr)
       launch_lds_mr(ctx->stream, cnt, ctx->dprm, desc, nullptr, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out, ctx->d_idx, ps,
-                    scan_id_base + lo, nullptr, nullptr, ctx->d_walk_cache, ++ctx->run_gen);
+                    scan_id_base + lo, nullptr, nullptr, ctx->d_walk_cache, next_run_gen(ctx));
     else
       launch_lds(ctx->stream, cnt, ctx->dprm, s == SEARCH_LDS3 ? 3 : 1, desc, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out,
                  ctx->d_idx, ps, scan_id_base + lo, nullptr);  // (the Joseph update is the kernels' epilogue)
@@ -681,9 +701,9 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
     if (g[0] == '1') {
       if (const char* e = std::getenv("LINS_LAUNCH_ORDER")) ctx->use_order = e[0] != '0';
       if (const char* e = std::getenv("LINS_RELAY_AT")) ctx->relay_at = std::max(0, std::atoi(e));  // (0: whole updates)
-      if (const char* e = std::getenv("LINS_TAIL_AT")) ctx->tail_at = std::max(0, std::atoi(e));    // (0: no tail kernel)
-      if (const char* e = std::getenv("LINS_RELAY_SPINS")) ctx->relay_spins = std::max(1, std::atoi(e));
-      if (const char* e = std::getenv("LINS_RELAY_SCRAMBLE")) ctx->relay_scramble = std::atoi(e);
+      if (const char* e = std::getenv("LINS_RELAY_CUTS")) ctx->relay_cuts = std::max(1, std::min(14, std::atoi(e)));
+      if (const char* e = std::getenv("LINS_RELAY_SPINS")) ctx->relay_spins = std::max(0, std::atoi(e));
+      if (const char* e = std::getenv("LINS_QUEUE_GRID")) ctx->queue_grid = std::max(1, std::atoi(e));  // (batches beyond this many scans are cut)
       if (const char* e = std::getenv("LINS_STREAMS_FUSE")) ctx->streams_fuse = e[0] != '0';  // (0: re-projection and index build as two kernels)
     }
   ctx->max_batch = max_batch;
@@ -719,8 +739,8 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   const size_t nb = (size_t)max_batch;
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_arena, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_desc, nb * sizeof(ScanDesc)));
-  CREATE_TRY(hipHostMalloc((void**)&ctx->h_order, (1 + kRelayMaxParts) * nb * sizeof(int)));  // (n entries: whole updates; then parts x n)
-  CREATE_TRY(hipMalloc((void**)&ctx->d_order, (1 + kRelayMaxParts) * nb * sizeof(int)));
+  CREATE_TRY(hipHostMalloc((void**)&ctx->h_order, 16 * nb * sizeof(int)));  // (n entries: launch order; from max_batch on: parts x n items)
+  CREATE_TRY(hipMalloc((void**)&ctx->d_order, 16 * nb * sizeof(int)));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_state, nb * 19 * 8));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_cov, nb * 324 * 8));
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_out, nb * sizeof(OutRecHost)));
@@ -728,15 +748,16 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   CREATE_TRY(hipMalloc((void**)&ctx->d_binned, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_gsorted, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_gridtab, (size_t)ctx->max_batch * sizeof(GridTables)));
-  if (ctx->max_batch > 2 * ctx->n_cu) {  // (only batches beyond the device's workgroup slots are cut into parts)
+  if (ctx->queue_grid <= 0) ctx->queue_grid = lds_mr_resident_workgroups(ctx->n_cu);
+  if (ctx->max_batch > ctx->queue_grid) {  // (only batches beyond the device's workgroup slots are cut into parts)
     CREATE_TRY(hipMalloc((void**)&ctx->d_relay_lane, (size_t)ctx->max_batch * kLaneIntsPerScan * sizeof(int)));  // (CarryWords by query)
     CREATE_TRY(hipMalloc((void**)&ctx->d_relay_hdr, (size_t)ctx->max_batch * 64 * sizeof(double)));
     CREATE_TRY(hipHostMalloc((void**)&ctx->h_relay_err, sizeof(int)));
     *ctx->h_relay_err = 0;
-    CREATE_TRY(hipMalloc((void**)&ctx->d_relay_flag, (size_t)ctx->max_batch * sizeof(int)));
-    CREATE_TRY(hipMemset(ctx->d_relay_flag, 0, (size_t)ctx->max_batch * sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_queue, (lds_mr_queue_flags_offset() + (size_t)ctx->max_batch) * sizeof(int)));
+    CREATE_TRY(hipMemset(ctx->d_queue, 0, (lds_mr_queue_flags_offset() + (size_t)ctx->max_batch) * sizeof(int)));
   } else {
-    ctx->relay_at = 0, ctx->tail_at = 0;
+    ctx->relay_at = 0;
   }
   CREATE_TRY(hipEventCreate(&ctx->ev_idx0));
   CREATE_TRY(hipEventCreate(&ctx->ev_idx1));
@@ -774,7 +795,7 @@ void lins_destroy(lins_ctx* ctx) {
   (void)hipFree(ctx->d_binned);
   (void)hipFree(ctx->d_gsorted);
   (void)hipFree(ctx->d_gridtab);
-  (void)hipFree(ctx->d_relay_hdr), (void)hipFree(ctx->d_relay_lane), (void)hipFree(ctx->d_relay_flag), (void)hipHostFree(ctx->h_relay_err);
+  (void)hipFree(ctx->d_relay_hdr), (void)hipFree(ctx->d_relay_lane), (void)hipFree(ctx->d_queue), (void)hipHostFree(ctx->h_relay_err);
   if (ctx->ev_idx0) (void)hipEventDestroy(ctx->ev_idx0);
   if (ctx->ev_idx1) (void)hipEventDestroy(ctx->ev_idx1);
   (void)hipFree(ctx->d_desc);
@@ -846,10 +867,11 @@ const char* lins_last_search(const lins_ctx* ctx) {
 
 int lins_batch_upload(lins_ctx* ctx, int n, const lins_scan_pair* in) { return upload(ctx, n, in); }
 
-int lins_last_cut(const lins_ctx* ctx, int* parts, int* tail_kernel) {
-  if (!ctx || !parts || !tail_kernel) return LINS_E_ARG;
+int lins_last_cut(const lins_ctx* ctx, int* parts, int* queue_timeouts) {
+  if (!ctx || !parts || !queue_timeouts) return LINS_E_ARG;
   if (!ctx->ran) return LINS_E_STATE;
-  *parts = ctx->last_parts, *tail_kernel = ctx->last_tail;
+  *parts = ctx->last_parts;
+  *queue_timeouts = (int)std::min<long long>(ctx->queue_timeouts, 0x7FFFFFFF);
   return LINS_OK;
 }
 
@@ -883,60 +905,30 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   const bool want_lds = search >= SEARCH_LDS, want_mr = search == SEARCH_MR;
   const bool use_mr = want_mr && ctx->mr_ok, use_lds = want_lds && !want_mr && ctx->lds_ok;
   ctx->last_search = use_mr ? (int)SEARCH_MR : (use_lds ? search : (want_lds ? (int)SEARCH_BINNED : search));
-  // Several-part updates (the kernel's relay): when the batch has more scans than the device has workgroup slots (two
-  // per CU), the launch ends with slots idle while the last whole updates finish; cut every relay_at iterations the
-  // same work is several times as many shorter jobs and that end shrinks.  Not with the phase profile (one record per
-  // scan), and only with ICP_FREQ 1: with a larger one the iterations in between read the triplets an earlier part of
-  // the scan left in idx_store — plain stores of another workgroup, possibly on another XCD.
-  // The iterations from tail_at on run in the tail kernel (ieskf_lds_tail.hip: four scans per CU) as a second launch
-  // behind this one — the last "part", handed over the same way, ordered by the stream instead of a flag wait.
-  const bool cut_ok = use_mr && ctx->n_uploaded > 2 * ctx->n_cu && !ctx->d_prof && ctx->prm.icp_freq == 1 && ctx->d_relay_hdr;
-  const bool tail = cut_ok && ctx->tail_at > 0 && ctx->tail_at < ctx->prm.num_iter && ctx->tail_ok;  // (the tail follows the head's schedule of layouts)
+  // Several-part updates (the kernel's relay + work queue): when the batch has more scans than the device has workgroup
+  // slots, a launch of one workgroup per scan ends with slots idle while the last whole updates finish; cut every relay_at
+  // iterations the same work is several times as many shorter jobs, pulled from the launch's queue by as many persistent
+  // workgroups as are resident at once, and that end shrinks.  Not with the phase profile (one record per scan), and
+  // only with ICP_FREQ 1: with a larger one the iterations in between read the triplets an earlier part of the scan left in
+  // idx_store — plain stores of another workgroup, possibly on another XCD.
+  const bool cut_ok = use_mr && ctx->n_uploaded > ctx->queue_grid && !ctx->d_prof && ctx->prm.icp_freq == 1 && ctx->d_relay_hdr;
+  const bool relay = cut_ok && ctx->relay_at > 0 && ctx->relay_at < ctx->prm.num_iter;
   RelayArgs ra;
-  if (tail) {  // head parts of relay_at iterations when that divides tail_at, else one head part; then the tail
-    const bool sub = ctx->relay_at > 0 && ctx->relay_at < ctx->tail_at && ctx->tail_at % ctx->relay_at == 0 && ctx->tail_at / ctx->relay_at < kRelayMaxParts;
-    ra.at = sub ? ctx->relay_at : ctx->tail_at;
-    ra.launched = ctx->tail_at / ra.at, ra.parts = ra.launched + 1;
-  } else if (cut_ok && ctx->relay_at > 0 && ctx->relay_at < ctx->prm.num_iter) {
-    ra.at = ctx->relay_at;
-    ra.parts = ra.launched = std::min(kRelayMaxParts, (ctx->prm.num_iter + ctx->relay_at - 1) / ctx->relay_at);
-  }
-  const bool relay = ra.parts > 1;
-  ctx->last_parts = relay ? ra.parts : 1, ctx->last_tail = tail ? 1 : 0;
-  if (relay && ctx->relay_gen >= (1 << 26)) {  // (flags are 16 gen + part: start over long before the int runs out)
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_relay_flag, 0, (size_t)ctx->max_batch * sizeof(int), ctx->stream));
-    ctx->relay_gen = 0;
-  }
-  if (relay && ctx->relay_list_parts != ra.launched) {  // the launch list of this many parts: every part 0, then every part 1, ...
-    int* list = ctx->h_order + ctx->n_uploaded;
-    const int np = ra.launched, n = ctx->n_uploaded;
-    for (int p = 0; p < np; ++p)
-      for (int k = 0; k < n; ++k) {
-        // (debug: 1 = parts in reverse order — every workgroup that waits is handed out before the part it waits for)
-        const int at = ctx->relay_scramble == 1 ? (np - 1 - p) * n + k : p * n + k;
-        list[at] = (ctx->use_order ? ctx->h_order[k] : k) | (p << 27);
-      }
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order + n, list, (size_t)np * n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    ctx->relay_list_parts = np;
-  }
   if (relay) {
-    ra.gen = ++ctx->relay_gen, ra.spins = ctx->relay_spins;
-    ra.hdr = ctx->d_relay_hdr, ra.lane = ctx->d_relay_lane, ra.flag = ctx->d_relay_flag, ra.err = ctx->h_relay_err;
+    const int rcq = relay_prepare(ctx, ctx->n_uploaded, ctx->use_order, ra);
+    if (rcq) return rcq;
   }
+  ctx->last_parts = relay ? ra.parts : 1;
   if (use_mr || use_lds) {
     if (use_mr)
       launch_lds_mr(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc,
-                    relay ? ctx->d_order + ctx->n_uploaded : (ctx->use_order ? ctx->d_order : nullptr), ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in,
+                    relay ? ctx->d_order + ctx->max_batch : (ctx->use_order ? ctx->d_order : nullptr), ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in,
                     ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx, (lins_pose_record*)d_poses,
-                    scan_id_base, ctx->d_prof, relay ? &ra : nullptr, ctx->d_walk_cache, ++ctx->run_gen);
+                    scan_id_base, ctx->d_prof, relay ? &ra : nullptr, ctx->d_walk_cache, next_run_gen(ctx));
     else
       launch_lds(ctx->stream, ctx->n_uploaded, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc,
                  ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx,
                  (lins_pose_record*)d_poses, scan_id_base, ctx->d_prof);
-    if (tail)
-      launch_lds_tail(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc, ctx->use_order ? ctx->d_order : nullptr, ctx->d_arena, ctx->d_gsorted,
-                      ctx->d_gridtab, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx,
-                      (lins_pose_record*)d_poses, scan_id_base, ra, ctx->d_walk_cache, ctx->run_gen);
     HIP_TRY(ctx, hipEventRecord(ctx->hist1[h], ctx->stream));
     if (q.on) HIP_TRY(ctx, hipEventRecord(q.ev_main[set], ctx->stream));  // (the pose records of this run are complete)
     // (The Joseph update, SE:594-598, is the update kernel's epilogue since round 3: ieskf_lds_impl.h joseph_epilogue.
@@ -1622,37 +1614,24 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
       // the search index of the last scan's clouds: left by the step before, which re-projected and indexed them in one
       // kernel (step 3 below) — built here only when that step could not (its first scan, another search mode)
       if (!t.index_ready) launch_grid_index(ctx->stream, n, t.d_desc, t.d_arena, t.d_gsorted, t.d_gridtab);
-      HIP_TRY(ctx, hipMemsetAsync(ctx->d_walk_cache, 0xFF, (size_t)n * LINS_MAX_QUERY * 32, ctx->stream));  // (slot_base = k * LINS_MAX_QUERY)
       if (use_mr) {
-        // several-part updates as in lins_batch_run (the relay): more streams than workgroup slots
+        // several-part updates as in lins_batch_run (the relay + work queue): more streams than workgroup slots
         RelayArgs ra;
-        const bool cut_ok = n > 2 * ctx->n_cu && ctx->prm.icp_freq == 1 && ctx->d_relay_hdr && ctx->relay_at > 0 && ctx->relay_at < ctx->prm.num_iter;
-        if (cut_ok) {
-          ra.at = ctx->relay_at;
-          ra.parts = ra.launched = std::min(kRelayMaxParts, (ctx->prm.num_iter + ctx->relay_at - 1) / ctx->relay_at);
-        }
-        const bool relay = ra.parts > 1;
+        const bool relay = n > ctx->queue_grid && ctx->prm.icp_freq == 1 && ctx->d_relay_hdr && ctx->relay_at > 0 && ctx->relay_at < ctx->prm.num_iter;
         // launch order as in the batch calls: longest-expected-first by the prior's translation (launch_order above;
         // h_state holds this step's priors)
-        const bool ordered = ctx->use_order && n > 2 * ctx->n_cu;
-        if (ordered) launch_order(ctx, n);
-        if (ordered && !relay) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->h_order, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        if (relay) {
-          if (ctx->relay_gen >= (1 << 26)) {
-            HIP_TRY(ctx, hipMemsetAsync(ctx->d_relay_flag, 0, (size_t)ctx->max_batch * sizeof(int), ctx->stream));
-            ctx->relay_gen = 0;
-          }
-          int* list = ctx->h_order + n;  // the launch list: every part 0, then every part 1, ... (the batch calls rebuild theirs)
-          for (int p = 0; p < ra.launched; ++p)
-            for (int k = 0; k < n; ++k) list[p * n + k] = (ordered ? ctx->h_order[k] : k) | (p << 27);
-          HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order + n, list, (size_t)ra.launched * n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-          ctx->relay_list_parts = -1;
-          ra.gen = ++ctx->relay_gen, ra.spins = ctx->relay_spins;
-          ra.hdr = ctx->d_relay_hdr, ra.lane = ctx->d_relay_lane, ra.flag = ctx->d_relay_flag, ra.err = ctx->h_relay_err;
+        const bool ordered = ctx->use_order && n > ctx->queue_grid;
+        if (ordered) {
+          launch_order(ctx, n);
+          HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->h_order, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         }
-        launch_lds_mr(ctx->stream, n, ctx->dprm, t.d_desc, relay ? ctx->d_order + n : (ordered ? ctx->d_order : nullptr), t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in,
+        if (relay) {
+          const int rcq = relay_prepare(ctx, n, ordered, ra);
+          if (rcq) return rcq;
+        }
+        launch_lds_mr(ctx->stream, n, ctx->dprm, t.d_desc, relay ? ctx->d_order + ctx->max_batch : (ordered ? ctx->d_order : nullptr), t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in,
                       ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr, relay ? &ra : nullptr,
-                      ctx->d_walk_cache, ++ctx->run_gen);
+                      ctx->d_walk_cache, next_run_gen(ctx));
       } else
         launch_lds(ctx->stream, n, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, t.d_desc, t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in,
                    ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr);
@@ -1852,9 +1831,12 @@ int lins_sync(lins_ctx* ctx) {
   int rc = pipe_join(ctx);  // (side streams of the pipelined mode: ordered before the wait below)
   if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->h_relay_err && *ctx->h_relay_err) {  // (the tail kernel met a scan that was neither handed over nor finished)
-    ctx->hip_err = "several-part update: a scan reached the tail kernel without its hand-over";
+  if (ctx->h_relay_err && *ctx->h_relay_err) {  // (a persistent workgroup's wait at the work queue ran out: results may be missing)
+    ctx->hip_err = "several-part update: a part's wait for its hand-over ran out (a workgroup of the launch was lost)";
+    ctx->queue_timeouts += *ctx->h_relay_err;
     *ctx->h_relay_err = 0;
+    (void)hipMemset(ctx->d_queue, 0, (lds_mr_queue_flags_offset() + (size_t)ctx->max_batch) * sizeof(int));  // (counters and flags start over)
+    ctx->relay_gen = 0;
     return LINS_E_HIP;
   }
   return LINS_OK;

@@ -356,7 +356,8 @@ class IeskfContext:
         return ms.value
 
     def last_cut(self):
-        """(parts, tail_kernel) of the last run(): pieces every update was cut into, and whether the last ran as the tail kernel."""
+        """(parts, queue_timeouts): pieces every update of the last run() was cut into (1 = whole updates), and the waits at
+        the work queue that ran out over the life of the context (0 in a healthy process)."""
         parts, tail = C.c_int(0), C.c_int(0)
         self._check(lib().lins_last_cut(self._h, C.byref(parts), C.byref(tail)))
         return parts.value, tail.value

@@ -238,12 +238,11 @@ def _same_bits(a, b):
     assert a.residual_norm == b.residual_norm and a.update_norm == b.update_norm
 
 
-def _run_cut(ieskf, monkeypatch, prm, batch, relay_at, tail_at, runs=2, **knobs):
-    """One context with the given cut settings (debug knobs): results + (parts, tail_kernel) of the last run."""
+def _run_cut(ieskf, monkeypatch, prm, batch, relay_at, runs=2, **knobs):
+    """One context with the given cut setting (debug knob): results + (parts, queue timeouts) of the last run."""
     monkeypatch.setenv("LINS_ENABLE_DEBUG_KNOBS", "1")
     monkeypatch.setenv("LINS_RELAY_AT", str(relay_at))
-    monkeypatch.setenv("LINS_TAIL_AT", str(tail_at))
-    for k in ("LINS_RELAY_SCRAMBLE", "LINS_RELAY_SPINS"):
+    for k in ("LINS_RELAY_SPINS", "LINS_QUEUE_GRID", "LINS_RELAY_CUTS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in knobs.items():
         monkeypatch.setenv(k, str(v))
@@ -256,34 +255,33 @@ def _run_cut(ieskf, monkeypatch, prm, batch, relay_at, tail_at, runs=2, **knobs)
         return c.download(), c.last_cut()
 
 
+def _max_parts(num_iter, at, cuts=2):
+    """relay_max_parts of csrc/ieskf_device.h: cuts at k x at for k = 1 .. cuts, while they lie inside the update."""
+    return 1 + sum(1 for k in range(1, cuts + 1) if k * at < num_iter)
+
+
 @pytest.mark.parametrize("stop_rule", [False, True])
 def test_two_part_updates_return_the_whole_updates_bits(pkg, ieskf, host, monkeypatch, stop_rule):
     """Batches beyond the device's workgroup slots run every update in parts that hand the loop state over through
-    global memory: consecutive workgroups of the batch kernel's launch (LINS_RELAY_AT iterations each) and / or the TAIL
-    kernel — the iterations from LINS_TAIL_AT on as a second launch, 256-thread workgroups that keep the carried state
-    of every query in LDS and walk the head's wave-rounds two per wave.  Same arithmetic in the same order: the
-    results are the whole updates' (both knobs 0) bit for bit — with fixed iterations and with the reference's stop
-    rule (updates that end before a cut never start the next part), run twice per context (the per-scan flags are
+    global memory; the launch has one workgroup per (scan, part), which draws its item by ticket.  Same arithmetic in
+    the same order: the results are the whole updates' (knob 0) bit for bit — with fixed iterations and with the
+    reference's stop rule (the later parts of an update that ended early find nothing to do), with two to five cuts,
+    run twice per context (the ticket counters are left at zero by the last workgroup out, the per-scan flags are
     numbered by launch, never reset).  601 scans: consecutive parts of a scan sit on different XCDs."""
     prm = pkg.default_params(num_iter=30) if stop_rule else pkg.default_params(num_iter=10, fixed_iters=1)
     batch = host.synth_batch(601, start=9000)
-    whole, cut0 = _run_cut(ieskf, monkeypatch, prm, batch, 0, 0)
+    whole, cut0 = _run_cut(ieskf, monkeypatch, prm, batch, 0)
     assert cut0 == (1, 0)
-    #            relay_at, tail_at -> (parts, tail kernel)
-    for at, tail_at, want in ((5, 0, None), (2, 0, None), (9, 0, None),  # parts of the batch kernel's launch only
-                              (4, 4, (2, 1)), (2, 4, (3, 1)), (3, 6, (3, 1)), (0, 5, (2, 1)), (4, 7, (2, 1))):
-        got, cut = _run_cut(ieskf, monkeypatch, prm, batch, at, tail_at)
-        if want is not None:
-            assert cut == want, (at, tail_at, cut)
-        else:
-            assert cut[0] > 1 and cut[1] == 0
+    for at, cuts in ((5, 2), (2, 2), (9, 2), (4, 2), (3, 5), (2, 14)):
+        got, cut = _run_cut(ieskf, monkeypatch, prm, batch, at, LINS_RELAY_CUTS=cuts)
+        assert cut == (_max_parts(prm.num_iter, at, cuts), 0), (at, cuts, cut)
         for a, b in zip(whole, got):
             _same_bits(a, b)
 
 
 def test_default_cut_of_a_large_batch(pkg, ieskf, host):
-    """What a caller gets without any knob: parts of four iterations inside the batch kernel's launch, no tail kernel
-    (measured slower); a batch within the device's workgroup slots: whole updates."""
+    """What a caller gets without any knob: cuts at iterations 4 and 8 of ten; a batch within the device's workgroup
+    slots: whole updates, one workgroup per scan."""
     prm = pkg.default_params(num_iter=10, fixed_iters=1)
     batch = host.synth_batch(520, start=12000)
     with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384) as c:
@@ -299,31 +297,92 @@ def test_default_cut_of_a_large_batch(pkg, ieskf, host):
     assert all(x.iters == 10 for x in r)
 
 
-def test_parts_handed_out_in_the_wrong_order_degrade_to_whole_updates(pkg, ieskf, host, monkeypatch):
-    """HIP promises nothing about the order workgroups are handed out in.  LINS_RELAY_SCRAMBLE=1 lists every part in
-    front of the part it waits for — the worst case: the waiting workgroups fill the device before any first part is
-    resident.  Each gives up after its bounded wait (LINS_RELAY_SPINS, shortened here) and runs the whole update alone:
-    the launch ends, the results are the whole updates' bits (round 3 ended such a wait in __builtin_trap())."""
-    prm = pkg.default_params(num_iter=10, fixed_iters=1)
-    batch = host.synth_batch(601, start=9000)
-    whole, _ = _run_cut(ieskf, monkeypatch, prm, batch, 0, 0, runs=1)
-    for at, tail_at in ((2, 0), (2, 4)):
-        got, cut = _run_cut(ieskf, monkeypatch, prm, batch, at, tail_at, runs=2, LINS_RELAY_SCRAMBLE=1, LINS_RELAY_SPINS=64)
-        assert cut[0] > 1
-        for a, b in zip(whole, got):
-            _same_bits(a, b)
+def test_a_competing_context_saturating_the_device_changes_no_bit(pkg, ieskf, host, monkeypatch):
+    """HIP promises nothing about the order workgroups are handed out in, and a production process shares the device.
+    While a second context on its own stream keeps every CU busy with several-part launches of its own, this context's
+    several-part updates — whose workgroups then start late, interleaved with the other launch's and in no order
+    anybody planned — return the bits of undisturbed whole updates, no wait for a hand-over runs out on either side
+    (lins_last_cut), and nothing is run twice (there is no fallback path: rounds 3-4 re-ran whole updates when a
+    hand-over was late).  Fixed iterations and the stop rule."""
+    import threading
+
+    for prm in (pkg.default_params(num_iter=10, fixed_iters=1), pkg.default_params(num_iter=30)):
+        batch = host.synth_batch(601, start=9000)
+        whole, _ = _run_cut(ieskf, monkeypatch, prm, batch, 0, runs=1)
+        other = host.synth_batch(700, start=15000)
+        monkeypatch.setenv("LINS_ENABLE_DEBUG_KNOBS", "1")
+        monkeypatch.setenv("LINS_RELAY_AT", "2")
+        stop = threading.Event()
+        side = {}
+
+        def hammer():
+            with ieskf.IeskfContext(prm, max_batch=len(other), max_targets=16384, search="mr") as c2:
+                c2.upload(other)
+                first = None
+                n_runs = 0
+                while not stop.is_set() or n_runs < 2:
+                    c2.run()
+                    c2.sync()
+                    n_runs += 1
+                    got = c2.download()
+                    if first is None:
+                        first = got
+                    else:
+                        for a, b in zip(first, got):
+                            _same_bits(a, b)
+                side["cut"], side["runs"] = c2.last_cut(), n_runs
+
+        th = threading.Thread(target=hammer)
+        th.start()
+        try:
+            with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384, search="mr") as c:
+                c.upload(batch)
+                for _ in range(6):
+                    c.run()
+                    c.sync()
+                    for a, b in zip(whole, c.download()):
+                        _same_bits(a, b)
+                cut = c.last_cut()
+        finally:
+            stop.set()
+            th.join()
+        assert cut == (_max_parts(prm.num_iter, 2), 0) and side["cut"][1] == 0 and side["runs"] >= 2
 
 
-def test_certificates_in_the_tail_kernel_never_disagree_with_a_real_search(pkg, ieskf, host, monkeypatch):
-    """LINS_DEBUG_SKIP=8 (search anyway, count disagreements on device) through head + tail: the KNOBS instantiations of
-    both kernels, the counters travelling in the hand-over."""
+def test_a_lost_hand_over_ends_the_launch_and_is_reported(pkg, ieskf, host, monkeypatch):
+    """A part's wait for its hand-over is bounded.  With the bound at zero polls (debug knob) a part that starts before
+    the part in front of it has handed over leaves at once: the launch ends — nothing spins for ever on a device that
+    lost a workgroup — and lins_sync reports it instead of returning partial results, and lins_last_cut counts it; a
+    fresh context is clean."""
     prm = pkg.default_params(num_iter=10, fixed_iters=1)
     batch = host.synth_batch(601, start=9000)
-    plain, _ = _run_cut(ieskf, monkeypatch, prm, batch, 4, 4, runs=1)
+    whole, _ = _run_cut(ieskf, monkeypatch, prm, batch, 0, runs=1)
+    monkeypatch.setenv("LINS_ENABLE_DEBUG_KNOBS", "1")
+    monkeypatch.setenv("LINS_RELAY_AT", "2")
+    monkeypatch.setenv("LINS_RELAY_SPINS", "0")
+    with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384, search="mr") as c:
+        c.upload(batch)
+        c.run()
+        with pytest.raises(ieskf.LinsError):
+            c.sync()
+        assert c.last_cut()[1] > 0
+    monkeypatch.delenv("LINS_RELAY_SPINS")
+    got, cut = _run_cut(ieskf, monkeypatch, prm, batch, 2, runs=1)
+    assert cut[1] == 0
+    for a, b in zip(whole, got):
+        _same_bits(a, b)
+
+
+def test_certificates_across_the_cuts_never_disagree_with_a_real_search(pkg, ieskf, host, monkeypatch):
+    """LINS_DEBUG_SKIP=8 (search anyway, count disagreements on device) through several-part updates: the KNOBS
+    instantiation of the batch kernel, the counters travelling in the hand-over."""
+    prm = pkg.default_params(num_iter=10, fixed_iters=1)
+    batch = host.synth_batch(601, start=9000)
+    plain, _ = _run_cut(ieskf, monkeypatch, prm, batch, 4, runs=1)
     monkeypatch.setenv("LINS_DEBUG_SKIP", "8")
-    got, cut = _run_cut(ieskf, monkeypatch, prm, batch, 4, 4, runs=1)
+    got, cut = _run_cut(ieskf, monkeypatch, prm, batch, 4, runs=1)
     monkeypatch.delenv("LINS_DEBUG_SKIP")
-    assert cut == (2, 1)
+    assert cut == (3, 0)
     for a, b in zip(plain, got):
         assert b.reserved[0] == 0, f"{b.reserved[0]} certificate disagreements"
         assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov)
@@ -331,7 +390,7 @@ def test_certificates_in_the_tail_kernel_never_disagree_with_a_real_search(pkg, 
     assert sum(a.reserved[1] + a.reserved[2] for a in plain) > 100 * len(batch)
 
 
-@pytest.mark.parametrize("search,n", [("mr", 601), ("mr", 96), ("lds1", 24)])
+@pytest.mark.parametrize("search,n", [("mr", 601), ("mr", 96)])  # (the kernels that have the cache: the batch shape)
 def test_walk_cache_never_changes_a_bit_and_saves_walks(pkg, ieskf, host, monkeypatch, search, n):
     """The one-lane-per-query kernels keep, per query, the second / third points (and their certificates) of the nearest
     neighbour the query had BEFORE: a query on the bisector of two target points flips between them from iteration to
@@ -366,7 +425,7 @@ def test_icp_freq_above_one_is_never_cut(pkg, ieskf, host, monkeypatch):
     (ADVICE round 3), and return what a small batch of the same scans returns."""
     prm = pkg.default_params(num_iter=9, fixed_iters=1, icp_freq=2)
     batch = host.synth_batch(603, start=9000)
-    got, cut = _run_cut(ieskf, monkeypatch, prm, batch, 2, 4, runs=1)
+    got, cut = _run_cut(ieskf, monkeypatch, prm, batch, 2, runs=1)
     assert cut == (1, 0)
     with ieskf.IeskfContext(prm, max_batch=64, max_targets=16384, search="mr") as c:
         c.upload(batch[:64])

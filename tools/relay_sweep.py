@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Kernel time of the batch kernel against the iteration its updates are cut at (LINS_RELAY_AT; 0 = whole updates).
-usage: tools/relay_sweep.py [batch] [at ...]   (one process, contexts alternated: boxes differ by a few per cent)"""
+"""Kernel time of the batch kernel against the iterations its updates are cut at (LINS_RELAY_AT, LINS_RELAY_CUTS: cuts at
+at, 2 at, ... cuts x at; 0 = whole updates).
+usage: tools/relay_sweep.py [batch] [at[:cuts] ...]   (one process, contexts alternated: boxes differ by a few per cent)"""
 import importlib
 import os
 import sys
@@ -25,7 +26,11 @@ prm = pkg.default_params(num_iter=iters, fixed_iters=fixed)
 os.environ["LINS_ENABLE_DEBUG_KNOBS"] = "1"
 ctxs = {}
 for at in ats:
-    os.environ["LINS_RELAY_AT"] = at
+    os.environ["LINS_RELAY_AT"] = at.partition(":")[0]
+    if at.partition(":")[2]:
+        os.environ["LINS_RELAY_CUTS"] = at.partition(":")[2]
+    else:
+        os.environ.pop("LINS_RELAY_CUTS", None)
     c = ieskf.IeskfContext(prm, max_batch=batch, max_targets=16384, search="mr")
     c.upload(pairs)
     ctxs[at] = c
