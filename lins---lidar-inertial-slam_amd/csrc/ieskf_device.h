@@ -69,6 +69,7 @@ __host__ __device__ inline int relay_max_parts(int num_iter, int at, int max_cut
 // is cut (relay_next_cut) into `parts` parts; the launch has one workgroup per (scan, part), which draws its item by ticket.
 struct RelayArgs {
   int at = 0, cuts = 0, parts = 0, gen = 0;
+  int cap = 0;            // scans the flag array holds
   int spins = 1 << 21;    // polls (~1 us each) a part waits for its hand-over before it gives up (reported by lins_sync)
   double* hdr = nullptr;  // per scan: 64 doubles of loop state
   int* lane = nullptr;    // per scan: the carried state of every query lane (ieskf_lds_impl.h CarryWords)

@@ -112,6 +112,7 @@ struct KernelArgs {
   unsigned* walk_cache;  // per query slot 8 words: the second / third points of the nearest neighbour the query had BEFORE (walk cache below); may be null
   int run_gen;           // number of this launch (tags of the walk cache: an entry of an earlier launch does not count)
   int iter_arg, scan_id_base, relay_n, relay_at, relay_cuts, relay_gen;
+  int relay_cap;    // scans the context's flag array holds (the debug trace lies behind it)
   int relay_spins;  // polls of ~1 us a part waits for its hand-over before it gives up (and the launch reports it)
 };
 typedef const KernelArgs __attribute__((address_space(4))) * ColdArgs;
@@ -1159,7 +1160,11 @@ __device__ __forceinline__ void relay_raise(int* p, int v) { __hip_atomic_fetch_
 // (Round 5 also built the other obvious design — a FIFO of continuations pushed by the workgroup that produced them,
 // drawn in push order, persistent or not — and measured it slower: 0.602 against 0.567 ms per 1024 scans x 10
 // iterations, 1.014 against 0.988 ms under the stop rule, profiles/r05_batch_kernel_variants.md: push order is
-// shortest-part-first, which is the wrong way round for the end of the launch; the list keeps longest-expected-first.)
+// shortest-part-first, which is the wrong way round for the end of the launch; the list keeps longest-expected-first.
+// And a priority FIFO on top of the list for the parts an update still runs behind its second cut — under the stop rule
+// those are the 30-iteration updates that end the launch: once its claims cost three atomics instead of a
+// compare-and-swap loop it neither gained nor lost, 0.979 against 0.981 ms: what ends the launch is the CHAIN of the
+// slowest of those updates, 22 iterations of ~25 us behind a second cut that cannot come before ~0.34 ms.  Not kept.)
 constexpr int kQHead = 0, kQExited = 32, kQFlags = 64;  // (ints; the counters on lines of their own)
 
 // The per-query loop state a part hands to the next: the
@@ -2057,6 +2062,10 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   constexpr bool kQueue = BLOCK == 512 && LANES == 1 && !PASS_ONLY && !ICP;  // (the shape that has the relay)
   const bool queued = kQueue && ka.relay_n > 0;  // (uniform) a workgroup of a ticketed batch launch, see "work items" above
   int item;  // scan | part << 27; -1: nothing to do
+#ifdef LINS_QUEUE_TRACE  // (debug builds, tools/queue_trace.py: per workgroup start / item in hand / end on the 100 MHz clock)
+  const long long qt0 = wall_clock64();
+  long long qt1 = qt0;
+#endif
   if (kQueue && queued) {
     if (threadIdx.x == 0) {
       int* const Q = ka.queue;
@@ -2079,6 +2088,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     }
     __syncthreads();
     item = g_lds.scan_tmp[0];
+#ifdef LINS_QUEUE_TRACE
+    qt1 = wall_clock64();
+#endif
     __syncthreads();  // (scan_tmp is the update's from here)
   } else {
     // one workgroup per scan, in the host's launch order (lins_capi.hip launch_order: longest-expected-first, so that
@@ -2089,6 +2101,12 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     ieskf_lds_update<BLOCK, LANES, PASS_ONLY, PROF, ICP, KNOBS>(ka, arena, sorted, idx_store, dump, item & 0x7FFFFFF, kQueue ? item >> 27 : 0);
   if (kQueue && queued && threadIdx.x == 0) {  // the last workgroup out leaves the counters at zero for the next launch
     int* const Q = cold_args()->queue;
+#ifdef LINS_QUEUE_TRACE
+    {
+      long long* tr = reinterpret_cast<long long*>(Q + kQFlags + cold_args()->relay_cap) + 4 * (size_t)blockIdx.x;
+      tr[0] = qt0, tr[1] = qt1, tr[2] = wall_clock64(), tr[3] = item;
+    }
+#endif
     if (relay_add(Q + kQExited, 1) == (int)gridDim.x - 1) relay_st(Q + kQHead, 0), relay_st(Q + kQExited, 0);
   }
 }

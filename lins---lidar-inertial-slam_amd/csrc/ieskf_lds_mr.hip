@@ -74,7 +74,7 @@ void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDe
   int grid = n;
   ka.walk_cache = walk_cache, ka.run_gen = run_gen;
   if (relay) {
-    ka.relay_n = n, ka.relay_at = relay->at, ka.relay_cuts = relay->cuts, ka.relay_gen = relay->gen, ka.relay_spins = relay->spins;
+    ka.relay_n = n, ka.relay_at = relay->at, ka.relay_cuts = relay->cuts, ka.relay_gen = relay->gen, ka.relay_spins = relay->spins, ka.relay_cap = relay->cap;
     ka.relay_hdr = relay->hdr, ka.relay_lane = relay->lane, ka.queue = relay->queue, ka.relay_err = relay->err;
     grid = relay->parts * n;
   }

@@ -589,11 +589,14 @@ int next_run_gen(lins_ctx* ctx) {
 // Several-part updates of a launch of n scans on the batch kernel: the cuts, the launch's number, the list of its
 // (scan, part) items on the device — every part 0 in launch order, then every part 1, ... — and the ticket counters and
 // flags (RelayArgs; ieskf_lds_impl.h "work items").  `listed`: the launch order of these n scans is on the device.
+size_t queue_ints(const lins_ctx* ctx) {  // counters, one flag per scan, the debug trace (8 ints per workgroup, <= 15 per scan)
+  return (size_t)lds_mr_queue_flags_offset() + (size_t)ctx->max_batch * (1 + 15 * 8);
+}
 int relay_prepare(lins_ctx* ctx, int n, bool ordered, RelayArgs& ra) {
   ra.at = ctx->relay_at, ra.cuts = ctx->relay_cuts;
   ra.parts = relay_max_parts(ctx->prm.num_iter, ra.at, ra.cuts);
   if (ctx->relay_gen >= (1 << 26)) {  // (flags are 16 gen + part: start over long before the int runs out)
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, (lds_mr_queue_flags_offset() + (size_t)ctx->max_batch) * sizeof(int), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_queue, 0, queue_ints(ctx) * sizeof(int), ctx->stream));
     ctx->relay_gen = 0;
   }
   if (ctx->relay_list_parts != ra.parts || ctx->relay_list_n != n) {
@@ -603,7 +606,7 @@ int relay_prepare(lins_ctx* ctx, int n, bool ordered, RelayArgs& ra) {
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order + ctx->max_batch, list, (size_t)ra.parts * n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     ctx->relay_list_parts = ra.parts, ctx->relay_list_n = n;
   }
-  ra.gen = ++ctx->relay_gen, ra.spins = ctx->relay_spins;
+  ra.gen = ++ctx->relay_gen, ra.spins = ctx->relay_spins, ra.cap = ctx->max_batch;
   ra.hdr = ctx->d_relay_hdr, ra.lane = ctx->d_relay_lane, ra.queue = ctx->d_queue, ra.err = ctx->h_relay_err;
   return LINS_OK;
 }
@@ -754,8 +757,8 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
     CREATE_TRY(hipMalloc((void**)&ctx->d_relay_hdr, (size_t)ctx->max_batch * 64 * sizeof(double)));
     CREATE_TRY(hipHostMalloc((void**)&ctx->h_relay_err, sizeof(int)));
     *ctx->h_relay_err = 0;
-    CREATE_TRY(hipMalloc((void**)&ctx->d_queue, (lds_mr_queue_flags_offset() + (size_t)ctx->max_batch) * sizeof(int)));
-    CREATE_TRY(hipMemset(ctx->d_queue, 0, (lds_mr_queue_flags_offset() + (size_t)ctx->max_batch) * sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&ctx->d_queue, queue_ints(ctx) * sizeof(int)));
+    CREATE_TRY(hipMemset(ctx->d_queue, 0, queue_ints(ctx) * sizeof(int)));
   } else {
     ctx->relay_at = 0;
   }
@@ -1156,6 +1159,18 @@ int lins_debug_phase_profile(lins_ctx* ctx, int enable, long long* out, int n_sc
     (void)hipFree(ctx->d_prof);
     ctx->d_prof = nullptr;
   }
+  return LINS_OK;
+}
+
+/* Debug aid (libraries built with -DLINS_QUEUE_TRACE=1, a several-part run): per workgroup of the last launch, in
+ * workgroup-index order, four words: start, item in hand, end (100 MHz wall clock) and the item (scan | part << 27, -1 =
+ * none: the later part of an update that had ended).                                                                  */
+int lins_debug_queue_trace(lins_ctx* ctx, long long* out, int n_wg) {
+  if (!ctx || !out || n_wg < 0) return LINS_E_ARG;
+  if (!ctx->d_queue || n_wg > 15 * ctx->max_batch) return LINS_E_STATE;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipMemcpy(out, ctx->d_queue + lds_mr_queue_flags_offset() + (size_t)ctx->max_batch, (size_t)n_wg * 32, hipMemcpyDeviceToHost));
   return LINS_OK;
 }
 
@@ -1835,7 +1850,7 @@ int lins_sync(lins_ctx* ctx) {
     ctx->hip_err = "several-part update: a part's wait for its hand-over ran out (a workgroup of the launch was lost)";
     ctx->queue_timeouts += *ctx->h_relay_err;
     *ctx->h_relay_err = 0;
-    (void)hipMemset(ctx->d_queue, 0, (lds_mr_queue_flags_offset() + (size_t)ctx->max_batch) * sizeof(int));  // (counters and flags start over)
+    (void)hipMemset(ctx->d_queue, 0, queue_ints(ctx) * sizeof(int));  // (counters and flags start over)
     ctx->relay_gen = 0;
     return LINS_E_HIP;
   }

@@ -27,10 +27,10 @@ os.environ["LINS_ENABLE_DEBUG_KNOBS"] = "1"
 ctxs = {}
 for at in ats:
     os.environ["LINS_RELAY_AT"] = at.partition(":")[0]
-    if at.partition(":")[2]:
-        os.environ["LINS_RELAY_CUTS"] = at.partition(":")[2]
-    else:
-        os.environ.pop("LINS_RELAY_CUTS", None)
+    f = at.split(":")  # at[:cuts]
+    os.environ.pop("LINS_RELAY_CUTS", None)
+    if len(f) > 1:
+        os.environ["LINS_RELAY_CUTS"] = f[1]
     c = ieskf.IeskfContext(prm, max_batch=batch, max_targets=16384, search="mr")
     c.upload(pairs)
     ctxs[at] = c
