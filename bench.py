@@ -114,6 +114,98 @@ def two_batches_in_flight(pkg, ieskf, pairs, args, max_targets):
             "note": "two contexts, launches alternated, one wait at the end; wall clock"}
 
 
+def scene_b_block(pkg, ieskf, host, args, workers):
+    """The second scene family (csrc/host/synth.cpp "open": open ground, ~60 trunks, far wall segments, 30 % of the returns
+    lost, a moving box): the same step on a batch of it — rate, kernel time, fraction of the HBM roofline on ITS algorithmic
+    bytes, the kernel family `auto` chose, how many selections the certificates decided without a search, and a sample of
+    the batch against the CPU oracle.  VERDICT r04: everything before round 5 ran one scene family."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(workers) as ex:
+        pairs = list(ex.map(lambda i: host.synth_pair(i, scene=1), range(50000, 50000 + args.batch)))
+    sizes = np.array([p.sizes() for p in pairs], dtype=np.float64)
+    alg = float(sum(p.bytes_per_iter() for p in pairs)) * args.iters
+    prm = pkg.default_params(num_iter=args.iters, fixed_iters=1)
+    with ieskf.IeskfContext(prm, max_batch=len(pairs), max_targets=16384, search=args.search) as c:
+        c.upload(pairs)
+        for _ in range(3):
+            c.run()
+        c.sync()
+        n = max(args.steps, 10)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            c.run()
+        c.sync()
+        dt = (time.perf_counter() - t0) / n
+        k_ms = float(np.mean(c.kernel_ms_history(min(n, 64))))
+        res = c.download()
+        search = c.last_search()
+    out = {"workload": f"{len(pairs)} scan pairs of the open scene family x {args.iters} fixed iterations",
+           "mean_sizes": {"n_sharp": float(sizes[:, 0].mean()), "n_flat": float(sizes[:, 1].mean()),
+                          "n_less_sharp_last": float(sizes[:, 2].mean()), "n_less_flat_last": float(sizes[:, 3].mean())},
+           "iterations_per_s": len(pairs) * args.iters / dt, "ms_per_step": dt * 1e3, "kernel_ms": k_ms, "lins_last_search": search,
+           "roofline": {"bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg},
+           # per query and search iteration: selections decided between the two tracked candidates, no search / no walk
+           "certified": {"nn_per_scan": float(np.mean([r.reserved[1] for r in res])), "walks_per_scan": float(np.mean([r.reserved[2] for r in res])),
+                         "queries_per_scan": float((sizes[:, 0] + sizes[:, 1]).mean()),
+                         "note": "counted by the production kernel over the 10 iterations of an update (the cold iteration certifies nothing)"},
+           "diverged_scans": int(sum(r.diverged for r in res))}
+    if not args.no_cpu:
+        from oracle import oracle
+
+        k = min(64, len(pairs))
+        with ThreadPoolExecutor(workers) as ex:
+            want = list(ex.map(lambda p: oracle.ieskf(prm, p, oracle.FORM_REDUCED, oracle.NN_KDTREE), pairs[:k]))
+        ok = all((g.iters, g.diverged, g.m_surf, g.m_corner) == (w.iters, w.diverged, w.m_surf, w.m_corner) for g, w in zip(res, want))
+        dp = max(float(np.abs(g.state[:3] - w.state[:3]).max()) for g, w in zip(res, want))
+        dc = max(float(np.abs(g.cov - w.cov).max() / np.abs(w.cov).max()) for g, w in zip(res, want))
+        out["parity_checked"] = {"scans": k, "ok": bool(ok and dp <= 1e-6 and dc <= 1e-9), "max_dp_m": dp, "max_rel_dP": dc, "against": "oracle (reduced form, kd-tree)"}
+    return out
+
+
+def rotating_inputs_block(pkg, ieskf, host, pairs, args, workers, max_targets):
+    """The timed step re-runs ONE resident batch (147 MB of clouds against a 256 MB Infinity Cache): a deployment streams new
+    scans.  Four different batches resident in HBM in four contexts, run in turn (a host wait after every launch, kernel
+    time by HIP events), against the same pattern on one batch: 4 x 147 MB walk through the cache between two launches
+    on the same clouds, so every launch reads its clouds from HBM."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+
+    prm = pkg.default_params(num_iter=args.iters, fixed_iters=1)
+    n = len(pairs)
+    with ThreadPoolExecutor(workers) as ex:
+        more = list(ex.map(host.synth_pair, range(60000, 60000 + 3 * n)))
+    batches = [pairs, more[:n], more[n:2 * n], more[2 * n:]]
+    ctxs = [ieskf.IeskfContext(prm, max_batch=n, max_targets=max(max_targets, 16384), search=args.search) for _ in batches]
+    try:
+        for c, b in zip(ctxs, batches):
+            c.upload(b)
+            c.run()
+            c.sync()
+        rot, same = [], []
+        for _ in range(6):
+            for c in ctxs:
+                c.run()
+                c.sync()
+                rot.append(c.last_kernel_ms())
+        for _ in range(24):
+            ctxs[0].run()
+            ctxs[0].sync()
+            same.append(ctxs[0].last_kernel_ms())
+    finally:
+        for c in ctxs:
+            c.close()
+    r, s0 = float(np.mean(rot[4:])), float(np.mean(same[4:]))
+    return {"batches": len(batches), "scans_per_batch": n, "bytes_of_clouds_per_batch": int(sum(16 * sum(p.sizes()) for p in pairs)),
+            "kernel_ms_rotating": r, "kernel_ms_one_batch": s0, "ratio": r / s0,
+            "note": "kernel time by HIP events, one launch at a time; rotating: four different batches in turn (other scans, so the mean "
+                    "differs by the batches' own work as well: ratio of the first batch's launches alone below)",
+            "kernel_ms_first_batch_when_rotating": float(np.mean(rot[4::4])),
+            "ratio_first_batch": float(np.mean(rot[4::4])) / s0}
+
+
 def single_scan_latency(pkg, ieskf, pair):
     """BASELINE.json configs[2]: ONE scan pair, full on-device loop (the live lins_fusion_node case): kernel time
     of the single-scan kernel and the end-to-end latency of lins_ieskf_update (upload + kernels + download)."""
@@ -227,6 +319,19 @@ def e2e_rates(pkg, ieskf, host, pairs, args):
         dt = float(np.median(ts[2:]))
         out["update_batch_it_s"] = sum(r.iters for r in res) / dt
         out["update_batch_ms"] = dt * 1e3
+        # the same call with the clouds as pcl::PointXYZI arrays (point_stride_bytes 32: no repacking loop in the caller, the
+        # library gathers the payload while it stages) and with the clouds written into the library's pinned staging arena
+        # in the first place (lins_batch_map: no staging copy at all)
+        arr32, keep = defs.pairs_strided(pairs)
+        arrm = c.map_batch(pairs)
+        for key, a in (("update_batch_ms_pcl_stride32", arr32), ("update_batch_ms_mapped_staging", arrm)):
+            ts = []
+            for k in range(6):
+                t0 = time.perf_counter()
+                assert L.lins_ieskf_update_batch(c._h, n, a, res) == 0
+                ts.append(time.perf_counter() - t0)
+            out[key] = float(np.median(ts[2:])) * 1e3
+        del keep
     # as many streams as the batch has scans (1024: the device's workgroup slots are filled as in the headline), built
     # from 256 distinct scan pairs dealt round-robin — the host-side segmentation of a scan costs more than its GPU time
     ns, nd = n, min(n, 256)
@@ -593,6 +698,9 @@ def main():
             out["single_scan"] = single_scan_latency(pkg, ieskf, pairs[0])
             out["two_batches_in_flight"] = two_batches_in_flight(pkg, ieskf, pairs, args, max_targets)
             out["e2e"] = e2e_rates(pkg, ieskf, host, pairs, args)
+            workers = min(16, os.cpu_count() or 1)
+            out["scene_b"] = scene_b_block(pkg, ieskf, host, args, workers)
+            out["rotating_inputs"] = rotating_inputs_block(pkg, ieskf, host, pairs, args, workers, max_targets)
     else:
         out = None
     ctx.close()

@@ -178,6 +178,11 @@ int lins_synth_generate(uint32_t seed, uint32_t scan_index, lins_synth_pair* out
 /* raw distorted cloud of one synthetic scan (k = 0 or 1), firing order        */
 int lins_synth_raw_scan(uint32_t seed, uint32_t scan_index, int k, lins_point* out,
                         int cap);
+/* The same for a scene FAMILY: 0 = the room of SURVEY.md section 8d (what the two calls above generate); 1 = "open":
+ * open ground to the range limit, ~60 trunks, six far wall segments, 30 % of the returns lost, one box that moves at
+ * up to 5 m/s (csrc/host/synth.cpp) — the second workload the parity sweeps and the bench line's scene_b block run.   */
+int lins_synth_generate_scene(int scene, uint32_t seed, uint32_t scan_index, lins_synth_pair* out);
+int lins_synth_raw_scan_scene(int scene, uint32_t seed, uint32_t scan_index, int k, lins_point* out, int cap);
 
 /* A SEQUENCE of scans along one seeded trajectory (a circle inside the synthetic room) with its IMU: what a
  * lins_fusion_node would receive over any number of consecutive sweeps — the input of the in-situ test of the drop-in

@@ -85,9 +85,23 @@ typedef struct lins_scan_pair {
   int32_t n_corner_sharp;
   int32_t n_surf_last;
   int32_t n_corner_last;
+  /* Bytes from one point of the four clouds to the next: 0 or 16 = packed lins_point arrays; 32 = the clouds as the
+   * reference holds them, pcl::PointXYZI (parameters.h:52: x, y, z at bytes 0 / 4 / 8, intensity at byte 16) — pass
+   * `reinterpret_cast<const lins_point*>(cloud->points.data())` and the library reads the 16 payload bytes of every
+   * point where they lie: no repacking loop in the caller (lins_point_load below is the one definition of the access). */
+  int32_t point_stride_bytes;
+  int32_t reserved;
   double state[LINS_STATE_DIM];         /* filter_->state_                      */
   double cov[LINS_ERR_DIM * LINS_ERR_DIM]; /* filter_->covariance_              */
 } lins_scan_pair;
+
+/* Point i of a cloud of a lins_scan_pair with the given point_stride_bytes.                                           */
+static inline lins_point lins_point_load(const lins_point* cloud, int32_t point_stride_bytes, int32_t i) {
+  const float* f = (const float*)((const char*)cloud + (size_t)(point_stride_bytes == 32 ? 32 : 16) * (size_t)i);
+  lins_point p;
+  p.x = f[0], p.y = f[1], p.z = f[2], p.intensity = f[point_stride_bytes == 32 ? 4 : 3];
+  return p;
+}
 
 /* What performIESKF() leaves behind (linState_, Pk_) + the flags the
  * reference keeps in locals (SE:471-474). When diverged != 0, `state`/`cov`
@@ -169,6 +183,14 @@ int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in,
  * lins_batch_run / lins_icp_update_batch / correspondence pass on this upload searches that index.  The host-buffer
  * entry points (lins_ieskf_update, lins_ieskf_update_batch) build it inside the call.                                 */
 int lins_batch_upload(lins_ctx* ctx, int n, const lins_scan_pair* in);
+/* Optional zero-copy staging.  The library sends host clouds from a pinned staging arena; lins_batch_map() lays that
+ * arena out for n scans with the given cloud sizes (counts[4 s + c], c = 0 surf_flat, 1 corner_sharp, 2
+ * surf_less_flat_last, 3 corner_less_sharp_last) and returns where each cloud belongs (clouds[4 s + c], packed 16-byte
+ * points, writable until the next map / upload of this context).  A caller that writes its clouds there — e.g. as the
+ * output buffers of its feature extraction — and passes those very pointers in the lins_scan_pair array of the next
+ * lins_batch_upload / lins_ieskf_update(_batch) call (same n, same sizes) skips the library's copy into the arena:
+ * the points are validated where they lie and sent by DMA.  Any other pointer is copied as before.                  */
+int lins_batch_map(lins_ctx* ctx, int n, const int32_t* counts, lins_point** clouds);
 /* HIP-event time (ms) of the index build of the last upload; 0 when the batch cannot take the grid kernels.          */
 int lins_last_index_ms(lins_ctx* ctx, float* ms);
 /* Runs the full IESKF loop for the uploaded batch on the context's stream.

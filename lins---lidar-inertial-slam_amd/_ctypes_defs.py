@@ -47,6 +47,8 @@ class ScanPairC(C.Structure):
         ("n_corner_sharp", C.c_int32),
         ("n_surf_last", C.c_int32),
         ("n_corner_last", C.c_int32),
+        ("point_stride_bytes", C.c_int32),  # 0 / 16: packed points; 32: pcl::PointXYZI arrays
+        ("reserved", C.c_int32),
         ("state", C.c_double * STATE_DIM),
         ("cov", C.c_double * (ERR_DIM * ERR_DIM)),
     ]
@@ -151,6 +153,23 @@ def pairs_to_c(pairs):
     for i, p in enumerate(pairs):
         p.fill_c(arr[i])
     return arr
+
+
+def pairs_strided(pairs):
+    """The same pairs with their clouds as pcl::PointXYZI lays them out (32 bytes a point: x, y, z, pad, intensity, 3 pads;
+    parameters.h:52) and point_stride_bytes = 32: what a lins_fusion_node passes without repacking.  Returns the ScanPairC
+    array and the arrays that own the memory (keep them alive)."""
+    arr = pairs_to_c(pairs)
+    keep = []
+    for i, p in enumerate(pairs):
+        for name, src in (("surf_flat", p.surf_flat), ("corner_sharp", p.corner_sharp), ("surf_less_flat_last", p.surf_last),
+                          ("corner_less_sharp_last", p.corner_last)):
+            wide = np.full((len(src), 8), np.float32(-77.0))  # (pads hold a value no cloud has: read by mistake, it shows)
+            wide[:, 0:3], wide[:, 4] = src[:, 0:3], src[:, 3]
+            keep.append(wide)
+            setattr(arr[i], name, wide.ctypes.data_as(C.POINTER(Point)))
+        arr[i].point_stride_bytes = 32
+    return arr, keep
 
 
 class Result:

@@ -40,9 +40,9 @@ bool gauss_newton_step(const lins_params& prm, double* t, Q4& q, const lins_scan
     }
   };
   for (int i = 0; i < in.n_surf_flat; ++i)
-    if (cs[i].accepted) add_row(in.surf_flat[i], cs[i]);
+    if (cs[i].accepted) add_row(lins_point_load(in.surf_flat, in.point_stride_bytes, i), cs[i]);
   for (int i = 0; i < in.n_corner_sharp; ++i)
-    if (cc[i].accepted) add_row(in.corner_sharp[i], cc[i]);
+    if (cc[i].accepted) add_row(lins_point_load(in.corner_sharp, in.point_stride_bytes, i), cc[i]);
   double x[6];
   double ws[kIcpWorkspace];
   icp_gn_solve(JTJ, JTb, iter, x, ws);

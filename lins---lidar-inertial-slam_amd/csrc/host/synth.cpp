@@ -20,7 +20,15 @@
 // — are >= 0.005 column (1.7e-5 rad) off them, two orders above any atan2f's error.  (Rounds 1-2 fired at exactly
 // (f + 0.5) * 0.2 deg: every point on a column edge, where the column hangs on the last bit of whichever atan2f is used.)
 // Motion: planar, constant forward speed U(0,10) m/s and yaw rate U(-0.5,0.5).
+//
+// Scene family B (round 5, lins_synth_*_scene(1, ...): "open"): the opposite of the room in everything the search
+// structures and the feature front-end could have been tuned to — no room: open ground to the 100 m range limit (the
+// upper rings see sky); ~60 trunks (vertical cylinders of radius 0.15 .. 0.45 m) scattered over 80 x 80 m; six far wall
+// segments (10 .. 25 m long, 5 m high, 35 .. 70 m away, any orientation); 30 % of the firings that hit something return
+// nothing (seeded per ray); and one 2 x 2 x 2 m box that MOVES at up to 5 m/s — every ray sees it where it is at its
+// own firing time, so its points disagree with the rigid motion the filter estimates.  Same sensor, motion and prior.
 
+#include <array>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -59,7 +67,14 @@ struct Scene {
   double pole[kPoles][2];
   double box[kBoxes][2];
   double x0, y0, yaw0, speed, yaw_rate;
+  // family B ("open"): no room, these instead
+  bool open = false;
+  double drop = 0.0;                       // probability that a ray that hit something returns nothing
+  std::vector<std::array<double, 3>> trunk;  // x, y, radius
+  std::vector<std::array<double, 4>> wall;   // segment x0, y0, x1, y1 (height kFarWallTop)
+  double mbox[4] = {0, 0, 0, 0};           // moving box: position at tau = 0, velocity
 };
+constexpr double kFarWallTop = 3.2;  // (5 m above the ground)
 
 Scene make_scene(uint32_t seed, uint32_t scan_index) {
   Rng r(((uint64_t)seed << 32) ^ (uint64_t)scan_index * 0x9E3779B1u ^ 0xA5A5A5A5ull);
@@ -83,6 +98,39 @@ Scene make_scene(uint32_t seed, uint32_t scan_index) {
   return s;
 }
 
+Scene make_open_scene(uint32_t seed, uint32_t scan_index) {
+  Rng r(((uint64_t)seed << 32) ^ (uint64_t)scan_index * 0x9E3779B1u ^ 0x0B0B0B0B0Bull);
+  Scene s;
+  s.open = true, s.drop = 0.30;
+  s.x0 = r.uni(-5, 5), s.y0 = r.uni(-4, 4), s.yaw0 = r.uni(-M_PI, M_PI);
+  s.speed = r.uni(0, 10), s.yaw_rate = r.uni(-0.5, 0.5);
+  for (auto& p : s.pole) p[0] = p[1] = 1e9;  // (unused: far outside the range limit)
+  for (auto& b : s.box) b[0] = b[1] = 1e9;
+  for (int k = 0; k < 60; ++k)
+    for (;;) {
+      const double x = s.x0 + r.uni(-40, 40), y = s.y0 + r.uni(-40, 40), rad = r.uni(0.15, 0.45);
+      const double dx = x - s.x0, dy = y - s.y0;
+      if (dx * dx + dy * dy < 4.5 * 4.5) continue;  // keep the sensor's 0.2 s path clear
+      s.trunk.push_back({x, y, rad});
+      break;
+    }
+  for (int k = 0; k < 6; ++k) {
+    const double dist = r.uni(35, 70), bearing = r.uni(-M_PI, M_PI), len = r.uni(10, 25), dir = r.uni(-M_PI, M_PI);
+    const double cx = s.x0 + dist * std::cos(bearing), cy = s.y0 + dist * std::sin(bearing);
+    s.wall.push_back({cx - 0.5 * len * std::cos(dir), cy - 0.5 * len * std::sin(dir), cx + 0.5 * len * std::cos(dir), cy + 0.5 * len * std::sin(dir)});
+  }
+  for (;;) {  // the moving box: 6 .. 15 m away at tau = 0, any heading, 1 .. 5 m/s; never within 3 m of the sensor's start
+    const double dist = r.uni(6, 15), bearing = r.uni(-M_PI, M_PI), v = r.uni(1, 5), h = r.uni(-M_PI, M_PI);
+    s.mbox[0] = s.x0 + dist * std::cos(bearing), s.mbox[1] = s.y0 + dist * std::sin(bearing);
+    s.mbox[2] = v * std::cos(h), s.mbox[3] = v * std::sin(h);
+    const double ex = s.mbox[0] + 0.2 * s.mbox[2] - s.x0, ey = s.mbox[1] + 0.2 * s.mbox[3] - s.y0;
+    if (ex * ex + ey * ey > 5.5 * 5.5) break;
+  }
+  return s;
+}
+
+Scene make_scene_of(int family, uint32_t seed, uint32_t scan_index) { return family == 1 ? make_open_scene(seed, scan_index) : make_scene(seed, scan_index); }
+
 // planar pose of the sensor at absolute time tau (since the start of scan 0)
 void pose_at(const Scene& s, double tau, double& x, double& y, double& yaw) {
   double w = s.yaw_rate, v = s.speed;
@@ -97,13 +145,57 @@ void pose_at(const Scene& s, double tau, double& x, double& y, double& yaw) {
   y = s.y0 + std::sin(s.yaw0) * lx + std::cos(s.yaw0) * ly;
 }
 
-// nearest hit distance of the ray o + r d (|d| = 1), or +inf
-double cast(const Scene& s, const double o[3], const double d[3]) {
+// an axis-aligned 2 x 2 x 2 m box standing on the ground at (bx, by): entry distance of the ray, or +inf
+double cast_box(double bx, double by, const double o[3], const double d[3]) {
+  double lo[3] = {bx - kBoxHalf, by - kBoxHalf, kGroundZ};
+  double hi[3] = {bx + kBoxHalf, by + kBoxHalf, kGroundZ + 2 * kBoxHalf};
+  double t0 = 0, t1 = INFINITY;
+  for (int k = 0; k < 3; ++k) {
+    if (std::fabs(d[k]) < 1e-12) {
+      if (o[k] < lo[k] || o[k] > hi[k]) return INFINITY;
+    } else {
+      double ta = (lo[k] - o[k]) / d[k], tb = (hi[k] - o[k]) / d[k];
+      if (ta > tb) std::swap(ta, tb);
+      t0 = std::max(t0, ta), t1 = std::min(t1, tb);
+      if (t0 > t1) return INFINITY;
+    }
+  }
+  return t0;
+}
+
+// nearest hit distance of the ray o + r d (|d| = 1) fired at time tau, or +inf
+double cast(const Scene& s, const double o[3], const double d[3], double tau = 0.0) {
   double best = INFINITY;
   auto consider = [&](double t) {
     if (t > 1e-6 && t < best) best = t;
   };
   if (d[2] < -1e-12) consider((kGroundZ - o[2]) / d[2]);
+  if (s.open) {  // family B: trunks, far wall segments, the moving box
+    const double a2 = d[0] * d[0] + d[1] * d[1];
+    if (a2 > 1e-12)
+      for (auto& p : s.trunk) {
+        const double fx = o[0] - p[0], fy = o[1] - p[1];
+        const double b = fx * d[0] + fy * d[1], c = fx * fx + fy * fy - p[2] * p[2];
+        const double disc = b * b - a2 * c;
+        if (disc < 0) continue;
+        const double t = (-b - std::sqrt(disc)) / a2;
+        if (t <= 0) continue;
+        const double z = o[2] + t * d[2];
+        if (z >= kGroundZ && z <= kWallTop) consider(t);
+      }
+    for (auto& w : s.wall) {  // ray against the vertical rectangle over the segment
+      const double ex = w[2] - w[0], ey = w[3] - w[1];
+      const double den = d[0] * ey - d[1] * ex;
+      if (std::fabs(den) < 1e-12) continue;
+      const double fx = w[0] - o[0], fy = w[1] - o[1];
+      const double t = (fx * ey - fy * ex) / den, u = (fx * d[1] - fy * d[0]) / den;
+      if (t <= 0 || u < 0 || u > 1) continue;
+      const double z = o[2] + t * d[2];
+      if (z >= kGroundZ && z <= kFarWallTop) consider(t);
+    }
+    consider(cast_box(s.mbox[0] + tau * s.mbox[2], s.mbox[1] + tau * s.mbox[3], o, d));
+    return best;
+  }
   // walls (bounded in the other horizontal axis and in z)
   for (int sgn = -1; sgn <= 1; sgn += 2) {
     if (std::fabs(d[0]) > 1e-12) {
@@ -175,9 +267,10 @@ int raw_scan(const Scene& s, uint32_t seed, uint32_t scan_index, int k, lins_poi
       double ds[3] = {std::cos(el) * std::cos(az), std::cos(el) * std::sin(az), std::sin(el)};
       double dw[3] = {std::cos(yaw) * ds[0] - std::sin(yaw) * ds[1], std::sin(yaw) * ds[0] + std::cos(yaw) * ds[1], ds[2]};
       double o[3] = {sx, sy, 0.0};
-      double r = cast(s, o, dw);
+      double r = cast(s, o, dw, tau);
       double nz = noise.gauss();  // always drawn: keeps streams aligned across hits/misses
-      if (!(r < kMaxRange) || r < kMinRange) continue;
+      const bool lost = s.drop > 0 && noise.uni() < s.drop;  // (family B only: the room's streams are what they were)
+      if (!(r < kMaxRange) || r < kMinRange || lost) continue;
       r += 0.02 * nz;
       if (n >= cap) return -1;
       out[n++] = {(float)(r * ds[0]), (float)(r * ds[1]), (float)(r * ds[2]), 0.f};
@@ -242,11 +335,14 @@ void rel_pose(const Scene& s, double t[3], double q[4]) {
 
 extern "C" {
 
-int lins_synth_raw_scan(uint32_t seed, uint32_t scan_index, int k, lins_point* out, int cap) {
-  if (!out || k < 0) return LINS_E_ARG;
-  Scene s = make_scene(seed, scan_index);
+int lins_synth_raw_scan_scene(int scene, uint32_t seed, uint32_t scan_index, int k, lins_point* out, int cap) {
+  if (!out || k < 0 || scene < 0 || scene > 1) return LINS_E_ARG;
+  Scene s = make_scene_of(scene, seed, scan_index);
   int n = raw_scan(s, seed, scan_index, k, out, cap);
   return n < 0 ? LINS_E_CAPACITY : n;
+}
+int lins_synth_raw_scan(uint32_t seed, uint32_t scan_index, int k, lins_point* out, int cap) {
+  return lins_synth_raw_scan_scene(0, seed, scan_index, k, out, cap);
 }
 
 /* scan k (k = 0, 1, ...: the k-th 0.1 s sweep) of sequence `seed`: raw distorted cloud, firing order */
@@ -286,10 +382,12 @@ int lins_synth_seq_truth(uint32_t seed, double tau, double* xyyaw, double* speed
   return LINS_OK;
 }
 
-int lins_synth_generate(uint32_t seed, uint32_t scan_index, lins_synth_pair* out) {
-  if (!out || !out->surf_flat || !out->corner_sharp || !out->surf_last || !out->corner_last)
+int lins_synth_generate(uint32_t seed, uint32_t scan_index, lins_synth_pair* out) { return lins_synth_generate_scene(0, seed, scan_index, out); }
+
+int lins_synth_generate_scene(int scene, uint32_t seed, uint32_t scan_index, lins_synth_pair* out) {
+  if (!out || !out->surf_flat || !out->corner_sharp || !out->surf_last || !out->corner_last || scene < 0 || scene > 1)
     return LINS_E_ARG;
-  Scene s = make_scene(seed, scan_index);
+  Scene s = make_scene_of(scene, seed, scan_index);
   std::vector<lins_point> raw(LINS_CLOUD_MAX);
   FeatBuf last, cur;
   int n0 = raw_scan(s, seed, scan_index, 0, raw.data(), LINS_CLOUD_MAX);

@@ -763,15 +763,17 @@ __device__ __forceinline__ LCloud make_cloud(const LdsStore& L, bool is_surf, co
 // Every move is unconditional on a CLAMPED index (the threads past the end re-copy the last word: same value to the
 // same address), so that nothing ties a read to a branch: written with guards, the compiler sinks each read into its
 // guard and waits for it there — nine dependent HBM round trips instead of one.
-// Out of line on purpose.  Inlined, every in-flight formulation of this copy (clamped or guarded stores, with and
-// without __restrict__, with and without the SLP vectoriser) changed what the 1024 x 3 PASS instantiation's corner
-// walk returns — every second point grid position 0 — while the plain guarded loops, and the same code with a store
-// added in front of the walk's lane merges, did not: a code-generation sensitivity of that instantiation that was not
-// traced to its root (ROCm 7.2 clang).  As a separate function nothing of it is scheduled into the kernel body; the
-// GPU suite (golden pairs, adversarial clouds, reference parity, every search mode) is the guard.
+// Inlined since round 5 (-2 % on the batch kernel: 0.560 against 0.572 ms).  Rounds 3-4 kept it out of line: inlined, the
+// 1024 x 3 correspondence-pass instantiation returned grid position 0 for every second point of the line queries — a wave
+// shuffle of the walk's lane merges (merge_query_lanes<3>) read a lane that was switched off — 23 GPU tests failed, and
+// the cause was narrowed (the copy itself and every s_waitcnt were right in the ISA) but never found.  With the tail
+// kernel and the losing forks removed from this header the same source inlined passes the whole GPU suite (194 tests;
+// LINS_GRID_INLINE=0 is the old guard).  Not root-caused, so it is WATCHED: build() also builds the other variant
+// (ab/canary_grid_noinline.so) and tests/test_gpu_canaries.py runs the tests that found it against both, holding the
+// outcome against tests/canaries.json; the reproduction notes are in tools/repro/README.md.
 template <int BLOCK>
 #ifndef LINS_GRID_INLINE
-#define LINS_GRID_INLINE 0
+#define LINS_GRID_INLINE 1
 #endif
 #if LINS_GRID_INLINE
 __device__ __forceinline__
@@ -1135,7 +1137,15 @@ __device__ __forceinline__ double relay_ld(const double* p) {
 __device__ __forceinline__ int relay_add(int* p, int v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // A scan's flag only ever rises within a launch (16 gen + next part ... 16 gen + 15 = finished): raised with an atomic max.
-__device__ __forceinline__ void relay_raise(int* p, int v) { __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#ifndef LINS_RELAY_RELEASE
+#define LINS_RELAY_RELEASE 0  // (1: the flag is raised with release / read with acquire semantics at agent scope — A/B knob)
+#endif
+__device__ __forceinline__ void relay_raise(int* p, int v) {
+  __hip_atomic_fetch_max(p, v, LINS_RELAY_RELEASE ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int relay_ld_acq(const int* p) {
+  return __hip_atomic_load(p, LINS_RELAY_RELEASE ? __ATOMIC_ACQUIRE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // ---- the work items of a batch launch: tickets (the batch shape only; KernelArgs::queue, relay_n > 0) ---------------------
 // A batch with more scans than the device has workgroup slots is launched with one workgroup per WORK ITEM — (scan, part):
@@ -2082,6 +2092,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
           __builtin_amdgcn_s_sleep(32);
           f = relay_ld(Q + kQFlags + scan);
         }
+        if (LINS_RELAY_RELEASE && f == want) f = relay_ld_acq(Q + kQFlags + scan);  // (the acquire that pairs with the raise)
         if (f != want) it = -1;  // the scan is finished (stop rule, divergence) — or the wait ran out
       }
       g_lds.scan_tmp[0] = it;

@@ -309,6 +309,7 @@ int pipe_join(lins_ctx* ctx) {
 // input contract: finite fields, int(intensity) in [0, LINS_MAX_RING) — the relative-time
 // fraction may be slightly negative (SE:631-650 produces -0.025..0.125), and C truncation
 // maps (-1, 0) to ring 0 exactly as the reference's int() does; reports ring-sortedness
+// (packed 16-byte points: the arena's own layout — also what a strided cloud is checked as after it was gathered there)
 int check_cloud(const lins_point* p, int n, bool* sorted) {
   int prev = -1;
   bool s = true;  // "grid-able": ring-sorted and every ring id < 16 (binned search precondition)
@@ -464,6 +465,7 @@ int layout_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, size_t* arena_u
   for (int s = 0; s < n; ++s) {
     const lins_scan_pair& p = in[s];
     if (p.n_surf_flat < 0 || p.n_corner_sharp < 0 || p.n_surf_last < 0 || p.n_corner_last < 0) return LINS_E_ARG;
+    if (p.point_stride_bytes != 0 && p.point_stride_bytes != 16 && p.point_stride_bytes != 32) return LINS_E_ARG;
     if ((p.n_surf_flat && !p.surf_flat) || (p.n_corner_sharp && !p.corner_sharp) ||
         (p.n_surf_last && !p.surf_less_flat_last) || (p.n_corner_last && !p.corner_less_sharp_last))
       return LINS_E_ARG;
@@ -497,18 +499,34 @@ int pack_one(lins_ctx* ctx, const lins_scan_pair* in, int s) {
   ScanDesc& d = ctx->h_desc[s];
   bool ss = true, cs = true;
   int r;
-  if ((r = check_cloud(p.surf_flat, p.n_surf_flat, nullptr))) return r;
-  if ((r = check_cloud(p.corner_sharp, p.n_corner_sharp, nullptr))) return r;
-  if ((r = check_cloud(p.surf_less_flat_last, p.n_surf_last, &ss))) return r;
-  if ((r = check_cloud(p.corner_less_sharp_last, p.n_corner_last, &cs))) return r;
-  d.surf_sorted = ss, d.corner_sorted = cs;
+  // The clouds go to the pinned staging arena first — a copy for packed points, a gather of the 16 payload bytes for
+  // pcl::PointXYZI arrays (point_stride_bytes 32), nothing at all for clouds the caller already wrote there
+  // (lins_batch_map) — and are validated where they then lie.
   const lins_point* src[4] = {p.surf_flat, p.corner_sharp, p.surf_less_flat_last, p.corner_less_sharp_last};
   const int cnt[4] = {d.n_surf_q, d.n_corner_q, d.n_surf_t, d.n_corner_t};
   const int offs[4] = {d.off_surf_q, d.off_corner_q, d.off_surf_t, d.off_corner_t};
   for (int c = 0; c < 4; ++c) {
-    if (cnt[c]) std::memcpy(ctx->h_arena + offs[c], src[c], sizeof(lins_point) * cnt[c]);
+    lins_point* dst = reinterpret_cast<lins_point*>(ctx->h_arena + offs[c]);
+    // (a cloud that lies in the staging arena but not where THIS layout wants it was mapped for another batch shape:
+    // moving it would race with the packing of its neighbours — refused, lins_batch_map's contract is same n, same sizes)
+    if (cnt[c] && src[c] != dst && reinterpret_cast<const float4*>(src[c]) >= ctx->h_arena &&
+        reinterpret_cast<const float4*>(src[c]) < ctx->h_arena + ctx->arena_cap)
+      return LINS_E_ARG;
+    if (cnt[c] && src[c] != dst) {
+      if (p.point_stride_bytes == 32)
+        for (int i = 0; i < cnt[c]; ++i) dst[i] = lins_point_load(src[c], 32, i);
+      else
+        std::memcpy(dst, src[c], sizeof(lins_point) * cnt[c]);
+    }
     for (size_t k2 = cnt[c]; k2 < align4(cnt[c]); ++k2) ctx->h_arena[offs[c] + k2] = make_float4(0, 0, 0, 0);
   }
+  const lins_point* at[4];
+  for (int c = 0; c < 4; ++c) at[c] = reinterpret_cast<const lins_point*>(ctx->h_arena + offs[c]);
+  if ((r = check_cloud(at[0], cnt[0], nullptr))) return r;
+  if ((r = check_cloud(at[1], cnt[1], nullptr))) return r;
+  if ((r = check_cloud(at[2], cnt[2], &ss))) return r;
+  if ((r = check_cloud(at[3], cnt[3], &cs))) return r;
+  d.surf_sorted = ss, d.corner_sorted = cs;
   std::memcpy(ctx->h_state + (size_t)s * 19, p.state, sizeof p.state);
   std::memcpy(ctx->h_cov + (size_t)s * 324, p.cov, sizeof p.cov);
   return 0;
@@ -611,7 +629,9 @@ int relay_prepare(lins_ctx* ctx, int n, bool ordered, RelayArgs& ra) {
   return LINS_OK;
 }
 
-int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
+// (wait = false: the caller synchronises the stream itself before it returns to its own caller — the single-call entry
+// points, whose download waits anyway: one host wait per call instead of two)
+int upload(lins_ctx* ctx, int n, const lins_scan_pair* in, bool wait = true) {
   {  // (pipelined mode: the side streams may still read the inputs this call replaces)
     int rcj = pipe_join(ctx);
     if (rcj) return rcj;
@@ -632,7 +652,7 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in) {
   ctx->idx_timed = true;
   launch_order(ctx, n);
   if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->h_order, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (wait) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   set_batch_state(ctx, n, fl, slots, bytes);
   return LINS_OK;
 }
@@ -869,6 +889,37 @@ const char* lins_last_search(const lins_ctx* ctx) {
 }
 
 int lins_batch_upload(lins_ctx* ctx, int n, const lins_scan_pair* in) { return upload(ctx, n, in); }
+
+/* The context's pinned staging arena, laid out for a batch of n scans with the given cloud sizes: clouds[4 s + c] is
+ * where cloud c (0 surf_flat, 1 corner_sharp, 2 surf_less_flat_last, 3 corner_less_sharp_last) of scan s belongs, as
+ * packed 16-byte points.  A caller that WRITES its clouds there (e.g. its feature extraction's output) and passes those
+ * very pointers in the lins_scan_pair array of the next lins_batch_upload / lins_ieskf_update(_batch) call skips the
+ * library's copy into the staging arena altogether: the points are validated where they lie and sent.                */
+int lins_batch_map(lins_ctx* ctx, int n, const int32_t* counts, lins_point** clouds) {
+  if (!ctx || n < 0 || (n && (!counts || !clouds))) return LINS_E_ARG;
+  {  // (the side streams of the pipelined mode / an earlier asynchronous run may still read the arena's device copy — not
+     // the pinned one: every upload waits for its own copies; nothing to join here)
+  }
+  std::vector<lins_scan_pair> shape((size_t)n);
+  lins_point* const some = reinterpret_cast<lins_point*>(ctx->h_arena);  // (layout_batch only checks for null)
+  for (int s = 0; s < n; ++s) {
+    lins_scan_pair& p = shape[s];
+    std::memset(&p, 0, offsetof(lins_scan_pair, state));
+    p.n_surf_flat = counts[4 * s], p.n_corner_sharp = counts[4 * s + 1], p.n_surf_last = counts[4 * s + 2], p.n_corner_last = counts[4 * s + 3];
+    p.surf_flat = p.corner_sharp = p.surf_less_flat_last = p.corner_less_sharp_last = some;
+  }
+  size_t off = 0, slots = 0;
+  uint64_t bytes = 0;
+  int rc = layout_batch(ctx, n, shape.data(), &off, &slots, &bytes);
+  if (rc) return rc;
+  ctx->n_uploaded = 0, ctx->ran = false;  // (the descriptors of whatever was uploaded are gone)
+  for (int s = 0; s < n; ++s) {
+    const ScanDesc& d = ctx->h_desc[s];
+    const int offs[4] = {d.off_surf_q, d.off_corner_q, d.off_surf_t, d.off_corner_t};
+    for (int c = 0; c < 4; ++c) clouds[4 * s + c] = reinterpret_cast<lins_point*>(ctx->h_arena + offs[c]);
+  }
+  return LINS_OK;
+}
 
 int lins_last_cut(const lins_ctx* ctx, int* parts, int* queue_timeouts) {
   if (!ctx || !parts || !queue_timeouts) return LINS_E_ARG;
@@ -1928,7 +1979,7 @@ int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins
   const auto t_begin = std::chrono::steady_clock::now();
   auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
   if (n < 2 * kChunk || ctx->d_prof) {
-    int rc = upload(ctx, n, in);
+    int rc = upload(ctx, n, in, /*wait*/ false);  // (lins_batch_download below waits for the whole chain)
     if (rc) return rc;
     if (n == 0) return LINS_OK;
     if ((rc = lins_batch_run(ctx, nullptr, 0))) return rc;

@@ -133,6 +133,10 @@ __global__ __launch_bounds__(kMapBlock) void map_corr_kernel(const MapDev* __res
         px[k] = t.x, py[k] = t.y, pz[k] = t.z;
         r.ind[k] = (int)(unsigned)key[k];
       }
+#ifdef LINS_MAP_GATHER_BARRIER  // (canary experiments: the gathered neighbours are opaque to the optimiser from here)
+#pragma unroll
+      for (int k = 0; k < 5; ++k) asm volatile("" : "+v"(px[k]), "+v"(py[k]), "+v"(pz[k]));
+#endif
       r.sq5 = sq5;
       float c[4];
       r.accepted = which == 0 ? map_corner_fit(px, py, pz, sx, sy, sz, c) : map_surf_fit(px, py, pz, sx, sy, sz, c);

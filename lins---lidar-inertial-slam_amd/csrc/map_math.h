@@ -90,6 +90,9 @@ LINS_HD void map_eig3(float (&a)[9], float (&d)[3], float (&v)[9]) {
 }
 
 // least squares of the 5x3 system A x = b by Householder QR in f32 (A, b destroyed)
+#ifdef LINS_MAP_QR_NOINLINE  // (canary experiments, tools/repro/README.md)
+__attribute__((noinline))
+#endif
 LINS_HD void map_qr_5x3(float (&a)[15], float (&b)[5], float (&x)[3]) {
   constexpr int M = 5, N = 3;
 #pragma unroll
@@ -168,6 +171,9 @@ LINS_HD int map_corner_fit(const float (&px)[5], const float (&py)[5], const flo
   return s > 0.1 ? 1 : 0;
 }
 
+#ifdef LINS_MAP_FIT_NOINLINE
+__attribute__((noinline))
+#endif
 LINS_HD int map_surf_fit(const float (&px)[5], const float (&py)[5], const float (&pz)[5], float sx, float sy, float sz,
                          float (&coeff)[4]) {
   coeff[0] = coeff[1] = coeff[2] = coeff[3] = 0.f;

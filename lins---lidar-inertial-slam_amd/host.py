@@ -158,6 +158,10 @@ def lib():
         L.lins_synth_generate.restype = C.c_int
         L.lins_synth_raw_scan.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(Point), C.c_int]
         L.lins_synth_raw_scan.restype = C.c_int
+        L.lins_synth_generate_scene.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.POINTER(SynthPairC)]
+        L.lins_synth_generate_scene.restype = C.c_int
+        L.lins_synth_raw_scan_scene.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(Point), C.c_int]
+        L.lins_synth_raw_scan_scene.restype = C.c_int
         dp = C.POINTER(C.c_double)
         L.lins_synth_seq_raw_scan.argtypes = [C.c_uint32, C.c_int, C.POINTER(Point), C.c_int]
         L.lins_synth_seq_imu.argtypes = [C.c_uint32, C.c_int, dp, dp]
@@ -184,30 +188,31 @@ def _buf(n):
     return a, a.ctypes.data_as(C.POINTER(Point))
 
 
-def synth_pair(index, seed=SYNTH_SEED):
-    """Seeded synthetic scan pair `index` as a ScanPair."""
+def synth_pair(index, seed=SYNTH_SEED, scene=0):
+    """Seeded synthetic scan pair `index` as a ScanPair.  scene: 0 = the room, 1 = the open scene family
+    (trunks, far wall segments, lost returns, a moving box: csrc/host/synth.cpp)."""
     sf, psf = _buf(MAX_QUERY)
     cs, pcs = _buf(MAX_QUERY)
     sl, psl = _buf(CLOUD_MAX)
     cl, pcl = _buf(1920)
     sp = SynthPairC()
     sp.surf_flat, sp.corner_sharp, sp.surf_last, sp.corner_last = psf, pcs, psl, pcl
-    rc = lib().lins_synth_generate(seed, index, C.byref(sp))
+    rc = lib().lins_synth_generate_scene(scene, seed, index, C.byref(sp))
     if rc != 0:
-        raise RuntimeError(f"lins_synth_generate failed: {rc}")
+        raise RuntimeError(f"lins_synth_generate_scene({scene}) failed: {rc}")
     meta = dict(true_t=np.array(sp.true_t[:]), true_q=np.array(sp.true_q[:]), speed=sp.speed,
-                yaw_rate=sp.yaw_rate, n_raw=(sp.n_raw_last, sp.n_raw_new), index=index, seed=seed)
+                yaw_rate=sp.yaw_rate, n_raw=(sp.n_raw_last, sp.n_raw_new), index=index, seed=seed, scene=scene)
     return ScanPair(sf[: sp.n_surf_flat].copy(), cs[: sp.n_corner_sharp].copy(), sl[: sp.n_surf_last].copy(),
                     cl[: sp.n_corner_last].copy(), np.array(sp.state[:]), np.array(sp.cov[:]), meta)
 
 
-def synth_batch(n, start=0, seed=SYNTH_SEED):
-    return [synth_pair(start + i, seed) for i in range(n)]
+def synth_batch(n, start=0, seed=SYNTH_SEED, scene=0):
+    return [synth_pair(start + i, seed, scene) for i in range(n)]
 
 
-def synth_raw_scan(index, k, seed=SYNTH_SEED):
+def synth_raw_scan(index, k, seed=SYNTH_SEED, scene=0):
     a, p = _buf(CLOUD_MAX)
-    n = lib().lins_synth_raw_scan(seed, index, k, p, CLOUD_MAX)
+    n = lib().lins_synth_raw_scan_scene(scene, seed, index, k, p, CLOUD_MAX)
     if n < 0:
         raise RuntimeError(f"lins_synth_raw_scan failed: {n}")
     return a[:n].copy()

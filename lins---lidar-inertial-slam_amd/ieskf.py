@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-from ._ctypes_defs import (CORR_DTYPE, POSE_DTYPE, Params, PoseRecordC, Result, ResultC, ScanPairC, default_params,
+from ._ctypes_defs import (CORR_DTYPE, POSE_DTYPE, Params, Point, PoseRecordC, Result, ResultC, ScanPairC, default_params,
                            pairs_to_c)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -25,6 +25,7 @@ EXPORTS = [
     "lins_last_segment_ms", "lins_streams_step_raw", "lins_map_correspondences", "lins_scan2map_batch",
     "lins_last_map_stats", "lins_last_search", "lins_kernel_ms_history", "lins_set_pipelined",
     "lins_rccl_unique_id", "lins_rccl_init", "lins_pose_allgather", "lins_rccl_destroy", "lins_last_index_ms", "lins_last_cut",
+    "lins_batch_map",
 ]
 
 
@@ -138,11 +139,30 @@ class IeskfContext:
         self._check(lib().lins_ieskf_update(self._h, C.byref(c), C.byref(r)))
         return Result(r)
 
-    def update_batch(self, pairs):
-        arr = pairs_to_c(pairs)
+    def update_batch(self, pairs, arr=None):
+        """lins_ieskf_update_batch; `arr`: a prepared ScanPairC array for these pairs (pairs_strided / map_batch)."""
+        arr = pairs_to_c(pairs) if arr is None else arr
         res = (ResultC * len(pairs))()
         self._check(lib().lins_ieskf_update_batch(self._h, len(pairs), arr, res))
         return [Result(r) for r in res]
+
+    def map_batch(self, pairs):
+        """lins_batch_map for the cloud sizes of `pairs`, then the clouds written into the context's pinned staging arena
+        where the library wants them — standing in for a caller whose feature extraction writes there in the first place.
+        Returns the ScanPairC array that points at them: passed to upload / update_batch, the library's staging copy is
+        skipped."""
+        n = len(pairs)
+        counts = np.array([[len(p.surf_flat), len(p.corner_sharp), len(p.surf_last), len(p.corner_last)] for p in pairs], dtype=np.int32)
+        clouds = (C.POINTER(Point) * (4 * n))()
+        self._check(lib().lins_batch_map(self._h, n, counts.ctypes.data_as(C.POINTER(C.c_int32)), clouds))
+        arr = pairs_to_c(pairs)
+        for i, p in enumerate(pairs):
+            for c, (name, src) in enumerate((("surf_flat", p.surf_flat), ("corner_sharp", p.corner_sharp),
+                                             ("surf_less_flat_last", p.surf_last), ("corner_less_sharp_last", p.corner_last))):
+                if len(src):
+                    C.memmove(clouds[4 * i + c], src.ctypes.data, src.nbytes)
+                setattr(arr[i], name, clouds[4 * i + c])
+        return arr
 
     def perform_ieskf(self, pair):
         """performIESKF as the node sees it: GPU loop + ICP fallback on divergence."""
@@ -327,8 +347,8 @@ class IeskfContext:
         return [Result(r) for r in res]
 
     # -- staged batch form -------------------------------------------------------------
-    def upload(self, pairs):
-        arr = pairs_to_c(pairs)
+    def upload(self, pairs, arr=None):
+        arr = pairs_to_c(pairs) if arr is None else arr
         self._check(lib().lins_batch_upload(self._h, len(pairs), arr))
         self._n = len(pairs)
 

@@ -1057,7 +1057,7 @@ extern "C" {
 
 int oracle_correspondences(const lins_params* prm, const lins_scan_pair* in, const double* lin_state,
                            int iter, int nn_mode, lins_corr* surf, lins_corr* corner) {
-  if (!prm || !in || !lin_state) return LINS_E_ARG;
+  if (!prm || !in || !lin_state || in->point_stride_bytes == 32) return LINS_E_ARG;  // (the checker takes packed points)
   Targets ts{in->surf_less_flat_last, in->n_surf_last, {}, nn_mode};
   Targets tc{in->corner_less_sharp_last, in->n_corner_last, {}, nn_mode};
   if (nn_mode == ORACLE_NN_KDTREE) {
@@ -1072,13 +1072,13 @@ int oracle_correspondences(const lins_params* prm, const lins_scan_pair* in, con
 
 int oracle_ieskf(const lins_params* prm, const lins_scan_pair* in, int form, int nn_mode,
                  lins_result* out, oracle_trace* trace) {
-  if (!prm || !in || !out) return LINS_E_ARG;
+  if (!prm || !in || !out || in->point_stride_bytes == 32) return LINS_E_ARG;  // (the checker takes packed points)
   return ieskf(*prm, *in, form, nn_mode, out, trace);
 }
 
 int oracle_icp(const lins_params* prm, const lins_scan_pair* in, double* t, double* q, int nn_mode,
                int32_t* iters_run) {
-  if (!prm || !in || !t || !q) return LINS_E_ARG;
+  if (!prm || !in || !t || !q || in->point_stride_bytes == 32) return LINS_E_ARG;
   return icp(*prm, *in, t, q, nn_mode, iters_run);
 }
 

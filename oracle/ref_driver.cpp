@@ -88,6 +88,7 @@ void dump(const pcl::PointCloud<PointType>& cloud, lins_point* out, int cap, int
 
 // inputs on which the reference itself reads out of bounds (see the header comment)
 bool reference_reads_oob(const lins_scan_pair* in) {
+  if (in->point_stride_bytes == 32) return true;  // (refused like them: this checker takes packed points)
   if (in->n_surf_flat > 0 && (in->n_surf_last == 0 || in->n_surf_flat > in->n_surf_last)) return true;
   if (in->n_corner_sharp > 0 && (in->n_corner_last == 0 || in->n_corner_sharp > in->n_corner_last)) return true;
   return false;

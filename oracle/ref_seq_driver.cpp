@@ -85,6 +85,7 @@ void fusion::StateEstimator::performIESKF() {
   pack(*scan_new_->surfPointsFlat_, sf), pack(*scan_new_->cornerPointsSharp_, cs);
   pack(*scan_last_->surfPointsLessFlat_, sl), pack(*scan_last_->cornerPointsLessSharp_, cl);
   lins_scan_pair in;
+  in.point_stride_bytes = 0, in.reserved = 0;  // (packed 16-byte points: this checker packs, like the round-4 binding did)
   in.surf_flat = sf.data(), in.n_surf_flat = (int)sf.size();
   in.corner_sharp = cs.data(), in.n_corner_sharp = (int)cs.size();
   in.surf_less_flat_last = sl.data(), in.n_surf_last = (int)sl.size();

@@ -44,6 +44,11 @@ def ieskf():
 
 
 @pytest.fixture(scope="session")
+def defs():
+    return importlib.import_module(PKG + "._ctypes_defs")
+
+
+@pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as o
 

@@ -84,22 +84,17 @@ struct StateEstimator {
       ROS_FATAL("lins_create failed");
   }
 
-  // pcl::PointXYZI is 32 bytes (xyz + pad, intensity + pad); the ABI takes the 16 payload bytes.
-  static void pack(const Cloud& c, std::vector<lins_point>& out) {
-    out.resize(c.size());
-    for (size_t i = 0; i < c.size(); ++i) out[i] = {c[i].x, c[i].y, c[i].z, c[i].intensity};
-  }
+  // pcl::PointXYZI is 32 bytes (xyz + pad, intensity + pad): the clouds are passed where they lie, the library reads
+  // the 16 payload bytes of every point (point_stride_bytes = 32) — no repacking loop here.
+  static const lins_point* points_of(const Cloud& c) { return reinterpret_cast<const lins_point*>(c.points.data()); }
 
   void performIESKF() {
-    static std::vector<lins_point> sf, cs, sl, cl;
-    pack(*scan_new_->surfPointsFlat_, sf);        pack(*scan_new_->cornerPointsSharp_, cs);
-    pack(*scan_last_->surfPointsLessFlat_, sl);   pack(*scan_last_->cornerPointsLessSharp_, cl);
-
     lins_scan_pair in;
-    in.surf_flat = sf.data();               in.n_surf_flat = (int)sf.size();
-    in.corner_sharp = cs.data();            in.n_corner_sharp = (int)cs.size();
-    in.surf_less_flat_last = sl.data();     in.n_surf_last = (int)sl.size();
-    in.corner_less_sharp_last = cl.data();  in.n_corner_last = (int)cl.size();
+    in.point_stride_bytes = (int32_t)sizeof(PointType);  in.reserved = 0;
+    in.surf_flat = points_of(*scan_new_->surfPointsFlat_);                  in.n_surf_flat = (int)scan_new_->surfPointsFlat_->size();
+    in.corner_sharp = points_of(*scan_new_->cornerPointsSharp_);            in.n_corner_sharp = (int)scan_new_->cornerPointsSharp_->size();
+    in.surf_less_flat_last = points_of(*scan_last_->surfPointsLessFlat_);   in.n_surf_last = (int)scan_last_->surfPointsLessFlat_->size();
+    in.corner_less_sharp_last = points_of(*scan_last_->cornerPointsLessSharp_);  in.n_corner_last = (int)scan_last_->cornerPointsLessSharp_->size();
     const GlobalState& x = filter_->state_;                               // KalmanFilter.hpp:35-116
     const double st[19] = {x.rn_[0], x.rn_[1], x.rn_[2], x.vn_[0], x.vn_[1], x.vn_[2],
                            x.qbn_.w(), x.qbn_.x(), x.qbn_.y(), x.qbn_.z(),

@@ -22,7 +22,7 @@ def snippet_from_stub():
     lines = [l[2:] if l.startswith("  ") else l for l in body.splitlines()]  # (member functions: one indent level less)
     text = "\n".join(lines)
     # the two places where the stub stands in for Eigen / PCL
-    text = text.replace("static void pack(const Cloud& c,", "static void pack(const pcl::PointCloud<PointType>& c,")
+    text = text.replace("static const lins_point* points_of(const Cloud& c)", "static const lins_point* points_of(const pcl::PointCloud<PointType>& c)")
     text = re.sub(r"copy_covariance_row_major\(filter_->covariance_, in\.cov\);\s*// Eigen: (.*)", r"\1;", text)
     text = re.sub(r"copy_covariance_row_major\(out\.cov, Pk_\);\s*// Eigen: (.*)", r"\1;", text)
     return text.strip() + "\n"

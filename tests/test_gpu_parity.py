@@ -463,3 +463,48 @@ def test_pipelined_staged_mode_returns_the_same_bits(pkg, ieskf, host):
         assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov)
         assert np.array_equal(a.state, d.state) and np.array_equal(a.cov, d.cov)
         assert (a.iters, a.m_surf, a.m_corner) == (b.iters, b.m_surf, b.m_corner)
+
+
+def test_pcl_point_arrays_and_mapped_staging_return_the_packed_inputs_bits(pkg, ieskf, host, defs):
+    """The two ways a caller avoids repacking / copying: (i) point_stride_bytes = 32 — the four clouds passed as
+    pcl::PointXYZI arrays (PH:52: x, y, z, pad, intensity, 3 pads), the library gathers the 16 payload bytes of every
+    point; the pads hold a value no cloud has, so a read of the wrong word would show; (ii) lins_batch_map — the clouds
+    written where the library's pinned staging arena wants them, the staging copy skipped.  Same bits as packed
+    16-byte points, through the single-scan call, the small-batch path and the chunk-pipelined path (> 512 scans), and
+    for the host shim (performIESKF with the ICP fallback wired)."""
+    prm = pkg.default_params(num_iter=10, fixed_iters=1)
+    for n in (1, 40, 530):
+        batch = host.synth_batch(n, start=20000)
+        with ieskf.IeskfContext(prm, max_batch=n, max_targets=16384) as c:
+            want = c.update_batch(batch)
+            arr32, keep = defs.pairs_strided(batch)
+            got32 = c.update_batch(batch, arr=arr32)
+            gotm = c.update_batch(batch, arr=c.map_batch(batch))
+            # mapped for one layout, passed with another (one scan fewer): refused — moving the clouds would race with
+            # the packing of their neighbours; the contract of lins_batch_map is "same n, same sizes"
+            if n > 1:
+                arr_shift = c.map_batch(batch)
+                shifted = (defs.ScanPairC * (n - 1))(*[arr_shift[i] for i in range(1, n)])
+                with pytest.raises(ieskf.LinsError):
+                    c.update_batch(batch[1:], arr=shifted)
+                gotm2 = c.update_batch(batch, arr=c.map_batch(batch))  # (and the context is fine afterwards)
+                for a, b in zip(want, gotm2):
+                    _same_bits(a, b)
+            del keep
+        for a, b, m in zip(want, got32, gotm):
+            _same_bits(a, b)
+            _same_bits(a, m)
+    pair = host.synth_pair(3)
+    with ieskf.IeskfContext(pkg.default_params(num_iter=30), max_batch=1, max_targets=16 * 1800) as c:
+        want, _ = c.perform_ieskf(pair)
+        arr32, keep = defs.pairs_strided([pair])
+        r, used = defs.ResultC(), __import__("ctypes").c_int32(0)
+        C = __import__("ctypes")
+        assert ieskf.lib().lins_host_perform_ieskf(c._h, C.byref(c.params), C.byref(arr32[0]), C.byref(r), C.byref(used)) == 0
+        _same_bits(want, defs.Result(r))
+    # a stride the ABI does not define is an argument error, not a guess
+    bad = defs.pairs_to_c([pair])
+    bad[0].point_stride_bytes = 24
+    with ieskf.IeskfContext(prm, max_batch=1, max_targets=16384) as c:
+        res = (defs.ResultC * 1)()
+        assert ieskf.lib().lins_ieskf_update_batch(c._h, 1, bad, res) != 0

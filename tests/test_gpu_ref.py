@@ -67,6 +67,56 @@ def test_update_matches_the_references_perform_ieskf(pkg, ieskf, host, ref, sear
         assert_result_close(g, w)
 
 
+@pytest.mark.parametrize("search", ["auto", "mr", "lds", "lds1", "binned", "brute"])
+def test_open_scene_family_matches_the_reference(pkg, ieskf, host, ref, search):
+    """The second scene family (open ground, ~60 trunks, far wall segments, 30 % of the returns lost, a moving box:
+    csrc/host/synth.cpp) through every search mode: correspondences along the reference's trajectory bit for bit,
+    performIESKF on 96 pairs as one batch against the reference's own code.  Sparse clouds (~2 k targets), many empty
+    grid cells, queries with nothing inside the search radius — what the room never showed the grid, the certificates'
+    margins and the walk cache."""
+    prm = pkg.default_params(num_iter=30)
+    start = 41000
+    with ieskf.IeskfContext(prm, max_batch=1, max_targets=16384, search=search) as ctx:
+        for idx in (start, start + 5):
+            pair = host.synth_pair(idx, scene=1)
+            states = [pair.state] + [r.state for r, _ in ref.replay(prm, pair)]
+            for k, lin in enumerate(states[:-1]):
+                want_s, want_c = ref.correspondences(prm, pair, lin, k)
+                surf, corner = ctx.correspondences(pair, lin, k)
+                assert_corr_equal(surf, want_s, f"open pair{idx}.iter{k}.surf")
+                assert_corr_equal(corner, want_c, f"open pair{idx}.iter{k}.corner")
+    pairs = host.synth_batch(96, start=start + 100, scene=1)
+    want = ref.perform_ieskf_batch(prm, pairs, threads=cores())
+    with ieskf.IeskfContext(prm, max_batch=len(pairs), max_targets=16384, search=search) as ctx:
+        got = ctx.update_batch(pairs)
+    for g, w in zip(got, want):
+        assert_result_close(g, w)
+
+
+def test_open_scene_family_in_several_parts_and_both_input_layouts(pkg, ieskf, host, defs):
+    """600 open-scene pairs on the batch kernel: several-part updates (tickets), pcl::PointXYZI-strided inputs and the
+    mapped staging arena return the whole updates' bits from packed inputs."""
+    prm = pkg.default_params(num_iter=30)
+    pairs = host.synth_batch(600, start=42000, scene=1)
+    with ieskf.IeskfContext(prm, max_batch=len(pairs), max_targets=16384, search="mr") as c:
+        c.upload(pairs[:300])  # (within the device's workgroup slots: whole updates)
+        c.run(); c.sync()
+        whole = c.download()
+        assert c.last_cut()[0] == 1
+        c.upload(pairs)
+        c.run(); c.sync()
+        cut = c.download()
+        assert c.last_cut()[0] > 1
+        arr32, keep = defs.pairs_strided(pairs)
+        got32 = c.update_batch(pairs, arr=arr32)
+        gotm = c.update_batch(pairs, arr=c.map_batch(pairs))
+    for a, b in zip(whole, cut[:300]):
+        assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov) and a.iters == b.iters
+    for a, b, m in zip(cut, got32, gotm):
+        assert np.array_equal(a.state, b.state) and np.array_equal(a.cov, b.cov) and a.iters == b.iters
+        assert np.array_equal(a.state, m.state) and np.array_equal(a.cov, m.cov)
+
+
 def test_divergence_and_fallback_match_the_reference(pkg, ieskf, ref):
     """SE:566-570 -> SE:585-592 through lins_host_perform_ieskf (device loop, device ICP) vs the reference."""
     from diverging import make_diverging_pair

@@ -280,6 +280,40 @@ def test_1024_seeded_pairs_oracle_equals_reference(pkg, host, oracle, ref, wide)
     assert flips <= 0.01 * n  # see f32_flip
 
 
+def test_open_scene_family_oracle_equals_reference(pkg, host, oracle, ref):
+    """The second scene family (csrc/host/synth.cpp "open": open ground, trunks, far wall segments, 30 % of the returns
+    lost, a moving box — ~2 k target points instead of ~8.7 k, corner-rich): the reference's own performIESKF vs the
+    oracle's dense and reduced forms on 256 seeded pairs, and the correspondence rows along the reference's trajectory
+    bit for bit on three of them.  Everything the room never showed the search structures is in here."""
+    n, start = 256, 40000
+    prm = pkg.default_params(num_iter=30)
+    workers = min(32, os.cpu_count() or 1)
+    with ThreadPoolExecutor(workers) as ex:
+        pairs = list(ex.map(lambda i: host.synth_pair(i, scene=1), range(start, start + n)))
+        want = list(ex.map(lambda p: oracle.perform_ieskf(prm, p, oracle.FORM_DENSE, oracle.NN_KDTREE), pairs))
+        reduced = list(ex.map(lambda p: oracle.perform_ieskf(prm, p, oracle.FORM_REDUCED, oracle.NN_BRUTE), pairs))
+    got = ref.perform_ieskf_batch(prm, pairs, threads=workers)
+    sizes = np.array([p.sizes() for p in pairs])
+    assert sizes[:, 3].mean() < 3000 and sizes[:, 0].mean() > 100  # (sharp, flat, lessSharp, lessFlat): a sparse cloud with its corners
+    loose = flips = 0
+    for i, (g, w, r) in enumerate(zip(got, want, reduced)):
+        assert g is not None
+        flip = f32_flip(g, w)
+        flips += flip
+        loose += assert_same_result(g, w, f"open pair {start + i}", tol=(1e-7, 1e-7) if flip else (STATE_TOL, COV_REL))
+        assert flags(r) == flags(g)
+    assert loose <= 0.25 * n and flips <= 0.02 * n
+    for idx in (start, start + 7, start + 101):
+        pair = host.synth_pair(idx, scene=1)
+        states = [pair.state] + [r.state for r, _ in ref.replay(prm, pair)]
+        for k, lin in enumerate(states[:-1]):
+            want_s, want_c = ref.correspondences(prm, pair, lin, k)
+            surf, corner = oracle.correspondences(prm, pair, lin, k, oracle.NN_BRUTE)
+            for a, b in ((surf, want_s), (corner, want_c)):
+                assert np.array_equal(a["ind1"], b["ind1"]) and np.array_equal(a["ind2"], b["ind2"]) and np.array_equal(a["ind3"], b["ind3"])
+                assert np.array_equal(a["accepted"], b["accepted"]) and np.array_equal(a["coeff"].view(np.int32), b["coeff"].view(np.int32))
+
+
 @pytest.mark.parametrize("freq", [2, 3])
 def test_icp_freq_reuses_indices_like_the_reference(pkg, host, oracle, ref, freq):
     prm = pkg.default_params(num_iter=30, icp_freq=freq)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Parity sweep: n seeded scans through every kernel shape (reference stop rule, NUM_ITER 30) vs the CPU oracle
-(reduced 6x6 form + kd-tree; the oracle's own tests pin reduced == dense).  Prints mismatch counts."""
+(reduced 6x6 form + kd-tree; the oracle's own tests pin reduced == dense).  Prints mismatch counts.
+usage: tools/parity_sweep.py [n] [first] [wide] [open]"""
 import importlib, os, sys, time
 from concurrent.futures import ThreadPoolExecutor
 import numpy as np
@@ -14,10 +15,14 @@ start = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 # third argument: a prior that MATTERS.  The shipped filter starts from init_pos_std = init_att_std = 0, so P_SS is tiny
 # and the posterior state hardly depends on the 28 sums; "wide" adds a seeded, fully correlated SPD block (5 cm / 0.5 deg
 # / 0.1 m/s and matching bias scales) to every prior covariance, so that gain, solve and Joseph update carry weight.
-wide = len(sys.argv) > 3 and sys.argv[3] == "wide"
+wide = "wide" in sys.argv[3:]
+scene = 1 if "open" in sys.argv[3:] else 0  # ("open": the second scene family of csrc/host/synth.cpp)
 prm = pkg.default_params(num_iter=30)
 with ThreadPoolExecutor(32) as ex:
-    pairs = list(ex.map(host.synth_pair, range(start, start + n)))
+    pairs = list(ex.map(lambda i: host.synth_pair(i, scene=scene), range(start, start + n)))
+if scene:
+    sz = np.array([p.sizes() for p in pairs])
+    print(f"# scene family 'open': mean sizes (sharp, flat, lessSharp, lessFlat) {np.round(sz.mean(0), 1)}")
 if wide:
     scale = np.array([0.05] * 3 + [0.1] * 3 + [0.009] * 3 + [0.02] * 3 + [0.002] * 3 + [0.01] * 3)
     for k, p in enumerate(pairs):
