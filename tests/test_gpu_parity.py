@@ -31,14 +31,29 @@ def assert_corr_equal(got, want, what):
         assert (u > 0).mean() <= 1e-3 if u.size else True, f"{what}.{f}: {(u > 0).mean():.2e} of values off by 1 ulp"
 
 
-def assert_result_close(got, want):
+# What "same result" means for a posterior.  The CONTRACT is POS_TOL / ATT_TOL /
+# COV_REL above; the device has always been ten orders inside it (1e-16), so the tests hold it to bars that would notice a
+# regression long before the contract would (a drift to 1e-6 would have passed): TIGHT_* on the whole state and
+# the covariance.  One documented exception, the same one tests/test_ref.py makes between the oracle and the reference: an
+# update that runs to NUM_ITER without meeting the stop rule (the period-2 correspondence cycles of BASELINE.md section 6)
+# amplifies a last-bit difference of the solve over thirty iterations — those are held to the contract's bars, and the
+# caller bounds how many of them there may be (loose_budget).
+TIGHT_STATE, TIGHT_COV = 1e-9, 1e-12
+
+
+def assert_result_close(got, want, loose_budget=None):
     assert (got.iters, got.converged, got.diverged) == (want.iters, want.converged, want.diverged), (got, want)
     assert (got.m_surf, got.m_corner) == (want.m_surf, want.m_corner), (got, want)
-    assert np.abs(got.state[:3] - want.state[:3]).max() <= POS_TOL
-    assert np.abs(got.state[6:10] - want.state[6:10]).max() <= ATT_TOL
-    assert np.abs(got.state - want.state).max() <= 1e-5  # v, biases, gravity
-    assert np.abs(got.cov - want.cov).max() <= COV_REL * np.abs(want.cov).max()
-    assert abs(got.residual_norm - want.residual_norm) <= 1e-9 * max(1.0, want.residual_norm)
+    ds = np.abs(got.state - want.state).max()
+    dc = np.abs(got.cov - want.cov).max() / np.abs(want.cov).max()
+    dr = abs(got.residual_norm - want.residual_norm) / max(1.0, want.residual_norm)
+    if ds <= TIGHT_STATE and dc <= TIGHT_COV and dr <= 1e-12:
+        return
+    ran_out = want.iters >= 30 and not want.converged and not want.diverged
+    assert ran_out and loose_budget is not None and loose_budget[0] > 0, f"state {ds:.2e}, covariance {dc:.2e} (rel), residual {dr:.2e}: {got} vs {want}"
+    loose_budget[0] -= 1
+    assert np.abs(got.state[:3] - want.state[:3]).max() <= POS_TOL and np.abs(got.state[6:10] - want.state[6:10]).max() <= ATT_TOL
+    assert ds <= 1e-5 and dc <= COV_REL and dr <= 1e-9
 
 
 @pytest.fixture(scope="module")

@@ -63,8 +63,9 @@ def test_update_matches_the_references_perform_ieskf(pkg, ieskf, host, ref, sear
     want = ref.perform_ieskf_batch(prm, pairs, threads=cores())
     with ieskf.IeskfContext(prm, max_batch=len(pairs), max_targets=16384, search=search) as ctx:
         got = ctx.update_batch(pairs)
+    budget = [len(pairs) // 4]  # (updates that run to NUM_ITER un-converged: the contract's bars, see assert_result_close)
     for g, w in zip(got, want):
-        assert_result_close(g, w)
+        assert_result_close(g, w, budget)
 
 
 @pytest.mark.parametrize("search", ["auto", "mr", "lds", "lds1", "binned", "brute"])
@@ -157,8 +158,9 @@ def test_bench_batch_all_1024_scans_against_the_dense_oracle_and_the_reference(p
     want = ref.perform_ieskf_batch(stop, pairs, threads=cores())
     with ieskf.IeskfContext(stop, max_batch=n, max_targets=16384, search="auto") as ctx:
         got = ctx.update_batch(pairs)
+    budget = [n // 4]
     for g, w in zip(got, want):
-        assert_result_close(g, w)
+        assert_result_close(g, w, budget)
 
 
 def test_device_segmentation_and_front_end_against_the_references_two_nodes(pkg, ieskf, host, ref):
