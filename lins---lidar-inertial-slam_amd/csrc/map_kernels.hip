@@ -43,16 +43,25 @@ constexpr int kMapQPerBlock = kMapBlock / kMapLanes;
 __global__ __launch_bounds__(kMapBlock) void map_corr_kernel(const MapDev* __restrict__ probs, const MapRound* __restrict__ rounds,
                                                              const float4* __restrict__ pts, const int* __restrict__ cells,
                                                              const float4* __restrict__ queries, lins_map_corr* __restrict__ recs,
-                                                             double* __restrict__ partials, int blocks_per_problem) {
-  const int prob = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                                             double* __restrict__ partials, int blocks_per_problem, int n_problems) {
+  // XCD-aware block -> (problem, block) mapping.  Workgroup b of a launch runs on XCD b % 8 (observed placement; it only
+  // matters for speed), every XCD has an L2 of its own, and all blocks of a problem read the same ~0.5 MB of map: with
+  // the problem index in blockIdx.y (rounds 1-4) the blocks of one problem were dealt over all eight XCDs and every L2
+  // fetched every map — 2-4 x the maps' bytes per dispatch (profiles/r04_rocprofv3_pmc_aux.txt: 33 MB counted for 17 MB).
+  // Here the blocks b, b + 8, b + 16, ... of one XCD walk through the problems x, x + 8, x + 16, ... block by block: a
+  // problem's map is fetched into ONE L2 (four problems of 0.5 MB per XCD at a time when 32 are in flight).
+  const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+  const int prob = (kk / blocks_per_problem) * 8 + xcd, blk = kk % blocks_per_problem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (prob >= n_problems) return;  // (the problem count is not a multiple of eight: this XCD's last group is short)
   const MapDev pd = probs[prob];
-  double* out = partials + ((size_t)prob * blocks_per_problem + blockIdx.x) * 28;
+  double* out = partials + ((size_t)prob * blocks_per_problem + blk) * 28;
   if (!pd.active) {
     if (tid < 28) out[tid] = 0.0;
     return;
   }
   const MapRound rd = rounds[prob];
-  const int q = blockIdx.x * kMapQPerBlock + tid / kMapLanes, sub = tid % kMapLanes, nq = pd.n_q[0] + pd.n_q[1];
+  const int q = blk * kMapQPerBlock + tid / kMapLanes, sub = tid % kMapLanes, nq = pd.n_q[0] + pd.n_q[1];
   double v[28];
 #pragma unroll
   for (int k = 0; k < 28; ++k) v[k] = 0.0;
@@ -339,8 +348,9 @@ size_t map_carry_size() { return sizeof(LmCarry); }
 
 void launch_map_corr(hipStream_t stream, int n_problems, int blocks_per_problem, const void* probs, const void* rounds,
                      const float4* pts, const int* cells, const float4* queries, lins_map_corr* recs, double* partials) {
-  hipLaunchKernelGGL(map_corr_kernel, dim3(blocks_per_problem, n_problems), dim3(kMapBlock), 0, stream, (const MapDev*)probs,
-                     (const MapRound*)rounds, pts, cells, queries, recs, partials, blocks_per_problem);
+  // (one-dimensional grid: 8 x blocks_per_problem x ceil(n_problems / 8) — the XCD-aware mapping of the kernel)
+  hipLaunchKernelGGL(map_corr_kernel, dim3(8 * blocks_per_problem * ((n_problems + 7) / 8)), dim3(kMapBlock), 0, stream, (const MapDev*)probs,
+                     (const MapRound*)rounds, pts, cells, queries, recs, partials, blocks_per_problem, n_problems);
 }
 // Start-up self-check of the plane fit: five points of the wall y = 2 and a query 5 cm in front of it must give a
 // normal along y.  (ROCm 7.2's SLP vectoriser loses the y column of the unrolled 5 x 3 QR at -O2 and above — this file
