@@ -1326,21 +1326,47 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
   constexpr int kWaves = BLOCK / 64, kSpreadSurf = LINS_SPREAD_S > 0 && BLOCK == 512 ? LINS_SPREAD_S : (kWaves * 5 + 4) / 8;
   constexpr int kWs = kSpreadSurf;
   constexpr int kWc = LINS_SPREAD_C > 0 && BLOCK == 512 ? LINS_SPREAD_C : kWaves - kWs;
-  const int lay_ps = (sd.n_surf_q + kWs - 1) / kWs, lay_pc = kWc > 0 ? (sd.n_corner_q + kWc - 1) / kWc : 65;
-  const bool spread_ok = kWs < kWaves && lay_ps <= 64 && lay_pc <= 64;  // the one-round spread layout holds the scan
+  // The spread layout's shares.  The queries of a kind come sorted by ring and what a search costs goes with the ring (the
+  // far ground rings' walks are the longest phase of every iteration: tools/wave_phases.py), so equal COUNTS leave the
+  // last plane wave the slowest in half of the workgroups; the waves of a kind take contiguous blocks whose sizes follow
+  // LINS_SPREAD_WS / _WC instead (weights; equal weights = equal counts).
+#ifndef LINS_SPREAD_WS
+#define LINS_SPREAD_WS 30, 24, 20, 14, 12  // (round 5, one GPU call: equal counts 0.5770 ms; 27,23,20,16,14 0.5721; 30,24,20,14,12 0.5686; 33,25,19,12,11 0.5740; weights on the line waves too: slower)
+#endif
+#ifndef LINS_SPREAD_WC
+#define LINS_SPREAD_WC 1, 1, 1
+#endif
+  constexpr int kWtS[] = {LINS_SPREAD_WS, 1, 1, 1, 1, 1, 1, 1, 1}, kWtC[] = {LINS_SPREAD_WC, 1, 1, 1, 1, 1, 1, 1, 1};
+  constexpr bool kWeighted = BLOCK == 512 && LINS_SPREAD_S > 0;  // (the batch shape; the other one-lane shapes deal equal counts)
+  // first query of wave-round j of a kind with n queries over nw waves: floor(n * (w_0 + ... + w_{j-1}) / (w_0 + ... + w_{nw-1}))
+  auto share_start = [&](const int* wt, int nw, int n, int j) {
+    int tot = 0, cum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += k < nw ? (kWeighted ? wt[k] : 1) : 0, cum += k < j ? (kWeighted ? wt[k] : 1) : 0;
+    return j >= nw ? n : (n * cum) / tot;
+  };
+  bool fits = kWs < kWaves;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < kWs) fits = fits && share_start(kWtS, kWs, sd.n_surf_q, k + 1) - share_start(kWtS, kWs, sd.n_surf_q, k) <= 64;
+    if (k < kWc) fits = fits && share_start(kWtC, kWc, sd.n_corner_q, k + 1) - share_start(kWtC, kWc, sd.n_corner_q, k) <= 64;
+  }
+  const bool spread_ok = fits;  // the one-round spread layout holds the scan
   auto wr_layout = [&](int rnd) {
     WrLay y;
-    int nws, per_s, per_c;
-    if (spread_ok) {
-      nws = kWs, per_s = lay_ps, per_c = lay_pc, y.n_wr = kWs + kWc;
-    } else {
-      nws = (sd.n_surf_q + 63) >> 6, per_s = per_c = 64, y.n_wr = nws + ((sd.n_corner_q + 63) >> 6);
-    }
     y.k = rnd * kWaves + wave;
-    y.kind_s = y.k < nws;
-    const int q0 = y.kind_s ? y.k * per_s : (y.k - nws) * per_c;
-    const int left = (y.kind_s ? sd.n_surf_q : sd.n_corner_q) - q0, per = y.kind_s ? per_s : per_c;
-    y.slot = (y.kind_s ? 0 : sd.n_surf_q) + q0 + lane, y.active = y.k < y.n_wr && lane < (left < per ? left : per);
+    if (spread_ok) {
+      y.n_wr = kWs + kWc, y.kind_s = y.k < kWs;
+      const int j = y.kind_s ? y.k : y.k - kWs, nw = y.kind_s ? kWs : kWc, n = y.kind_s ? sd.n_surf_q : sd.n_corner_q;
+      const int q0 = share_start(y.kind_s ? kWtS : kWtC, nw, n, j), q1 = share_start(y.kind_s ? kWtS : kWtC, nw, n, j + 1);
+      y.slot = (y.kind_s ? 0 : sd.n_surf_q) + q0 + lane, y.active = y.k < y.n_wr && lane < q1 - q0;
+    } else {
+      const int nws = (sd.n_surf_q + 63) >> 6;
+      y.n_wr = nws + ((sd.n_corner_q + 63) >> 6), y.kind_s = y.k < nws;
+      const int q0 = y.kind_s ? y.k * 64 : (y.k - nws) * 64;
+      const int left = (y.kind_s ? sd.n_surf_q : sd.n_corner_q) - q0;
+      y.slot = (y.kind_s ? 0 : sd.n_surf_q) + q0 + lane, y.active = y.k < y.n_wr && lane < (left < 64 ? left : 64);
+    }
     return y;
   };
 
@@ -1412,6 +1438,10 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
     }
     __syncthreads();  // everyone has read the loop state before it is rewritten
     if (tid == 0) L.m_surf = 0, L.m_corner = 0;
+    // (Round 5 built the iteration with three block-wide barriers instead of five — the row counters as two slots taken in
+    // turn, the fold of the wave partials ordered before the solve inside wave 0 — bit-identical, 144 GPU tests green, and
+    // no faster: 0.5761 against 0.5735 ms, two more spilled registers; the waves that would skip a barrier are waiting for
+    // wave 0 anyway.  Not kept.)
 
     const bool do_search = PASS_ONLY || (iter % prm.icp_freq) == 0;
     double acc = 0;
