@@ -101,3 +101,23 @@ def test_state_predictor_mirror(host):
     assert abs(np.linalg.norm(s1[3:6]) - np.linalg.norm(s[3:6])) < 1e-12  # velocity rotated into the new frame
     assert c1[0, 0] == 0 and c1[6, 6] == 0 and np.allclose(c1[0:3, 3:6], 0)  # cross terms dropped
     assert np.allclose(np.trace(c1[3:6, 3:6]), np.trace(cov[3:6, 3:6]))
+
+
+def test_open_scene_family_is_seeded_sparse_and_leaves_the_room_alone(host):
+    """The second scene family of the generator (csrc/host/synth.cpp, scene 1: open ground, trunks, far wall segments,
+    30 % of the returns lost, a moving box): deterministic in (seed, index), far sparser than the room and still
+    corner-rich, its truth consistent with its own motion — and asking for it changes nothing about scene 0."""
+    a, b = host.synth_pair(5, scene=1), host.synth_pair(5, scene=1)
+    for f in ("surf_flat", "corner_sharp", "surf_last", "corner_last", "state", "cov"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    room = host.synth_pair(5)
+    assert np.array_equal(room.surf_last, host.synth_pair(5, scene=0).surf_last)
+    assert len(a.surf_last) < 0.4 * len(room.surf_last) and len(a.corner_sharp) > 60 and len(a.surf_flat) > 60
+    assert a.meta["n_raw"][0] < 0.6 * room.meta["n_raw"][0]  # (lost returns and sky)
+    # ring-sorted targets with ring ids < 16 (what the grid kernels need), queries never outnumber the targets
+    for cloud in (a.surf_last, a.corner_last):
+        rings = cloud[:, 3].astype(int)
+        assert (np.diff(rings) >= 0).all() and rings.max() < 16
+    assert len(a.surf_flat) <= len(a.surf_last) and len(a.corner_sharp) <= len(a.corner_last)
+    raw = host.synth_raw_scan(5, 1, scene=1)
+    assert len(raw) == a.meta["n_raw"][1] and np.isfinite(raw).all()

@@ -1,13 +1,15 @@
 #!/bin/bash
-# Regenerates the line-of-record artifacts for round $1 (default r03) on the GPU box into gpurun_out/; copy what is
+# Regenerates the line-of-record artifacts for round $1 (default r05) on the GPU box into gpurun_out/; copy what is
 # to be judged into profiles/ afterwards (tools/README.md).  PMC passes are separate rocprofv3 runs with
 # --kernel-trace only (never combined with other trace domains).
-tag=${1:-r04}
+tag=${1:-r05}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out
 cd $root
+rm -f $out/canaries.log
 python -m pytest tests -q -m gpu > $out/${tag}_pytest_gpu.log 2>&1; tail -2 $out/${tag}_pytest_gpu.log
+cat $out/canaries.log >> $out/${tag}_pytest_gpu.log 2>/dev/null
 python tools/pmc_traffic.py $tag > $out/${tag}_pmc_traffic.log 2>&1; tail -3 $out/${tag}_pmc_traffic.log
 cp $out/${tag}_pmc_traffic.json profiles/ 2>/dev/null   # (bench.py reads the record from profiles/, stamp-checked)
 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
@@ -42,6 +44,13 @@ cat $out/${tag}_aux_rates.txt
   python tools/relay_sweep.py 1024 0 3 4 5 6 2>&1 | tail -5
   echo "== RS_ITERS=30 RS_FIXED=0 tools/relay_sweep.py 1024 0 4  (the reference's stop rule)"
   RS_ITERS=30 RS_FIXED=0 python tools/relay_sweep.py 1024 0 4 2>&1 | tail -2
+  echo "== tools/stop_rule_timeline.py  (whole updates under the stop rule: who ends the launch)"
+  python tools/stop_rule_timeline.py 2>&1 | tail -9
+  if [ -f ab/qtrace.so ]; then
+    echo "== LINS_IESKF_LIB=ab/qtrace.so tools/queue_trace.py 1024 10 1 / 1024 30 0  (the ticketed launch's timeline; -DLINS_QUEUE_TRACE=1 build)"
+    LINS_IESKF_LIB=$PWD/ab/qtrace.so python tools/queue_trace.py 1024 10 1 2>&1 | tail -9
+    LINS_IESKF_LIB=$PWD/ab/qtrace.so python tools/queue_trace.py 1024 30 0 2>&1 | tail -9
+  fi
   echo "== tools/index_time.py 1024  (grid_index_kernel at lins_batch_upload)"
   python tools/index_time.py 1024 2>&1 | tail -1
   if [ -f ab/prof2.so ]; then
@@ -63,6 +72,7 @@ tail -40 $out/${tag}_pmc_all.txt
 {
   python tools/parity_sweep.py 2048 60000 2>&1 | tail -7
   python tools/parity_sweep.py 1024 70000 wide 2>&1 | tail -7
+  python tools/parity_sweep.py 2048 80000 open 2>&1 | tail -7
   python tools/frontend_sweep.py 1024 50000 2>&1 | tail -2
 } > $out/${tag}_parity_sweep.txt 2>&1
 cat $out/${tag}_parity_sweep.txt
