@@ -377,14 +377,16 @@ def test_device_front_end_matches_the_host_restatement(pkg, ieskf, host):
         assert g["n_segmented"] == w["n_segmented"] and g["n_outlier"] == w["n_outlier"]
 
 
-def test_device_resident_streams_reproduce_the_staged_path(pkg, ieskf, host):
+@pytest.mark.parametrize("scene", [0, 1], ids=["room", "open"])
+def test_device_resident_streams_reproduce_the_staged_path(pkg, ieskf, host, scene):
     """Two scans per stream through lins_streams_step (front-end -> update -> re-projection, clouds
     resident in HBM) == the staged path on the same data: host front-end, host re-projection of the
-    first scan's clouds with the bootstrap pose, lins_ieskf_update_batch on the resulting pairs."""
+    first scan's clouds with the bootstrap pose, lins_ieskf_update_batch on the resulting pairs.  Both scene
+    families of the generator (the open one: sparse rings, lost returns, a moving box)."""
     n = 6
-    pairs = host.synth_batch(n, start=40)  # built by the host from the same two raw scans per index
-    seg0 = [host.frontend_segment(host.synth_raw_scan(40 + i, 0)) for i in range(n)]
-    seg1 = [host.frontend_segment(host.synth_raw_scan(40 + i, 1)) for i in range(n)]
+    pairs = host.synth_batch(n, start=40, scene=scene)  # built by the host from the same two raw scans per index
+    seg0 = [host.frontend_segment(host.synth_raw_scan(40 + i, 0, scene=scene)) for i in range(n)]
+    seg1 = [host.frontend_segment(host.synth_raw_scan(40 + i, 1, scene=scene)) for i in range(n)]
     boot = np.zeros((n, 19))
     for i, p in enumerate(pairs):  # bootstrap pose = what the synthetic pairs re-project the first scan with
         boot[i, 0:3], boot[i, 6:10] = p.meta["true_t"], p.meta["true_q"]
@@ -415,8 +417,8 @@ def test_device_resident_streams_reproduce_the_staged_path(pkg, ieskf, host):
             assert np.abs(g.cov - w.cov).max() <= 1e-6 * np.abs(w.cov).max()
         # the same two steps from RAW clouds (image projection on the device too): identical results, bit for bit
         c.streams_init(n)
-        raw0 = [host.synth_raw_scan(40 + i, 0) for i in range(n)]
-        raw1 = [host.synth_raw_scan(40 + i, 1) for i in range(n)]
+        raw0 = [host.synth_raw_scan(40 + i, 0, scene=scene) for i in range(n)]
+        raw1 = [host.synth_raw_scan(40 + i, 1, scene=scene) for i in range(n)]
         c.streams_step_raw(raw0, boot, cov0)
         r1r, cnt1r = c.streams_step_raw(raw1, np.stack([p.state for p in pairs]), np.stack([p.cov for p in pairs]))
         assert np.array_equal(cnt1r, cnt1)

@@ -193,6 +193,43 @@ def test_device_segmentation_and_front_end_against_the_references_two_nodes(pkg,
         assert a.shape == b.shape and np.abs(a - b).max() <= 4e-6
 
 
+def test_open_scene_family_through_the_device_front_end(pkg, ieskf, host, ref):
+    """The stages in front of the update on the second scene family (open ground to the range limit, trunks, far wall
+    segments, 30 % of the returns lost, a moving box): sparse rings, sky, ragged segments — raw clouds through the device
+    projection / segmentation and feature front-end against the reference's two nodes (segmented cloud bit for bit, same
+    picks and voxels) and against the host restatement bit for bit on 64 scans."""
+    from test_ref import assert_same_picks, assert_same_segmentation
+
+    prm = pkg.default_params()
+    raws = [host.synth_raw_scan(43000 + i // 2, i & 1, scene=1) for i in range(64)]
+    with ieskf.IeskfContext(prm, max_batch=1, max_targets=1024) as c:
+        got = c.segment_batch(raws)
+        feats = c.extract_features_batch(got)
+    with ThreadPoolExecutor(cores()) as ex:
+        want = list(ex.map(ref.segment, raws[:12]))
+        hseg = list(ex.map(host.frontend_segment, raws))
+        hfe = list(ex.map(host.frontend_extract_segmented, hseg))
+    for i, (g, r) in enumerate(zip(got, want)):
+        assert_same_segmentation(r, g, f"open scan {i}")
+    for i in (0, 3, 7, 10):
+        r = want[i]
+        k = r.n
+        seg = dict(cloud=r.cloud[:k], range=r.range[:k], col=r.col[:k], ground=r.ground[:k], n=k, start_ring=list(r.c.start_ring),
+                   end_ring=list(r.c.end_ring), orientation=(r.c.start_ori, r.c.end_ori, r.c.ori_diff), n_outlier=r.c.n_outlier)
+        fr = ref.extract_features(prm, seg)
+        fd = feats[i]
+        for name in ("corner_sharp", "corner_less_sharp", "surf_flat"):
+            assert_same_picks(fr[name][:, :3], fd[name][:, :3], seg, fr["undistorted"][:, :3], name)
+        a, b = fr["surf_less_flat"], fd["surf_less_flat"]
+        assert a.shape == b.shape and np.abs(a - b).max() <= 4e-6
+    for i, (g, w, f, r) in enumerate(zip(got, hseg, feats, hfe)):
+        k = w.n
+        assert g.n == k and np.array_equal(g.cloud[:k], w.cloud[:k]) and np.array_equal(g.range[:k], w.range[:k]), i
+        assert np.array_equal(g.col[:k], w.col[:k]) and np.array_equal(g.ground[:k], w.ground[:k]), i
+        for key in ("corner_sharp", "corner_less_sharp", "surf_flat", "surf_less_flat"):
+            assert np.array_equal(f[key], r[key]), (i, key)
+
+
 def test_device_scan_to_map_against_the_references_mapping_node(pkg, ieskf, ref):
     """lins_map_correspondences / lins_scan2map_batch against the reference's own lidar_mapping_node.cpp (compiled verbatim,
     oracle/ref_map_driver.cpp): the rows cornerOptimization / surfOptimization push — same queries, coefficients bit for

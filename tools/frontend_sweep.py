@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Parity sweep of the stages in front of the update: n seeded raw scans through the device projection /
-segmentation and feature front-end vs the host restatement (bit-for-bit).  Prints mismatch counts."""
+segmentation and feature front-end vs the host restatement (bit-for-bit).  Prints mismatch counts.
+usage: tools/frontend_sweep.py [n] [first] [open]"""
 import importlib, os, sys
 from concurrent.futures import ThreadPoolExecutor
 import numpy as np
@@ -10,8 +11,9 @@ PKG = "lins---lidar-inertial-slam_amd"
 pkg = importlib.import_module(PKG); host = importlib.import_module(PKG + ".host"); ieskf = importlib.import_module(PKG + ".ieskf")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 start = int(sys.argv[2]) if len(sys.argv) > 2 else 30000
+scene = 1 if "open" in sys.argv[3:] else 0  # ("open": the second scene family of csrc/host/synth.cpp)
 with ThreadPoolExecutor(32) as ex:
-    raws = list(ex.map(lambda i: host.synth_raw_scan(start + i // 2, i & 1), range(n)))
+    raws = list(ex.map(lambda i: host.synth_raw_scan(start + i // 2, i & 1, scene=scene), range(n)))
     want = list(ex.map(host.frontend_segment, raws))
     ref = list(ex.map(host.frontend_extract_segmented, want))
 bad_seg = bad_fe = 0
@@ -29,5 +31,5 @@ with ieskf.IeskfContext(pkg.default_params(), max_batch=1, max_targets=1024) as 
             bad_seg += not same
             bad_fe += not all(np.array_equal(f[key], r[key]) for key in ("corner_sharp", "corner_less_sharp", "surf_flat", "surf_less_flat"))
 pts = sum(w.n for w in want)
-print(f"{n} raw scans ({pts} segmented points): scans whose segmented cloud / cloud_info differ from the host restatement: {bad_seg}; "
+print(f"{'open scene family: ' if scene else ''}{n} raw scans ({pts} segmented points): scans whose segmented cloud / cloud_info differ from the host restatement: {bad_seg}; "
       f"scans whose four feature clouds differ: {bad_fe}")
