@@ -23,6 +23,9 @@
 
 namespace lins {
 
+#ifndef LINS_FE_D2_GROUP
+#define LINS_FE_D2_GROUP 2  // the centroid pass: a wave takes the 64-position chunks of the less-flat cloud in this many groups of consecutive chunks
+#endif
 #ifndef LINS_FE_COMPACT_MAX
 #define LINS_FE_COMPACT_MAX 64  // edge candidates of a sector up to which they are dealt one per lane
 #endif
@@ -227,6 +230,11 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     int first = n;
     constexpr int kIn = 4;  // points per thread whose reads are in flight together
     for (int i0 = tid; i0 < n; i0 += kIn * kFeBlock) {
+      // Round 5: the flip is the FIRST index that passes pi — a point behind an index already found cannot be it, so its
+      // coordinates are not read and its arctangent is not taken.  The organised cloud is ring-major and ring 0 sweeps
+      // the whole turn: the first trip of this loop (indices < 4096) usually finds it, the other six skip 40 of their
+      // ~80 instructions per point and 16 of its 33 bytes.  (A stale `seen` only costs work: the minimum only falls.)
+      const int seen = __builtin_amdgcn_readfirstlane(*(volatile int*)&L.first_half_end);
       float4 p[kIn];
       unsigned char g[kIn];
       unsigned c[kIn], c1[kIn];
@@ -235,19 +243,22 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
       for (int u = 0; u < kIn; ++u) {
         const int i = i0 + u * kFeBlock, ic = i < n ? i : n - 1;  // (clamped reads; an empty scan does not get here)
         const int im = ic > 0 ? ic - 1 : 0, ip = ic < n - 1 ? ic + 1 : n - 1;
-        p[u] = pts[ic], g[u] = gd[ic], c[u] = cl[ic], c1[u] = cl[ip];
+        if (i < seen) p[u] = pts[ic];
+        g[u] = gd[ic], c[u] = cl[ic], c1[u] = cl[ip];
         rm[u] = rg[im], r0[u] = rg[ic], rp[u] = rg[ip];
       }
 #pragma unroll
       for (int u = 0; u < kIn; ++u) {
         const int i = i0 + u * kFeBlock;
         if (i < n) {
-          double ori = (double)(-lins_atan2f(p[u].y, p[u].x));
-          if (ori < s_ori - kPi / 2)
-            ori += 2 * kPi;
-          else if (ori > s_ori + kPi * 3 / 2)
-            ori -= 2 * kPi;
-          if (ori - s_ori > kPi && i < first) first = i;
+          if (i < seen) {
+            double ori = (double)(-lins_atan2f(p[u].y, p[u].x));
+            if (ori < s_ori - kPi / 2)
+              ori += 2 * kPi;
+            else if (ori > s_ori + kPi * 3 / 2)
+              ori -= 2 * kPi;
+            if (ori - s_ori > kPi && i < first) first = i;
+          }
           if (g[u]) atomicOr(&fw[i >> 2], 8u << ((i & 3) * 8));
           L.a.col[i] = (unsigned short)c[u];
           if (i >= 5 && i < n - 6) {  // markOccludedPoints (SE:680-713)
@@ -266,9 +277,11 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           }
         }
       }
+      if (__any(first < seen)) {  // (told at once: the waves still on their way stop taking arctangents)
+        for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
+        if (lane == 0) atomicMin(&L.first_half_end, first);
+      }
     }
-    for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
-    if (lane == 0) atomicMin(&L.first_half_end, first);
   }
   __syncthreads();
   const int flip = L.first_half_end;
@@ -754,25 +767,34 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
 #ifdef LINS_FE_PROF
   long long d2_t[4] = {0, 0, 0, 0};
 #endif
+  // (Round 5: a wave takes kD2Group CONSECUTIVE chunks at a time and carries the partial sums of a voxel that goes on beyond
+  // a chunk's last lane into the next chunk — lane 0 continues it — instead of finishing it alone, one dependent gather and
+  // one arctangent per point: with ~5 points a voxel nearly every chunk ended in such a run, 37 k of the phase's 87 k
+  // clocks.  Only a group's last chunk still finishes its last run alone.)
   const int n_chunks = L.chunk_off[kFeRows];
-  for (int ch = wave; ch < n_chunks; ch += kFeBlock / 64) {
-    // the chunk's ring: lane r < 16 tests ring r's first chunk, the ballot counts (chunk_off is non-decreasing)
-    const int ring = __popcll(__ballot(lane >= 1 && lane < kFeRows && L.chunk_off[lane] <= ch));
-    const int m = L.ring_m[ring], base = L.ring_base[ring];
-    const unsigned short* vs = L.vso[ring];
-    const unsigned short* slot = reinterpret_cast<const unsigned short*>(L.a.skey[ring]);
-    float4* dst = olf + L.ring_off[ring];
-    // A wave takes 64 consecutive sorted positions per step: every lane reads ITS point and forms its tag (one gather
-    // and one arctangent per lane, no divergence); a voxel's lanes are neighbours, so its first lane collects the
-    // others' values left to right with shuffles — the sums in the order VoxelGrid adds them (ascending original
-    // index).  Only a run that crosses the step's last lane is finished by its first lane alone.  (Issuing the next
-    // step's gather before working on the current one was measured: no faster — the other waves cover the latency.)
-    {
+  const int kD2Group = max(1, (n_chunks + (kFeBlock / 64) * LINS_FE_D2_GROUP - 1) / ((kFeBlock / 64) * LINS_FE_D2_GROUP));
+  for (int g0 = wave * kD2Group; g0 < n_chunks; g0 += (kFeBlock / 64) * kD2Group) {
+    float cx = 0.f, cy = 0.f, cz = 0.f, ci = 0.f;  // the carried run (wave-uniform): sums so far, points so far, output slot
+    int c_cnt = 0, c_slot = -1;
+    for (int ch = g0; ch < min(g0 + kD2Group, n_chunks); ++ch) {
+      // the chunk's ring: lane r < 16 tests ring r's first chunk, the ballot counts (chunk_off is non-decreasing)
+      const int ring = __popcll(__ballot(lane >= 1 && lane < kFeRows && L.chunk_off[lane] <= ch));
+      const int m = L.ring_m[ring], base = L.ring_base[ring];
+      const unsigned short* vs = L.vso[ring];
+      const unsigned short* slot = reinterpret_cast<const unsigned short*>(L.a.skey[ring]);
+      float4* dst = olf + L.ring_off[ring];
+      // A wave takes 64 consecutive sorted positions per step: every lane reads ITS point and forms its tag (one gather
+      // and one arctangent per lane, no divergence); a voxel's lanes are neighbours, so its first lane collects the
+      // others' values left to right with shuffles — the sums in the order VoxelGrid adds them (ascending original
+      // index).  (Issuing the next step's gather before working on the current one was measured: no faster — the other
+      // waves cover the latency.)
       const int e0 = (ch - L.chunk_off[ring]) * 64;
       const int e = e0 + lane;
       const bool valid = e < m;
       const unsigned v = valid ? (unsigned)vs[e] : 0x8000u;
       const bool start = valid && (v & 0x8000u);
+      const bool head = lane == 0 && c_slot >= 0 && !start;  // (a carried run is of this ring: it crossed a chunk end inside it)
+      const bool st = start || head;
       const int i = base + (int)(v & 2047u);
       float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
       float tg = 0.f;
@@ -795,10 +817,10 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
       const unsigned long long above = lane < 63 ? bounds & ~((2ull << lane) - 1ull) : 0ull;
       const int nxt = above ? __ffsll((long long)above) - 1 : 64;
       const int len_in = nxt - lane;  // this run's points inside the step (meaningful for start lanes)
-      float sx = 0.f + p.x, sy = 0.f + p.y, sz = 0.f + p.z, si = 0.f + tg;
-      for (int d = 1; __any(start && d < len_in); ++d) {
+      float sx = (head ? cx : 0.f) + p.x, sy = (head ? cy : 0.f) + p.y, sz = (head ? cz : 0.f) + p.z, si = (head ? ci : 0.f) + tg;
+      for (int d = 1; __any(st && d < len_in); ++d) {
         const float ax = __shfl_down(p.x, d), ay = __shfl_down(p.y, d), az = __shfl_down(p.z, d), at = __shfl_down(tg, d);
-        if (start && d < len_in) sx += ax, sy += ay, sz += az, si += at;
+        if (st && d < len_in) sx += ax, sy += ay, sz += az, si += at;
       }
 #ifdef LINS_FE_PROF
       asm volatile("" ::"v"(sx) : "memory");
@@ -806,9 +828,23 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
       d2_t[2] += d2d - d2c;
       d2_t[3] += 1;
 #endif
-      if (start) {
-        int total = len_in;
-        if (nxt == 64) {  // the run may go on beyond this step
+      int total = len_in + (head ? c_cnt : 0);
+      const int my_slot = head ? c_slot : (valid ? (int)slot[e] : 0);
+      // does the run that reaches the last lane go on in the next chunk?  (wave-uniform)
+      const unsigned long long stm = __ballot(st);
+      const bool goes_on = stm != 0ull && e0 + 64 < m && !(vs[e0 + 64] & 0x8000u);
+      const int last_st = stm ? 63 - __builtin_clzll(stm) : 0;  // its first lane (the run above it reaches lane 63: valid lanes throughout)
+      const bool carry = goes_on && ch + 1 < min(g0 + kD2Group, n_chunks);
+      if (st && !(goes_on && lane == last_st)) {
+        const float cnt = (float)total;
+        dst[my_slot] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+      }
+      if (carry) {
+        cx = __shfl(sx, last_st), cy = __shfl(sy, last_st), cz = __shfl(sz, last_st), ci = __shfl(si, last_st);
+        c_cnt = __shfl(total, last_st), c_slot = __shfl(my_slot, last_st);
+      } else {
+        c_slot = -1;
+        if (goes_on && lane == last_st) {  // a group's last chunk: its last run is finished by its first lane alone
           int j = e0 + 64;
           while (j < m && !(vs[j] & 0x8000u)) {
             const int i2 = base + (int)(vs[j] & 2047u);
@@ -816,10 +852,10 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
             sx += p2.x, sy += p2.y, sz += p2.z, si += tag_of(i2, p2);
             ++j;
           }
-          total = j - e;
+          total += j - (e0 + 64);
+          const float cnt = (float)total;
+          dst[my_slot] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
         }
-        const float cnt = (float)total;
-        dst[slot[e]] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
       }
     }
   }
