@@ -55,6 +55,7 @@ struct FeLds {
     } a;                                              // stencils, masks, sector picks
     unsigned short vso[kFeRows][kRingCap];            // VoxelGrid: per ring, sorted (run start << 15) | order
   };
+  unsigned long long headbits[kFeRows][kRingCap / 64];  // VoxelGrid: bit e: kept point e opens a run of consecutive points of one voxel
   int first_half_end;      // first point with ori - startOri > pi (halfPassed flips after it)
   int ring_m[kFeRows];     // less-flat points of each ring
   int ring_base[kFeRows];  // the ring's first sector's start: what its kept-point list is relative to
@@ -639,6 +640,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
       const int ring = __builtin_amdgcn_readfirstlane(wave);
       const int m = L.ring_m[ring], base = L.ring_base[ring];
       unsigned short* vs = L.vso[wave];
+      unsigned long long* const hbw = L.headbits[wave];
       int nvox = 0;
       if (m > 0) {
         const float inv = 1.0f / 0.2f;
@@ -674,6 +676,124 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           // arithmetic throughout), or — a ring whose box needs 64-bit keys or whose coordinates do not pack — from a
           // second read of the point
           unsigned startmask = 0;  // bit u: this lane's u-th sorted position starts a voxel
+          // Round 5: RUNS, not points, are sorted.  Along a ring consecutive kept points mostly fall into the same 0.2 m
+          // voxel (beam spacing 3.5 cm at 10 m), and a run of them stays together under the (voxel index, order) sort, in
+          // order.  So only the first point of every run — a "head" — goes through the bitonic network (64 * 2 .. 16 keys
+          // instead of 64 * 8 .. 32; the network is the one VALU-saturated phase of the kernel), the sorted heads' run
+          // lengths give every run its place by a prefix sum, and each head writes its run's points behind it.  Two runs
+          // of one voxel (the beam left it and came back) end up adjacent, the earlier first: the same order.
+          int heads = 0;
+          if (narrow && packed) {
+            unsigned* hk = reinterpret_cast<unsigned*>(vs);  // [1024] the heads' keys in order of appearance (vs is written after the sort)
+            unsigned carry_vox = ~0u;                        // the voxel of element u * 64 - 1
+#pragma unroll
+            for (int u = 0; u < kP; ++u) {
+              if (u * 64 < m) {  // (wave-uniform)
+                const int e = u * 64 + lane;
+                if (e < m) {
+                  const int ix = (int)(pkd[u] & 2047u) - 1024, iy = (int)((pkd[u] >> 11) & 2047u) - 1024, iz = (int)(pkd[u] >> 22) - 512;
+                  pkd[u] = ((unsigned)((ix - mnx) + (iy - mny) * (int)dx + (iz - mnz) * (int)(dx * dy)) << 11) | (unsigned)e;
+                }
+                const unsigned vox = pkd[u] >> 11;  // (no point: 0x1FFFFF, above every voxel index of a narrow box)
+                unsigned pv = __shfl_up(vox, 1);
+                if (lane == 0) pv = carry_vox;
+                carry_vox = __shfl(vox, 63);
+                const bool head = e < m && vox != pv;
+                const unsigned long long bm = __ballot(head);
+                if (head) {
+                  const int r = heads + __popcll(bm & ((1ull << lane) - 1ull));
+                  if (r < 1024) hk[r] = pkd[u];
+                }
+                if (lane == 0) hbw[u] = bm;
+                heads += __popcll(bm);
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          }
+          auto sort_heads = [&](auto qtag) {
+            constexpr int kQ = decltype(qtag)::value;
+            const unsigned* hk = reinterpret_cast<const unsigned*>(vs);
+            const unsigned long long* hb = hbw;
+            unsigned kv[kQ];
+#pragma unroll
+            for (int u = 0; u < kQ; ++u) kv[u] = u * 64 + lane < heads ? hk[u * 64 + lane] : ~0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // (every lane has its keys: vs, the same bytes, is written below)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            wave_bitonic_sort<kQ, unsigned>(kv, lane);
+            // sorted head lane * kQ + u: its run's length (to the next head in order of appearance, or the ring's end),
+            // whether it opens a voxel (the sorted predecessor is of another one)
+            unsigned prev = __shfl_up(kv[kQ - 1], 1);
+            int len[kQ], my_len = 0;
+#pragma unroll
+            for (int u = 0; u < kQ; ++u) {
+              const int sidx = lane * kQ + u;
+              len[u] = 0;
+              if (sidx < heads) {
+                const int e = (int)(kv[u] & 2047u), q = e + 1;
+                int nx = m;
+                const unsigned long long x = q < m ? hb[q >> 6] >> (q & 63) : 0ull;  // (words from m / 64 rounded up on are not written)
+                if (x) {
+                  nx = q + __ffsll((long long)x) - 1;
+                } else {
+                  for (int w = (q >> 6) + 1; w < (m + 63) >> 6; ++w)
+                    if (hb[w]) {
+                      nx = w * 64 + __ffsll((long long)hb[w]) - 1;
+                      break;
+                    }
+                }
+                len[u] = nx - e;
+                const bool start = sidx == 0 || (prev >> 11) != (kv[u] >> 11);
+                mine += start ? 1 : 0;
+                startmask |= start ? (1u << u) : 0u;
+                prev = kv[u];
+              }
+              my_len += len[u];
+            }
+            int incl_len = my_len;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+              const int nb = __shfl_up(incl_len, o, 64);
+              if (lane >= o) incl_len += nb;
+            }
+            int pos = incl_len - my_len;
+#pragma unroll
+            for (int u = 0; u < kQ; ++u) {
+              const int e = (int)(kv[u] & 2047u);
+              for (int t = 0; t < len[u]; ++t) vs[pos + t] = (unsigned short)((t == 0 && ((startmask >> u) & 1u) ? 0x8000u : 0u) | (unsigned)kept[e + t]);
+              pos += len[u];
+            }
+            int incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+              const int nb = __shfl_up(incl, o, 64);
+              if (lane >= o) incl += nb;
+            }
+            nvox = __shfl(incl, 63);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();  // (the list of kept points has been folded into vs: see the other route below)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int run = incl - mine;
+            pos = incl_len - my_len;
+#pragma unroll
+            for (int u = 0; u < kQ; ++u) {
+              if ((startmask >> u) & 1u) kept[pos] = (unsigned short)run++;
+              pos += len[u];
+            }
+          };
+          if (narrow && packed && heads <= 1024 && heads * 2 <= kP * 64) {  // (fewer keys per lane than the points' network)
+            if (heads <= 128)
+              sort_heads(FeInt<2>{});
+            else if (heads <= 256)
+              sort_heads(FeInt<4>{});
+            else if (heads <= 512)
+              sort_heads(FeInt<8>{});
+            else
+              sort_heads(FeInt<16>{});
+            return;
+          }
           auto sort_and_mark = [&](auto key_zero, auto from_pack) {
             using K = decltype(key_zero);  // 32-bit keys when (voxel index << 11 | order) fits: half the shuffles and compares
             K kv[kP];
@@ -683,8 +803,7 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
               K k = (K)~key_zero;
               if (e < m) {
                 if (decltype(from_pack)::value) {
-                  const int ix = (int)(pkd[u] & 2047u) - 1024, iy = (int)((pkd[u] >> 11) & 2047u) - 1024, iz = (int)(pkd[u] >> 22) - 512;
-                  k = (K)(((unsigned)((ix - mnx) + (iy - mny) * (int)dx + (iz - mnz) * (int)(dx * dy)) << 11) | (unsigned)e);
+                  k = (K)pkd[u];  // (the key was formed in place above)
                 } else {
                   const float4 p = pts[base + (int)kept[e]];
                   const long long ix = (long long)floorf(p.x * inv), iy = (long long)floorf(p.y * inv), iz = (long long)floorf(p.z * inv);
