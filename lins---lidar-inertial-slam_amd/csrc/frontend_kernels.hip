@@ -6,16 +6,11 @@
 //   markOccludedPoints  SE:680-713   occlusion / parallel-beam masks
 //   extractFeatures     SE:719-827   per ring, 6 sectors: sort by curvature, greedy picks with
 //                                    neighbour suppression, less-flat collection, VoxelGrid 0.2 m
-// Round 5: TWO kernels of (scan, ring) workgroups instead of one 1024-thread workgroup per scan (rounds 1-4).
-//   fe_ring_kernel   one WAVE per (scan, ring), ~10 KB of LDS: the ring's masks, its six sectors' picks, its less-flat
-//                    points' voxel order.  Nothing in it looks at another ring (the masks of a ring's first and last
-//                    points come from a halo of 6 points either side, read from global memory), so there is no barrier
-//                    and sixteen rings of whatever scans share a CU, each in its own phase: the point reads of one
-//                    overlap the pick rounds of another (the one-workgroup kernel ran every CU of the device through
-//                    the same phase at the same time — HBM-bound passes followed by passes that left it idle).
-//   fe_out_kernel    256 threads per (scan, ring): offsets from the rings' counts, the three picked clouds, the less-flat
-//                    cloud's centroids; the relative-time tags are formed here, where a point is written.
-// The per-point stencils read the range / column arrays coalesced in index order — the organised cloud is ring-major.
+// One 1024-thread workgroup per scan (16 waves = one wave per ring for the sequential greedy
+// part).  The per-point stencils read the range / column arrays coalesced in index order — the
+// organised cloud is ring-major; flags and columns of the whole scan live in LDS for the greedy
+// picks, the per-sector sort is a 512-key and the per-ring VoxelGrid sort a 2048-key bitonic network
+// per wave with the keys in registers (wave shuffles across lanes).
 //
 // Sort keys carry the point index as tie-break ((|diffRange| bits, index): the reference's
 // std::sort leaves the order of equal curvatures unspecified; the host restatement uses the same
@@ -23,21 +18,20 @@
 
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "../../include/lins_host.h"
 #include "lins_math.h"
 
 namespace lins {
 
 #ifndef LINS_FE_D2_GROUP
-#define LINS_FE_D2_GROUP 1  // the centroid pass: a wave takes a ring's 64-position chunks in this many groups of consecutive chunks
+#define LINS_FE_D2_GROUP 2  // the centroid pass: a wave takes the 64-position chunks of the less-flat cloud in this many groups of consecutive chunks
 #endif
 #ifndef LINS_FE_COMPACT_MAX
 #define LINS_FE_COMPACT_MAX 64  // edge candidates of a sector up to which they are dealt one per lane
 #endif
 constexpr int kFeRows = LINS_LINE_NUM;
-constexpr int kOutBlock = 256;           // fe_out_kernel: four waves per (scan, ring)
+constexpr int kFeMaxN = LINS_CLOUD_MAX;  // 28 800 cells
+constexpr int kFeBlock = 1024;
 constexpr int kSectorCap = 512;          // >= points of one sector (a ring has <= 1800 -> <= 300 + margins)
 constexpr int kRingCap = 2048;           // >= less-flat points of one ring
 constexpr int kPickStride = 32;          // per sector: [0..1] sharp, [2..21] less sharp (incl. sharp), [22..25] flat, [26..28] counts
@@ -51,39 +45,30 @@ struct FeScan {  // device view of one lins_segmented_scan + its outputs
   long long o_sharp, o_less_sharp, o_flat, o_less_flat;  // where the four feature clouds go (points from `out`)
 };
 
-constexpr int kHalo = 6;         // how far a point's occlusion mark reaches (SE:693-704)
-constexpr int kRingWin = 1856;   // a ring's window in LDS: its <= 1800 cells + the 4 + 6 points cloud_info's ring indices leave out + 2 halos + alignment
-struct FeRingLds {               // fe_ring_kernel: one wave, one ring
+struct FeLds {
   union {
     struct {
-      unsigned flagw[kRingWin / 4];  // a byte per point of the window: bit 0 picked (cloudNeighborPicked); bits 1-2 cloudLabel: 0 = 0,
-                                     // 1 = 1 (less sharp), 2 = 2 (sharp), 3 = -1 (flat); bit 3 ground
-      unsigned short col[kRingWin];
-    } a;                             // masks, sector picks, less-flat collection
-    unsigned hk[1024];               // VoxelGrid: the run heads' keys in order of appearance
-    unsigned short vs[kRingCap];     // VoxelGrid: sorted (voxel start << 15) | point position
+      unsigned char flags[kFeMaxN + 16];  // bit 0 picked (cloudNeighborPicked); bits 1-2 cloudLabel: 0 = 0, 1 = 1 (less
+                                          // sharp), 2 = 2 (sharp), 3 = -1 (flat); bit 3 ground
+      unsigned short col[kFeMaxN + 16];
+      unsigned long long skey[kFeRows][kSectorCap];  // per wave: 4 KB of work space (the less-flat stage's index lists; rounds 1-3: the sector sort's keys)
+    } a;                                              // stencils, masks, sector picks
+    unsigned short vso[kFeRows][kRingCap];            // VoxelGrid: per ring, sorted (run start << 15) | order
   };
-  unsigned long long work[kSectorCap];          // 4 KB: a sector's edge candidates; the kept points' positions (u16[kRingCap]); the voxels' output slots
-  unsigned long long headbits[kRingCap / 64];   // VoxelGrid: bit e: kept point e opens a run of consecutive points of one voxel
+  int first_half_end;      // first point with ori - startOri > pi (halfPassed flips after it)
+  int ring_m[kFeRows];     // less-flat points of each ring
+  int ring_base[kFeRows];  // the ring's first sector's start: what its kept-point list is relative to
+  int ring_out[kFeRows];   // voxels (= output points) of each ring
+  int ring_off[kFeRows + 1];
+  int chunk_off[kFeRows + 1];  // D2: 64-position chunks of the rings' sorted lists, prefix sum
+  int bad;
 };
-static_assert(sizeof(FeRingLds) <= 10240, "sixteen rings per CU");
-static_assert(sizeof(unsigned long long) * kSectorCap >= kRingCap * sizeof(unsigned short), "index list of a ring");
+static_assert(sizeof(FeLds) <= 160 * 1024, "LDS budget");
 
-struct FeRingInfo {  // what fe_ring_kernel leaves per (scan, ring) for fe_out_kernel
-  int m;             // less-flat points of the ring before VoxelGrid (-1: a ring beyond the kernel's limits)
-  int base;          // the ring's first sector's start: positions in `order` are relative to it; the list sits at order[off + base ..]
-  int nvox;          // voxels = less-flat output points of the ring
-  int flip;          // (ring 0) first point with ori - startOri > pi (halfPassed flips after it), n if none
-  int n_sharp, n_less_sharp, n_flat, pad;  // the ring's six sectors' picks
-};
-
-__shared__ FeRingLds g_ring;
-template <class T>
-struct FeWin {  // a window array addressed by the cloud's flat index
-  T* p;
-  int first;
-  __device__ __forceinline__ T& operator[](int i) const { return p[i - first]; }
-};
+__shared__ FeLds g_fe;
+#ifdef LINS_FE_PROF
+__device__ long long g_fe_prof[16 * 8];
+#endif
 
 __device__ __forceinline__ int fe_ordered_int(float f) {
   int i = __float_as_int(f);
@@ -166,89 +151,57 @@ __device__ __forceinline__ unsigned long long fe_xor_lane(unsigned long long v, 
 }
 // Bitonic sort of 64 * P keys by one wave, the keys in registers (lane l owns positions l P .. l P + P - 1):
 // compare-exchanges whose partner lies inside the lane's own block are register selects, the others one lane-xor move
-// per key (both lanes of a pair evaluate it and keep the min or the max) — no LDS round trips, no fences.
-// Round 5: the network is a LOOP over its merge levels (rounds 3-4 unrolled all of it by template recursion: 66 steps of
-// 32 keys are 80 KB of straight-line code per instantiation, half a megabyte for the kernel).  With one wave per ring
-// every wave of a CU is somewhere else in the code, and straight-line code is fetched once per wave, not once per CU:
-// a level's body — the six possible lane distances behind a switch, the in-lane steps unrolled — is a few KB that stay
-// in the instruction cache.
-template <int P, int LM, class K>
-__device__ __forceinline__ void bitonic_cross(K (&v)[P], int lane, bool up) {
-  const bool keep_min = ((lane & LM) == 0) == up;
+// per key (both lanes of a pair evaluate it and keep the min or the max) — no LDS round trips, no fences.  The network
+// is unrolled by template recursion: every register index and every lane distance is a compile-time constant.
+template <int P, int K2, int J2, class K>
+__device__ __forceinline__ void bitonic_step(K (&v)[P], int lane) {
+  if constexpr (J2 < P) {
 #pragma unroll
-  for (int u = 0; u < P; ++u) {
-    const K w = fe_xor_lane<LM>(v[u], lane);
-    v[u] = keep_min ? (w < v[u] ? w : v[u]) : (w > v[u] ? w : v[u]);
-  }
-}
-template <int P, int J2, class K>
-__device__ __forceinline__ void bitonic_inlane(K (&v)[P], int lane, int k2) {
-  if constexpr (J2 >= 1) {
-    if (J2 < k2) {  // (wave-uniform)
-#pragma unroll
-      for (int u = 0; u < P; ++u)
-        if ((u & J2) == 0) {
-          const bool up = (((lane * P) | u) & k2) == 0;
-          const K a = v[u], b = v[u | J2];
-          const bool sw = (a > b) == up;
-          v[u] = sw ? b : a, v[u | J2] = sw ? a : b;
-        }
-    }
-    bitonic_inlane<P, J2 / 2, K>(v, lane, k2);
-  }
-}
-// (One copy per size and key type in the binary, called from wherever a sort is needed: the arguments travel through
-// registers, what is live across the call is saved around it — once per ring.)
-template <int P, class K>
-__device__ __noinline__ void wave_bitonic_sort_mem(K (&v)[P], int lane);
-template <int P, class K>
-__device__ __forceinline__ void wave_bitonic_sort(K (&v)[P], int lane) {  // (the caller's keys stay registers: a copy goes through memory)
-  K t[P];
-#pragma unroll
-  for (int u = 0; u < P; ++u) t[u] = v[u];
-  wave_bitonic_sort_mem<P, K>(t, lane);
-#pragma unroll
-  for (int u = 0; u < P; ++u) v[u] = t[u];
-}
-template <int P, class K>
-__device__ __noinline__ void wave_bitonic_sort_mem(K (&v)[P], int lane) {
-#pragma unroll 1
-  for (int k2 = 2; k2 <= 64 * P; k2 <<= 1) {
-    const bool up = ((lane * P) & k2) == 0;  // (for the lane-crossing steps k2 >= 2 P: the direction is the lane's)
-#pragma unroll 1
-    for (int lm = (k2 >> 1) / P; lm >= 1; lm >>= 1) {
-      switch (lm) {
-        case 32: bitonic_cross<P, 32, K>(v, lane, up); break;
-        case 16: bitonic_cross<P, 16, K>(v, lane, up); break;
-        case 8: bitonic_cross<P, 8, K>(v, lane, up); break;
-        case 4: bitonic_cross<P, 4, K>(v, lane, up); break;
-        case 2: bitonic_cross<P, 2, K>(v, lane, up); break;
-        default: bitonic_cross<P, 1, K>(v, lane, up); break;
+    for (int u = 0; u < P; ++u)
+      if ((u & J2) == 0) {
+        const bool up = ((lane * P + u) & K2) == 0;
+        const K a = v[u], b = v[u | J2];
+        const bool sw = (a > b) == up;
+        v[u] = sw ? b : a, v[u | J2] = sw ? a : b;
       }
+  } else {
+    constexpr int kLm = J2 / P;
+    const bool lower = (lane & kLm) == 0;
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const bool up = ((lane * P + u) & K2) == 0;
+      const K w = fe_xor_lane<kLm>(v[u], lane);
+      const bool keep_min = lower == up;
+      v[u] = keep_min ? (w < v[u] ? w : v[u]) : (w > v[u] ? w : v[u]);
     }
-    bitonic_inlane<P, P / 2, K>(v, lane, k2);
   }
+  if constexpr (J2 > 1) bitonic_step<P, K2, J2 / 2, K>(v, lane);
+}
+template <int P, int K2, class K>
+__device__ __forceinline__ void bitonic_merge(K (&v)[P], int lane) {
+  bitonic_step<P, K2, K2 / 2, K>(v, lane);
+  if constexpr (K2 < 64 * P) bitonic_merge<P, K2 * 2, K>(v, lane);
+}
+template <int P, class K>
+__device__ __forceinline__ void wave_bitonic_sort(K (&v)[P], int lane) {
+  bitonic_merge<P, 2, K>(v, lane);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// fe_ring_kernel: one wave per (scan, ring).  Leaves per sector its pick list (`picks`, 32 ints), per ring its counts
-// (FeRingInfo) and the voxel order of its less-flat points: order[off + base + e], e < m, = (voxel's slot in the ring's
-// output << 16) | (voxel start << 15) | the point's position relative to base — what the centroid pass walks.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void fe_ring_kernel(
+__global__ __launch_bounds__(kFeBlock) void frontend_kernel(
     const FeScan* __restrict__ scans, const float4* __restrict__ cloud, const float* __restrict__ range,
-    const unsigned* __restrict__ col, const unsigned char* __restrict__ ground, int* __restrict__ picks,
-    unsigned* __restrict__ order, FeRingInfo* __restrict__ info) {
-  FeRingLds& L = g_ring;
-  const int lane = threadIdx.x;
-  const int scan = blockIdx.x / kFeRows, ring = blockIdx.x % kFeRows;
+    const unsigned* __restrict__ col, const unsigned char* __restrict__ ground, double scan_period,
+    int* __restrict__ picks, float4* __restrict__ out, int* __restrict__ out_counts) {
+  FeLds& L = g_fe;
 #ifdef LINS_FE_PROF
-  long long fe_t0 = clock64(), fe_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long fe_t0 = clock64(), fe_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define FE_MARK(id) \
-  { long long t_ = clock64(); fe_t[id] += t_ - fe_t0; fe_t0 = t_; }
+  { long long t_ = clock64(); fe_t[id] = t_ - fe_t0; fe_t0 = t_; }
 #else
 #define FE_MARK(id)
 #endif
-  const FeScan& sc = scans[scan];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int scan = blockIdx.x;
+  const FeScan& sc = scans[scan];  // (read where it is used: a private copy indexed by the ring lives in scratch)
   const int n = sc.n;
   const float4* pts = cloud + sc.off;
   const float* rg = range + sc.off;
@@ -257,121 +210,102 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   int* pk = picks + (size_t)scan * kFeRows * 6 * kPickStride;
   const double kPi = 3.14159265358979323846;
 
-  // ---- undistortPcl, pass 1 (ring 0's wave): where does halfPassed flip?  (SE:631-638: first-half adjustment) ----
-  // The relative-time tag of a point is a function of the point, its index and the flip position; its consumers (the
-  // picked points, the kept points of the less-flat cloud) evaluate it in fe_out_kernel where they write the point.
-  // The flip is the FIRST index that passes pi: the organised cloud is ring-major and ring 0 sweeps the whole turn, so
-  // the search stops after a few hundred points (it walks the whole cloud only when no point passes).
-  int flip = n;
-  if (ring == 0) {
-    const double s_ori = (double)sc.start_ori;
-    constexpr int kIn = 4;
-    for (int i0 = 0; i0 < n && flip == n; i0 += kIn * 64) {
-      float4 p[kIn];
-#pragma unroll
-      for (int u = 0; u < kIn; ++u) {
-        const int i = i0 + u * 64 + lane;
-        p[u] = pts[i < n ? i : n - 1];
-      }
-      int first = n;
-#pragma unroll
-      for (int u = kIn - 1; u >= 0; --u) {
-        const int i = i0 + u * 64 + lane;
-        double ori = (double)(-lins_atan2f(p[u].y, p[u].x));
-        if (ori < s_ori - kPi / 2)
-          ori += 2 * kPi;
-        else if (ori > s_ori + kPi * 3 / 2)
-          ori -= 2 * kPi;
-        if (ori - s_ori > kPi && i < n) first = i;
-      }
-      for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
-      flip = first;
-    }
-  }
-
-  FE_MARK(0)
-  // ---- the ring's window: its points [start - 4, end + 6) (cloud_info's ring indices leave 5 points out either side,
-  // IP:395-410) and a halo of kHalo points, whose occlusion marks reach into the ring ----
-  const int w0 = max(0, min(sc.start_ring[ring], n) - 4 - kHalo) & ~3;  // (a multiple of 4: a flag word of the window is a flag word of the cloud)
-  const int w1 = max(w0, min(n, sc.end_ring[ring] + 6 + kHalo));
-  FeRingInfo* const my = info + blockIdx.x;
-  if (w1 - w0 > kRingWin) {  // never a VLP-16's ring (1800 cells): refused, not truncated
-    if (lane == 0) my->m = -1, my->base = 0, my->nvox = 0, my->flip = flip, my->n_sharp = 0, my->n_less_sharp = 0, my->n_flat = 0, my->pad = 0;
-    return;
-  }
-  const FeWin<unsigned> fw{L.a.flagw, w0 >> 2};                                              // fw[i >> 2]: the flag word of point i
-  const FeWin<unsigned char> flb{reinterpret_cast<unsigned char*>(L.a.flagw), w0};         // flb[i]: its flag byte
-  const FeWin<unsigned short> colb{L.a.col, w0};                                             // colb[i]: its column
-  // markOccludedPoints (SE:680-713) over the window, as bit masks: a chunk of 64 consecutive points is a wave, a condition
-  // a ballot.  Pass 1 reads a point's column and range and both neighbours' (global memory, coalesced, eight chunks in
-  // flight) and keeps, per chunk, four 64-bit masks in the registers of the lane of the chunk's number (a window has at
-  // most 29 chunks): A — the point hides its successor's surface: it and the five before it are marked (SE:693-697);
-  // B — the successor hides it: the six behind it (SE:698-704); C — a beam nearly parallel to the surface: itself
-  // (SE:707-711); G — ground.  Pass 2 smears A downwards and B upwards across the chunk borders (shifts of the chunk's
-  // and its neighbour's masks: scalar instructions) and every lane stores its point's flag byte once — no atomics, no
-  // zeroed array, no loop per mark.  Conditions of points outside the window do not exist (they belong to other rings'
-  // waves; the halo covers every source that reaches this ring).
+  if (tid == 0) L.first_half_end = n, L.bad = 0;
+  // ---- load + undistortPcl, pass 1: where does halfPassed flip?  (SE:631-638: first-half adjustment) ----
+  // Round 3: no per-point array is written at all.  The relative-time tag of a point is a function of the point, its
+  // index and the flip position; the few consumers (the picked points, the kept points of the less-flat cloud: each
+  // point at most once) evaluate it where they read the point — rounds 1-2 stored a de-skewed copy of the whole cloud.
+  const double s_ori = (double)sc.start_ori, e_ori = (double)sc.end_ori;
+  // Round 4: ONE pass over the cloud does what two did (where halfPassed flips; flags and columns into LDS; then, behind a
+  // barrier, the occlusion / parallel-beam masks of SE:680-713 from a second read of the ranges): the masks need a
+  // point's own column and its successor's — both read from global memory here — and their marks are 32-bit LDS atomic
+  // ORs, as is the ground bit, so that nothing orders a point's own initialisation against its neighbours' marks: the
+  // flag words are zeroed first (LDS only), then everything is an OR.
+  unsigned* fw = reinterpret_cast<unsigned*>(L.a.flags);  // (marks are idempotent bit sets: 32-bit LDS atomics)
+  auto mark = [&](int i) { atomicOr(&fw[i >> 2], 1u << ((i & 3) * 8)); };
+  for (int w = tid; w < (n + 16 + 3) / 4; w += kFeBlock) fw[w] = 0u;
+  if (tid < 16) L.a.col[n + tid] = 0;
+  __syncthreads();
   {
-    static_assert(kRingWin <= 64 * 64, "a chunk per lane");
-    unsigned long long keep_a = 0ull, keep_b = 0ull, keep_c = 0ull, keep_g = 0ull;
-    const int n_ch = (w1 - w0 + 63) >> 6;
-    constexpr int kIn = 8;
-    for (int c0 = 0; c0 < n_ch; c0 += kIn) {
+    int first = n;
+    constexpr int kIn = 4;  // points per thread whose reads are in flight together
+    for (int i0 = tid; i0 < n; i0 += kIn * kFeBlock) {
+      // Round 5: the flip is the FIRST index that passes pi — a point behind an index already found cannot be it, so its
+      // coordinates are not read and its arctangent is not taken.  The organised cloud is ring-major and ring 0 sweeps
+      // the whole turn: the first trip of this loop (indices < 4096) usually finds it, the other six skip 40 of their
+      // ~80 instructions per point and 16 of its 33 bytes.  (A stale `seen` only costs work: the minimum only falls.)
+      const int seen = __builtin_amdgcn_readfirstlane(*(volatile int*)&L.first_half_end);
+      float4 p[kIn];
       unsigned char g[kIn];
       unsigned c[kIn], c1[kIn];
       float rm[kIn], r0[kIn], rp[kIn];
 #pragma unroll
       for (int u = 0; u < kIn; ++u) {
-        const int i = w0 + (c0 + u) * 64 + lane, ic = i < w1 ? i : w1 - 1;  // (clamped reads; an empty window does not get here)
+        const int i = i0 + u * kFeBlock, ic = i < n ? i : n - 1;  // (clamped reads; an empty scan does not get here)
         const int im = ic > 0 ? ic - 1 : 0, ip = ic < n - 1 ? ic + 1 : n - 1;
+        if (i < seen) p[u] = pts[ic];
         g[u] = gd[ic], c[u] = cl[ic], c1[u] = cl[ip];
         rm[u] = rg[im], r0[u] = rg[ic], rp[u] = rg[ip];
       }
 #pragma unroll
       for (int u = 0; u < kIn; ++u) {
-        const int i = w0 + (c0 + u) * 64 + lane;
-        bool ca = false, cb = false, cc = false;
-        if (i < w1) {
-          colb[i] = (unsigned short)c[u];
-          if (i >= 5 && i < n - 6) {
+        const int i = i0 + u * kFeBlock;
+        if (i < n) {
+          if (i < seen) {
+            double ori = (double)(-lins_atan2f(p[u].y, p[u].x));
+            if (ori < s_ori - kPi / 2)
+              ori += 2 * kPi;
+            else if (ori > s_ori + kPi * 3 / 2)
+              ori -= 2 * kPi;
+            if (ori - s_ori > kPi && i < first) first = i;
+          }
+          if (g[u]) atomicOr(&fw[i >> 2], 8u << ((i & 3) * 8));
+          L.a.col[i] = (unsigned short)c[u];
+          if (i >= 5 && i < n - 6) {  // markOccludedPoints (SE:680-713)
             const float d1 = r0[u], d2 = rp[u];
             int cd = (int)c1[u] - (int)c[u];
             cd = cd < 0 ? -cd : cd;
             if (cd < 10) {
-              ca = d1 - d2 > 0.3;
-              cb = !ca && d2 - d1 > 0.3;
+              if (d1 - d2 > 0.3) {
+                for (int k = 0; k <= 5; ++k) mark(i - k);
+              } else if (d2 - d1 > 0.3) {
+                for (int k = 1; k <= 6; ++k) mark(i + k);
+              }
             }
             const float f1 = fabsf(rm[u] - r0[u]), f2 = fabsf(rp[u] - r0[u]);
-            cc = f1 > 0.02 * r0[u] && f2 > 0.02 * r0[u];
+            if (f1 > 0.02 * r0[u] && f2 > 0.02 * r0[u]) mark(i);
           }
         }
-        const unsigned long long ma = __ballot(ca), mb = __ballot(cb), mc = __ballot(cc), mg = __ballot(i < w1 && g[u] != 0);
-        if (lane == c0 + u) keep_a = ma, keep_b = mb, keep_c = mc, keep_g = mg;
+      }
+      if (__any(first < seen)) {  // (told at once: the waves still on their way stop taking arctangents)
+        for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
+        if (lane == 0) atomicMin(&L.first_half_end, first);
       }
     }
-    auto chunk_mask = [&](unsigned long long keep, int c) {  // chunk c's mask (0 outside the window), in every lane
-      const int cc = c < 0 ? 0 : (c > 63 ? 63 : c);
-      const unsigned lo = __builtin_amdgcn_readlane((unsigned)keep, cc), hi = __builtin_amdgcn_readlane((unsigned)(keep >> 32), cc);
-      return (c < 0 || c >= n_ch) ? 0ull : ((unsigned long long)hi << 32) | lo;
-    };
-    for (int c = 0; c < n_ch; ++c) {
-      const unsigned long long a0 = chunk_mask(keep_a, c), a1 = chunk_mask(keep_a, c + 1);
-      const unsigned long long b0 = chunk_mask(keep_b, c), bp = chunk_mask(keep_b, c - 1);
-      unsigned long long mk = chunk_mask(keep_c, c) | a0;
-#pragma unroll
-      for (int k = 1; k <= 5; ++k) mk |= (a0 >> k) | (a1 << (64 - k));  // a source marks the five points before it
-#pragma unroll
-      for (int k = 1; k <= 6; ++k) mk |= (b0 << k) | (bp >> (64 - k));  // ... the six behind it
-      const unsigned long long gm = chunk_mask(keep_g, c);
-      const int i = w0 + c * 64 + lane;
-      if (i < w1) flb[i] = (unsigned char)(((mk >> lane) & 1ull) | (((gm >> lane) & 1ull) << 3));
-    }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // calculateSmoothness (SE:656-678) is evaluated where it is consumed — a sector's candidate keys below — from the range
-  // array (f32, left to right, as written in SE:660-666); cloudCurvature / cloudSmoothness are never materialised.
+  __syncthreads();
+  const int flip = L.first_half_end;
+  FE_MARK(1)
+  const double ori_diff = (double)sc.ori_diff;
+  auto tag_of = [&](int i, const float4& p) {  // undistortPcl's intensity (SE:639-650) of point i
+    double ori = (double)(-lins_atan2f(p.y, p.x));
+    if (i <= flip) {
+      if (ori < s_ori - kPi / 2)
+        ori += 2 * kPi;
+      else if (ori > s_ori + kPi * 3 / 2)
+        ori -= 2 * kPi;
+    } else {
+      ori += 2 * kPi;
+      if (ori < e_ori - kPi * 3 / 2)
+        ori += 2 * kPi;
+      else if (ori > e_ori + kPi / 2)
+        ori -= 2 * kPi;
+    }
+    const double rel = (ori - s_ori) / ori_diff;
+    return (float)((double)(int)p.w + scan_period * rel);
+  };
+  // calculateSmoothness (SE:656-678) is evaluated where it is consumed — the sector sort below — from the range array
+  // (f32, left to right, as written in SE:660-666); cloudCurvature / cloudSmoothness are never materialised.
   auto diff_at = [&](int i) {
     float d = 0.f;
     if (i >= 5 && i < n - 5)
@@ -379,10 +313,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           rg[i + 4] + rg[i + 5];
     return d;
   };
-  // ---- extractFeatures: the ring's sectors in order (marks of one sector reach the next) ---
-  FE_MARK(1)
-  int r_sharp = 0, r_ls = 0, r_flat = 0;
+  FE_MARK(2)
+  // ---- extractFeatures: one wave per ring, sectors in order (marks of one sector reach the next) ---
   {
+    const int ring = __builtin_amdgcn_readfirstlane(wave);
+#ifdef LINS_FE_PROF
+    long long p3_t[5] = {0, 0, 0, 0, 0};
+    const long long p3_begin = clock64();
+#endif
     for (int j = 0; j < 6; ++j) {
       const int sp = (sc.start_ring[ring] * (6 - j) + sc.end_ring[ring] * j) / 6;
       const int ep = (sc.start_ring[ring] * (5 - j) + sc.end_ring[ring] * (j + 1)) / 6 - 1;
@@ -409,6 +347,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       // neighbours it marks — so the masks are kept up to date in registers (drop_range) and a round reads no flag at
       // all: local best (registers), wave arg-max (VALU), the pick's column-gap test (the one LDS round trip), marks.
       constexpr int kPmax = kSectorCap / 64;
+#ifdef LINS_FE_PROF
+      long long p3a = clock64();
+#endif
       unsigned dbits[kPmax];
       unsigned ecand = 0, pcand = 0;
 #pragma unroll
@@ -419,7 +360,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           if (e < m) {
             const float d = fabsf(diff_at(sp + e));
             const double c = (double)d * (double)d;  // cloudCurvature (SE:668), compared as the reference compares it
-            const unsigned char f = flb[smooth_ind(sp + e)];
+            const unsigned char f = L.a.flags[smooth_ind(sp + e)];
             dbits[u] = __float_as_uint(d);
             ecand |= (c > 0.5 && !(f & 9)) ? 1u << u : 0u;
             pcand |= (c < 0.5 && (f & 8)) ? 1u << u : 0u;  // (picked or not is looked up when the edges are done)
@@ -429,6 +370,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       const int ind_ep = smooth_ind(ep);
       const float d_ep = fabsf(diff_at(ep));
       const double c_ep = (double)d_ep * (double)d_ep;
+#ifdef LINS_FE_PROF
+      asm volatile("" ::"v"(ecand), "v"(pcand), "v"(d_ep) : "memory");
+      long long p3b = clock64();
+      p3_t[0] += p3b - p3a;
+#endif
       {
         // Flags change by 32-bit LDS atomic ORs with no return value (`mark`, above) and are read as bytes: the LDS unit
         // takes a wave's instructions in order, so a flag read issued after an OR sees it — nothing to wait for; what
@@ -437,12 +383,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           asm volatile("" ::: "memory");
           __builtin_amdgcn_wave_barrier();
         };
-        auto set_bits = [&](int i, unsigned bits) {
-          if (i >= w0 && i < w1) atomicOr(&fw[i >> 2], bits << ((i & 3) * 8));
-        };
+        auto set_bits = [&](int i, unsigned bits) { atomicOr(&fw[i >> 2], bits << ((i & 3) * 8)); };
         auto col_gap = [&](int a, int b) {
           if (a < 0 || b < 0 || a >= n || b >= n) return 1000;
-          const int g = (int)colb[a] - (int)colb[b];
+          const int g = (int)L.a.col[a] - (int)L.a.col[b];
           return g < 0 ? -g : g;
         };
         // cloudNeighborPicked of the +-5 neighbours up to the first column gap > 10 (SE:764-779): lanes 0-4
@@ -495,7 +439,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           mark_nbrs(pind);
           wave_sync();
         };
-        if (c_ep > 0.5 && !(flb[ind_ep] & 9)) {  // position ep comes first whatever its curvature
+        if (c_ep > 0.5 && !(L.a.flags[ind_ep] & 9)) {  // position ep comes first whatever its curvature
           edge_pick(ind_ep);
           drop_range(ecand, mk_lo, mk_hi);
         }
@@ -514,7 +458,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           // ONE candidate per lane (the usual case: a sector has a few dozen points of curvature > 0.5): through the
           // wave's 4 KB of LDS work space into lane order; a round is then the wave arg-max of one register, the pick, and
           // a three-instruction range test — the block masks are not touched again.
-          unsigned long long* sk = L.work;
+          unsigned long long* sk = L.a.skey[ring];
 #pragma unroll
           for (int u = 0; u < kPmax; ++u)
             if (u * 64 < m && ((ecand >> u) & 1u)) sk[my_rank[u]] = ((unsigned long long)dbits[u] << 32) | (unsigned)smooth_ind(sp + u * 64 + lane);
@@ -535,6 +479,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             drop_range(ecand, mk_lo, mk_hi);
           }
         }
+#ifdef LINS_FE_PROF
+        long long p3c = clock64();
+        p3_t[1] += p3c - p3b;
+        p3_t[3] += n_ls;
+#endif
         // planes: smallest curvature first, ground points only, at most 4; the 4th is not marked (SE:782-813)
         auto plane_pick = [&](int pind) {
           const bool last = n_flat + 1 >= 4;
@@ -551,7 +500,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           {  // the plane candidates the edge picks (and everything before this sector) have left unpicked
             unsigned char fl[kPmax];
 #pragma unroll
-            for (int u = 0; u < kPmax; ++u) fl[u] = u * 64 < m ? flb[smooth_ind(sp + u * 64 + lane)] : (unsigned char)1;
+            for (int u = 0; u < kPmax; ++u) fl[u] = u * 64 < m ? L.a.flags[smooth_ind(sp + u * 64 + lane)] : (unsigned char)1;
 #pragma unroll
             for (int u = 0; u < kPmax; ++u) pcand &= (fl[u] & 1) ? ~(1u << u) : ~0u;
           }
@@ -563,10 +512,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           }
         }
         if (n_flat < 4 && c_ep < 0.5) {  // position ep comes last
-          const unsigned char f = flb[ind_ep];
+          const unsigned char f = L.a.flags[ind_ep];
           if ((f & 8) && !(f & 1)) plane_pick(ind_ep);
         }
-        r_sharp += n_sharp, r_ls += n_ls, r_flat += n_flat;
+#ifdef LINS_FE_PROF
+        p3_t[2] += clock64() - p3c;
+        p3_t[4] += n_flat;
+#endif
         if (lane == 26) pick_entry = n_sharp;
         if (lane == 27) pick_entry = n_ls;
         if (lane == 28) pick_entry = n_flat;
@@ -576,19 +528,75 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+#ifdef LINS_FE_PROF
+    if (lane == 0 && scan == 0) {
+      long long* o = g_fe_prof + ring * 8;
+      o[0] = p3_t[0], o[1] = p3_t[1], o[2] = p3_t[2], o[3] = p3_t[3], o[4] = p3_t[4], o[5] = sc.end_ring[ring] - sc.start_ring[ring], o[6] = clock64() - p3_begin;
+    }
+#endif
   }
-  FE_MARK(2)
+  __threadfence_block();
+  __syncthreads();
+
+  FE_MARK(3)
   auto label_le0 = [&](int k) {  // cloudLabel <= 0: untouched (0) or flat (-1)
-    const int b = (flb[k] >> 1) & 3;
+    const int b = (L.a.flags[k] >> 1) & 3;
     return b == 0 || b == 3;
   };
+
+  // ---- feature clouds in the reference's order: rings, sectors, pick order -------------------------
+  {
+    int* cnt = reinterpret_cast<int*>(L.a.skey);  // [3][96] counts, then [3][96] exclusive offsets (sort buffers idle here)
+    constexpr int kSec = kFeRows * 6;
+    if (tid < kSec) {
+      const int* spk = pk + tid * kPickStride;
+      cnt[tid] = spk[26], cnt[kSec + tid] = spk[27], cnt[2 * kSec + tid] = spk[28];
+    }
+    __syncthreads();
+    if (wave < 3) {  // exclusive offsets of the 96 sectors' counts: a wave per kind, two sectors per lane (48 lanes)
+      static_assert(kSec <= 128, "two sectors per lane");
+      const int a = 2 * lane < kSec ? cnt[wave * kSec + 2 * lane] : 0, b = 2 * lane + 1 < kSec ? cnt[wave * kSec + 2 * lane + 1] : 0;
+      int incl = a + b;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int nb = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += nb;
+      }
+      if (2 * lane < kSec) cnt[(3 + wave) * kSec + 2 * lane] = incl - a - b;
+      if (2 * lane + 1 < kSec) cnt[(3 + wave) * kSec + 2 * lane + 1] = incl - b;
+      if (lane == 63) out_counts[scan * 4 + wave] = incl;
+    }
+    __syncthreads();
+    auto und_pt = [&](int i) {  // the de-skewed point: coordinates as they came, the relative-time tag as intensity (SE:649-650)
+      float4 q = pts[i];
+      q.w = tag_of(i, q);
+      return q;
+    };
+    for (int t = tid; t < kSec * 26; t += kFeBlock) {
+      const int s2 = t / 26, k = t - s2 * 26;
+      const int* spk = pk + s2 * kPickStride;
+      if (k < 2) {
+        if (k < spk[26]) out[sc.o_sharp + cnt[3 * kSec + s2] + k] = und_pt(spk[k]);
+      } else if (k < 22) {
+        if (k - 2 < spk[27]) out[sc.o_less_sharp + cnt[4 * kSec + s2] + (k - 2)] = und_pt(spk[k]);
+      } else {
+        if (k - 22 < spk[28]) out[sc.o_flat + cnt[5 * kSec + s2] + (k - 22)] = und_pt(spk[k]);
+      }
+    }
+    __syncthreads();
+  }
+
+  FE_MARK(4)
   // ---- less-flat cloud: per ring, every point of its sectors with label <= 0 (SE:815-820) ... -----
-  // D0, the kept points' positions (relative to the ring's first sector) as a compact u16 list in
+  // D0, one wave per ring: the kept points' positions (relative to the ring's first sector) as a compact u16 list in
   // LDS — the sector sort buffers are idle.  Round 3: the points themselves are not touched here (rounds 1-2 copied
   // the kept points to a compact global list and read that list back twice).
-  unsigned short* const kept = reinterpret_cast<unsigned short*>(L.work);  // [kRingCap]
-  int m = 0, base = -1;
+  float4* olf = out + sc.o_less_flat;
+  unsigned short* const kept = reinterpret_cast<unsigned short*>(L.a.skey[wave]);  // [kRingCap] of this ring
+  static_assert(sizeof(L.a.skey[0]) >= kRingCap * sizeof(unsigned short), "index list of a ring");
   {
+    const int ring = __builtin_amdgcn_readfirstlane(wave);
+    int m = 0, base = -1;
     for (int j = 0; j < 6; ++j) {
       const int sp = (sc.start_ring[ring] * (6 - j) + sc.end_ring[ring] * j) / 6;
       const int ep = (sc.start_ring[ring] * (5 - j) + sc.end_ring[ring] * (j + 1)) / 6 - 1;
@@ -605,12 +613,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         m += __popcll(mask);
       }
     }
-    if (m > kRingCap || (m > 0 && sc.end_ring[ring] - base >= 2048)) m = -1;  // cannot happen for a 16 x 1800 sensor; refuse rather than truncate silently
-    base = base < 0 ? 0 : base;
+    if (lane == 0) {
+      L.ring_m[ring] = m, L.ring_base[ring] = base < 0 ? 0 : base;
+      if (m > kRingCap || (m > 0 && sc.end_ring[ring] - base >= 2048)) L.bad = 1;  // cannot happen for a 16 x 1800 sensor; refuse rather than truncate silently
+    }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();  // (every read of the flags is done: the voxel orders below overlay them)
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __threadfence_block();
+  __syncthreads();  // (every reader of the flags is done: the voxel orders below overlay them)
+  if (L.bad) {
+    if (tid == 0) out_counts[scan * 4 + 3] = -1;
+    return;
+  }
+  FE_MARK(5)
   // D1, pcl::VoxelGrid 0.2 m with all-field averaging, output ordered by voxel index (SE:189, 822-825):
   // one wave per ring; 2048 keys (voxel index << 11 | order) sorted in registers, then only the order
   // and a run-start bit per sorted position go to LDS.  Sorted position e belongs to lane e / 32.
@@ -618,13 +632,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   // zero: +-204 m / +-102 m) into one register per point, the wave folds the bounding box VoxelGrid needs
   // (getMinMax3D), and the keys are built from the packed coordinates.  A ring that does not pack (never a VLP-16's)
   // takes the same route with a second read of its points.
-  // The centroids are fe_out_kernel's: the rings' output offsets are known once every ring has counted its voxels.
-  FE_MARK(3)
-  int nvox = 0;
+  // Two phases: every ring sorts and counts its voxels first; after one block barrier the rings' output
+  // offsets are known and the centroids go straight to their final place.
   {
     {
-      unsigned short* vs = L.vs;
-      unsigned long long* const hbw = L.headbits;
+      const int ring = __builtin_amdgcn_readfirstlane(wave);
+      const int m = L.ring_m[ring], base = L.ring_base[ring];
+      unsigned short* vs = L.vso[wave];
+      int nvox = 0;
       if (m > 0) {
         const float inv = 1.0f / 0.2f;
         auto voxel_grid = [&](auto tag) {
@@ -659,171 +674,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           // arithmetic throughout), or — a ring whose box needs 64-bit keys or whose coordinates do not pack — from a
           // second read of the point
           unsigned startmask = 0;  // bit u: this lane's u-th sorted position starts a voxel
-          // Round 5: RUNS, not points, are sorted.  Along a ring consecutive kept points mostly fall into the same 0.2 m
-          // voxel (beam spacing 3.5 cm at 10 m), and a run of them stays together under the (voxel index, order) sort, in
-          // order.  So only the first point of every run — a "head" — goes through the bitonic network (64 * 2 .. 16 keys
-          // instead of 64 * 8 .. 32; the network is the one VALU-saturated phase of the kernel), the sorted heads' run
-          // lengths give every run its place by a prefix sum, and each head writes its run's points behind it.  Two runs
-          // of one voxel (the beam left it and came back) end up adjacent, the earlier first: the same order.
-          int heads = 0;
-          if (narrow && packed) {
-            unsigned* hk = reinterpret_cast<unsigned*>(vs);  // [1024] the heads' keys in order of appearance (vs is written after the sort)
-            unsigned carry_vox = ~0u;                        // the voxel of element u * 64 - 1
-#pragma unroll
-            for (int u = 0; u < kP; ++u) {
-              if (u * 64 < m) {  // (wave-uniform)
-                const int e = u * 64 + lane;
-                if (e < m) {
-                  const int ix = (int)(pkd[u] & 2047u) - 1024, iy = (int)((pkd[u] >> 11) & 2047u) - 1024, iz = (int)(pkd[u] >> 22) - 512;
-                  pkd[u] = ((unsigned)((ix - mnx) + (iy - mny) * (int)dx + (iz - mnz) * (int)(dx * dy)) << 11) | (unsigned)e;
-                }
-                const unsigned vox = pkd[u] >> 11;  // (no point: 0x1FFFFF, above every voxel index of a narrow box)
-                unsigned pv = __shfl_up(vox, 1);
-                if (lane == 0) pv = carry_vox;
-                carry_vox = __shfl(vox, 63);
-                const bool head = e < m && vox != pv;
-                const unsigned long long bm = __ballot(head);
-                if (head) {
-                  const int r = heads + __popcll(bm & ((1ull << lane) - 1ull));
-                  if (r < 1024) hk[r] = pkd[u];
-                }
-                if (lane == 0) hbw[u] = bm;
-                heads += __popcll(bm);
-              }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-          }
-          auto sort_heads = [&](auto qtag) {
-            constexpr int kQ = decltype(qtag)::value;
-            const unsigned* hk = reinterpret_cast<const unsigned*>(vs);
-            const unsigned long long* hb = hbw;
-            unsigned kv[kQ];
-#pragma unroll
-            for (int u = 0; u < kQ; ++u) kv[u] = u * 64 + lane < heads ? hk[u * 64 + lane] : ~0u;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();  // (every lane has its keys: vs, the same bytes, is written below)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            FE_MARK(4)
-            wave_bitonic_sort<kQ, unsigned>(kv, lane);
-            FE_MARK(5)
-            // sorted head lane * kQ + u: its run's length (to the next head in order of appearance, or the ring's end),
-            // whether it opens a voxel (the sorted predecessor is of another one)
-            unsigned prev = __shfl_up(kv[kQ - 1], 1);
-            int len[kQ], my_len = 0;
-#pragma unroll
-            for (int u = 0; u < kQ; ++u) {
-              const int sidx = lane * kQ + u;
-              len[u] = 0;
-              if (sidx < heads) {
-                const int e = (int)(kv[u] & 2047u), q = e + 1;
-                int nx = m;
-                const unsigned long long x = q < m ? hb[q >> 6] >> (q & 63) : 0ull;  // (words from m / 64 rounded up on are not written)
-                if (x) {
-                  nx = q + __ffsll((long long)x) - 1;
-                } else {
-                  for (int w = (q >> 6) + 1; w < (m + 63) >> 6; ++w)
-                    if (hb[w]) {
-                      nx = w * 64 + __ffsll((long long)hb[w]) - 1;
-                      break;
-                    }
-                }
-                len[u] = nx - e;
-                const bool start = sidx == 0 || (prev >> 11) != (kv[u] >> 11);
-                mine += start ? 1 : 0;
-                startmask |= start ? (1u << u) : 0u;
-                prev = kv[u];
-              }
-              my_len += len[u];
-            }
-            int incl_len = my_len;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-              const int nb = __shfl_up(incl_len, o, 64);
-              if (lane >= o) incl_len += nb;
-            }
-            // Every run's points behind its head, without a loop per run: a head leaves a marker at its position — the
-            // distance from a sorted position of its run to the point's place in the kept list, e - pos, is the same for
-            // the whole run — then every lane walks its own block of consecutive positions, carrying the last marker
-            // along (the block's first positions take the last marker of the lanes before: one shuffle), and replaces
-            // each position by (voxel start, kept[position + distance]).  Marker: bit 15 set, bit 14 voxel start, bits
-            // 0-11 distance + 2048.
-            const int blk = (((m + 63) >> 6) + 3) & ~3;  // positions per lane (a multiple of 4: 64-bit LDS words), <= 32
-            unsigned long long* const vw = reinterpret_cast<unsigned long long*>(vs);
-            for (int g = 0; g < blk; g += 4) vw[(lane * blk + g) >> 2] = 0ull;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            int pos = incl_len - my_len;
-#pragma unroll
-            for (int u = 0; u < kQ; ++u) {
-              const int e = (int)(kv[u] & 2047u);
-              if (len[u] > 0) vs[pos] = (unsigned short)(0x8000u | (((startmask >> u) & 1u) ? 0x4000u : 0u) | (unsigned)(e - pos + 2048));
-              pos += len[u];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            {
-              const int p0 = lane * blk;
-              unsigned last = 0u;  // this block's last marker
-              for (int g = 0; g < blk; g += 4) {
-                const unsigned long long w = vw[(p0 + g) >> 2];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  const unsigned x = (unsigned)(w >> (16 * k)) & 0xFFFFu;
-                  last = (x & 0x8000u) ? x : last;
-                }
-              }
-              const unsigned long long below = __ballot(last != 0u) & ((1ull << lane) - 1ull);
-              const unsigned from_left = __shfl(last, below ? 63 - __builtin_clzll(below) : 0);
-              unsigned cur = below ? from_left : 0u;
-              for (int g = 0; g < blk; g += 4) {
-                const unsigned long long w = vw[(p0 + g) >> 2];
-                unsigned long long o = 0ull;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  const unsigned x = (unsigned)(w >> (16 * k)) & 0xFFFFu;
-                  const bool mk = (x & 0x8000u) != 0u;
-                  cur = mk ? x : cur;
-                  const int q = p0 + g + k;
-                  unsigned val = 0u;
-                  if (q < m) val = (unsigned)kept[q + (int)(cur & 0xFFFu) - 2048] | ((mk && (x & 0x4000u)) ? 0x8000u : 0u);
-                  o |= (unsigned long long)val << (16 * k);
-                }
-                vw[(p0 + g) >> 2] = o;
-              }
-            }
-            int incl = mine;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-              const int nb = __shfl_up(incl, o, 64);
-              if (lane >= o) incl += nb;
-            }
-            nvox = __shfl(incl, 63);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();  // (the list of kept points has been folded into vs: see the other route below)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            int run = incl - mine;
-            pos = incl_len - my_len;
-#pragma unroll
-            for (int u = 0; u < kQ; ++u) {
-              if ((startmask >> u) & 1u) kept[pos] = (unsigned short)run++;
-              pos += len[u];
-            }
-          };
-          if (narrow && packed && heads <= 1024 && heads * 2 <= kP * 64) {  // (fewer keys per lane than the points' network)
-            if (heads <= 128)
-              sort_heads(FeInt<2>{});
-            else if (heads <= 256)
-              sort_heads(FeInt<4>{});
-            else if (heads <= 512)
-              sort_heads(FeInt<8>{});
-            else
-              sort_heads(FeInt<16>{});
-            return;
-          }
           auto sort_and_mark = [&](auto key_zero, auto from_pack) {
             using K = decltype(key_zero);  // 32-bit keys when (voxel index << 11 | order) fits: half the shuffles and compares
             K kv[kP];
@@ -833,7 +683,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
               K k = (K)~key_zero;
               if (e < m) {
                 if (decltype(from_pack)::value) {
-                  k = (K)pkd[u];  // (the key was formed in place above)
+                  const int ix = (int)(pkd[u] & 2047u) - 1024, iy = (int)((pkd[u] >> 11) & 2047u) - 1024, iz = (int)(pkd[u] >> 22) - 512;
+                  k = (K)(((unsigned)((ix - mnx) + (iy - mny) * (int)dx + (iz - mnz) * (int)(dx * dy)) << 11) | (unsigned)e);
                 } else {
                   const float4 p = pts[base + (int)kept[e]];
                   const long long ix = (long long)floorf(p.x * inv), iy = (long long)floorf(p.y * inv), iz = (long long)floorf(p.z * inv);
@@ -842,9 +693,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
               }
               kv[u] = k;
             }
-            FE_MARK(4)
             wave_bitonic_sort<kP, K>(kv, lane);
-            FE_MARK(5)
             // run starts: the voxel index differs from the predecessor's (the previous lane's last key for u = 0)
             const unsigned plo = __shfl_up((unsigned)kv[kP - 1], 1), phi = __shfl_up((unsigned)((unsigned long long)kv[kP - 1] >> 32), 1);
             K prev = (K)(((unsigned long long)phi << 32) | plo);
@@ -891,149 +740,79 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         else
           voxel_grid(FeInt<32>{});
       }
+      if (lane == 0) L.ring_out[ring] = nvox;
     }
+    __threadfence_block();
+    __syncthreads();
   }
   FE_MARK(6)
-  // ---- what fe_out_kernel needs ----
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (m > 0) {
-    unsigned* const ord = order + sc.off + base;
-    for (int e = lane; e < m; e += 64) {
-      const unsigned v = L.vs[e];
-      ord[e] = v | ((v & 0x8000u) ? (unsigned)kept[e] << 16 : 0u);
-    }
+  if (tid == 0) {
+    int run = 0;
+    for (int r = 0; r < kFeRows; ++r) L.ring_off[r] = run, run += L.ring_out[r];
+    L.ring_off[kFeRows] = run;
+    out_counts[scan * 4 + 3] = run;
+    int ch = 0;
+    for (int r = 0; r < kFeRows; ++r) L.chunk_off[r] = ch, ch += (L.ring_m[r] + 63) >> 6;
+    L.chunk_off[kFeRows] = ch;
   }
-  if (lane == 0) my->m = m, my->base = base, my->nvox = nvox, my->flip = flip, my->n_sharp = r_sharp, my->n_less_sharp = r_ls, my->n_flat = r_flat, my->pad = 0;
-#ifdef LINS_FE_PROF
-  FE_MARK(7)
-  if (lane == 0 && scan == 0)
-    printf("FE ring %2d: flip %6lld masks %6lld picks %7lld compact %6lld | voxel: read+heads %6lld sort %6lld fill %6lld | out %6lld | m %d picks %d\n", ring, fe_t[0], fe_t[1], fe_t[2],
-           fe_t[3], fe_t[4], fe_t[5], fe_t[6], fe_t[7], m, r_ls + r_flat);
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// fe_out_kernel: 256 threads per (scan, ring).  The ring's place in the four feature clouds follows from the counts of the
-// rings before it (sixteen FeRingInfo records); then
-//  * the picked clouds in the reference's order — rings, sectors, pick order (SE:743-813) — one thread per pick slot;
-//  * D2, the less-flat cloud: one centroid per voxel — f32 sums of all four fields in stable (original) order (PCL's
-//    VoxelGrid with all-field averaging, SE:189, 822-825) — at the ring's offset + the voxel's slot.
-__global__ __launch_bounds__(kOutBlock) void fe_out_kernel(
-    const FeScan* __restrict__ scans, const float4* __restrict__ cloud, double scan_period, const int* __restrict__ picks,
-    const unsigned* __restrict__ order, const FeRingInfo* __restrict__ info, float4* __restrict__ out, int* __restrict__ out_counts) {
-  __shared__ int s_pick[6 * kPickStride];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int scan = blockIdx.x / kFeRows, ring = blockIdx.x % kFeRows;
-  const FeScan& sc = scans[scan];
-  const float4* pts = cloud + sc.off;
-  const FeRingInfo* inf = info + (size_t)scan * kFeRows;
-  const double kPi = 3.14159265358979323846;
-  // the rings before this one (every wave for itself: sixteen records, a wave scan — no barrier)
-  int off_sharp, off_ls, off_flat, off_lf, m, base;
-  bool bad;
-  {
-    const bool in = lane < kFeRows;
-    const int rm = in ? inf[lane].m : 0, rv = in ? inf[lane].nvox : 0;
-    const int a = in ? inf[lane].n_sharp : 0, b = in ? inf[lane].n_less_sharp : 0, c = in ? inf[lane].n_flat : 0;
-    bad = __any(rm < 0);
-    int ia = a, ib = b, ic = c, iv = rv;
-#pragma unroll
-    for (int o = 1; o < kFeRows; o <<= 1) {
-      const int na = __shfl_up(ia, o, 64), nb = __shfl_up(ib, o, 64), nc = __shfl_up(ic, o, 64), nv = __shfl_up(iv, o, 64);
-      if (lane >= o) ia += na, ib += nb, ic += nc, iv += nv;
-    }
-    off_sharp = __shfl(ia - a, ring), off_ls = __shfl(ib - b, ring), off_flat = __shfl(ic - c, ring), off_lf = __shfl(iv - rv, ring);
-    m = __shfl(rm, ring), base = in ? inf[ring].base : 0;
-    base = __shfl(base, 0);
-    if (ring == 0 && wave == 0 && lane == kFeRows - 1) {
-      out_counts[scan * 4 + 0] = ia, out_counts[scan * 4 + 1] = ib, out_counts[scan * 4 + 2] = ic;
-      out_counts[scan * 4 + 3] = bad ? -1 : iv;  // (-1: a ring beyond the kernels' limits, LINS_E_UNSUPPORTED)
-    }
-  }
-  if (bad) return;
-  const int flip = inf[0].flip;
-  const double s_ori = (double)sc.start_ori, e_ori = (double)sc.end_ori, ori_diff = (double)sc.ori_diff;
-  auto tag_of = [&](int i, const float4& p) {  // undistortPcl's intensity (SE:639-650) of point i
-    double ori = (double)(-lins_atan2f(p.y, p.x));
-    if (i <= flip) {
-      if (ori < s_ori - kPi / 2)
-        ori += 2 * kPi;
-      else if (ori > s_ori + kPi * 3 / 2)
-        ori -= 2 * kPi;
-    } else {
-      ori += 2 * kPi;
-      if (ori < e_ori - kPi * 3 / 2)
-        ori += 2 * kPi;
-      else if (ori > e_ori + kPi / 2)
-        ori -= 2 * kPi;
-    }
-    const double rel = (ori - s_ori) / ori_diff;
-    return (float)((double)(int)p.w + scan_period * rel);
-  };
-  // ---- the picked clouds: the ring's six sectors' lists (29 ints each) through LDS, a thread per slot ----
-  static_assert(kOutBlock >= 6 * kPickStride && kOutBlock >= 6 * 26, "a thread per pick slot");
-  if (tid < 6 * kPickStride) s_pick[tid] = picks[((size_t)scan * kFeRows + ring) * 6 * kPickStride + tid];
   __syncthreads();
-  if (tid < 6 * 26) {
-    const int s2 = tid / 26, k = tid - s2 * 26;
-    const int* spk = s_pick + s2 * kPickStride;
-    int before_sharp = 0, before_ls = 0, before_flat = 0;  // the ring's sectors before this one
-    for (int j = 0; j < s2; ++j) before_sharp += s_pick[j * kPickStride + 26], before_ls += s_pick[j * kPickStride + 27], before_flat += s_pick[j * kPickStride + 28];
-    long long dst = -1;
-    if (k < 2) {
-      if (k < spk[26]) dst = sc.o_sharp + off_sharp + before_sharp + k;
-    } else if (k < 22) {
-      if (k - 2 < spk[27]) dst = sc.o_less_sharp + off_ls + before_ls + (k - 2);
-    } else {
-      if (k - 22 < spk[28]) dst = sc.o_flat + off_flat + before_flat + (k - 22);
-    }
-    if (dst >= 0) {  // the de-skewed point: coordinates as they came, the relative-time tag as intensity (SE:649-650)
-      const int i = spk[k];
-      float4 q = pts[i];
-      q.w = tag_of(i, q);
-      out[dst] = q;
-    }
-  }
-  // ---- D2: the ring's centroids ----
-  // A wave takes 64 consecutive sorted positions per step: every lane reads ITS point and forms its tag (one gather and
-  // one arctangent per lane, no divergence); a voxel's lanes are neighbours, so its first lane collects the others' values
-  // left to right with shuffles — the sums in the order VoxelGrid adds them (ascending original index).  A wave takes
-  // CONSECUTIVE chunks and carries the partial sums of a voxel that goes on beyond a chunk's last lane into the next
-  // chunk — lane 0 continues it; only a group's last chunk finishes its last run alone, one dependent gather and one
-  // arctangent per point (with ~5 points a voxel nearly every chunk ends in such a run).
-  if (m <= 0) return;
-  const unsigned* ord = order + sc.off + base;
-  float4* dst = out + sc.o_less_flat + off_lf;
-  const int n_chunks = (m + 63) >> 6;
-  const int group = max(1, (n_chunks + (kOutBlock / 64) * LINS_FE_D2_GROUP - 1) / ((kOutBlock / 64) * LINS_FE_D2_GROUP));
-  for (int g0 = wave * group; g0 < n_chunks; g0 += (kOutBlock / 64) * group) {
+  // D2: one centroid per run start — f32 sums of all four fields in stable (original) order — at the ring's final
+  // offset + the voxel's position in the ring.  The whole workgroup takes the rings one after the other (round 3; one
+  // wave per ring before): a thread per sorted position, so the gathers of all sixteen waves fall into ONE ring's points
+  // at a time (they stay in the caches between the first touch of a line and the last) and neighbouring threads write
+  // neighbouring centroids.
+  // (Round 4: the 64-position chunks of all rings are dealt to the waves as ONE list — ring after ring, a ring's last
+  // chunks together with the next ring's first — instead of a pass of the workgroup per ring, whose second step kept
+  // 1024 threads for the ~200 positions a ring has beyond the first 1024: 32 steps a wave -> ~19.)
+#ifdef LINS_FE_PROF
+  long long d2_t[4] = {0, 0, 0, 0};
+#endif
+  // (Round 5: a wave takes kD2Group CONSECUTIVE chunks at a time and carries the partial sums of a voxel that goes on beyond
+  // a chunk's last lane into the next chunk — lane 0 continues it — instead of finishing it alone, one dependent gather and
+  // one arctangent per point: with ~5 points a voxel nearly every chunk ended in such a run, 37 k of the phase's 87 k
+  // clocks.  Only a group's last chunk still finishes its last run alone.)
+  const int n_chunks = L.chunk_off[kFeRows];
+  const int kD2Group = max(1, (n_chunks + (kFeBlock / 64) * LINS_FE_D2_GROUP - 1) / ((kFeBlock / 64) * LINS_FE_D2_GROUP));
+  for (int g0 = wave * kD2Group; g0 < n_chunks; g0 += (kFeBlock / 64) * kD2Group) {
     float cx = 0.f, cy = 0.f, cz = 0.f, ci = 0.f;  // the carried run (wave-uniform): sums so far, points so far, output slot
     int c_cnt = 0, c_slot = -1;
-    const int g1 = min(g0 + group, n_chunks);
-    // two deep: while chunk c is worked on, chunk c + 1's points and chunk c + 2's entries are in flight (a chunk is a
-    // chain of two dependent reads — the entry, then the point it names — and a wave has only a handful of chunks)
-    unsigned v_cur = g0 * 64 + lane < m ? ord[g0 * 64 + lane] : 0x8000u;
-    unsigned v_next = g0 * 64 + 64 + lane < m ? ord[g0 * 64 + 64 + lane] : 0x8000u;
-    float4 p_cur = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g0 * 64 + lane < m) p_cur = pts[base + (int)(v_cur & 2047u)];
-    for (int ch = g0; ch < g1; ++ch) {
-      const int e0 = ch * 64, e = e0 + lane;
+    for (int ch = g0; ch < min(g0 + kD2Group, n_chunks); ++ch) {
+      // the chunk's ring: lane r < 16 tests ring r's first chunk, the ballot counts (chunk_off is non-decreasing)
+      const int ring = __popcll(__ballot(lane >= 1 && lane < kFeRows && L.chunk_off[lane] <= ch));
+      const int m = L.ring_m[ring], base = L.ring_base[ring];
+      const unsigned short* vs = L.vso[ring];
+      const unsigned short* slot = reinterpret_cast<const unsigned short*>(L.a.skey[ring]);
+      float4* dst = olf + L.ring_off[ring];
+      // A wave takes 64 consecutive sorted positions per step: every lane reads ITS point and forms its tag (one gather
+      // and one arctangent per lane, no divergence); a voxel's lanes are neighbours, so its first lane collects the
+      // others' values left to right with shuffles — the sums in the order VoxelGrid adds them (ascending original
+      // index).  (Issuing the next step's gather before working on the current one was measured: no faster — the other
+      // waves cover the latency.)
+      const int e0 = (ch - L.chunk_off[ring]) * 64;
+      const int e = e0 + lane;
       const bool valid = e < m;
-      const unsigned v = v_cur;
-      float4 p = p_cur;
-      const unsigned v_after = e + 128 < m ? ord[e + 128] : 0x8000u;
-      p_cur = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e + 64 < m && ch + 1 < g1) p_cur = pts[base + (int)(v_next & 2047u)];
-      const unsigned v_first = __shfl(v_next, 0);  // (the next chunk's first entry tells whether this chunk's last run goes on)
-      v_cur = v_next, v_next = v_after;
+      const unsigned v = valid ? (unsigned)vs[e] : 0x8000u;
       const bool start = valid && (v & 0x8000u);
-      const bool head = lane == 0 && c_slot >= 0 && !start;
+      const bool head = lane == 0 && c_slot >= 0 && !start;  // (a carried run is of this ring: it crossed a chunk end inside it)
       const bool st = start || head;
       const int i = base + (int)(v & 2047u);
+      float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
       float tg = 0.f;
+#ifdef LINS_FE_PROF
+      long long d2a = clock64();
+#endif
+      if (valid) p = pts[i];
+#ifdef LINS_FE_PROF
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      long long d2b = clock64();
+      d2_t[0] += d2b - d2a;
+#endif
       if (valid) tg = tag_of(i, p);
+#ifdef LINS_FE_PROF
+      asm volatile("" ::"v"(tg) : "memory");
+      long long d2c = clock64();
+      d2_t[1] += d2c - d2b;
+#endif
       const unsigned long long bounds = __ballot(start || !valid);  // where a run ends: the next start, or the end of the ring
       const unsigned long long above = lane < 63 ? bounds & ~((2ull << lane) - 1ull) : 0ull;
       const int nxt = above ? __ffsll((long long)above) - 1 : 64;
@@ -1043,13 +822,19 @@ __global__ __launch_bounds__(kOutBlock) void fe_out_kernel(
         const float ax = __shfl_down(p.x, d), ay = __shfl_down(p.y, d), az = __shfl_down(p.z, d), at = __shfl_down(tg, d);
         if (st && d < len_in) sx += ax, sy += ay, sz += az, si += at;
       }
+#ifdef LINS_FE_PROF
+      asm volatile("" ::"v"(sx) : "memory");
+      long long d2d = clock64();
+      d2_t[2] += d2d - d2c;
+      d2_t[3] += 1;
+#endif
       int total = len_in + (head ? c_cnt : 0);
-      const int my_slot = head ? c_slot : (int)(v >> 16);
+      const int my_slot = head ? c_slot : (valid ? (int)slot[e] : 0);
       // does the run that reaches the last lane go on in the next chunk?  (wave-uniform)
       const unsigned long long stm = __ballot(st);
-      const bool goes_on = stm != 0ull && e0 + 64 < m && !(v_first & 0x8000u);
+      const bool goes_on = stm != 0ull && e0 + 64 < m && !(vs[e0 + 64] & 0x8000u);
       const int last_st = stm ? 63 - __builtin_clzll(stm) : 0;  // its first lane (the run above it reaches lane 63: valid lanes throughout)
-      const bool carry = goes_on && ch + 1 < g1;
+      const bool carry = goes_on && ch + 1 < min(g0 + kD2Group, n_chunks);
       if (st && !(goes_on && lane == last_st)) {
         const float cnt = (float)total;
         dst[my_slot] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
@@ -1061,10 +846,8 @@ __global__ __launch_bounds__(kOutBlock) void fe_out_kernel(
         c_slot = -1;
         if (goes_on && lane == last_st) {  // a group's last chunk: its last run is finished by its first lane alone
           int j = e0 + 64;
-          while (j < m) {
-            const unsigned v2 = ord[j];
-            if (v2 & 0x8000u) break;
-            const int i2 = base + (int)(v2 & 2047u);
+          while (j < m && !(vs[j] & 0x8000u)) {
+            const int i2 = base + (int)(vs[j] & 2047u);
             const float4 p2 = pts[i2];
             sx += p2.x, sy += p2.y, sz += p2.z, si += tag_of(i2, p2);
             ++j;
@@ -1076,26 +859,24 @@ __global__ __launch_bounds__(kOutBlock) void fe_out_kernel(
       }
     }
   }
+#ifdef LINS_FE_PROF
+  FE_MARK(7)
+  if (tid < 16 && scan == 0)
+    printf("FE scan 0 ring %d: keys %lld edges %lld (%lld picks) planes %lld (%lld picks), n %lld, whole %lld\n", tid, g_fe_prof[tid * 8], g_fe_prof[tid * 8 + 1], g_fe_prof[tid * 8 + 3],
+           g_fe_prof[tid * 8 + 2], g_fe_prof[tid * 8 + 4], g_fe_prof[tid * 8 + 5], g_fe_prof[tid * 8 + 6]);
+  if (tid == 0 && (scan & 255) == 0)
+    printf("FE scan %d: load %lld flip %lld tags+stencil+masks %lld sort+picks %lld labels %lld compact %lld voxel grid %lld gaps %lld | D2 wave 0: gather %lld tag %lld sums %lld chunks %lld\n", scan, fe_t[0],
+           fe_t[1], fe_t[2], fe_t[3], fe_t[4], fe_t[5], fe_t[6], fe_t[7], d2_t[0], d2_t[1], d2_t[2], d2_t[3]);
+#endif
 }
 
 void launch_frontend(hipStream_t stream, int n_scans, const void* scans, const float4* cloud, const float* range,
-                     const unsigned* col, const unsigned char* ground, double scan_period, int* picks, unsigned* order,
-                     void* ring_info, float4* out, int* out_counts) {
-  if (n_scans <= 0) return;
-  static const int stages = [] {  // (debug knob: time one kernel without the other — tools/frontend_rate.py)
-    const char* g = std::getenv("LINS_ENABLE_DEBUG_KNOBS");
-    const char* e = std::getenv("LINS_FE_STAGES");
-    return g && g[0] == '1' && e ? std::atoi(e) : 3;
-  }();
-  if (stages & 1)
-  hipLaunchKernelGGL(fe_ring_kernel, dim3(n_scans * kFeRows), dim3(64), 0, stream, (const FeScan*)scans, cloud, range, col, ground,
-                     picks, order, (FeRingInfo*)ring_info);
-  if (stages & 2)
-  hipLaunchKernelGGL(fe_out_kernel, dim3(n_scans * kFeRows), dim3(kOutBlock), 0, stream, (const FeScan*)scans, cloud, scan_period,
-                     picks, order, (const FeRingInfo*)ring_info, out, out_counts);
+                     const unsigned* col, const unsigned char* ground, double scan_period, int* picks, float4* out,
+                     int* out_counts) {
+  hipLaunchKernelGGL(frontend_kernel, dim3(n_scans), dim3(kFeBlock), 0, stream, (const FeScan*)scans, cloud, range, col,
+                     ground, scan_period, picks, out, out_counts);
 }
 size_t fe_scan_size() { return sizeof(FeScan); }
 int fe_pick_stride() { return kFeRows * 6 * kPickStride; }
-size_t fe_ring_info_size() { return sizeof(FeRingInfo) * kFeRows; }
 
 }  // namespace lins

@@ -70,8 +70,7 @@ void launch_transform_to_end(hipStream_t, int, int, const void*, const float4*, 
 size_t reproject_job_size();
 void launch_stream_copy(hipStream_t, const float4*, float4*, size_t);
 void launch_frontend(hipStream_t, int, const void*, const float4*, const float*, const unsigned*, const unsigned char*,
-                     double, int*, unsigned*, void*, float4*, int*);
-size_t fe_ring_info_size();
+                     double, int*, float4*, int*);
 void launch_reproject_in_place(hipStream_t, int, int, const void*, const double*, float4*, double);
 size_t stream_cloud_size();
 void launch_segment(hipStream_t, int, const void*, const float4*, float, float, float, float, float, unsigned*, int*, void*, float4*,
@@ -171,8 +170,6 @@ struct lins_ctx {
     unsigned* d_col = nullptr;
     unsigned char* d_ground = nullptr;
     int *d_picks = nullptr, *d_counts = nullptr;
-    unsigned* d_order = nullptr;  // per point: the less-flat cloud's voxel order (fe_ring_kernel -> fe_out_kernel)
-    void* d_ring = nullptr;       // per (scan, ring): FeRingInfo
     // pinned host staging of the packed inputs (grow-only, h_cap points)
     size_t h_cap = 0;
     float4* h_cloud = nullptr;
@@ -373,7 +370,7 @@ void streams_free(lins_ctx* ctx) {
 
 void fe_free(lins_ctx* ctx) {
   auto& f = ctx->fe;
-  void* ptrs[] = {f.d_scans, f.d_cloud, f.d_out, f.d_range, f.d_col, f.d_ground, f.d_picks, f.d_counts, f.d_order, f.d_ring};
+  void* ptrs[] = {f.d_scans, f.d_cloud, f.d_out, f.d_range, f.d_col, f.d_ground, f.d_picks, f.d_counts};
   for (void* p : ptrs) (void)hipFree(p);
   void* sg[] = {f.d_raw, f.d_raws, f.d_cellidx, f.d_segrows, f.d_outliers};
   for (void* p : sg) (void)hipFree(p);
@@ -1303,8 +1300,6 @@ static int fe_alloc(lins_ctx* ctx, int n) {
   HIP_TRY(ctx, hipMalloc((void**)&f.d_picks, c * fe_pick_stride() * sizeof(int)));
   HIP_TRY(ctx, hipMalloc((void**)&f.d_out, c * (192 + 1920 + 384 + N) * sizeof(float4)));
   HIP_TRY(ctx, hipMalloc((void**)&f.d_counts, c * 4 * sizeof(int)));
-  HIP_TRY(ctx, hipMalloc((void**)&f.d_order, c * N * sizeof(unsigned)));
-  HIP_TRY(ctx, hipMalloc(&f.d_ring, c * fe_ring_info_size()));
   f.cap = n;
   return LINS_OK;
 }
@@ -1390,8 +1385,8 @@ static int fe_run(lins_ctx* ctx, int n, const lins_segmented_scan* in, double sc
 static int fe_launch(lins_ctx* ctx, int n, double scan_period, float4* out_base, std::vector<int>& counts, uint64_t bytes) {
   auto& f = ctx->fe;
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  launch_frontend(ctx->stream, n, f.d_scans, f.d_cloud, f.d_range, f.d_col, f.d_ground, scan_period, f.d_picks, f.d_order,
-                  f.d_ring, out_base, f.d_counts);
+  launch_frontend(ctx->stream, n, f.d_scans, f.d_cloud, f.d_range, f.d_col, f.d_ground, scan_period, f.d_picks, out_base,
+                  f.d_counts);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
   counts.resize((size_t)n * 4);
