@@ -121,6 +121,23 @@ __device__ __forceinline__ unsigned long long wave_best64(unsigned long long v) 
   return v;
 }
 
+// The largest 32-bit value of a wave, in every lane (the same moves as wave_best64, one v_max_u32 each).
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0u, v, 0xB1, 0xF, 0xF, true));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0u, v, 0x4E, 0xF, 0xF, true));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0u, v, 0x141, 0xF, 0xF, true));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0u, v, 0x140, 0xF, 0xF, true));
+  {
+    const fe_v2u s = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = max(s.x, s.y);
+  }
+  {
+    const fe_v2u s = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    v = max(s.x, s.y);
+  }
+  return v;
+}
+
 // v of lane (l ^ LM), LM a power of two below 64, as VALU moves: DPP inside a row of 16 (quad swaps; xor 4 as two
 // bank-masked row shifts; xor 8 as a row rotation), the row swaps of gfx950 beyond.  (__shfl_xor is a ds_bpermute: an LDS
 // instruction and a wait each — the 2048-key network of the VoxelGrid stage issues 672 of them per ring.)
@@ -384,13 +401,13 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           __builtin_amdgcn_wave_barrier();
         };
         auto set_bits = [&](int i, unsigned bits) { atomicOr(&fw[i >> 2], bits << ((i & 3) * 8)); };
-        auto col_gap = [&](int a, int b) {
-          if (a < 0 || b < 0 || a >= n || b >= n) return 1000;
-          const int g = (int)L.a.col[a] - (int)L.a.col[b];
-          return g < 0 ? -g : g;
-        };
-        // cloudNeighborPicked of the +-5 neighbours up to the first column gap > 10 (SE:764-779): lanes 0-4
-        // look forward, 5-9 backward, the break position comes from a ballot
+        // A pick: its own flag (label, picked) and cloudNeighborPicked of the +-5 neighbours up to the first column gap > 10
+        // (SE:764-779), in one step.  Lane t <= 10 stands for point ind - 5 + t: it reads that point's column, takes its
+        // right neighbour's by a row shift, and bit t of one ballot says "gap between t and t + 1" (a point outside the
+        // cloud is a gap: the reference's loops stop there); the first gap either side of t = 5 bounds the marked run, and
+        // every lane of the run ORs its point's flag (the LDS unit takes a wave's instructions in order: a later flag read
+        // sees it).  Round 5: one LDS read and one OR per lane, no branch (rounds 3-4: two reads per neighbour behind three
+        // nested bounds tests, the pick's own flag as a separate instruction).
         // this lane's candidates whose point index lies in [lo, hi] are picked now: out of the mask.  Only the blocks
         // of 64 elements the range touches are looked at (wave-uniform test; a range that reaches index 0 — where the
         // elements outside the stencil's reach point, smooth_ind — looks at all).
@@ -404,14 +421,19 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           }
         };
         int mk_lo = 0, mk_hi = -1;  // the run of indices the last pick marked (itself included)
-        auto mark_nbrs = [&](int ind) {
-          const bool fwd = lane < 5, bwd = lane >= 5 && lane < 10;
-          const int l = fwd ? lane + 1 : -(lane - 5 + 1);
-          const bool gap = (fwd || bwd) && col_gap(ind + l, ind + l + (fwd ? -1 : 1)) > 10;
-          const unsigned long long gm = __ballot(gap);
-          const int stop_f = __ffsll((long long)(gm & 0x1Full)), stop_b = __ffsll((long long)((gm >> 5) & 0x1Full));
-          const int reach_f = stop_f ? stop_f - 1 : 5, reach_b = stop_b ? stop_b - 1 : 5;  // neighbours marked per side
-          if ((fwd && lane < reach_f) || (bwd && lane - 5 < reach_b)) set_bits(ind + l, 1u);
+        auto pick_and_mark = [&](int ind, unsigned own_bits, bool nbrs) {
+          const int j = ind - 5 + lane;
+          const bool in = lane <= 10 && j >= 0 && j < n;
+          const int c = (int)L.a.col[in ? j : 0];
+          const int cn = __builtin_amdgcn_update_dpp(0, c, 0x101, 0xF, 0xF, true);  // row_shl:1: lane t reads lane t + 1
+          const int inn = __builtin_amdgcn_update_dpp(0, (int)in, 0x101, 0xF, 0xF, true);
+          const int d = cn - c;
+          const unsigned gm = (unsigned)__ballot(!in || !inn || (d < 0 ? -d : d) > 10) & 0x3FFu;
+          const unsigned gf = gm >> 5, gb = gm & 0x1Fu;  // forward: bits 0..4 = neighbours +1..+5; backward: bit 4..0 = -1..-5
+          int reach_f = gf ? __builtin_ctz(gf) : 5, reach_b = gb ? __builtin_clz(gb) - 27 : 5;  // neighbours marked per side
+          if (!nbrs) reach_f = 0, reach_b = 0;
+          const int t = lane - 5;
+          if (lane <= 10 && t >= -reach_b && t <= reach_f) set_bits(j, t == 0 ? own_bits : 1u);
           mk_lo = ind - reach_b, mk_hi = ind + reach_f;
         };
         // the best key among this lane's candidates (kMax: largest, else smallest), then over the wave
@@ -425,18 +447,23 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
               if ((cand >> u) & 1u) best = fe_pick64<kMax>(best, k);
             }
           }
-          return wave_best64<kMax>(best);
+          // (two steps as in the edge loop below: the 32-bit extreme of |diffRange| over the wave, its owner by ballot; the
+          // 64-bit keys only when two lanes share it)
+          const unsigned hi = (unsigned)(best >> 32);
+          const unsigned ex = kMax ? wave_max_u32(hi) : ~wave_max_u32(~hi);
+          const unsigned long long owners = __ballot(hi == ex);
+          if ((owners & (owners - 1ull)) == 0ull)
+            return ((unsigned long long)ex << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)best, __ffsll((long long)owners) - 1);
+          return wave_best64<kMax>(hi == ex ? best : (kMax ? 0ull : ~0ull));
         };
         int n_sharp = 0, n_ls = 0, n_flat = 0;
         // edges: largest curvature first, at most 2 sharp + 18 less sharp (SE:743-780)
         auto edge_pick = [&](int pind) {
           // cloudLabel 2 / 1, picked: ORed in — an eligible edge candidate (not ground, not picked) carries no label yet
-          if (lane == 0) set_bits(pind, ((n_ls < 2 ? 2u : 1u) << 1) | 1u);
-          if ((n_ls < 2 && lane == n_sharp) || lane == 2 + n_ls) pick_entry = pind;
+          pick_and_mark(pind, ((n_ls < 2 ? 2u : 1u) << 1) | 1u, true);
+          pick_entry = ((n_ls < 2 && lane == n_sharp) || lane == 2 + n_ls) ? pind : pick_entry;
           n_sharp += n_ls < 2 ? 1 : 0;
           ++n_ls;
-          wave_sync();
-          mark_nbrs(pind);
           wave_sync();
         };
         if (c_ep > 0.5 && !(L.a.flags[ind_ep] & 9)) {  // position ep comes first whatever its curvature
@@ -465,8 +492,17 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
           wave_sync();
           unsigned long long ck = lane < n_ec ? sk[lane] : 0ull;
           while (n_ls < 20) {  // the 21st eligible candidate would only end the loop (SE:757-759)
-            const unsigned long long best = wave_best64<true>(ck);
-            if (!best) break;  // (an edge candidate's key is > 0: its |diffRange| is)
+            // (Round 5: the arg-max in two steps — the largest |diffRange| as a 32-bit wave maximum, 14 instructions; its
+            // owner by ballot.  Only when two candidates share it does the 64-bit key, 44 instructions, decide by index.)
+            const unsigned hi = (unsigned)(ck >> 32);
+            const unsigned mx = wave_max_u32(hi);
+            if (!mx) break;  // (an edge candidate's key is > 0: its |diffRange| is)
+            const unsigned long long owners = __ballot(hi == mx);
+            unsigned long long best;
+            if ((owners & (owners - 1ull)) == 0ull)
+              best = ((unsigned long long)mx << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)ck, __ffsll((long long)owners) - 1);
+            else
+              best = wave_best64<true>(hi == mx ? ck : 0ull);
             edge_pick((int)(unsigned)best);
             const int ci = (int)(unsigned)ck;
             ck = (ci >= mk_lo && ci <= mk_hi) ? 0ull : ck;
@@ -487,14 +523,10 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
         // planes: smallest curvature first, ground points only, at most 4; the 4th is not marked (SE:782-813)
         auto plane_pick = [&](int pind) {
           const bool last = n_flat + 1 >= 4;
-          if (lane == 0) set_bits(pind, (3u << 1) | (last ? 0u : 1u));  // cloudLabel -1 (+ picked unless the 4th)
-          if (lane == 22 + n_flat) pick_entry = pind;
+          pick_and_mark(pind, (3u << 1) | (last ? 0u : 1u), !last);  // cloudLabel -1 (+ picked and the neighbours unless the 4th)
+          pick_entry = lane == 22 + n_flat ? pind : pick_entry;
           ++n_flat;
           wave_sync();
-          if (!last) {
-            mark_nbrs(pind);
-            wave_sync();
-          }
         };
         if (__any(pcand != 0)) {
           {  // the plane candidates the edge picks (and everything before this sector) have left unpicked
