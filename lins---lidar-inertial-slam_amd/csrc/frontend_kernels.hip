@@ -495,15 +495,15 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
             // (Round 5: the arg-max in two steps — the largest |diffRange| as a 32-bit wave maximum, 14 instructions; its
             // owner by ballot.  Only when two candidates share it does the 64-bit key, 44 instructions, decide by index.)
             const unsigned hi = (unsigned)(ck >> 32);
-            const unsigned mx = wave_max_u32(hi);
+            const unsigned mx = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_max_u32(hi));  // (every lane holds it: say so)
             if (!mx) break;  // (an edge candidate's key is > 0: its |diffRange| is)
             const unsigned long long owners = __ballot(hi == mx);
-            unsigned long long best;
+            int pind;
             if ((owners & (owners - 1ull)) == 0ull)
-              best = ((unsigned long long)mx << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)ck, __ffsll((long long)owners) - 1);
+              pind = __builtin_amdgcn_readlane((int)(unsigned)ck, __ffsll((long long)owners) - 1);
             else
-              best = wave_best64<true>(hi == mx ? ck : 0ull);
-            edge_pick((int)(unsigned)best);
+              pind = __builtin_amdgcn_readfirstlane((int)(unsigned)wave_best64<true>(hi == mx ? ck : 0ull));
+            edge_pick(pind);
             const int ci = (int)(unsigned)ck;
             ck = (ci >= mk_lo && ci <= mk_hi) ? 0ull : ck;
           }
