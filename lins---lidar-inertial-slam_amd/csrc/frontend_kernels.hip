@@ -170,9 +170,32 @@ __device__ __forceinline__ unsigned long long fe_xor_lane(unsigned long long v, 
 // compare-exchanges whose partner lies inside the lane's own block are register selects, the others one lane-xor move
 // per key (both lanes of a pair evaluate it and keep the min or the max) — no LDS round trips, no fences.  The network
 // is unrolled by template recursion: every register index and every lane distance is a compile-time constant.
+// The median of three: with c = 0 it is min(a, b), with c = ~0 max(a, b) — ONE instruction (v_med3_u32) where "keep the
+// smaller or the larger, depending on the lane" was a minimum, a maximum and a select.  (Written as the min / max tree the
+// back end matches to it.)
+__device__ __forceinline__ unsigned fe_med3(unsigned a, unsigned b, unsigned c) {
+  return max(min(a, b), min(max(a, b), c));
+}
 template <int P, int K2, int J2, class K>
 __device__ __forceinline__ void bitonic_step(K (&v)[P], int lane) {
-  if constexpr (J2 < P) {
+  if constexpr (sizeof(K) == 4 && J2 < P) {  // 32-bit keys, partner inside the lane: two medians per pair
+#pragma unroll
+    for (int u = 0; u < P; ++u)
+      if ((u & J2) == 0) {
+        const unsigned c = (((lane * P + u) & K2) == 0) ? 0u : ~0u;  // ascending: the smaller key first
+        const unsigned a = (unsigned)v[u], b = (unsigned)v[u | J2];
+        v[u] = (K)fe_med3(a, b, c), v[u | J2] = (K)fe_med3(a, b, ~c);
+      }
+  } else if constexpr (sizeof(K) == 4) {  // ... in another lane: the move and one median
+    constexpr int kLm = J2 / P;
+    const bool lower = (lane & kLm) == 0;
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+      const bool up = ((lane * P + u) & K2) == 0;
+      const unsigned w = fe_xor_lane<kLm>((unsigned)v[u], lane);
+      v[u] = (K)fe_med3(w, (unsigned)v[u], lower == up ? 0u : ~0u);
+    }
+  } else if constexpr (J2 < P) {
 #pragma unroll
     for (int u = 0; u < P; ++u)
       if ((u & J2) == 0) {
