@@ -698,6 +698,31 @@ def test_pipelined_batch_call_equals_the_staged_path(pkg, oracle, ieskf):
         c.close()
 
 
+def test_front_end_centroids_of_voxels_that_span_many_chunks(pkg, ieskf, host):
+    """Round 5's centroid pass carries a voxel's partial sums from one 64-position chunk of the sorted order into the next
+    and finishes a run alone only at the end of a wave's group of chunks.  Clouds shrunk towards the origin put hundreds
+    (x 0.02) or all (x 0.001: one or two voxels per ring, runs of ~1700 points across every chunk and group border) of a
+    ring's kept points into one 0.2 m voxel; picks are untouched (they follow the ranges).  Same f32 sums, in the same
+    order, as the host restatement: bit for bit."""
+    base = [host.frontend_segment(host.synth_raw_scan(40 + i, i % 2)) for i in range(2)]
+    segs = []
+    for w in base:
+        n = w.n
+        for scale in (0.02, 0.001):
+            cloud = w.cloud[:n].copy()
+            cloud[:, :3] *= np.float32(scale)
+            segs.append(host.segmented_from_arrays(cloud, w.range[:n], w.col[:n], w.ground[:n], n, list(w.c.start_ring), list(w.c.end_ring),
+                                                   (w.c.start_ori, w.c.end_ori, w.c.ori_diff), w.c.n_outlier))
+    with ieskf.IeskfContext(pkg.default_params(), max_batch=1, max_targets=1024) as c:
+        feats = c.extract_features_batch(segs)
+    for i, (f, w) in enumerate(zip(feats, segs)):
+        ref = host.frontend_extract_segmented(w)
+        if i % 2:  # (everything within a few centimetres of the origin: a handful of voxels for the whole scan)
+            assert len(ref["surf_less_flat"]) <= 16 * 8, len(ref["surf_less_flat"])
+        for k in ("corner_sharp", "corner_less_sharp", "surf_flat", "surf_less_flat"):
+            assert np.array_equal(f[k], ref[k]), (i, k)
+
+
 def test_front_end_on_empty_and_tiny_segmented_scans(pkg, ieskf, host):
     """A segmented scan without a single point (first, in the middle and last of a batch) and scans of a handful of
     points: no feature, no fault, the neighbours' results untouched — and the host restatement says the same."""
