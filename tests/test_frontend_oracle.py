@@ -76,6 +76,24 @@ def test_host_restatement_equals_the_independent_checker_on_rippled_and_all_grou
         assert_same_features(fo, fx)
 
 
+def test_host_restatement_equals_the_independent_checker_on_clouds_shrunk_into_a_few_voxels(host, oracle):
+    """The inputs of tests/test_gpu_edge_cases.py::test_front_end_centroids_of_voxels_that_span_many_chunks (a ring's kept
+    points in one or a few 0.2 m voxels: centroids of hundreds to ~1700 points, f32 sums in order) through the two CPU
+    implementations of VoxelGrid: the same centroids, bit for bit."""
+    for k in range(2):
+        o = oracle.fe_segment(host.synth_raw_scan(40 + k, k % 2))
+        n = o["n"]
+        for scale in (0.02, 0.001):
+            cloud = o["cloud"][:n].copy()
+            cloud[:, :3] *= np.float32(scale)
+            o2 = dict(o, cloud=np.ascontiguousarray(cloud))
+            hs = host.segmented_from_arrays(cloud, o["range"][:n], o["col"][:n], o["ground"][:n], n, o["start_ring"], o["end_ring"],
+                                            o["orientation"], o["n_outlier"])
+            fo, fx = oracle.fe_features(o2), host.frontend_extract_segmented(hs)
+            assert len(fx["surf_less_flat"]) < 400
+            assert_same_features(fo, fx)
+
+
 def test_stock_scans_are_off_the_column_edges_and_edge_aligned_clouds_are_not(host, oracle):
     """The generator's promise (no firing within 0.1 column of an edge) as the libm checker and the product's
     fixed-sequence atan2f see it: identical range images on stock scans; on a cloud snapped onto the edges the two
