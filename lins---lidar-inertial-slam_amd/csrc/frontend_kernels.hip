@@ -269,7 +269,10 @@ __global__ __launch_bounds__(kFeBlock) void frontend_kernel(
   {
     int first = n;
     constexpr int kIn = 4;  // points per thread whose reads are in flight together
-    for (int i0 = tid; i0 < n; i0 += kIn * kFeBlock) {
+    // (the trip count is WAVE-UNIFORM — the test is on the wave's first index, the points are predicated by i < n below —
+    // so that the wave reduction at the end of the body runs with every lane present: with `i0 < n` the wave that straddles
+    // n lost its upper lanes one trip early and the shuffles read switched-off lanes)
+    for (int i0 = tid; i0 - lane < n; i0 += kIn * kFeBlock) {
       // Round 5: the flip is the FIRST index that passes pi — a point behind an index already found cannot be it, so its
       // coordinates are not read and its arctangent is not taken.  The organised cloud is ring-major and ring 0 sweeps
       // the whole turn: the first trip of this loop (indices < 4096) usually finds it, the other six skip 40 of their

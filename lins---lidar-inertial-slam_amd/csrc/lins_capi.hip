@@ -512,6 +512,9 @@ int pack_one(lins_ctx* ctx, const lins_scan_pair* in, int s) {
     if (cnt[c] && src[c] != dst && reinterpret_cast<const float4*>(src[c]) >= ctx->h_arena &&
         reinterpret_cast<const float4*>(src[c]) < ctx->h_arena + ctx->arena_cap)
       return LINS_E_ARG;
+    // (a cloud that already lies at its arena slot is packed 16-byte points by construction — lins_batch_map hands out
+    // lins_point arrays; a pair that claims the 32-byte stride for it would be misread in silence: refused)
+    if (cnt[c] && src[c] == dst && p.point_stride_bytes == 32) return LINS_E_ARG;
     if (cnt[c] && src[c] != dst) {
       if (p.point_stride_bytes == 32)
         for (int i = 0; i < cnt[c]; ++i) dst[i] = lins_point_load(src[c], 32, i);
@@ -687,6 +690,21 @@ int run_range(lins_ctx* ctx, int lo, int cnt, int n_total, const RangeFlags& fl,
   }
   HIP_TRY(ctx, hipGetLastError());
   return LINS_OK;
+}
+
+// After a host wait that follows a launch of the batch kernel: did a part of a several-part update give up waiting for its
+// hand-over (KernelArgs::relay_err)?  Nothing was written for that scan then — its result buffers hold an earlier launch's
+// values — so EVERY call that hands results to the caller after a wait checks here (lins_sync, lins_batch_download, the
+// streams steps, the single-call updates), not only lins_sync.  The word is cleared: the error is reported once,
+// by the call whose launch it belongs to.
+int relay_check(lins_ctx* ctx) {
+  if (!ctx->h_relay_err || !*ctx->h_relay_err) return LINS_OK;
+  ctx->hip_err = "several-part update: a part's wait for its hand-over ran out (a workgroup of the launch was lost)";
+  ctx->queue_timeouts += *ctx->h_relay_err;
+  *ctx->h_relay_err = 0;
+  (void)hipMemset(ctx->d_queue, 0, queue_ints(ctx) * sizeof(int));  // (counters and flags start over)
+  ctx->relay_gen = 0;
+  return LINS_E_HIP;
 }
 
 }  // namespace
@@ -897,6 +915,7 @@ int lins_batch_upload(lins_ctx* ctx, int n, const lins_scan_pair* in) { return u
  * library's copy into the staging arena altogether: the points are validated where they lie and sent.                */
 int lins_batch_map(lins_ctx* ctx, int n, const int32_t* counts, lins_point** clouds) {
   if (!ctx || n < 0 || (n && (!counts || !clouds))) return LINS_E_ARG;
+  if (n == 0) return LINS_OK;  // (nothing to lay out: the header allows n >= 0)
   {  // (the side streams of the pipelined mode / an earlier asynchronous run may still read the arena's device copy — not
      // the pinned one: every upload waits for its own copies; nothing to join here)
   }
@@ -1714,6 +1733,7 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cov, ctx->d_cov_out, (size_t)n * 324 * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)n * sizeof(OutRecHost), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (int rc = relay_check(ctx)) return rc;  // (the guard marks the streams context failed: no stale posterior is re-projected)
   HIP_TRY(ctx, hipEventElapsedTime(&t.update_ms, ctx->ev0, ctx->ev1));
   trace.mark("update done (synced)");
   for (int k = 0; k < n; ++k) {
@@ -1897,15 +1917,7 @@ int lins_sync(lins_ctx* ctx) {
   int rc = pipe_join(ctx);  // (side streams of the pipelined mode: ordered before the wait below)
   if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->h_relay_err && *ctx->h_relay_err) {  // (a persistent workgroup's wait at the work queue ran out: results may be missing)
-    ctx->hip_err = "several-part update: a part's wait for its hand-over ran out (a workgroup of the launch was lost)";
-    ctx->queue_timeouts += *ctx->h_relay_err;
-    *ctx->h_relay_err = 0;
-    (void)hipMemset(ctx->d_queue, 0, queue_ints(ctx) * sizeof(int));  // (counters and flags start over)
-    ctx->relay_gen = 0;
-    return LINS_E_HIP;
-  }
-  return LINS_OK;
+  return relay_check(ctx);
 }
 
 int lins_batch_download(lins_ctx* ctx, int n, lins_result* out) {
@@ -1920,6 +1932,7 @@ int lins_batch_download(lins_ctx* ctx, int n, lins_result* out) {
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cov, ctx->d_cov_out, (size_t)n * 324 * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)n * sizeof(OutRecHost), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (int rc = relay_check(ctx)) return rc;  // (a scan whose hand-over never arrived holds an earlier launch's values)
   uint64_t tot = 0;
   for (int s = 0; s < n; ++s) {
     lins_result& r = out[s];

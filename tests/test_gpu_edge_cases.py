@@ -561,6 +561,39 @@ def test_front_end_on_a_wide_hall_takes_the_large_sort_paths(pkg, ieskf, host):
             assert np.array_equal(f[k], ref[k]), k
 
 
+def test_front_end_flip_in_the_last_partial_wave(pkg, ieskf, host):
+    """undistortPcl's halfPassed flip (SE:631-638) found by the wave that straddles the end of the cloud: clouds of n points,
+    n % 64 != 0, cut so that the flip index lies among the last n % 64 points — the device pass reduces the flip over the
+    wave there, and every lane has to be present for it (the loop's trip count used to differ inside that wave).
+    A wrong flip shows in every relative-time tag; the feature clouds still equal the host restatement bit for bit."""
+    segs, flips = [], []
+    for seed in (21, 22, 23):
+        w = host.frontend_segment(host.synth_raw_scan(seed, 0))
+        x, y = w.cloud[:w.n, 0].astype(np.float64), w.cloud[:w.n, 1].astype(np.float64)
+        s_ori = float(w.c.start_ori)
+        ori = -np.arctan2(y, x)
+        ori = np.where(ori < s_ori - np.pi / 2, ori + 2 * np.pi, np.where(ori > s_ori + 1.5 * np.pi, ori - 2 * np.pi, ori))
+        flip = int(np.argmax(ori - s_ori > np.pi))  # (ring 0 sweeps the whole turn: somewhere in its second half)
+        assert 64 < flip < w.n - 70
+        n = flip + 3 + (1 if (flip + 3) % 64 == 0 else 0)  # the flip among the last n % 64 points of the cut cloud
+        assert n % 64 != 0 and (n - 1) // 64 == flip // 64 and n - (n % 64) <= flip < n
+        # (the cut cloud is one ring — ring 0 up to index n: the other rings are empty, SE:731-735's sp / ep from IP:296, 320)
+        start = [n - 1 + 5] * 16
+        end = [n - 1 - 5] * 16
+        start[0], end[0] = int(w.c.start_ring[0]), n - 1 - 5
+        assert int(w.c.end_ring[0]) + 5 >= n - 1  # (the cut lies inside ring 0)
+        segs.append(host.segmented_from_arrays(w.cloud[:n], w.range[:n], w.col[:n], w.ground[:n], n, start, end,
+                                               (w.c.start_ori, w.c.end_ori, w.c.ori_diff), 0))
+        flips.append((flip, n))
+    with ieskf.IeskfContext(pkg.default_params(), max_batch=1, max_targets=1024) as c:
+        feats = c.extract_features_batch(segs)
+    for (flip, n), f, w in zip(flips, feats, segs):
+        ref = host.frontend_extract_segmented(w)
+        assert len(ref["surf_less_flat"]) > 20, (flip, n)
+        for k in ("corner_sharp", "corner_less_sharp", "surf_flat", "surf_less_flat"):
+            assert np.array_equal(f[k], ref[k]), (k, flip, n)
+
+
 def test_front_end_on_rough_ranges_takes_the_many_candidates_paths(pkg, ieskf, host):
     """Round 4's front-end picks the edge candidates of a sector one per lane when there are at most 64 of them and from
     per-lane bit masks otherwise, and the plane candidates always from the masks; ties between equal curvatures go by index.
