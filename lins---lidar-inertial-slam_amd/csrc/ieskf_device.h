@@ -50,7 +50,8 @@ struct DevParams {
   int pad;            // debug / profiling flags (LINS_DEBUG_SKIP)
   float margin_cold;  // certificate margins of the LDS search [m] (ieskf_lds.hip)
   float margin_warm;
-  int pad2[2];
+  float reseed_drift;  // [m] a warm search whose query moved farther than this since its last search seeds like a cold one (ieskf_lds_lean.h)
+  int pad2;
 };
 
 // The iterations an update is cut at: k x at for k = 1 .. max_cuts, none afterwards (the last part runs to the end).

@@ -64,6 +64,12 @@
 #include "icp_wave.h"
 #include "ieskf_rowsum.h"
 
+#ifndef LINS_PRIO_SHIFT
+#define LINS_PRIO_SHIFT 0  // (0: off)
+#endif
+#ifndef LINS_PRIO_LEVEL
+#define LINS_PRIO_LEVEL 3
+#endif
 #ifndef LINS_WALK_CACHE
 #define LINS_WALK_CACHE 1  // (the second / third points of a query's previous nearest neighbour kept for its return: see the kernel)
 #endif
@@ -123,6 +129,10 @@ __device__ __forceinline__ ColdArgs cold_args() {
 }
 
 constexpr int kMaxLWaves = LINS_LDS_WAVES;  // waves of the largest workgroup shape instantiated
+#ifndef LINS_LDS_BATCH_BLOCK
+#define LINS_LDS_BATCH_BLOCK 512
+#endif
+constexpr int kBatchBlock = LINS_LDS_BATCH_BLOCK;  // threads of the batch shape (the instantiation with the spread layout, the tickets and the relay)
 constexpr int kNpCap = LINS_LDS_CAP;   // grid positions (corner cloud first, then surf ring-major) resident in LDS
 constexpr int kNpMax = LINS_LDS_NMAX;  // target points of an eligible scan
 constexpr bool kHybrid = kNpMax > kNpCap;  // positions >= kNpCap live in the sorted global copy
@@ -751,6 +761,16 @@ __device__ __forceinline__ WalkOut coop_walk(const LdsStore& L, const LCloud& c,
   }
   return r;
 }
+// ---- the register-lean search core of the batch kernel (round 6): Top2, nn_lean, walk_lean, the carry records ----------
+constexpr int kRelayLanes = 512;                    // query slots of a scan's carry records
+constexpr int kRelayRegionInts = 4 * kRelayLanes * 4;  // ints per scan in KernelArgs::relay_lane: [4][512] 16-byte words, by QUERY slot
+constexpr int kRelayLaneInts = kRelayRegionInts;
+#ifdef LINS_LDS_LEAN
+#include "ieskf_lds_lean.h"
+constexpr bool kLeanBuild = true;
+#else
+constexpr bool kLeanBuild = false;
+#endif
 // one target cloud's grid view of the workgroup's LDS block (cs / cc of the kernel)
 __device__ __forceinline__ LCloud make_cloud(const LdsStore& L, bool is_surf, const float4* gs, int n_corner_t, int n_surf_t, int n_lds) {
   return is_surf ? LCloud{L.gt.cell_end + kCellsCorner, L.gt.ring_start[0], &L.gt.el_ang[0][0], kAzSurf, 1, n_corner_t, n_surf_t, gs, n_lds}
@@ -1187,9 +1207,6 @@ struct CarryWords {
   v4u w0, w1, w2;
   unsigned w3;
 };
-constexpr int kRelayLanes = 512;                    // query slots of a scan (the batch kernel's one-round layouts hold at most 320 + 192)
-constexpr int kRelayRegionInts = 4 * kRelayLanes * 4;  // ints per scan in relay_lane: [4][512] 16-byte words, by QUERY slot
-constexpr int kRelayLaneInts = kRelayRegionInts;
 __device__ __forceinline__ void relay_st_carry(int* scan_base /*wave-uniform*/, int head_lane, const CarryWords& c) {
   const auto rs = __builtin_amdgcn_make_buffer_rsrc(scan_base, 0, kRelayRegionInts * 4, 0x00020000);
   __builtin_amdgcn_raw_buffer_store_b128(c.w0, rs, (0 * kRelayLanes + head_lane) * 16, 0, 16);  // (aux 16 = sc1)
@@ -1264,7 +1281,9 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
   // A part takes over the loop state through global memory (relay_out / the take-over below).  Same arithmetic in the same
   // order: results do not depend on the cuts, bit for bit (tests/test_gpu_parity.py
   // test_two_part_updates_return_the_whole_updates_bits).
-  constexpr bool kRelay = BLOCK == 512 && LANES == 1 && !PASS_ONLY && !ICP;
+  constexpr bool kRelay = BLOCK == kBatchBlock && LANES == 1 && !PASS_ONLY && !ICP;
+  // the register-lean form of the correspondence phase (ieskf_lds_lean.h): per-query state in the scan's carry records
+  constexpr bool kLean = kLeanBuild && LANES == 1 && !PASS_ONLY && !ICP;
   const ScanDesc sd = ka.descs[scan];
   const int total = sd.n_surf_q + sd.n_corner_q;
   // hybrid storage: this scan's slice of the sorted copy (same offsets as its targets in the arena:
@@ -1323,9 +1342,9 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
     int slot;     // this lane's query: plane queries first, then line queries
     bool active;
   };
-  constexpr int kWaves = BLOCK / 64, kSpreadSurf = LINS_SPREAD_S > 0 && BLOCK == 512 ? LINS_SPREAD_S : (kWaves * 5 + 4) / 8;
+  constexpr int kWaves = BLOCK / 64, kSpreadSurf = LINS_SPREAD_S > 0 && BLOCK == kBatchBlock ? LINS_SPREAD_S : (kWaves * 5 + 4) / 8;
   constexpr int kWs = kSpreadSurf;
-  constexpr int kWc = LINS_SPREAD_C > 0 && BLOCK == 512 ? LINS_SPREAD_C : kWaves - kWs;
+  constexpr int kWc = LINS_SPREAD_C > 0 && BLOCK == kBatchBlock ? LINS_SPREAD_C : kWaves - kWs;
   // The spread layout's shares.  The queries of a kind come sorted by ring and what a search costs goes with the ring (the
   // far ground rings' walks are the longest phase of every iteration: tools/wave_phases.py), so equal COUNTS leave the
   // last plane wave the slowest in half of the workgroups; the waves of a kind take contiguous blocks whose sizes follow
@@ -1336,18 +1355,20 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
 #ifndef LINS_SPREAD_WC
 #define LINS_SPREAD_WC 1, 1, 1
 #endif
-  constexpr int kWtS[] = {LINS_SPREAD_WS, 1, 1, 1, 1, 1, 1, 1, 1}, kWtC[] = {LINS_SPREAD_WC, 1, 1, 1, 1, 1, 1, 1, 1};
-  constexpr bool kWeighted = BLOCK == 512 && LINS_SPREAD_S > 0;  // (the batch shape; the other one-lane shapes deal equal counts)
+  constexpr int kWtS[] = {LINS_SPREAD_WS, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}, kWtC[] = {LINS_SPREAD_WC, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+  constexpr int kSpreadMax = 12;  // waves of one kind at most
+  static_assert(LANES != 1 || kWaves <= kSpreadMax + 1, "spread layout: weights for every wave");
+  constexpr bool kWeighted = BLOCK == kBatchBlock && LINS_SPREAD_S > 0;  // (the batch shape; the other one-lane shapes deal equal counts)
   // first query of wave-round j of a kind with n queries over nw waves: floor(n * (w_0 + ... + w_{j-1}) / (w_0 + ... + w_{nw-1}))
   auto share_start = [&](const int* wt, int nw, int n, int j) {
     int tot = 0, cum = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) tot += k < nw ? (kWeighted ? wt[k] : 1) : 0, cum += k < j ? (kWeighted ? wt[k] : 1) : 0;
+    for (int k = 0; k < kSpreadMax; ++k) tot += k < nw ? (kWeighted ? wt[k] : 1) : 0, cum += k < j ? (kWeighted ? wt[k] : 1) : 0;
     return j >= nw ? n : (n * cum) / tot;
   };
   bool fits = kWs < kWaves;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < kSpreadMax; ++k) {
     if (k < kWs) fits = fits && share_start(kWtS, kWs, sd.n_surf_q, k + 1) - share_start(kWtS, kWs, sd.n_surf_q, k) <= 64;
     if (k < kWc) fits = fits && share_start(kWtC, kWc, sd.n_corner_q, k + 1) - share_start(kWtC, kWc, sd.n_corner_q, k) <= 64;
   }
@@ -1412,8 +1433,8 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
       const int* hi = reinterpret_cast<const int*>(h + 61);
       L.iter = relay_ld(hi), L.dbg[0] = relay_ld(hi + 1), L.dbg[1] = relay_ld(hi + 2), L.dbg[2] = relay_ld(hi + 3), L.dbg[3] = relay_ld(hi + 4);
     }
-    const int* ln = ka.relay_lane + (size_t)scan * kRelayLaneInts;
-    {
+    if constexpr (!kLean) {  // (lean: the carry records lie where the part before left them)
+      const int* ln = ka.relay_lane + (size_t)scan * kRelayLaneInts;
       const WrLay y = wr_layout(0);
       if (y.active) carry_unpack(relay_ld_carry(ln, y.slot));
     }
@@ -1465,7 +1486,7 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
       if (LANES == 1) {
         const WrLay y = wr_layout(base / kQPerRound);
         wr_k = y.k, kind_s = y.kind_s, slot = y.slot, active = y.active;
-        if (base == 0) part_k = y.k & (kMaxLWaves - 1);
+        if (base == 0) part_k = wave;  // (= y.k of the first round)
       } else if (aligned) {
         if (wave < surf_waves)
           active = active && vslot < sd.n_surf_q;
@@ -1477,7 +1498,11 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
         a1 = b1c = ra1 = rb1 = a2 = b2c = a3 = b3c = sel1 = -1, have_cert = false;
         lb1 = lb2 = lb3 = 0.f;
       }
-      if constexpr (LANES == 1) {
+      if constexpr (kLean) {
+#ifdef LINS_LDS_LEAN
+#include "ieskf_lds_lean_body.inc"
+#endif
+      } else if constexpr (LANES == 1) {
         // ---- one owner lane per query, wave-cooperative searches --------------------------------------
         // The owner de-skews its query and tests the certificates; the queries of the wave that do need a
         // search are then served several lanes at a time (inputs and results travel by bpermute, no LDS
@@ -2043,7 +2068,7 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
       int* hi = reinterpret_cast<int*>(h + 61);
       relay_st(hi, L.iter), relay_st(hi + 1, L.dbg[0]), relay_st(hi + 2, L.dbg[1]), relay_st(hi + 3, L.dbg[2]), relay_st(hi + 4, L.dbg[3]);
     }
-    {
+    if constexpr (!kLean) {
       const WrLay y = wr_layout(0);
       if (y.active)
         relay_out_carry(KP(relay_lane) + (size_t)scan * kRelayLaneInts, y.slot, a1, b1c, ra1, rb1, a2, b2c, a3, b3c, sel1, lb1, lb2, lb3,
@@ -2095,9 +2120,13 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
 // of the update kernels are built without them — twenty-odd tests of a run-time word in the hottest code of a kernel that is
 // short of scalar registers; the launchers take the KNOBS twin whenever pad != 0 (tools/, the certificate tests).
 template <int BLOCK, int LANES, bool PASS_ONLY, bool PROF, bool ICP = false, bool KNOBS = true>
-#if LINS_LDS_MINW > 1
-// (second argument: waves per SIMD the register allocation must allow)
-__global__ __launch_bounds__(BLOCK, LINS_LDS_MINW) void ieskf_lds_kernel(
+#if defined(LINS_LDS_NUMVGPR)
+// (A/B aid: a register budget without the occupancy that goes with it — the compiler relaxes waves-per-SIMD to what the LDS allows)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_num_vgpr(LINS_LDS_NUMVGPR))) void ieskf_lds_kernel(
+#elif LINS_LDS_MINW > 1
+// (second argument: waves per SIMD the register allocation must allow — the update kernels' budget; the correspondence pass
+// and the ICP fallback, which run once per scan, take what their workgroup shape leaves them)
+__global__ __launch_bounds__(BLOCK, (PASS_ONLY || ICP) ? 1 : LINS_LDS_MINW) void ieskf_lds_kernel(
 #else
 __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
 #endif
@@ -2105,7 +2134,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     lins_corr* __restrict__ dump) {
   // (the four pointers the loop reads and writes through stay parameters of their own: only a parameter carries
   // `noalias`, and without it the register allocation of every instantiation got worse)
-  constexpr bool kQueue = BLOCK == 512 && LANES == 1 && !PASS_ONLY && !ICP;  // (the shape that has the relay)
+  constexpr bool kQueue = BLOCK == kBatchBlock && LANES == 1 && !PASS_ONLY && !ICP;  // (the shape that has the relay)
   const bool queued = kQueue && ka.relay_n > 0;  // (uniform) a workgroup of a ticketed batch launch, see "work items" above
   int item;  // scan | part << 27; -1: nothing to do
 #ifdef LINS_QUEUE_TRACE  // (debug builds, tools/queue_trace.py: per workgroup start / item in hand / end on the 100 MHz clock)
@@ -2118,8 +2147,10 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   if (kQueue && queued) {
     if (threadIdx.x == 0) {
       int* const Q = ka.queue;
-      int it = ka.order[relay_add(Q + kQHead, 1)];
+      const int ticket = relay_add(Q + kQHead, 1);
+      int it = ka.order[ticket];
       const int part = it >> 27, scan = it & 0x7FFFFFF;
+      g_lds.scan_tmp[1] = ticket - part * ka.relay_n;  // the scan's place in the launch order (longest-expected-first)
       if (part) {
         const int want = ka.relay_gen * 16 + part;
         int f = relay_ld(Q + kQFlags + scan);
@@ -2138,6 +2169,13 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     }
     __syncthreads();
     item = g_lds.scan_tmp[0];
+#if LINS_PRIO_SHIFT > 0
+    // The launch ends with the CHAIN of its slowest updates (tools/queue_trace.py: the parts of the scan with the largest
+    // prior translation take 2.2-2.5 x the mean and follow one another); the scans the host expects to be the longest — the
+    // first n >> LINS_PRIO_SHIFT of the launch order — run their waves at raised issue priority: their chain shortens at
+    // the expense of the co-resident updates, which have slack.
+    if (g_lds.scan_tmp[1] < (ka.relay_n >> LINS_PRIO_SHIFT)) __builtin_amdgcn_s_setprio(LINS_PRIO_LEVEL);
+#endif
 #ifdef LINS_QUEUE_TRACE
     qt1 = wall_clock64();
 #endif

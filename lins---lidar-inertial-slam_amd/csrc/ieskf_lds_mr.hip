@@ -27,16 +27,25 @@
 #define LINS_LDS_SCANBATCH 2  // (measured: 1 -> 7.9, 2 -> 8.1, 3 -> 8.0, 4 -> 7.75, 8 -> 7.1 M it/s at 128 VGPRs;
                               // re-timed at the end of round 2: 3 -> -0.5 % (noise, 18 spilled registers), 4 -> +2 %)
 #endif
-#define LINS_LDS_WAVES 8
+#ifndef LINS_MR_BLOCK
+#define LINS_MR_BLOCK 512
+#endif
+#define LINS_LDS_WAVES (LINS_MR_BLOCK / 64)
+#define LINS_LDS_BATCH_BLOCK LINS_MR_BLOCK
 #ifndef LINS_MR_MINW
 #define LINS_MR_MINW 4
 #endif
 #define LINS_LDS_MINW LINS_MR_MINW
-#define LINS_MR_BLOCK 512
 #ifndef LINS_MR_LDSBYTES
 #define LINS_MR_LDSBYTES 80896
 #endif
 #define LINS_LDS_BYTES LINS_MR_LDSBYTES
+#ifndef LINS_MR_LEAN
+#define LINS_MR_LEAN 1  // (0: the round-5 form of the correspondence phase, per-lane carried state in registers — A/B)
+#endif
+#if LINS_MR_LEAN
+#define LINS_LDS_LEAN 1
+#endif
 #include "ieskf_lds_impl.h"
 
 namespace lins {
@@ -66,8 +75,10 @@ int lds_mr_resident_workgroups(int n_cu) {
 void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const int* order, const float4* arena,
                    const float4* sorted, const GridTables* tabs, const double* state_in, const double* cov_in, double* state_out, double* a6,
                    double* cov_out, void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof,
-                   const RelayArgs* relay, unsigned* walk_cache, int run_gen) {
+                   const RelayArgs* relay, unsigned* walk_cache, int run_gen, int* carry) {
+  // (carry: the carry records of these n scans — 4 x 512 16-byte words each, ieskf_lds_lean.h; every launch needs them)
   lds_mr::KernelArgs ka{};
+  ka.relay_lane = carry;
   ka.prm = prm, ka.descs = descs, ka.order = order, ka.tabs = tabs;
   ka.state_in = state_in, ka.cov_in = cov_in, ka.state_out = state_out, ka.a6_out = a6, ka.cov_out = cov_out;
   ka.out = (lds_mr::OutRec*)out, ka.poses = poses, ka.scan_id_base = scan_id_base, ka.prof_buf = prof;
@@ -75,7 +86,8 @@ void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDe
   ka.walk_cache = walk_cache, ka.run_gen = run_gen;
   if (relay) {
     ka.relay_n = n, ka.relay_at = relay->at, ka.relay_cuts = relay->cuts, ka.relay_gen = relay->gen, ka.relay_spins = relay->spins, ka.relay_cap = relay->cap;
-    ka.relay_hdr = relay->hdr, ka.relay_lane = relay->lane, ka.queue = relay->queue, ka.relay_err = relay->err;
+    ka.relay_hdr = relay->hdr, ka.queue = relay->queue, ka.relay_err = relay->err;
+    if (!carry) ka.relay_lane = relay->lane;
     grid = relay->parts * n;
   }
   if (prof)
@@ -96,7 +108,7 @@ void launch_lds_mr_icp(hipStream_t stream, int n, const DevParams& prm, const Sc
   ka.prm = prm, ka.descs = descs, ka.tabs = tabs;
   ka.state_in = state_in, ka.cov_in = state_in /*unused: no covariance on this path*/, ka.state_out = state_out;
   ka.out = (lds_mr::OutRec*)out;
-  launch_args(lds_mr::ieskf_lds_kernel<512, 1, false, false, true>, n, 512, stream, ka, arena, sorted, idx_store);
+  launch_args(lds_mr::ieskf_lds_kernel<LINS_MR_BLOCK, 1, false, false, true>, n, LINS_MR_BLOCK, stream, ka, arena, sorted, idx_store);
 }
 
 void launch_lds_mr_pass(hipStream_t stream, int n, const DevParams& prm, const ScanDesc* descs, const float4* arena,
@@ -106,7 +118,7 @@ void launch_lds_mr_pass(hipStream_t stream, int n, const DevParams& prm, const S
   ka.prm = prm, ka.descs = descs, ka.tabs = tabs;
   ka.state_in = filt_state, ka.lin_in = lin_state, ka.iter_arg = iter;
   ka.sums_out = sums_out, ka.counts_out = counts_out;
-  launch_args(lds_mr::ieskf_lds_kernel<512, 1, true, false>, n, 512, stream, ka, arena, sorted, idx_store, dump);
+  launch_args(lds_mr::ieskf_lds_kernel<LINS_MR_BLOCK, 1, true, false>, n, LINS_MR_BLOCK, stream, ka, arena, sorted, idx_store, dump);
 }
 
 }  // namespace lins

@@ -51,7 +51,7 @@ void launch_lds_pass(hipStream_t, int, const DevParams&, int, const ScanDesc*, c
                      const double*, int, int4*, lins_corr*, double*, int*);
 int lds_np_cap();
 void launch_lds_mr(hipStream_t, int, const DevParams&, const ScanDesc*, const int*, const float4*, const float4*, const GridTables*, const double*,
-                   const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*, const RelayArgs*, unsigned*, int);
+                   const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*, const RelayArgs*, unsigned*, int, int*);
 int lds_mr_resident_workgroups(int n_cu);
 int lds_mr_queue_flags_offset();
 void launch_lds_mr_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const float4*, const GridTables*, const double*,
@@ -338,6 +338,8 @@ void make_dev_params(const lins_params& p, int search, DevParams& d) {
   d.pad = 0;
   d.margin_cold = 0.20f;  // (metres; swept on the batch workload after the late iterations got cheaper: 0.10 / 0.04 -> 0.789 ms, 0.20 / 0.08 -> 0.771 ms)
   d.margin_warm = 0.08f;
+  d.reseed_drift = 0.15f;  // (metres; any value gives the same results: it only picks between two bounds of an exact search)
+  d.pad2 = 0;
   // Tuning / profiling knobs, honoured only when LINS_ENABLE_DEBUG_KNOBS=1 is set as well: a stray variable in a
   // production environment changes nothing.  The margins only trade search work for certificate hits (any value
   // >= 0 gives the same results); LINS_DEBUG_SKIP deliberately breaks the searches (profiling aid).
@@ -345,6 +347,7 @@ void make_dev_params(const lins_params& p, int search, DevParams& d) {
   if (gate && gate[0] == '1') {
     if (const char* e = std::getenv("LINS_MARGIN_COLD")) d.margin_cold = std::max(0.f, (float)std::atof(e));
     if (const char* e = std::getenv("LINS_MARGIN_WARM")) d.margin_warm = std::max(0.f, (float)std::atof(e));
+    if (const char* e = std::getenv("LINS_RESEED_DRIFT")) d.reseed_drift = std::max(0.f, (float)std::atof(e));
     if (const char* e = std::getenv("LINS_DEBUG_SKIP")) d.pad = std::atoi(e);  // 1 = skip walks, 2 = skip search, 8 = verify
   }
 }
@@ -678,7 +681,7 @@ int run_range(lins_ctx* ctx, int lo, int cnt, int n_total, const RangeFlags& fl,
   if (use_mr || use_lds) {
     if (use_mr)
       launch_lds_mr(ctx->stream, cnt, ctx->dprm, desc, nullptr, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out, ctx->d_idx, ps,
-                    scan_id_base + lo, nullptr, nullptr, ctx->d_walk_cache, next_run_gen(ctx));
+                    scan_id_base + lo, nullptr, nullptr, ctx->d_walk_cache, next_run_gen(ctx), ctx->d_relay_lane + (size_t)lo * kLaneIntsPerScan);
     else
       launch_lds(ctx->stream, cnt, ctx->dprm, s == SEARCH_LDS3 ? 3 : 1, desc, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out,
                  ctx->d_idx, ps, scan_id_base + lo, nullptr);  // (the Joseph update is the kernels' epilogue)
@@ -790,8 +793,10 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   CREATE_TRY(hipMalloc((void**)&ctx->d_gsorted, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_gridtab, (size_t)ctx->max_batch * sizeof(GridTables)));
   if (ctx->queue_grid <= 0) ctx->queue_grid = lds_mr_resident_workgroups(ctx->n_cu);
+  // the carry records of the batch kernel's queries (ieskf_lds_lean.h: tracked candidates and certificates between the
+  // iterations of an update; 32 KB per scan): every launch of that kernel uses them, cut into parts or not
+  CREATE_TRY(hipMalloc((void**)&ctx->d_relay_lane, (size_t)ctx->max_batch * kLaneIntsPerScan * sizeof(int)));
   if (ctx->max_batch > ctx->queue_grid) {  // (only batches beyond the device's workgroup slots are cut into parts)
-    CREATE_TRY(hipMalloc((void**)&ctx->d_relay_lane, (size_t)ctx->max_batch * kLaneIntsPerScan * sizeof(int)));  // (CarryWords by query)
     CREATE_TRY(hipMalloc((void**)&ctx->d_relay_hdr, (size_t)ctx->max_batch * 64 * sizeof(double)));
     CREATE_TRY(hipHostMalloc((void**)&ctx->h_relay_err, sizeof(int)));
     *ctx->h_relay_err = 0;
@@ -997,7 +1002,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
       launch_lds_mr(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc,
                     relay ? ctx->d_order + ctx->max_batch : (ctx->use_order ? ctx->d_order : nullptr), ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in,
                     ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx, (lins_pose_record*)d_poses,
-                    scan_id_base, ctx->d_prof, relay ? &ra : nullptr, ctx->d_walk_cache, next_run_gen(ctx));
+                    scan_id_base, ctx->d_prof, relay ? &ra : nullptr, ctx->d_walk_cache, next_run_gen(ctx), ctx->d_relay_lane);
     else
       launch_lds(ctx->stream, ctx->n_uploaded, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc,
                  ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx,
@@ -1716,7 +1721,7 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
         }
         launch_lds_mr(ctx->stream, n, ctx->dprm, t.d_desc, relay ? ctx->d_order + ctx->max_batch : (ordered ? ctx->d_order : nullptr), t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in,
                       ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr, relay ? &ra : nullptr,
-                      ctx->d_walk_cache, next_run_gen(ctx));
+                      ctx->d_walk_cache, next_run_gen(ctx), ctx->d_relay_lane);
       } else
         launch_lds(ctx->stream, n, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, t.d_desc, t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in,
                    ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr);

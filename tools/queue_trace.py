@@ -47,3 +47,15 @@ for p in range(parts):
 it = np.array([r.iters for r in res])
 last = np.argsort(end)[-5:]
 print("  the five last ends:", " | ".join(f"scan {scan[i]} part {part[i]} {it[scan[i]]} it: in hand {got[i]:.0f}, {end[i] - got[i]:.0f} us" for i in last))
+# which scans are the slow ones (round 6): part-0 run time against what the host knows about a scan
+p0 = part == 0
+dur0 = np.zeros(batch); dur0[scan[p0]] = (end - got)[p0]
+rs = lambda c: np.bincount(np.clip(c[:, 3].astype(int), 0, 15), minlength=16)
+sizes = np.array([[len(p.surf_flat), len(p.corner_sharp), len(p.surf_last), len(p.corner_last),
+                   int(rs(p.surf_last)[:8].sum()), float(np.linalg.norm(p.state[:3]))] for p in pairs], dtype=float)
+names = ["n_flat", "n_sharp", "n_less_flat", "n_less_sharp", "less-flat rings 0-7", "|p| prior"]
+order = np.argsort(dur0)[::-1]
+print("  part-0 run time: mean %.0f, p90 %.0f, p99 %.0f, max %.0f us" % (dur0.mean(), np.percentile(dur0, 90), np.percentile(dur0, 99), dur0.max()))
+print("  correlation of the part-0 run time with", ", ".join(f"{n} {np.corrcoef(dur0, sizes[:, k])[0, 1]:+.2f}" for k, n in enumerate(names)))
+print("  the ten slowest:", " | ".join(f"scan {s}: {dur0[s]:.0f} us " + "/".join(f"{sizes[s, k]:.0f}" if k < 5 else f"{sizes[s, k]:.2f}" for k in range(6)) for s in order[:10]))
+print("  batch means   :", "/".join(f"{sizes[:, k].mean():.0f}" if k < 5 else f"{sizes[:, k].mean():.2f}" for k in range(6)), " resident positions (corner + less-flat rings 0-7): mean %.0f, p90 %.0f, max %.0f" % ((sizes[:, 3] + sizes[:, 4]).mean(), np.percentile(sizes[:, 3] + sizes[:, 4], 90), (sizes[:, 3] + sizes[:, 4]).max()))
