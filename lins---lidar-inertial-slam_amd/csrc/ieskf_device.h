@@ -56,7 +56,17 @@ struct DevParams {
 
 // The iterations an update is cut at: k x at for k = 1 .. max_cuts, none afterwards (the last part runs to the end).
 // Shared by the kernel (where an item ends) and the host (how many items a launch has).
+// (at == -1: max_cuts is a MASK of the iterations an update is cut at — bit i: a part ends before iteration i, i < 31 —
+// for cuts that are not evenly spaced, e.g. 0x92 = after the cold iteration, then at 4 and 7)
 __host__ __device__ inline int relay_next_cut(int iter, int at, int max_cuts) {
+  if (at < 0) {
+    const unsigned m = iter >= 30 ? 0u : ((unsigned)max_cuts >> (iter + 1)) << (iter + 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return m ? __ffs((int)m) - 1 : 0x7FFFFFFF;
+#else
+    return m ? __builtin_ctz(m) : 0x7FFFFFFF;
+#endif
+  }
   const int k = iter / at + 1;
   return k <= max_cuts ? k * at : 0x7FFFFFFF;
 }
@@ -71,6 +81,7 @@ __host__ __device__ inline int relay_max_parts(int num_iter, int at, int max_cut
 struct RelayArgs {
   int at = 0, cuts = 0, parts = 0, gen = 0;
   int cap = 0;            // scans the flag array holds
+  int slots = 0;          // workgroups of the batch kernel resident at once on the device
   int spins = 1 << 21;    // polls (~1 us each) a part waits for its hand-over before it gives up (reported by lins_sync)
   double* hdr = nullptr;  // per scan: 64 doubles of loop state
   int* lane = nullptr;    // per scan: the carried state of every query lane (ieskf_lds_impl.h CarryWords)

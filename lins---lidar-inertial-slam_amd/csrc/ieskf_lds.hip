@@ -15,6 +15,18 @@
 #define LINS_LDS_WAVES 16
 #define LINS_LDS_MINW 1
 #define LINS_LDS_BYTES 163840
+#ifndef LINS_FULL_LEAN
+// (1: the one-lane shape's update kernels in the register-lean form of ieskf_lds_lean.h.  Round 6 measured the single-scan
+// update through a lean 1024 x 1 shape — sixteen waves, up to eight lanes per cold search: 216 us against 182 us of the
+// three-lane shape and 188 us of the batch kernel's 512 x 1 on one scan: more waves, more barrier and per-wave fixed cost.)
+#define LINS_FULL_LEAN 0
+#endif
+#if LINS_FULL_LEAN
+#define LINS_LDS_LEAN 1
+#endif
+#ifndef LINS_FULL_BLOCK1
+#define LINS_FULL_BLOCK1 384  // threads of the one-lane-per-query shape
+#endif
 #include "ieskf_lds_impl.h"
 
 namespace lins {
@@ -30,8 +42,9 @@ int lds_np_cap() { return lds_full::kNpMax; }
 // (one workgroup per CU: nothing to order; the batch shape's several-part updates do not exist here)
 void launch_lds(hipStream_t stream, int n, const DevParams& prm, int lanes, const ScanDesc* descs,
                 const float4* arena, const float4* sorted, const GridTables* tabs, const double* state_in, const double* cov_in, double* state_out, double* a6,
-                double* cov_out, void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof) {
+                double* cov_out, void* out, int4* idx_store, lins_pose_record* poses, int scan_id_base, long long* prof, int* carry) {
   lds_full::KernelArgs ka{};
+  ka.relay_lane = carry;  // (the carry records of these n scans: the one-lane shape's per-query state, ieskf_lds_lean.h)
   ka.prm = prm, ka.descs = descs, ka.tabs = tabs;
   ka.state_in = state_in, ka.cov_in = cov_in, ka.state_out = state_out, ka.a6_out = a6, ka.cov_out = cov_out;
   ka.out = (lds_full::OutRec*)out, ka.poses = poses, ka.scan_id_base = scan_id_base, ka.prof_buf = prof;
@@ -44,9 +57,9 @@ void launch_lds(hipStream_t stream, int n, const DevParams& prm, int lanes, cons
       launch_args(lds_full::ieskf_lds_kernel<1024, 3, false, false, false, false>, n, 1024, stream, ka, arena, sorted, idx_store);
   } else {
     if (prof)
-      launch_args(lds_full::ieskf_lds_kernel<384, 1, false, true>, n, 384, stream, ka, arena, sorted, idx_store);
+      launch_args(lds_full::ieskf_lds_kernel<LINS_FULL_BLOCK1, 1, false, true>, n, LINS_FULL_BLOCK1, stream, ka, arena, sorted, idx_store);
     else
-      launch_args(lds_full::ieskf_lds_kernel<384, 1, false, false>, n, 384, stream, ka, arena, sorted, idx_store);
+      launch_args(lds_full::ieskf_lds_kernel<LINS_FULL_BLOCK1, 1, false, false>, n, LINS_FULL_BLOCK1, stream, ka, arena, sorted, idx_store);
   }
 }
 

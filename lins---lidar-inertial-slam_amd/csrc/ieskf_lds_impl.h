@@ -64,6 +64,9 @@
 #include "icp_wave.h"
 #include "ieskf_rowsum.h"
 
+#ifndef LINS_PERSIST
+#define LINS_PERSIST 0
+#endif
 #ifndef LINS_PRIO_SHIFT
 #define LINS_PRIO_SHIFT 0  // (0: off)
 #endif
@@ -119,6 +122,7 @@ struct KernelArgs {
   int run_gen;           // number of this launch (tags of the walk cache: an entry of an earlier launch does not count)
   int iter_arg, scan_id_base, relay_n, relay_at, relay_cuts, relay_gen;
   int relay_cap;    // scans the context's flag array holds (the debug trace lies behind it)
+  int relay_items;  // (persistent launch, LINS_PERSIST) items of the launch: the workgroups draw tickets until they run out
   int relay_spins;  // polls of ~1 us a part waits for its hand-over before it gives up (and the launch reports it)
 };
 typedef const KernelArgs __attribute__((address_space(4))) * ColdArgs;
@@ -418,6 +422,33 @@ __device__ __forceinline__ bool ring_in_reach(const LCloud& c, int r, float el_q
   return el_q >= w.x - delta && el_q <= w.y + delta;
 }
 
+// ---- azimuth windows from the query's COLUMN COORDINATE ---------------------------------------------------------------------
+// reach() above — the windows of the three-lane single-scan kernel and of the correspondence pass / ICP shapes, whose register budget the two extra window words do not fit: measured 181.5 -> 196.3 us per single-scan update with them — opens a0 - K .. a0 + K with K = floor(D / w) + 2 columns (D = asin(sqrt(bound) / rho), w the
+// column width): one column for the query's place inside its own column, one for the errors of the column function — five
+// columns of slack around a window whose real width is 2 D / w.  With the query's column coordinate gq = g(q) / w itself
+// (the real number az_bin_lds truncates) the window is exact up to the column function's error: a point within angular
+// distance D of the query has |g(p) - g(q)| <= D + 2 eps (eps = 4e-3 rad bounds lins_atan2_coarse, lins_math.h), so its
+// column lies in floor(gq - D / w - e) .. floor(gq + D / w + e), e = 2 eps / w + 2e-3 — on average 2 D / w + 1.3 columns
+// instead of 2 floor(D / w) + 5: about half the points of a typical window.  A superset decision like every other pruning
+// step: results cannot change.
+struct ColWin {
+  int lo, hi;  // columns, unwrapped (spans_of reduces them)
+};
+__device__ __forceinline__ float az_col_f(float x, float y, int naz) { return (lins_atan2_coarse(y, x) + kPiF) * ((float)naz * (0.5f / kPiF)); }
+__device__ __forceinline__ int az_col_of(float gq, int naz) {  // az_bin_lds(): the column the build puts the point in
+  const int a = (int)gq;
+  return a < 0 ? 0 : (a >= naz ? naz - 1 : a);
+}
+__device__ __forceinline__ ColWin reach_cols(const LCloud& c, float rho, float sqrt_bound, float gq) {
+  const float s = bound_divf(sqrt_bound * (1.f + 1e-6f) + kSlack * rho + 1e-6f, rho);  // rho == 0 -> inf/nan -> all columns
+  const int half = c.naz / 2;
+  if (!(s < 1.f)) return ColWin{(int)gq - half, (int)gq + half};
+  const float cpr = (float)c.naz * (0.5f / kPiF);  // columns per radian
+  const float d = asin_ub(s) * (1.f + 1e-6f) * cpr + (2.f * 4e-3f) * cpr + 2e-3f;
+  const float lo = floorf(gq - d), hi = floorf(gq + d);
+  return (hi - lo >= (float)(c.naz - 1)) ? ColWin{(int)gq - half, (int)gq + half} : ColWin{(int)lo, (int)hi};
+}
+
 // ---- pass 1: exact NN; with LANES = 3 the ring windows of a query are split over its lanes
 template <int LANES>
 __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float sx, float sy, float sz,
@@ -665,6 +696,8 @@ __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, boo
     int dr;
     if (is_surf)
       dr = t == 0 ? 0 : (t == 1 ? -1 : (t == 2 ? -2 : (t == 3 ? 1 : (t == 4 ? 2 : 99))));
+    // (this order suits the three-lane shape: the forward bound j < N_query, SE:859, leaves rho, rho -1, rho -2 as the only
+    // rings with candidates for nearly every query — one per lane; walk_lean deals adjacent rings first for its 1 / 2 / 4 / 8 lanes)
     else
       dr = t == 0 ? -1 : (t == 1 ? 1 : (t == 2 ? -2 : (t == 3 ? 2 : 99)));
     const bool use2 = !is_surf || dr == 0;
@@ -1158,7 +1191,7 @@ __device__ __forceinline__ int relay_add(int* p, int v) { return __hip_atomic_fe
 
 // A scan's flag only ever rises within a launch (16 gen + next part ... 16 gen + 15 = finished): raised with an atomic max.
 #ifndef LINS_RELAY_RELEASE
-#define LINS_RELAY_RELEASE 0  // (1: the flag is raised with release / read with acquire semantics at agent scope — A/B knob)
+#define LINS_RELAY_RELEASE 1  // (the flag is raised with release / read with acquire semantics at agent scope; 0: the relaxed forms of rounds 3-5 — A/B knob)
 #endif
 __device__ __forceinline__ void relay_raise(int* p, int v) {
   __hip_atomic_fetch_max(p, v, LINS_RELAY_RELEASE ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1355,8 +1388,8 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
 #ifndef LINS_SPREAD_WC
 #define LINS_SPREAD_WC 1, 1, 1
 #endif
-  constexpr int kWtS[] = {LINS_SPREAD_WS, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}, kWtC[] = {LINS_SPREAD_WC, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
-  constexpr int kSpreadMax = 12;  // waves of one kind at most
+  constexpr int kWtS[] = {LINS_SPREAD_WS, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}, kWtC[] = {LINS_SPREAD_WC, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+  constexpr int kSpreadMax = 16;  // waves of one kind at most
   static_assert(LANES != 1 || kWaves <= kSpreadMax + 1, "spread layout: weights for every wave");
   constexpr bool kWeighted = BLOCK == kBatchBlock && LINS_SPREAD_S > 0;  // (the batch shape; the other one-lane shapes deal equal counts)
   // first query of wave-round j of a kind with n queries over nw waves: floor(n * (w_0 + ... + w_{j-1}) / (w_0 + ... + w_{nw-1}))
@@ -2141,13 +2174,25 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   const long long qt0 = wall_clock64();
   long long qt1 = qt0;
 #endif
-  // (Round 5 also ran the ticket draw as a LOOP — as many persistent workgroups as the device holds, each drawing tickets
-  // until the list is exhausted, no workgroup turnover between items: 0.5767 against 0.5636 ms with 15 spilled registers
-  // even without MachineLICM, 109 with it — the loop around the update costs more than the turnover it saves.)
+  // (Rounds 5 and 6 also ran the ticket draw as a LOOP — as many persistent workgroups as the device holds, each drawing
+  // tickets until the list is exhausted, no workgroup turnover between items and no static share of the items per XCD
+  // (-DLINS_PERSIST=1): round 5 0.5767 against 0.5636 ms with 15 spilled registers; round 6, on the register-lean
+  // correspondence phase, 0.5754 against 0.5563 ms with 10 — the loop around the update costs more than the turnover it saves.)
+#if LINS_PERSIST
+  // (round 6, with the register-lean correspondence phase: as many workgroups as the device holds, each drawing tickets
+  // until the list is exhausted — no workgroup turnover between items)
+#pragma unroll 1
+  for (;;) {
+#endif
   if (kQueue && queued) {
     if (threadIdx.x == 0) {
       int* const Q = ka.queue;
       const int ticket = relay_add(Q + kQHead, 1);
+#if LINS_PERSIST
+      if (ticket >= ka.relay_items) {
+        g_lds.scan_tmp[0] = -2;
+      } else {
+#endif
       int it = ka.order[ticket];
       const int part = it >> 27, scan = it & 0x7FFFFFF;
       g_lds.scan_tmp[1] = ticket - part * ka.relay_n;  // the scan's place in the launch order (longest-expected-first)
@@ -2166,6 +2211,9 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
         if (f != want) it = -1;  // the scan is finished (stop rule, divergence) — or the wait ran out
       }
       g_lds.scan_tmp[0] = it;
+#if LINS_PERSIST
+      }
+#endif
     }
     __syncthreads();
     item = g_lds.scan_tmp[0];
@@ -2185,8 +2233,16 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     // the dispatcher, which hands workgroups out in index order as slots free up, ends the launch with the short ones)
     item = ka.order ? ka.order[blockIdx.x] : (int)blockIdx.x;
   }
+#if LINS_PERSIST
+  if (kQueue && queued && item == -2) break;
+#endif
   if (item >= 0)
     ieskf_lds_update<BLOCK, LANES, PASS_ONLY, PROF, ICP, KNOBS>(ka, arena, sorted, idx_store, dump, item & 0x7FFFFFF, kQueue ? item >> 27 : 0);
+#if LINS_PERSIST
+  if (!(kQueue && queued)) break;
+  __syncthreads();  // (the workgroup's LDS block is the next item's)
+  }
+#endif
   if (kQueue && queued && threadIdx.x == 0) {  // the last workgroup out leaves the counters at zero for the next launch
     int* const Q = cold_args()->queue;
 #ifdef LINS_QUEUE_TRACE

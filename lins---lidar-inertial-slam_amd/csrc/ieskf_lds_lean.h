@@ -85,37 +85,17 @@ __device__ __forceinline__ float t2_cert_lb(const Top2& b, float margin) {  // c
   return fminf(bound_sqrtf(b.omin), bound_sqrtf(t2_d(b.k)) + margin);
 }
 
-// ---- azimuth windows from the query's COLUMN COORDINATE ---------------------------------------------------------------------
-// reach() of ieskf_lds_impl.h opens a0 - K .. a0 + K with K = floor(D / w) + 2 columns (D = asin(sqrt(bound) / rho), w the
-// column width): one column for the query's place inside its own column, one for the errors of the column function — five
-// columns of slack around a window whose real width is 2 D / w.  With the query's column coordinate gq = g(q) / w itself
-// (the real number az_bin_lds truncates) the window is exact up to the column function's error: a point within angular
-// distance D of the query has |g(p) - g(q)| <= D + 2 eps (eps = 4e-3 rad bounds lins_atan2_coarse, lins_math.h), so its
-// column lies in floor(gq - D / w - e) .. floor(gq + D / w + e), e = 2 eps / w + 2e-3 — on average 2 D / w + 1.3 columns
-// instead of 2 floor(D / w) + 5: about half the points of a typical window.  A superset decision like every other pruning
-// step: results cannot change.
-struct ColWin {
-  int lo, hi;  // columns, unwrapped (spans_of reduces them)
-};
-__device__ __forceinline__ float az_col_f(float x, float y, int naz) { return (lins_atan2_coarse(y, x) + kPiF) * ((float)naz * (0.5f / kPiF)); }
-__device__ __forceinline__ int az_col_of(float gq, int naz) {  // az_bin_lds(): the column the build puts the point in
-  const int a = (int)gq;
-  return a < 0 ? 0 : (a >= naz ? naz - 1 : a);
-}
-__device__ __forceinline__ ColWin reach_cols(const LCloud& c, float rho, float sqrt_bound, float gq) {
-  const float s = bound_divf(sqrt_bound * (1.f + 1e-6f) + kSlack * rho + 1e-6f, rho);  // rho == 0 -> inf/nan -> all columns
-  const int half = c.naz / 2;
-  if (!(s < 1.f)) return ColWin{(int)gq - half, (int)gq + half};
-  const float cpr = (float)c.naz * (0.5f / kPiF);  // columns per radian
-  const float d = asin_ub(s) * (1.f + 1e-6f) * cpr + (2.f * 4e-3f) * cpr + 2e-3f;
-  const float lo = floorf(gq - d), hi = floorf(gq + d);
-  return (hi - lo >= (float)(c.naz - 1)) ? ColWin{(int)gq - half, (int)gq + half} : ColWin{(int)lo, (int)hi};
-}
-
+#ifndef LINS_HARD_COLS
+#define LINS_HARD_COLS 16
+#endif
+constexpr int kHardCols = LINS_HARD_COLS;  // columns of a cold search's window beyond which the search is deferred (nn_lean)
+constexpr int kHardLanes = 32;             // lanes a deferred search may take (32 ring windows)
 // ---- pass 1: exact nearest neighbour (nn_lds<0> on Top2).  ln lanes per query, role = this lane's number among them ---------
 __device__ __forceinline__ Top2 nn_lean(const LdsStore& L, const LCloud& c, float sx, float sy, float sz, float rho, float qn3, float el_q, float gq,
-                                        float thr, float margin, int rq, int ln, int role, int lane, int warm_pos, int warm_ring, bool reseed) {
+                                        float thr, float margin, int rq, int ln, int role, int lane, int warm_pos, int warm_ring, bool reseed,
+                                        bool may_defer, bool& deferred) {
   Top2 b = t2_init(thr);
+  deferred = false;
   // Warm start: last search's nearest neighbour is still a candidate, and its distance to the re-de-skewed query bounds
   // the search from the start.  That bound is only as good as the query stood still: after a large step of the state (the
   // first iterations of an update whose prior is off by a metre) it is the step's length, and the windows it opens hold
@@ -153,6 +133,16 @@ __device__ __forceinline__ Top2 nn_lean(const LdsStore& L, const LCloud& c, floa
   const int cin = warm ? 0 : 2;  // first column either side that the seed has not covered
   const float sqrtB = bound_sqrtf(t2_d(b.k)) + margin;  // fixed bound for everything below, inflated by the certificate margin
   const ColWin cw = reach_cols(c, rho, sqrtB, gq);
+  // A HARD search: the seed found nothing near (an empty neighbourhood, a query displaced by a prior that is a metre off) and
+  // the windows of the bound it left hold hundreds to thousands of points — swept by this query's one or two lanes while
+  // the other 62 of the wave, then the workgroup at its barrier, then the launch wait for it: round 6 found single waves
+  // at 330-390 k ticks of nearest-neighbour phase against 30-60 k of the other seven in the updates that end a launch
+  // (tools/wave_phases.py WP_SLOWEST=1).  Such a search is DEFERRED: the wave runs its hard searches afterwards, up to 32
+  // lanes each (one ring window per lane).  The lanes of a query agree: b is the same in all of them after the seed's merge.
+  if (may_defer && !warm && cw.hi - cw.lo > kHardCols) {
+    deferred = true;
+    return b;
+  }
   const int own_r = a0 + cin, own_l = a0 - (warm ? 1 : 2);  // own ring: first column right / left of what the seed covered
   const float delta = reach_elev(qn3, sqrtB);
   // this lane's tasks as a bit mask: ln == 1: bit 0 / 1 = own ring right / left of the seed, bit 2 + r = ring r;
@@ -257,13 +247,16 @@ __device__ __forceinline__ void walk_lean(const LdsStore& L, const LCloud& c, bo
     scan_cols(L, c, rho, go ? a0 - 1 : 1, go ? a0 + 1 : 0, f);
   }
   // tasks dealt round-robin to the query's lanes:
-  //   surf    t0: rho (class 2, extensions)  t1: rho-1  t2: rho-2  t3: rho+1  t4: rho+2  (class 3)
+  //   surf    t0: rho (class 2, extensions)  t1: rho-1  t2: rho+1  t3: rho-2  t4: rho+2  (class 3)
   //   corner  t0: rho-1  t1: rho+1  t2: rho-2  t3: rho+2
+  // Adjacent rings before the rings two away, for every number of lanes: a lane's running best carries from task to task,
+  // and on the ground the next ring is metres closer than the one after it — with rho -2 dealt before rho +1 (rounds 1-5)
+  // the first of a query's two lanes swept rho -2 and rho +2 under the 5 m threshold without ever seeing an adjacent ring.
 #pragma unroll 1
   for (int t = role; t <= 4; t += ln) {
     int dr;
     if (is_surf)
-      dr = t == 0 ? 0 : (t == 1 ? -1 : (t == 2 ? -2 : (t == 3 ? 1 : 2)));
+      dr = t == 0 ? 0 : (t == 1 ? -1 : (t == 2 ? 1 : (t == 3 ? -2 : 2)));
     else
       dr = t == 0 ? -1 : (t == 1 ? 1 : (t == 2 ? -2 : (t == 3 ? 2 : 99)));
     const bool use2 = !is_surf || dr == 0;
@@ -305,7 +298,7 @@ __device__ __forceinline__ int hi16(unsigned w) { return (int)w >> 16; }
 // feeds pruning windows) is made BY the serving lanes from the shipped point: four registers and four shuffles less than
 // shipping it, and nobody holds it across a search.  Results come back as the low words of the two keys + the bound.
 struct NnRes {
-  unsigned low, low2;  // winner / runner-up (nn_low: position and ring inside; 0 = none)
+  unsigned low, low2;  // winner / runner-up (nn_low: position and ring inside; 0 = none); low2 = 0xFFFFFFFF: the search was deferred
   float lb;
 };
 struct WalkRes {
@@ -318,7 +311,8 @@ __device__ __forceinline__ unsigned t2_pos_pair(const Top2& b) {  // (walk keys)
   return w | (r << 16);
 }
 __device__ __forceinline__ NnRes coop_nn_lean(const LdsStore& L, const LCloud& c, const CoopMap& cm, int coop_cap, bool need_nn, int lane, float sx,
-                                              float sy, float sz, int rq /* ring | reseed << 8 */, int a1, int ra1, float thr, float margin, bool skip) {
+                                              float sy, float sz, int rq /* ring | reseed << 8 */, int a1, int ra1, float thr, float margin, bool skip,
+                                              bool may_defer) {
   const int ln = coop_lanes(cm.n, coop_cap);
   const int role = lane & (ln - 1), item = lane >> (31 - __clz(ln));
   bool valid = need_nn;
@@ -329,11 +323,13 @@ __device__ __forceinline__ NnRes coop_nn_lean(const LdsStore& L, const LCloud& c
     rq = __shfl(rq, owner), a1 = __shfl(a1, owner), ra1 = __shfl(ra1, owner);
   }
   Top2 b = t2_init(thr);
+  bool deferred = false;
   if (valid && !skip) {
     const float rho = sqrtf(sx * sx + sy * sy), qn3 = sqrtf(rho * rho + sz * sz);
-    b = nn_lean(L, c, sx, sy, sz, rho, qn3, atan2f(sz, rho), az_col_f(sx, sy, c.naz), thr, margin, rq & 0xFF, ln, role, lane, a1, ra1, (rq & 0x100) != 0);
+    b = nn_lean(L, c, sx, sy, sz, rho, qn3, atan2f(sz, rho), az_col_f(sx, sy, c.naz), thr, margin, rq & 0xFF, ln, role, lane, a1, ra1, (rq & 0x100) != 0,
+                may_defer, deferred);
   }
-  NnRes r{(unsigned)b.k, t2_real(b.k2) ? (unsigned)b.k2 : 0u, t2_cert_lb(b, margin)};
+  NnRes r{(unsigned)b.k, deferred ? 0xFFFFFFFFu : (t2_real(b.k2) ? (unsigned)b.k2 : 0u), t2_cert_lb(b, margin)};
   if (ln > 1) {  // hand back: the owner of rank r reads the first lane of group r
     const int src = (cm.rank * ln) & 63;
     r.low = __shfl(r.low, src), r.low2 = __shfl(r.low2, src), r.lb = __shfl(r.lb, src);

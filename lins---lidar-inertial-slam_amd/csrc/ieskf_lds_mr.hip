@@ -15,6 +15,7 @@
 // SIMDs, every workgroup starting on the same one, so a second / third workgroup only fits with
 // <= 128 / 80 VGPRs even when LDS would allow it); three workgroups per CU at 96 VGPRs (588 B of
 // scratch per lane: no faster than two).
+#include <algorithm>
 #define LINS_LDS_NS lds_mr
 // (16-byte point records (x, y, z, original index bits): a candidate is ONE ds_read_b128; round 1's 14-byte SoA layout
 // held 4736 instead of 4224 positions but cost four reads per candidate: +2.9 % kernel time, removed in round 3)
@@ -89,6 +90,10 @@ void launch_lds_mr(hipStream_t stream, int n, const DevParams& prm, const ScanDe
     ka.relay_hdr = relay->hdr, ka.queue = relay->queue, ka.relay_err = relay->err;
     if (!carry) ka.relay_lane = relay->lane;
     grid = relay->parts * n;
+    ka.relay_items = grid;
+#if LINS_PERSIST
+    grid = std::min(grid, relay->slots);
+#endif
   }
   if (prof)
     launch_args(lds_mr::ieskf_lds_kernel<LINS_MR_BLOCK, 1, false, true>, grid, LINS_MR_BLOCK, stream, ka, arena, sorted, idx_store);

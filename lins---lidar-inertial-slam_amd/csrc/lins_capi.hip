@@ -46,7 +46,7 @@ void launch_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const floa
                  int, int4*, lins_corr*, double*, int*, float4*);
 void launch_joseph(hipStream_t, int, const DevParams&, const double*, const double*, const void*, double*);
 void launch_lds(hipStream_t, int, const DevParams&, int, const ScanDesc*, const float4*, const float4*, const GridTables*, const double*, const double*,
-                double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*);
+                double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*, int*);
 void launch_lds_pass(hipStream_t, int, const DevParams&, int, const ScanDesc*, const float4*, const float4*, const GridTables*, const double*,
                      const double*, int, int4*, lins_corr*, double*, int*);
 int lds_np_cap();
@@ -630,7 +630,7 @@ int relay_prepare(lins_ctx* ctx, int n, bool ordered, RelayArgs& ra) {
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order + ctx->max_batch, list, (size_t)ra.parts * n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     ctx->relay_list_parts = ra.parts, ctx->relay_list_n = n;
   }
-  ra.gen = ++ctx->relay_gen, ra.spins = ctx->relay_spins, ra.cap = ctx->max_batch;
+  ra.gen = ++ctx->relay_gen, ra.spins = ctx->relay_spins, ra.cap = ctx->max_batch, ra.slots = ctx->queue_grid;
   ra.hdr = ctx->d_relay_hdr, ra.lane = ctx->d_relay_lane, ra.queue = ctx->d_queue, ra.err = ctx->h_relay_err;
   return LINS_OK;
 }
@@ -684,7 +684,7 @@ int run_range(lins_ctx* ctx, int lo, int cnt, int n_total, const RangeFlags& fl,
                     scan_id_base + lo, nullptr, nullptr, ctx->d_walk_cache, next_run_gen(ctx), ctx->d_relay_lane + (size_t)lo * kLaneIntsPerScan);
     else
       launch_lds(ctx->stream, cnt, ctx->dprm, s == SEARCH_LDS3 ? 3 : 1, desc, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out,
-                 ctx->d_idx, ps, scan_id_base + lo, nullptr);  // (the Joseph update is the kernels' epilogue)
+                 ctx->d_idx, ps, scan_id_base + lo, nullptr, ctx->d_relay_lane + (size_t)lo * kLaneIntsPerScan);  // (the Joseph update is the kernels' epilogue)
   } else {
     DevParams dp = ctx->dprm;
     dp.search = want_lds ? (int)SEARCH_BINNED : s;  // a scan does not fit LDS: global-memory grid
@@ -746,6 +746,10 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
       if (const char* e = std::getenv("LINS_LAUNCH_ORDER")) ctx->use_order = e[0] != '0';
       if (const char* e = std::getenv("LINS_RELAY_AT")) ctx->relay_at = std::max(0, std::atoi(e));  // (0: whole updates)
       if (const char* e = std::getenv("LINS_RELAY_CUTS")) ctx->relay_cuts = std::max(1, std::min(14, std::atoi(e)));
+      if (const char* e = std::getenv("LINS_RELAY_MASK")) {  // (cuts that are not evenly spaced: bit i = a part ends before iteration i)
+        const long m = std::strtol(e, nullptr, 0) & 0x7FFFFFFEl;
+        if (m && __builtin_popcountl(m) <= 14) ctx->relay_at = -1, ctx->relay_cuts = (int)m;
+      }
       if (const char* e = std::getenv("LINS_RELAY_SPINS")) ctx->relay_spins = std::max(0, std::atoi(e));
       if (const char* e = std::getenv("LINS_QUEUE_GRID")) ctx->queue_grid = std::max(1, std::atoi(e));  // (batches beyond this many scans are cut)
       if (const char* e = std::getenv("LINS_STREAMS_FUSE")) ctx->streams_fuse = e[0] != '0';  // (0: re-projection and index build as two kernels)
@@ -990,7 +994,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   // only with ICP_FREQ 1: with a larger one the iterations in between read the triplets an earlier part of the scan left in
   // idx_store — plain stores of another workgroup, possibly on another XCD.
   const bool cut_ok = use_mr && ctx->n_uploaded > ctx->queue_grid && !ctx->d_prof && ctx->prm.icp_freq == 1 && ctx->d_relay_hdr;
-  const bool relay = cut_ok && ctx->relay_at > 0 && ctx->relay_at < ctx->prm.num_iter;
+  const bool relay = cut_ok && ctx->relay_at != 0 && relay_max_parts(ctx->prm.num_iter, ctx->relay_at, ctx->relay_cuts) > 1;
   RelayArgs ra;
   if (relay) {
     const int rcq = relay_prepare(ctx, ctx->n_uploaded, ctx->use_order, ra);
@@ -1006,7 +1010,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
     else
       launch_lds(ctx->stream, ctx->n_uploaded, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, ctx->d_desc,
                  ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx,
-                 (lins_pose_record*)d_poses, scan_id_base, ctx->d_prof);
+                 (lins_pose_record*)d_poses, scan_id_base, ctx->d_prof, ctx->d_relay_lane);
     HIP_TRY(ctx, hipEventRecord(ctx->hist1[h], ctx->stream));
     if (q.on) HIP_TRY(ctx, hipEventRecord(q.ev_main[set], ctx->stream));  // (the pose records of this run are complete)
     // (The Joseph update, SE:594-598, is the update kernel's epilogue since round 3: ieskf_lds_impl.h joseph_epilogue.
@@ -1707,7 +1711,7 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
       if (use_mr) {
         // several-part updates as in lins_batch_run (the relay + work queue): more streams than workgroup slots
         RelayArgs ra;
-        const bool relay = n > ctx->queue_grid && ctx->prm.icp_freq == 1 && ctx->d_relay_hdr && ctx->relay_at > 0 && ctx->relay_at < ctx->prm.num_iter;
+        const bool relay = n > ctx->queue_grid && ctx->prm.icp_freq == 1 && ctx->d_relay_hdr && ctx->relay_at != 0 && relay_max_parts(ctx->prm.num_iter, ctx->relay_at, ctx->relay_cuts) > 1;
         // launch order as in the batch calls: longest-expected-first by the prior's translation (launch_order above;
         // h_state holds this step's priors)
         const bool ordered = ctx->use_order && n > ctx->queue_grid;
@@ -1724,7 +1728,7 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
                       ctx->d_walk_cache, next_run_gen(ctx), ctx->d_relay_lane);
       } else
         launch_lds(ctx->stream, n, ctx->dprm, search == SEARCH_LDS3 ? 3 : 1, t.d_desc, t.d_arena, t.d_gsorted, t.d_gridtab, ctx->d_state_in,
-                   ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr);
+                   ctx->d_cov_in, ctx->d_state_out, ctx->d_a6, ctx->d_cov_out, ctx->d_out, ctx->d_idx, nullptr, 0, nullptr, ctx->d_relay_lane);
     } else {
       DevParams dp = ctx->dprm;
       dp.search = want_lds ? (int)SEARCH_BINNED : search;

@@ -41,6 +41,10 @@ for w in range(8):
 work = p[:, :, :5].sum(2)  # a wave's own work before the barrier
 print("own work before the barrier (phases 0-4): mean over waves %.0f, max over waves %.0f (mean over workgroups); slowest wave: %s" %
       (work.mean(), work.max(1).mean(), np.bincount(work.argmax(1), minlength=8)))
+for s_ in (np.argsort(p[:, 0].sum(1))[::-1][:3] if os.environ.get("WP_SLOWEST") else []):  # (round 6) the slowest workgroups, wave by wave
+    print(f"  scan {s_} (|p| prior {np.linalg.norm(pairs[s_].state[:3]):.2f}): ticks per iteration by wave")
+    for w in range(8):
+        print(f"  {w:4d}   " + "".join(f"{p[s_, w, j]:12.0f}" for j in range(8)) + f"{p[s_, w].sum():12.0f}")
 slow = work.argmax(1)
 sel = p[np.arange(batch), slow]
 print("the slowest wave's phases: " + ", ".join(f"{names[j]} {sel[:, j].mean():.0f}" for j in range(5)))
