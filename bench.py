@@ -39,7 +39,7 @@ PKG = "lins---lidar-inertial-slam_amd"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def traffic_from_profiles(search):
+def traffic_from_profiles(search, live=True):
     """HBM-side bytes per launch of the dominant kernel from the PMC counters.  PMC collection needs rocprofv3 around
     the process, so it happens in a separate run of this same command (tools/pmc_traffic.py on the GPU box, which
     also calibrates FETCH_SIZE / WRITE_SIZE on a streaming copy of known size) and is read back from the newest
@@ -47,8 +47,28 @@ def traffic_from_profiles(search):
     of csrc/ + include/, the stamp build() uses): a record of another build is reported as stale, not as a number.
     -> (traffic dict | None, note)"""
     import glob
+    import shutil
 
     import __graft_entry__ as g
+
+    keep = ("bytes_lo", "bytes_hi", "fetch_size_bytes", "write_size_bytes", "calibration", "kernel", "meaning", "valu")
+    # Measured in THIS run when rocprofv3 is on the box (VERDICT r05 item 8): the same command under --pmc FETCH_SIZE /
+    # WRITE_SIZE (+ one SQ pass), each in its own rocprofv3 pass with --kernel-trace only, ~10 s per pass
+    # (tools/pmc_traffic.py measure()).  LINS_BENCH_NO_LIVE_PMC=1 — set for the runs under the counters themselves —
+    # or any failure falls back to the committed record below, and traffic_source says which it was.
+    if live and shutil.which("rocprofv3") and os.environ.get("LINS_BENCH_NO_LIVE_PMC") != "1":
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import pmc_traffic
+
+            t0 = time.perf_counter()
+            rec = pmc_traffic.measure("live", ["--search", search])
+            if rec.get("kernel") and rec.get("bytes_hi"):
+                return {k: rec[k] for k in keep if k in rec}, "live: rocprofv3 --pmc passes of this bench run (%.0f s)" % (time.perf_counter() - t0)
+        except Exception as e:  # noqa: BLE001  (a profiler that is missing a counter must not fail the bench)
+            print("bench: live PMC measurement failed (%s), using the committed record" % e, file=sys.stderr)
+        finally:
+            os.environ.pop("LINS_BENCH_NO_LIVE_PMC", None)
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
     if not files:
@@ -61,7 +81,6 @@ def traffic_from_profiles(search):
         return None, f"PMC record is for search={rec.get('search')}"
     if rec.get("source_digest") != g._source_digest():
         return None, "stale: PMC record taken from other sources (" + os.path.basename(files[-1]) + ")"
-    keep = ("bytes_lo", "bytes_hi", "fetch_size_bytes", "write_size_bytes", "calibration", "kernel", "meaning", "valu")
     return {k: rec[k] for k in keep if k in rec}, os.path.basename(files[-1])
 
 
@@ -614,7 +633,7 @@ def main():
         # algorithmic bytes per launch = sum_scans B_iter(scan) * iterations(scan); with the
         # fixed-iteration mode every non-diverged scan runs args.iters iterations
         alg_bytes = bytes_iter_local / len(pairs) * iters_local
-        traffic = traffic_from_profiles(args.search)
+        traffic = traffic_from_profiles(args.search, live=(world == 1))  # (single-GPU runs only: the counter passes are runs of their own)
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "ESKF iterations/sec (16x1800 VLP-16, ~2k feat)",
@@ -665,7 +684,8 @@ def main():
                 "traffic_detail": {k: v for k, v in traffic[0].items() if k != "valu"} if traffic[0] else None,
                 # VALU side ("report both the HBM fraction and the VALU fraction"): SQ counters of the
                 # same PMC record — busy_frac of the 1024 SIMDs' issue cycles, active lanes per VALU instruction (of 64)
-                "valu": ({k: traffic[0]["valu"].get(k) for k in ("busy_frac", "lanes_per_inst", "insts_valu_per_launch", "wave_wait_frac")}
+                "valu": ({k: traffic[0]["valu"].get(k) for k in ("busy_frac", "lanes_per_inst", "insts_valu_per_launch", "wave_wait_frac", "lds_conflict_per_active",
+                                                                    "insts_lds_per_launch", "insts_salu_per_launch")}
                          if traffic[0] and traffic[0].get("valu") else None),
                 "traffic_source": traffic[1],
                 "copy_ceiling_GBs": copy_gbs,  # measured stream-copy rate (read + write) on this box

@@ -252,9 +252,7 @@ __device__ __forceinline__ void consider(Best& b, float d, int key, int pos, int
 // runner-up and only lowers `omin` — one compare and a select, no branch; the 64-bit key logic runs
 // for the few that can enter the top two (ties on the runner-up's distance included).  `ok` masks
 // points that are not candidates at all (walk rank filter, batch padding).
-// (Round 4 measured the insertion WITHOUT a branch — four 64-bit compares and a dozen selects at every point instead of
-// insert_key() under a saved exec mask where a lane has a candidate: + 11 % kernel time, 0.6219 against 0.5598 ms in one
-// call.  Candidates are rare after a scan's first points; the compare-and-min below is what nearly every point costs.)
+// (a branch-free insertion was measured: + 11 % — profiles/history/kernel_notes.md #insert)
 __device__ __forceinline__ void consider_scan(Best& b, bool ok, float d, int key, int pos, int ring) {
   const bool cand = ok && d <= __uint_as_float((unsigned)(b.k2 >> 32));
   b.omin = (ok && !cand) ? fminf(b.omin, d) : b.omin;
@@ -368,10 +366,8 @@ __device__ __forceinline__ void scan_spans(const LdsStore& L, const LCloud& c, c
       for (int u = 0; u < kScanBatch; ++u) f(x[u], y[u], z[u], j[u], p + u, p + u < el);
     }
     if (kHybrid) {
-      // the positions past the resident ones, from the sorted global copy (L2).  One record per trip (kGlobBatch = 1):
-      // four in flight like the LDS loop above measured +2.0 % on the batch kernel (round 4, 0.5876 against 0.5761 ms in
-      // one call: four more spilled registers, and these scans are short — the searches of the upper rings end in a
-      // few columns).
+      // the positions past the resident ones, from the sorted global copy (L2), one record per trip (four in flight: + 2.0 %,
+      // profiles/history/kernel_notes.md #globbatch)
 #pragma unroll 1
       for (int p = s > c.n_lds ? s : c.n_lds; p < e; p += kGlobBatch) {
         float4 g[kGlobBatch];
@@ -516,8 +512,7 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
       if (LANES == 0 && t >= kTasks) break;
       const int k = t - 2, off = (k >> 1) + 1;
       const int r = t < 2 ? rq : rq + ((k & 1) ? -off : off);
-      // (Round 4: these thirty tests take 8 k of the cold search's 44 k ticks — tools/r04_call21.sh; issuing the ring
-      // reads unconditionally instead of behind the && chain: + 0.75 % kernel time, not kept)
+      // (the ring reads issued unconditionally: + 0.75 %, profiles/history/kernel_notes.md #reachtests)
       bool go;
       if (t < 2)
         go = own && K >= cin;
@@ -627,9 +622,7 @@ __device__ __forceinline__ void walk_task(const LdsStore& L, const LCloud& c, co
   // candidate shows up, instead of one sweep over the whole search radius.
   int kk = done ? 1 : -1;  // columns a0-kk..a0+kk are covered (-1: nothing yet)
   const int half = c.naz / 2;
-  // (Round 4 tried, one GPU call each: ONE scan per round over the whole window a0-nk..a0+nk, re-seeing the covered
-  // columns: +6.8 % kernel time — the points are paid for; the whole window of the current bound at once when it holds at
-  // most 96 / 256 / any number of points, decided from two cell_end reads: +0.1 / +0.4 / -0.8 % — not the rounds either.)
+  // (one scan per round / the whole window at once: + 6.8 % / +- 0.5 %, profiles/history/kernel_notes.md #walkrounds)
 #pragma unroll 1
   for (int round = 0; round < 8 && go; ++round) {
     const int K = reach(c, rho_q, bound_sqrtf(cur.d()) + margin);
@@ -816,14 +809,8 @@ __device__ __forceinline__ LCloud make_cloud(const LdsStore& L, bool is_surf, co
 // Every move is unconditional on a CLAMPED index (the threads past the end re-copy the last word: same value to the
 // same address), so that nothing ties a read to a branch: written with guards, the compiler sinks each read into its
 // guard and waits for it there — nine dependent HBM round trips instead of one.
-// Inlined since round 5 (-2 % on the batch kernel: 0.560 against 0.572 ms).  Rounds 3-4 kept it out of line: inlined, the
-// 1024 x 3 correspondence-pass instantiation returned grid position 0 for every second point of the line queries — a wave
-// shuffle of the walk's lane merges (merge_query_lanes<3>) read a lane that was switched off — 23 GPU tests failed, and
-// the cause was narrowed (the copy itself and every s_waitcnt were right in the ISA) but never found.  With the tail
-// kernel and the losing forks removed from this header the same source inlined passes the whole GPU suite (194 tests;
-// LINS_GRID_INLINE=0 is the old guard).  Not root-caused, so it is WATCHED: build() also builds the other variant
-// (ab/canary_grid_noinline.so) and tests/test_gpu_canaries.py runs the tests that found it against both, holding the
-// outcome against tests/canaries.json; the reproduction notes are in tools/repro/README.md.
+// Inlined since round 5 (-2 %); the code-generation sensitivity that kept it out of line in rounds 3-4 is WATCHED
+// (ab/canary_grid_noinline.so, tests/test_gpu_canaries.py; history: profiles/history/kernel_notes.md #gridinline, tools/repro/README.md).
 template <int BLOCK>
 #ifndef LINS_GRID_INLINE
 #define LINS_GRID_INLINE 1
@@ -858,318 +845,7 @@ __device__ __noinline__
   __syncthreads();
 }
 
-// ---------------------------------------------------------------------------
-// The serial tail of one iteration, kept out of line: its register needs (a 6x7 system in
-// registers, the 19-state) are allocated on their own instead of inflating — and spilling —
-// the search loop it would otherwise be fused with.  Called by every thread (barriers inside).
-// ---------------------------------------------------------------------------
-// Round 4: the out-of-line bodies are entered by the waves that work in them only — solve_wave0 by wave 0,
-// next_iter_consts by waves 0-2 — and the barriers between them are the caller's.  As one function called by all eight
-// waves (rounds 2-3) every wave ran its prologue and epilogue, nine callee-saved registers to scratch and back per wave
-// and iteration: ~190 MB of scratch stores per launch of 1024 scans, most of the 208 MB WRITE_SIZE counted (the
-// hand-over of the several-part updates is 35 MB of it).
-__device__ __noinline__ long long solve_wave0(double prm_r2, int prm_fixed_iters, int lane, bool prof) {
-  long long t3 = 0;
-  LdsStore& L = g_lds;
-  // ---- wave 0: (sigma^2 I + A P_SS) w = g + A d_S  (push-through form of SE:542-549) solved across the wave
-  // (wave_gj_solve6: Gauss-Jordan, one element per lane, no back-substitution), dx = d - P[:,S] w, NaN / divergence /
-  // convergence tests and boxPlus (SE:552-580).  This wave walks a chain of dependent f64 operations while the other
-  // seven wait at the barrier, so the chain is kept short: the rotation maps take their short-series forms
-  // (lins_math.h axis2quat_fast, quat2axis_fast, phi_and_gt_small — no libm call, no square root, one division for
-  // the rotations an update sees) and fall back to libm outside their range.  Round 2, measured in isolation
-  // (tools/tail_cycles.py): solve 3418 -> 2487 cycles, boxPlus' axis2quat 1487 -> 582, phi + Rinvleft 2087 -> 863;
-  // in the kernel the tail's share of a late iteration fell from 12.8 to 5.4 us per launch.  The new linearisation state is STAGED in LDS — the old one may
-  // still be read by the other waves until the barrier — and after it three waves split the constants of the next
-  // iteration: wave 0 -> linState_, R^T;  wave 1 -> phi, Rinvleft(-phi)^T;  wave 2 -> x_filter (-) x_lin.
-  // (Until round 2 the first three waves each ran the whole solve redundantly to save the staging: 2 x ~2.5 k
-  // issued instructions per iteration for nothing.)
-  double* const stage = &L.aug[0][0];  // 22 doubles: linState_ (19), |r|, |r| kept, |dx|
-  int* const stage_flags = reinterpret_cast<int*>(&L.aug[1][0]);  // diverged, converged
-  {
-    double v = 0.0;
-    if (lane < 42) {
-      const int i = lane / 7, j = lane % 7;
-      if (j < 6) {
-        v = (i == j ? prm_r2 : 0.0);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) v += sym6(L.sums, i, k) * L.P[sidx(k) * 18 + sidx(j)];
-      } else {
-        v = L.sums[21 + i];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) v += sym6(L.sums, i, k) * L.ic.d[sidx(k)];
-      }
-    }
-    // (what dx needs from LDS besides the solution is read BEFORE the solve: the reads then wait behind nothing)
-    double pls[6] = {0, 0, 0, 0, 0, 0}, dl = 0;
-    if (lane < 18) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) pls[k] = L.P[lane * 18 + sidx(k)];
-      dl = L.ic.d[lane];
-    }
-    double wsol[6];
-    wave_gj_solve6(v, lane, wsol);
-    double dxi = 0;
-    if (lane < 18) {
-      double sacc = 0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) sacc += pls[k] * wsol[k];
-      dxi = dl - sacc;
-    }
-    if (prof) t3 = clock64();
-    double lin[19];
-#pragma unroll
-    for (int k = 0; k < 19; ++k) lin[k] = L.ic.lin[k];
-    double dth[3] = {0, 0, 0};
-    bool has_nan = false;
-    double un = 0;
-#pragma unroll
-    for (int k = 0; k < 18; ++k) {
-      const double vk = readlane_f64(dxi, k);
-      has_nan = has_nan || isnan(vk);
-      un += vk * vk;
-      if (k >= 6 && k < 9)
-        dth[k - 6] = vk;
-      else
-        lin[k < 6 ? k : k + 1] += vk;  // p,v at 0..5; ba,bw,g at 10..18 (q occupies 6..9)
-    }
-    un = sqrt(un);
-    const double rn = sqrt(L.sums[27]);
-    double res_prev = L.res_prev;
-    int div = 0, conv = 0;
-    if (has_nan) {
-      div = 2, un = L.upd_norm;
-    } else if (rn > res_prev * 10) {
-      div = 1, un = L.upd_norm;
-    } else {
-      const Q4 qn = qnormalized(qmul(Q4{lin[6], lin[7], lin[8], lin[9]}, axis2quat_fast(V3{dth[0], dth[1], dth[2]})));
-      lin[6] = qn.w, lin[7] = qn.x, lin[8] = qn.y, lin[9] = qn.z;
-      if (un <= 1e-2 && !prm_fixed_iters) conv = 1;
-      res_prev = rn;
-    }
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < 19; ++k) stage[k] = lin[k];
-      stage[19] = rn, stage[20] = res_prev, stage[21] = un;
-      stage_flags[0] = div, stage_flags[1] = conv;
-    }
-  }
-  return t3;
-}
-// the constants of the next iteration from the staged linearisation state: wave 0 -> linState_, R^T; wave 1 -> phi,
-// Rinvleft(-phi)^T; wave 2 -> x_filter (-) x_lin
-__device__ __noinline__ void next_iter_consts(int wave, int lane) {
-  LdsStore& L = g_lds;
-  const double* const stage = &L.aug[0][0];
-  {
-    const Q4 q{stage[6], stage[7], stage[8], stage[9]};
-    // (static indices only: a lane-indexed register array would be spilled to scratch)
-    if (wave == 0) {
-      const M3 Rt = mtrans(qmat(q));
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 19; ++k) L.ic.lin[k] = stage[k];
-        L.ic.Rt = Rt;
-      }
-    } else if (wave == 1) {
-      V3 phi;
-      M3 Gt;
-      phi_and_Gt(q, phi, Gt);
-      if (lane == 0) L.ic.phi = phi, L.ic.Gt = Gt;
-    } else {
-      // boxMinus(filter, lin), KF:84-94
-      const Q4 qf{L.filt[6], L.filt[7], L.filt[8], L.filt[9]};
-      const V3 da = quat2axis_fast(qmul(qinverse(q), qf));
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          L.ic.d[0 + k] = L.filt[0 + k] - stage[0 + k];
-          L.ic.d[3 + k] = L.filt[3 + k] - stage[3 + k];
-          L.ic.d[9 + k] = L.filt[10 + k] - stage[10 + k];
-          L.ic.d[12 + k] = L.filt[13 + k] - stage[13 + k];
-          L.ic.d[15 + k] = L.filt[16 + k] - stage[16 + k];
-        }
-        L.ic.d[6] = da.x, L.ic.d[7] = da.y, L.ic.d[8] = da.z;
-      }
-    }
-  }
-}
-// (Scalars by value, the profile stamp returned: a reference to the kernel's parameter struct or to a local would
-// force them into scratch for the whole kernel — every later read of a parameter a scratch load.)
-__device__ __forceinline__ long long solve_and_update(double prm_r2, int prm_fixed_iters, int prm_pad, int tid, int iter, bool prof) {
-  long long t3 = 0;
-  LdsStore& L = g_lds;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (prm_pad & 0x10000) {  // counting aid (LINS_DEBUG_SKIP bit 0x10000): no solve, no update — the state stands still
-    if (tid == 0) L.iter = iter + 1;
-    __syncthreads();
-    return t3;
-  }
-  const double* const stage = &L.aug[0][0];  // 22 doubles: linState_ (19), |r|, |r| kept, |dx|
-  const int* const stage_flags = reinterpret_cast<const int*>(&L.aug[1][0]);  // diverged, converged
-  if (wave == 0) t3 = solve_wave0(prm_r2, prm_fixed_iters, lane, prof);
-  __syncthreads();  // every reader of the old linearisation state is done; the staged one is visible
-  const int div = stage_flags[0];
-  if (wave < 3 && !div) next_iter_consts(wave, lane);
-  if (tid == 0) {
-    L.res_last = stage[19], L.res_prev = stage[20], L.upd_norm = stage[21];
-    L.conv = stage_flags[1], L.div = div;
-    L.iter = iter + 1;
-  }
-  __syncthreads();
-  return t3;
-}
-
-// The Gauss-Newton row of the fallback, out of line: inlined into the search loop its rotation matrix and the 3 x 3
-// product (R(s phi), -R [p]x) cost the loop 124 spilled registers (1.7 KB of scratch per lane, round 2) for a path that
-// runs once per accepted row.  Scalars by value, the row comes back by value.
-struct IcpRow {
-  double v[7];
-};
-__device__ __noinline__ IcpRow icp_row_dev(double inv_period, double phx, double phy, double phz, float px, float py, float pz,
-                                           float intensity, float c0, float c1, float c2, float c3) {
-  IcpRow r;
-  const float c[4] = {c0, c1, c2, c3};
-  icp_row(inv_period, V3{phx, phy, phz}, px, py, pz, intensity, c, r.v, r.v[6]);
-  return r;
-}
-
-// ---------------------------------------------------------------------------
-// Serial tail of one ICP iteration (estimateTransform's loop body after the correspondences,
-// SE:1170-1195): needs >= 10 plane and >= 5 line rows, else the iteration is spent without a step
-// (SE:1175-1184); Gauss-Newton step + degeneracy projection + stop rule in icp_math.h.  A handful
-// of 6x6 factorizations per divergence: one lane, its arrays in LDS.
-// ---------------------------------------------------------------------------
-// (called by wave 0 only — the out-of-line call's register saves then cost one wave, not eight; the caller's barrier
-// publishes the new state)
-__device__ __noinline__ void icp_solve_and_update(int lane, int iter) {
-  LdsStore& L = g_lds;
-  {  // the step over the wave (icp_wave.h: a matrix column per lane, the scalar routine's bits)
-    int conv = 0;
-    if (L.m_surf >= 10 && L.m_corner >= 5) {  // (uniform)
-      static_assert(sizeof(L.partial) >= kIcpWorkspace * sizeof(double) && sizeof(L.aug) >= 48 * sizeof(double), "ICP workspace");
-      double* const ws = L.partial;  // (the wave partials and the solve's staging area are idle here)
-      double *const JTJ = &L.aug[0][0], *const JTb = JTJ + 36;
-      if (lane < 36) {
-        const int i = lane / 6, j = lane % 6;
-        JTJ[lane] = L.sums[i <= j ? tri6(i, j) : tri6(j, i)];
-      }
-      if (lane < 6) JTb[lane] = L.sums[21 + lane];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      double x[6];
-      wave_icp_gn_solve(JTJ, JTb, iter, lane, x, ws);
-      double t[3] = {L.ic.lin[0], L.ic.lin[1], L.ic.lin[2]};
-      Q4 q{L.ic.lin[6], L.ic.lin[7], L.ic.lin[8], L.ic.lin[9]};
-      conv = icp_apply(x, t, q) ? 1 : 0;
-      const V3 phi = quat2axis(q);
-      if (lane == 0) {
-        L.ic.lin[0] = t[0], L.ic.lin[1] = t[1], L.ic.lin[2] = t[2];
-        L.ic.lin[6] = q.w, L.ic.lin[7] = q.x, L.ic.lin[8] = q.y, L.ic.lin[9] = q.z;
-        L.ic.phi = phi;
-      }
-    }
-    if (lane == 0) {
-      L.conv = conv;
-      L.iter = iter + 1;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Joseph covariance update (SE:594-598) as the workgroup's epilogue, in a form that is a rank-6 update of the prior:
-// with S = {0,1,2,6,7,8}, C = P[:,S] (18 x 6), R = P[S,:], N = sigma^2 I + A P_SS, Y = N^-1 A, Z = Y N^-T (so that
-// KH = C Y E_S^T and K R K^T = sigma^2 C Z C^T),
-//   (I - KH) P (I - KH)^T + K R K^T  =  P  -  C Y R  -  C Y^T C^T  +  C (Y P_SS Y^T + sigma^2 Z) C^T
-// — the four 18 x 18 x 18 products of the textbook form collapse to 18 x 6 x 6 and 18 x 18 x 6 ones, and the two
-// 6 x 12 eliminations to ONE inverse: two waves run the 6 x 9 Gauss-Jordan of ieskf_rowsum.h side by side (left and
-// right half of the identity), no block-wide elimination with its fourteen barriers.  Rounds 1-2 ran this update as
-// a kernel of its own (ieskf_joseph_kernel, 128 threads per scan, ~20 us + a launch after every update kernel; a
-// fused version of that block-wide algorithm cost as much as it saved); this epilogue costs a few microseconds of a
-// workgroup that is about to exit.  The scratch is the grid's point storage, dead by now.  diverged: Pk_ is passed
-// through un-updated (SE:592).  Called by every thread (barriers inside).
-// ---------------------------------------------------------------------------
-template <int BLOCK>
-__device__ __noinline__ void joseph_epilogue(double r2, int diverged, double* __restrict__ out, int tid) {
-  LdsStore& L = g_lds;
-  const double* P = L.P;
-  if (diverged) {  // (block-uniform)
-    for (int k = tid; k < 324; k += BLOCK) out[k] = P[k];
-    return;
-  }
-  double* const sc = reinterpret_cast<double*>(L.pt);  // >= 66 KB, no longer read
-  double* const Ninv = sc;          // 36
-  double* const Y = sc + 36;        // 36  Y = N^-1 A
-  double* const T1 = sc + 72;       // 36  Y P_SS
-  double* const M = sc + 108;       // 36  Y P_SS Y^T + sigma^2 Z - Y^T
-  double* const D = sc + 144;       // 108 C M
-  double* const E2 = sc + 252;      // 108 C Y
-  double* const O = sc + 360;       // 324
-  static_assert(sizeof(L.pt) >= (360 + 324) * sizeof(double), "scratch of the Joseph epilogue");
-  __syncthreads();  // (every reader of the grid is done)
-  const int lane = tid & 63, wave = tid >> 6;
-  if (wave < 2) {  // N^-1, columns 3 wave .. 3 wave + 2
-    double v = 0.0;
-    if (lane < 54) {
-      const int i = lane / 9, j = lane % 9;
-      if (j < 6) {
-        v = (i == j ? r2 : 0.0);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) v += sym6(L.sums, i, k) * P[sidx(k) * 18 + sidx(j)];
-      } else {
-        v = (i == 3 * wave + (j - 6)) ? 1.0 : 0.0;
-      }
-    }
-    v = wave_gj_solve6x3(v, lane);
-    if (lane < 54 && lane % 9 >= 6) Ninv[(lane / 9) * 6 + 3 * wave + (lane % 9 - 6)] = v;
-  }
-  __syncthreads();
-  if (tid < 36) {
-    const int i = tid / 6, j = tid % 6;
-    double y = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) y += Ninv[i * 6 + k] * sym6(L.sums, k, j);
-    Y[tid] = y;
-  }
-  __syncthreads();
-  if (tid < 36) {
-    const int i = tid / 6, j = tid % 6;
-    double t = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) t += Y[i * 6 + k] * P[sidx(k) * 18 + sidx(j)];
-    T1[tid] = t;
-  }
-  __syncthreads();
-  if (tid < 36) {
-    const int i = tid / 6, j = tid % 6;
-    double m = 0, z = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) m += T1[i * 6 + k] * Y[j * 6 + k], z += Y[i * 6 + k] * Ninv[j * 6 + k];
-    M[tid] = (m + r2 * z) - Y[j * 6 + i];
-  }
-  __syncthreads();
-  if (tid < 216) {
-    const int e = tid < 108 ? tid : tid - 108, i = e / 6, b = e % 6;
-    const double* W = tid < 108 ? M : Y;
-    double acc = 0;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) acc += P[i * 18 + sidx(a)] * W[a * 6 + b];
-    (tid < 108 ? D : E2)[e] = acc;
-  }
-  __syncthreads();
-  for (int e = tid; e < 324; e += BLOCK) {
-    const int i = e / 18, j = e % 18;
-    double acc = P[e];
-#pragma unroll
-    for (int b = 0; b < 6; ++b) acc += D[i * 6 + b] * P[j * 18 + sidx(b)] - E2[i * 6 + b] * P[sidx(b) * 18 + j];
-    O[e] = acc;
-  }
-  __syncthreads();
-  for (int e = tid; e < 324; e += BLOCK) {
-    const int i = e / 18, j = e % 18;
-    out[e] = 0.5 * (O[i * 18 + j] + O[j * 18 + i]);  // enforceSymmetry (MU:39-41)
-  }
-}
+#include "ieskf_lds_tail.h"  // the serial tail of an iteration (solve, next constants, ICP step) and the Joseph epilogue
 
 // ---------------------------------------------------------------------------
 // the kernel.  PASS_ONLY: one correspondence pass at a caller-supplied linearisation
@@ -1220,56 +896,12 @@ __device__ __forceinline__ int relay_ld_acq(const int* p) {
 //                    gen would overflow)
 // All of these are device-scope atomics (the parts of a scan may sit on different XCDs); the hand-over data is complete at
 // the memory side before the flag rises, and the taker reads it with device-coherent loads.
-// (Round 5 also built the other obvious design — a FIFO of continuations pushed by the workgroup that produced them,
-// drawn in push order, persistent or not — and measured it slower: 0.602 against 0.567 ms per 1024 scans x 10
-// iterations, 1.014 against 0.988 ms under the stop rule, profiles/r05_batch_kernel_variants.md: push order is
-// shortest-part-first, which is the wrong way round for the end of the launch; the list keeps longest-expected-first.
-// And a priority FIFO on top of the list for the parts an update still runs behind its second cut — under the stop rule
-// those are the 30-iteration updates that end the launch: once its claims cost three atomics instead of a
-// compare-and-swap loop it neither gained nor lost, 0.979 against 0.981 ms: what ends the launch is the CHAIN of the
-// slowest of those updates, 22 iterations of ~25 us behind a second cut that cannot come before ~0.34 ms.  Not kept.)
+// (a FIFO of continuations and a priority FIFO for the late parts were built and measured slower / equal in round 5:
+// profiles/r05_batch_kernel_variants.md, profiles/history/kernel_notes.md #fifo)
 constexpr int kQHead = 0, kQExited = 32, kQFlags = 64;  // (ints; the counters on lines of their own)
 
-// The per-query loop state a part hands to the next: the
-// tracked candidates of the three selections as 16-bit grid positions (< 12288; -1 = none), the rings of the nearest
-// neighbour's two candidates, the certificates' bounds and the query positions they were established at: 13 words
-// (round 3 stored 18 words as 18 four-byte device-scope stores per lane, each a fabric write of its own: 264 MB written
-// per launch for 37 MB of hand-over).  In global memory: [scan][4][512 head lanes] 16-byte words, written and read as
-// dwordx4 with sc1 through a buffer descriptor — one 1 KB store per wave and word.
-struct CarryWords {
-  v4u w0, w1, w2;
-  unsigned w3;
-};
-__device__ __forceinline__ void relay_st_carry(int* scan_base /*wave-uniform*/, int head_lane, const CarryWords& c) {
-  const auto rs = __builtin_amdgcn_make_buffer_rsrc(scan_base, 0, kRelayRegionInts * 4, 0x00020000);
-  __builtin_amdgcn_raw_buffer_store_b128(c.w0, rs, (0 * kRelayLanes + head_lane) * 16, 0, 16);  // (aux 16 = sc1)
-  __builtin_amdgcn_raw_buffer_store_b128(c.w1, rs, (1 * kRelayLanes + head_lane) * 16, 0, 16);
-  __builtin_amdgcn_raw_buffer_store_b128(c.w2, rs, (2 * kRelayLanes + head_lane) * 16, 0, 16);
-  __builtin_amdgcn_raw_buffer_store_b128(v4u{c.w3, 0u, 0u, 0u}, rs, (3 * kRelayLanes + head_lane) * 16, 0, 16);
-}
-// (out of line: the packing arithmetic then cannot be scheduled into the loop the values come out of — inlined it cost the
-// batch kernel sixteen more spilled registers)
-__device__ __noinline__ void relay_out_carry(int* scan_base, int head_lane, int a1, int b1c, int ra1, int rb1, int a2, int b2c, int a3,
-                                             int b3c, int sel1, float lb1, float lb2, float lb3, float ca0, float ca1, float ca2, float cb0,
-                                             float cb1, float cb2) {
-  CarryWords c;
-  c.w0 = v4u{((unsigned)a1 & 0xFFFFu) | ((unsigned)b1c << 16), ((unsigned)a2 & 0xFFFFu) | ((unsigned)b2c << 16),
-             ((unsigned)a3 & 0xFFFFu) | ((unsigned)b3c << 16),
-             ((unsigned)sel1 & 0xFFFFu) | (((unsigned)ra1 & 0xFFu) << 16) | ((unsigned)rb1 << 24)};
-  c.w1 = v4u{__float_as_uint(lb1), __float_as_uint(lb2), __float_as_uint(lb3), __float_as_uint(ca0)};
-  c.w2 = v4u{__float_as_uint(ca1), __float_as_uint(ca2), __float_as_uint(cb0), __float_as_uint(cb1)};
-  c.w3 = __float_as_uint(cb2);
-  relay_st_carry(scan_base, head_lane, c);
-}
-__device__ __forceinline__ CarryWords relay_ld_carry(const int* scan_base /*wave-uniform*/, int head_lane) {
-  const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(scan_base), 0, kRelayRegionInts * 4, 0x00020000);
-  CarryWords c;
-  c.w0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (0 * kRelayLanes + head_lane) * 16, 0, 16);
-  c.w1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (1 * kRelayLanes + head_lane) * 16, 0, 16);
-  c.w2 = __builtin_amdgcn_raw_buffer_load_b128(rs, (2 * kRelayLanes + head_lane) * 16, 0, 16);
-  c.w3 = __builtin_amdgcn_raw_buffer_load_b32(rs, (3 * kRelayLanes + head_lane) * 16, 0, 16);
-  return c;
-}
+// (The per-query loop state of an update lives in the scan's carry records — ieskf_lds_lean.h — so a part hands over only the
+// header below; rounds 3-5 packed 13 words per lane into the same buffer at every cut: history at 51c48b0.)
 
 // One work item: the update of scan `scan` — from its start (cont = false) or from the loop state another workgroup
 // handed over (cont = true: the batch shape under the work queue) — to its end or to the next cut.  Returns true when
@@ -1314,9 +946,9 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
   // A part takes over the loop state through global memory (relay_out / the take-over below).  Same arithmetic in the same
   // order: results do not depend on the cuts, bit for bit (tests/test_gpu_parity.py
   // test_two_part_updates_return_the_whole_updates_bits).
-  constexpr bool kRelay = BLOCK == kBatchBlock && LANES == 1 && !PASS_ONLY && !ICP;
   // the register-lean form of the correspondence phase (ieskf_lds_lean.h): per-query state in the scan's carry records
   constexpr bool kLean = kLeanBuild && LANES == 1 && !PASS_ONLY && !ICP;
+  constexpr bool kRelay = kLean && BLOCK == kBatchBlock;  // (the several-part updates rest on those records)
   const ScanDesc sd = ka.descs[scan];
   const int total = sd.n_surf_q + sd.n_corner_q;
   // hybrid storage: this scan's slice of the sorted copy (same offsets as its targets in the arena:
@@ -1366,9 +998,7 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
   //           queries are spread as thin as the waves allow; the lane <-> query mapping is fixed for the whole update;
   //   rounds  query sets that do not fit one round: wave-rounds of 64 dealt to the waves round after round (nothing is
   //           carried between iterations then).
-  // (Round 4 measured a third one for the late iterations — as few wave-rounds as hold the queries, 2 + 3 instead of 5 + 3,
-  // the extra waves placed so that the two scans of a CU double different SIMDs, the change of layout through the
-  // hand-over words: +1.9 % kernel time from iteration 4 on, +9 % from iteration 1)
+  // (a third, denser layout for the late iterations: + 1.9 ... + 9 %, profiles/history/kernel_notes.md #denselate)
   struct WrLay {
     int n_wr, k;  // wave-rounds of the scan, this wave's wave-round (>= n_wr: none)
     bool kind_s;  // its kind
@@ -1436,28 +1066,7 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
   bool searched = false;  // a search iteration has run: certificates and warm candidates exist (uniform)
   constexpr int kRelayHdr = 64;  // doubles per scan: IterConst (58), res_prev, res_last, upd_norm, then 6 ints
   static_assert(sizeof(IterConst) == 58 * sizeof(double), "relay header layout");
-  // carried state <-> its 13 hand-over words (CarryWords)
-  auto carry_pack = [&]() {
-    CarryWords c;
-    c.w0 = v4u{((unsigned)a1 & 0xFFFFu) | ((unsigned)b1c << 16), ((unsigned)a2 & 0xFFFFu) | ((unsigned)b2c << 16),
-               ((unsigned)a3 & 0xFFFFu) | ((unsigned)b3c << 16),
-               ((unsigned)sel1 & 0xFFFFu) | (((unsigned)ra1 & 0xFFu) << 16) | ((unsigned)rb1 << 24)};
-    c.w1 = v4u{__float_as_uint(lb1), __float_as_uint(lb2), __float_as_uint(lb3), __float_as_uint(certA[0])};
-    c.w2 = v4u{__float_as_uint(certA[1]), __float_as_uint(certA[2]), __float_as_uint(certB[0]), __float_as_uint(certB[1])};
-    c.w3 = __float_as_uint(certB[2]);
-    return c;
-  };
-  auto carry_unpack = [&](const CarryWords& c) {
-    a1 = (int)(short)(c.w0.x & 0xFFFFu), b1c = (int)c.w0.x >> 16;  // (-1 <-> 0xFFFF: positions are < 12288)
-    a2 = (int)(short)(c.w0.y & 0xFFFFu), b2c = (int)c.w0.y >> 16;
-    a3 = (int)(short)(c.w0.z & 0xFFFFu), b3c = (int)c.w0.z >> 16;
-    sel1 = (int)(short)(c.w0.w & 0xFFFFu), ra1 = (int)(signed char)((c.w0.w >> 16) & 0xFFu), rb1 = (int)c.w0.w >> 24;
-    lb1 = __uint_as_float(c.w1.x), lb2 = __uint_as_float(c.w1.y), lb3 = __uint_as_float(c.w1.z);
-    certA[0] = __uint_as_float(c.w1.w), certA[1] = __uint_as_float(c.w2.x), certA[2] = __uint_as_float(c.w2.y);
-    certB[0] = __uint_as_float(c.w2.z), certB[1] = __uint_as_float(c.w2.w), certB[2] = __uint_as_float(c.w3);
-  };
   static_assert(kGridNpMax < 32768, "grid positions travel as signed 16-bit words");
-  (void)carry_pack, (void)carry_unpack;
   if (kRelay && cont) {  // take-over: the loop state the part before left (the barrier of the grid load has passed)
     const double* h = ka.relay_hdr + (size_t)scan * kRelayHdr;
     if (tid < 58) reinterpret_cast<double*>(&L.ic)[tid] = relay_ld(h + tid);
@@ -1466,16 +1075,9 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
       const int* hi = reinterpret_cast<const int*>(h + 61);
       L.iter = relay_ld(hi), L.dbg[0] = relay_ld(hi + 1), L.dbg[1] = relay_ld(hi + 2), L.dbg[2] = relay_ld(hi + 3), L.dbg[3] = relay_ld(hi + 4);
     }
-    if constexpr (!kLean) {  // (lean: the carry records lie where the part before left them)
-      const int* ln = ka.relay_lane + (size_t)scan * kRelayLaneInts;
-      const WrLay y = wr_layout(0);
-      if (y.active) carry_unpack(relay_ld_carry(ln, y.slot));
-    }
-    searched = true;
+    searched = true;  // (the carry records lie where the part before left them)
     __syncthreads();
   }
-  // (Round 5 measured the lane's raw query point loaded once per item instead of once per iteration — it never changes:
-  // four more live registers, 5 -> 9 spilled, 0.579 against 0.562 ms.  Not kept.)
   bool relay_out = false;
   // (ticketed launch) this item ends at the scan's next cut
   const int cut_at = (kRelay && relay_n > 0) ? relay_next_cut(L.iter, relay_at, ka.relay_cuts) : 0x7FFFFFFF;
@@ -1492,10 +1094,6 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
     }
     __syncthreads();  // everyone has read the loop state before it is rewritten
     if (tid == 0) L.m_surf = 0, L.m_corner = 0;
-    // (Round 5 built the iteration with three block-wide barriers instead of five — the row counters as two slots taken in
-    // turn, the fold of the wave partials ordered before the solve inside wave 0 — bit-identical, 144 GPU tests green, and
-    // no faster: 0.5761 against 0.5735 ms, two more spilled registers; the waves that would skip a barrier are waiting for
-    // wave 0 anyway.  Not kept.)
 
     const bool do_search = PASS_ONLY || (iter % prm.icp_freq) == 0;
     double acc = 0;
@@ -1581,10 +1179,6 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
 #endif
           PROF2_ADD(0, s1 - s0);
         }
-        // (VERDICT r04 item 4 asked for the records of the up to six tracked candidates read TOGETHER at the top of the
-        // iteration and all three certificates decided from registers.  Built in round 5, bit-identical, and slower: 38
-        // spilled registers, 0.6122 against 0.5622 ms — the 24 registers of the records meet the search code's peak.  The
-        // reads stay where their values are used.)
         auto dist_to = [&](int pos) { return pt_sqdist(L, c, pos, o.sel[0], o.sel[1], o.sel[2]); };
         auto drift_from = [&](const float* cp) {
           float ex = o.sel[0] - cp[0], ey = o.sel[1] - cp[1], ez = o.sel[2] - cp[2];
@@ -2101,12 +1695,6 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
       int* hi = reinterpret_cast<int*>(h + 61);
       relay_st(hi, L.iter), relay_st(hi + 1, L.dbg[0]), relay_st(hi + 2, L.dbg[1]), relay_st(hi + 3, L.dbg[2]), relay_st(hi + 4, L.dbg[3]);
     }
-    if constexpr (!kLean) {
-      const WrLay y = wr_layout(0);
-      if (y.active)
-        relay_out_carry(KP(relay_lane) + (size_t)scan * kRelayLaneInts, y.slot, a1, b1c, ra1, rb1, a2, b2c, a3, b3c, sel1, lb1, lb2, lb3,
-                        certA[0], certA[1], certA[2], certB[0], certB[1], certB[2]);
-    }
     // every store of this wave has completed — write-through stores: at the memory side — before the barrier, the queue
     // slot after it: whoever pops the continuation sees the hand-over
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2167,7 +1755,7 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
     lins_corr* __restrict__ dump) {
   // (the four pointers the loop reads and writes through stay parameters of their own: only a parameter carries
   // `noalias`, and without it the register allocation of every instantiation got worse)
-  constexpr bool kQueue = BLOCK == kBatchBlock && LANES == 1 && !PASS_ONLY && !ICP;  // (the shape that has the relay)
+  constexpr bool kQueue = kLeanBuild && BLOCK == kBatchBlock && LANES == 1 && !PASS_ONLY && !ICP;  // (the shape that has the relay)
   const bool queued = kQueue && ka.relay_n > 0;  // (uniform) a workgroup of a ticketed batch launch, see "work items" above
   int item;  // scan | part << 27; -1: nothing to do
 #ifdef LINS_QUEUE_TRACE  // (debug builds, tools/queue_trace.py: per workgroup start / item in hand / end on the 100 MHz clock)

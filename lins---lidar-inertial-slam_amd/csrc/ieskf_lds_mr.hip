@@ -59,6 +59,7 @@ static void launch_args(K kernel, int grid, int block, hipStream_t stream, const
 }
 
 int lds_mr_np_cap() { return lds_mr::kNpMax; }
+bool lds_mr_has_parts() { return lds_mr::kLeanBuild; }  // (the several-part updates rest on the carry records of the lean form)
 int lds_mr_queue_flags_offset() { return lds_mr::kQFlags; }
 
 // workgroups of the production batch kernel that are resident at once on the current device (larger batches are cut into parts)

@@ -53,6 +53,7 @@ int lds_np_cap();
 void launch_lds_mr(hipStream_t, int, const DevParams&, const ScanDesc*, const int*, const float4*, const float4*, const GridTables*, const double*,
                    const double*, double*, double*, double*, void*, int4*, lins_pose_record*, int, long long*, const RelayArgs*, unsigned*, int, int*);
 int lds_mr_resident_workgroups(int n_cu);
+bool lds_mr_has_parts();
 int lds_mr_queue_flags_offset();
 void launch_lds_mr_pass(hipStream_t, int, const DevParams&, const ScanDesc*, const float4*, const float4*, const GridTables*, const double*,
                         const double*, int, int4*, lins_corr*, double*, int*);
@@ -800,7 +801,7 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   // the carry records of the batch kernel's queries (ieskf_lds_lean.h: tracked candidates and certificates between the
   // iterations of an update; 32 KB per scan): every launch of that kernel uses them, cut into parts or not
   CREATE_TRY(hipMalloc((void**)&ctx->d_relay_lane, (size_t)ctx->max_batch * kLaneIntsPerScan * sizeof(int)));
-  if (ctx->max_batch > ctx->queue_grid) {  // (only batches beyond the device's workgroup slots are cut into parts)
+  if (ctx->max_batch > ctx->queue_grid && lds_mr_has_parts()) {  // (only batches beyond the device's workgroup slots are cut into parts)
     CREATE_TRY(hipMalloc((void**)&ctx->d_relay_hdr, (size_t)ctx->max_batch * 64 * sizeof(double)));
     CREATE_TRY(hipHostMalloc((void**)&ctx->h_relay_err, sizeof(int)));
     *ctx->h_relay_err = 0;

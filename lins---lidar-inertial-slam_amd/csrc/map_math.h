@@ -106,6 +106,17 @@ LINS_HD void map_qr_5x3(float (&a)[15], float (&b)[5], float (&x)[3]) {
 #pragma unroll
     for (int i = 0; i < M; ++i) v[i] = i >= k ? a[i * N + k] : 0.f;
     v[k] -= alpha;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LINS_MAP_QR_NO_GUARD)
+    // Guard against an SLP-vectoriser miscompile of ROCm 7.2's clang (root-caused in round 6, tools/repro/README.md,
+    // tools/repro/slp_surf_fit_gather.hip): below the pivot v[i] IS a[i * N + k], so the products of the loop over j start with
+    // the pair { a_ik * a_ik, a_ik * a_i,k+1 }, whose first member is also a term of nrm2 above and already sits in another
+    // vectorised tree; for the last row the pass then emits  fmul <2 x float> %row, %row  — (a_ik^2, a_i,k+1^2) — where
+    // (a_ik * a_ik, a_ik * a_i,k+1) was asked for: the column right of the pivot is updated with the wrong reflection (plane
+    // normals of y-walls came out tilted: 8 scan-to-map tests).  An opaque copy of the vector breaks the identity of the
+    // two values, not the arithmetic; it replaces the file-wide -fno-slp-vectorize of rounds 3-5.
+#pragma unroll
+    for (int i = 0; i < M; ++i) asm volatile("" : "+v"(v[i]));
+#endif
     float vv = 0.f;
 #pragma unroll
     for (int i = k; i < M; ++i) vv += v[i] * v[i];

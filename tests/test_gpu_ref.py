@@ -63,7 +63,9 @@ def test_update_matches_the_references_perform_ieskf(pkg, ieskf, host, ref, sear
     want = ref.perform_ieskf_batch(prm, pairs, threads=cores())
     with ieskf.IeskfContext(prm, max_batch=len(pairs), max_targets=16384, search=search) as ctx:
         got = ctx.update_batch(pairs)
-    budget = [len(pairs) // 4]  # (updates that run to NUM_ITER un-converged: the contract's bars, see assert_result_close)
+    # (the contract's bars instead of the tight ones only for the updates the REFERENCE itself ran to NUM_ITER un-converged —
+    # counted, not guessed: see assert_result_close)
+    budget = [sum(1 for w in want if w.iters >= 30 and not w.converged and not w.diverged)]
     for g, w in zip(got, want):
         assert_result_close(g, w, budget)
 
@@ -158,7 +160,7 @@ def test_bench_batch_all_1024_scans_against_the_dense_oracle_and_the_reference(p
     want = ref.perform_ieskf_batch(stop, pairs, threads=cores())
     with ieskf.IeskfContext(stop, max_batch=n, max_targets=16384, search="auto") as ctx:
         got = ctx.update_batch(pairs)
-    budget = [n // 4]
+    budget = [sum(1 for w in want if w.iters >= 30 and not w.converged and not w.diverged)]  # (the updates the reference ran out on)
     for g, w in zip(got, want):
         assert_result_close(g, w, budget)
 

@@ -53,10 +53,12 @@ def counters(cmd, counter, tag):
     return res, p.stdout.decode()[-400:]
 
 
-def main():
-    tag = sys.argv[1]
-    bench_args = sys.argv[2:]
+def measure(tag, bench_args, with_valu=True):
+    """The record (dict) of one measurement: FETCH_SIZE / WRITE_SIZE passes over bench.py and over the calibration copy,
+    then (with_valu) one SQ pass.  bench.py calls this itself when rocprofv3 is on the box (traffic_source "live")."""
     import __graft_entry__ as g
+
+    os.environ["LINS_BENCH_NO_LIVE_PMC"] = "1"  # (the bench runs under the counters must not start counter runs of their own)
 
     bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras"] + bench_args
     copy = [sys.executable, "-c",
@@ -74,7 +76,7 @@ def main():
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         res, tail = counters(bench, counter, tag)
         if not res:
-            print("no counters from", counter, tail)
+            print("no counters from", counter, tail, file=sys.stderr)
         for name, (val, n) in res.items():
             rec["kernels"].setdefault(name, {})[counter + "_KB_per_launch"] = val / n
         cres, ctail = counters(copy, counter, tag + "cal")
@@ -96,7 +98,7 @@ def main():
                            "of HBM traffic; lo = counters as reported, hi = with the factors calibrated on a streaming copy")
     # VALU side of the same kernel (SURVEY.md section 8d asks for both fractions): SQ counters are quad-cycles summed
     # over all SIMDs; GRBM_GUI_ACTIVE is the launch in shader cycles
-    sq, tail = counters(bench, ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+    sq, tail = ({}, "") if not with_valu else counters(bench, ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
                                 "SQ_WAIT_INST_ANY", "GRBM_GUI_ACTIVE"], tag + "sq")
     if iesk and rec.get("kernel") in sq:
         c = sq[rec["kernel"]]
@@ -111,7 +113,24 @@ def main():
                        "meaning": "per launch of the dominant kernel; busy_frac = VALU-issuing quad-cycles summed over the SIMDs / (1024 SIMDs x "
                                   "launch quad-cycles); lanes_per_inst = thread-cycles / instruction-cycles of VALU work (of 64)"}
     else:
-        print("no SQ counters:", tail)
+        print("no SQ counters:", tail, file=sys.stderr)
+    # LDS side (bank-conflict cycles per active LDS cycle, next to round 5's 0.85) and the scalar instruction count
+    if with_valu and rec.get("valu") is not None:
+        lds, tail = counters(bench, ["SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_LDS", "SQ_INSTS_SALU"], tag + "lds")
+        c = lds.get(rec["kernel"]) or {}
+        if c.get("SQ_ACTIVE_INST_LDS"):
+            rec["valu"].update(lds_bank_conflict_cycles=c.get("SQ_LDS_BANK_CONFLICT"), lds_active_cycles=c.get("SQ_ACTIVE_INST_LDS"),
+                               lds_conflict_per_active=c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_ACTIVE_INST_LDS"],
+                               insts_lds_per_launch=c.get("SQ_INSTS_LDS"), insts_salu_per_launch=c.get("SQ_INSTS_SALU"))
+        else:
+            print("no LDS counters:", tail, file=sys.stderr)
+    return rec
+
+
+def main():
+    tag = sys.argv[1]
+    rec = measure(tag, sys.argv[2:])
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     path = os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_traffic.json")
     with open(path, "w") as fh:
         json.dump(rec, fh, indent=1)
