@@ -116,6 +116,7 @@ def two_batches_in_flight(pkg, ieskf, pairs, args, max_targets):
     ctxs = [ieskf.IeskfContext(prm, max_batch=len(pairs), max_targets=max(max_targets, 1024), search=args.search) for _ in range(2)]
     try:
         for c in ctxs:
+            c.set_launch_queues(1)  # (the one-launch form in both: since round 6 ONE context overlaps its queued runs by itself — the headline)
             c.upload(pairs)
             c.run()
             c.sync()
@@ -130,7 +131,7 @@ def two_batches_in_flight(pkg, ieskf, pairs, args, max_targets):
         for c in ctxs:
             c.close()
     return {"iterations_per_s": len(pairs) * args.iters / dt, "ms_per_launch": dt * 1e3,
-            "note": "two contexts, launches alternated, one wait at the end; wall clock"}
+            "note": "two contexts in the one-launch form (lins_set_launch_queues 1), launches alternated, one wait at the end; wall clock"}
 
 
 def scene_b_block(pkg, ieskf, host, args, workers):
@@ -157,13 +158,15 @@ def scene_b_block(pkg, ieskf, host, args, workers):
             c.run()
         c.sync()
         dt = (time.perf_counter() - t0) / n
-        k_ms = float(np.mean(c.kernel_ms_history(min(n, 64))))
+        k_ms = c.runs_span_ms(min(n, 64)) / min(n, 64)  # (device time per step over the timed steps: their launches overlap, see roofline.launches)
+        lm = c.launch_ms_history(min(n, 64))
         res = c.download()
         search = c.last_search()
     out = {"workload": f"{len(pairs)} scan pairs of the open scene family x {args.iters} fixed iterations",
            "mean_sizes": {"n_sharp": float(sizes[:, 0].mean()), "n_flat": float(sizes[:, 1].mean()),
                           "n_less_sharp_last": float(sizes[:, 2].mean()), "n_less_flat_last": float(sizes[:, 3].mean())},
            "iterations_per_s": len(pairs) * args.iters / dt, "ms_per_step": dt * 1e3, "kernel_ms": k_ms, "lins_last_search": search,
+           "launches_per_step": float(np.mean([1 + (b > 0) for _, b in lm])), "mean_launch_ms": float(np.mean([t for ab in lm for t in ab if t > 0])),
            "roofline": {"bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": alg},
            # per query and search iteration: selections decided between the two tracked candidates, no search / no walk
@@ -571,7 +574,12 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ctx.kernel_ms_history(min(args.steps, 64))  # HIP events on the context's stream, the timed steps
+    kernel_ms = ctx.kernel_ms_history(min(args.steps, 64))  # HIP events of the timed steps, each step's first launch start to its last launch end
+    # Runs queued back to back go out on the context's two launch queues (include/lins_ieskf.h lins_set_launch_queues): their
+    # launches OVERLAP — the slots one launch leaves idle at its end are taken by the other queue's workgroups — so what the
+    # timed steps took on the device is the span of all of them, not the sum of per-launch durations.
+    span_ms = ctx.runs_span_ms(min(args.steps, 64))
+    launches = ctx.launch_ms_history(min(args.steps, 64))
     # N > 1: what a scaling curve needs to explain itself — every rank's own kernel time and step time, and the cost of the
     # exchange step alone (the same flat all-gather, back to back with one wait, outside the timed region)
     per_rank = None
@@ -629,7 +637,7 @@ def main():
         res = ctx.download()
         n_div = sum(1 for r in res if r.diverged)
         value = iters_all * args.steps / elapsed_max
-        k_ms = float(np.mean(kernel_ms))
+        k_ms = span_ms / min(args.steps, 64)  # device time per step over the timed region (launches of successive steps overlap)
         # algorithmic bytes per launch = sum_scans B_iter(scan) * iterations(scan); with the
         # fixed-iteration mode every non-diverged scan runs args.iters iterations
         alg_bytes = bytes_iter_local / len(pairs) * iters_local
@@ -650,9 +658,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"configs[3]: batch of {args.batch} independent scan pairs per GPU, "
-                            f"{args.iters} IESKF iterations each (fixed), 2 scans resident per CU, an update = consecutive workgroups of "
-                            "one launch handing the loop state over (13 words per query, by query) every four iterations when the batch "
-                            "exceeds the 512 slots; "
+                            f"{args.iters} IESKF iterations each (fixed), 2 scans resident per CU; a step queued behind another runs as two launches of "
+                            "<= 512 scans on the context's two streams, a step issued into an idle context as one launch whose updates hand "
+                            "over between workgroups every four iterations; "
                             "inputs resident in HBM before the timed region (PCIe-inclusive rates: see e2e), the target clouds' search "
                             "index built with them (see search_index)",
                 "scans_per_gpu": len(pairs),
@@ -690,8 +698,19 @@ def main():
                 "traffic_source": traffic[1],
                 "copy_ceiling_GBs": copy_gbs,  # measured stream-copy rate (read + write) on this box
                 "frac_of_copy_ceiling": (achieved / copy_gbs) if copy_gbs else None,
-                "alg_bytes_per_launch": alg_bytes,
+                "alg_bytes_per_step": alg_bytes,
+                "alg_bytes_per_launch": alg_bytes,  # (per step; kept under the name the earlier rounds' records use: see launches for the bytes of one launch)
                 "kernel_ms": k_ms,
+                "kernel_ms_meaning": "device time of the timed steps (HIP events: first launch's start to last launch's end, both launch queues) / steps",
+                # the launches behind it: a step issued into a busy context is two launches of <= 512 scans (whole updates) on the
+                # context's two streams; their own durations (events of each queue; = what rocprofv3 --kernel-trace lists per launch)
+                # include the time a launch's workgroups wait for slots the other launch holds, so bytes / launch duration is
+                # NOT the device's rate — the span above is
+                "launches": {"per_step": float(np.mean([1 + (b > 0) for _, b in launches])),
+                             "mean_launch_ms": float(np.mean([t for ab in launches for t in ab if t > 0])),
+                             "step_bracket_ms_mean": float(np.mean(kernel_ms)),
+                             "alg_bytes_per_launch_mean": alg_bytes / float(np.mean([1 + (b > 0) for _, b in launches])),
+                             "note": "two launch queues when runs are queued (lins_set_launch_queues 2, the default): the first timed step finds the context idle and is ONE launch with several-part updates"},
                 "bytes_per_iter_mean": bytes_iter_local / len(pairs),
             },
         }

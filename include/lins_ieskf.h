@@ -227,6 +227,23 @@ int lins_kernel_ms_history(lins_ctx* ctx, int n, float* ms);
  * total_iters / kernel-time queries); each of them re-joins the streams where it must.                            */
 int lins_set_pipelined(lins_ctx* ctx, int on);
 
+/* Launch queues of lins_batch_run() for a batch beyond the device's workgroup slots (2 per CU: 512 on an MI355X).
+ *   2 (default)  a run issued while the run before it is still in flight is launched as launches of at most that many
+ *                scans — whole updates — dealt alternately to two HIP streams inside the context: the slots a launch
+ *                leaves idle while its slowest updates finish are taken by the other queue's workgroups, of this run or
+ *                of the next (successive runs are not joined; lins_sync / lins_batch_download and every other call wait
+ *                for both queues): the higher throughput for runs queued back to back.  A run issued into an idle
+ *                context is ONE launch whose updates are cut into parts that hand over inside the launch (rounds 3-5):
+ *                the shorter latency for a run that is waited for.
+ *   1            always the one-launch form.
+ * A scan's results are the same bits either way.  (LINS_E_ARG for other values.)                                   */
+int lins_set_launch_queues(lins_ctx* ctx, int queues);
+/* GPU time (ms) the last n lins_batch_run() calls took together (first launch's start to last launch's end, both queues)
+ * and the duration of each of their launches by its own queue's events (2 n values; 0 for the launch a one-launch run
+ * does not have). */
+int lins_runs_span_ms(lins_ctx* ctx, int n, float* ms);
+int lins_launch_ms_history(lins_ctx* ctx, int n, float* ms);
+
 /* --- multi-GPU: the one exchange step of the path --------------------------------------- */
 /* Scan pairs are independent, so a batch shards over GPUs with no data-path collective; the results meet in ONE
  * all-gather of the fixed-size 192-byte pose records over RCCL (xGMI).  One lins_ctx (= one GPU) per rank.

@@ -1765,7 +1765,8 @@ __global__ __launch_bounds__(BLOCK) void ieskf_lds_kernel(
   // (Rounds 5 and 6 also ran the ticket draw as a LOOP — as many persistent workgroups as the device holds, each drawing
   // tickets until the list is exhausted, no workgroup turnover between items and no static share of the items per XCD
   // (-DLINS_PERSIST=1): round 5 0.5767 against 0.5636 ms with 15 spilled registers; round 6, on the register-lean
-  // correspondence phase, 0.5754 against 0.5563 ms with 10 — the loop around the update costs more than the turnover it saves.)
+  // correspondence phase, 0.5754 against 0.5563 ms with 10 (fresh copies of the parameters inside the loop, so that nothing is
+  // hoisted out of it: 38) — the loop around the update costs more than the turnover it saves.)
 #if LINS_PERSIST
   // (round 6, with the register-lean correspondence phase: as many workgroups as the device holds, each drawing tickets
   // until the list is exhausted — no workgroup turnover between items)

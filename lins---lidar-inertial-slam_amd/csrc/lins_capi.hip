@@ -234,6 +234,18 @@ struct lins_ctx {
   static constexpr int kHist = 64;
   hipEvent_t hist0[kHist] = {}, hist1[kHist] = {};
   unsigned hist_n = 0;
+  // Two launch queues (round 6).  A batch beyond the device's workgroup slots is run as launches of at most that many
+  // scans — whole updates, every workgroup resident from its launch's start — dealt alternately to the context's stream
+  // and to `stream2`: the slots one launch leaves idle while its slowest updates finish are taken by the workgroups of the
+  // other queue's launch, of this run or of the next (runs are not joined: each queue is in order, the two own disjoint
+  // scan ranges).  Everything else the context enqueues goes to `stream` behind a join (split_join).
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_split = nullptr;
+  hipEvent_t hist0b[kHist] = {}, hist1b[kHist] = {};  // start / end of a run's launches on stream2 (null timing when it had none)
+  bool hist_split[kHist] = {};
+  bool split_pending = false;  // stream2 holds work the context's stream has not been ordered behind
+  bool split_dirty = true;     // the context's stream holds work (uploads, other calls) stream2 has not been ordered behind
+  int split_mode = 1;          // 0: one launch per run (several-part updates when the batch exceeds the slots)
   // RCCL (dlopen): one communicator per context
   struct Rccl {
     void* lib = nullptr;
@@ -297,7 +309,20 @@ void rccl_free(lins_ctx* ctx) {
 
 // Everything the side streams of the pipelined mode still have in flight is ordered before what is enqueued on the
 // main stream next (no host wait).  Called by every staged entry point that touches buffers the side streams read.
+// Order the context's stream behind whatever the second launch queue still runs, and mark that queue as behind the
+// context's stream (the next split run forks again).  Called by every entry point that enqueues on ctx->stream or reads
+// what the update kernels wrote; lins_batch_run() itself does not join (see lins_ctx::stream2).
+int split_join(lins_ctx* ctx) {
+  ctx->split_dirty = true;
+  if (ctx->split_pending) {
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_split, 0));
+    ctx->split_pending = false;
+  }
+  return LINS_OK;
+}
+
 int pipe_join(lins_ctx* ctx) {
+  if (int rc = split_join(ctx)) return rc;
   auto& q = ctx->pipe;
   for (int k = 0; k < 2; ++k) {
     if (q.comm_pending[k]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, q.ev_comm[k], 0));
@@ -667,7 +692,9 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in, bool wait = true) {
 // The kernels of scans [lo, lo + cnt) of the uploaded batch on the context's stream (no events, no state)
 // (`n_total`: the batch the range belongs to — "auto" picks the kernel family by the batch, so that a scan's bits do
 // not depend on how the batch was cut)
-int run_range(lins_ctx* ctx, int lo, int cnt, int n_total, const RangeFlags& fl, lins_pose_record* poses, int32_t scan_id_base) {
+int run_range(lins_ctx* ctx, int lo, int cnt, int n_total, const RangeFlags& fl, lins_pose_record* poses, int32_t scan_id_base,
+              hipStream_t st = nullptr) {
+  if (!st) st = ctx->stream;
   int s = ctx->dprm.search;
   if (s == SEARCH_AUTO) s = n_total > ctx->n_cu ? (int)SEARCH_MR : (int)SEARCH_LDS3;
   if (s == SEARCH_LDS3 && !fl.lds3_ok) s = SEARCH_LDS;
@@ -681,15 +708,15 @@ int run_range(lins_ctx* ctx, int lo, int cnt, int n_total, const RangeFlags& fl,
   lins_pose_record* ps = poses ? poses + lo : nullptr;
   if (use_mr || use_lds) {
     if (use_mr)
-      launch_lds_mr(ctx->stream, cnt, ctx->dprm, desc, nullptr, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out, ctx->d_idx, ps,
+      launch_lds_mr(st, cnt, ctx->dprm, desc, nullptr, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out, ctx->d_idx, ps,
                     scan_id_base + lo, nullptr, nullptr, ctx->d_walk_cache, next_run_gen(ctx), ctx->d_relay_lane + (size_t)lo * kLaneIntsPerScan);
     else
-      launch_lds(ctx->stream, cnt, ctx->dprm, s == SEARCH_LDS3 ? 3 : 1, desc, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out,
+      launch_lds(st, cnt, ctx->dprm, s == SEARCH_LDS3 ? 3 : 1, desc, ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab + lo, st_in, cov_in, st_out, a6, cov_out, out,
                  ctx->d_idx, ps, scan_id_base + lo, nullptr, ctx->d_relay_lane + (size_t)lo * kLaneIntsPerScan);  // (the Joseph update is the kernels' epilogue)
   } else {
     DevParams dp = ctx->dprm;
     dp.search = want_lds ? (int)SEARCH_BINNED : s;  // a scan does not fit LDS: global-memory grid
-    launch_persistent(ctx->stream, cnt, dp, desc, ctx->d_arena, st_in, cov_in, st_out, cov_out, a6, out, ctx->d_idx, ps,
+    launch_persistent(st, cnt, dp, desc, ctx->d_arena, st_in, cov_in, st_out, cov_out, a6, out, ctx->d_idx, ps,
                       scan_id_base + lo, ctx->d_binned, nullptr);
   }
   HIP_TRY(ctx, hipGetLastError());
@@ -745,6 +772,8 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   if (const char* g = std::getenv("LINS_ENABLE_DEBUG_KNOBS"))
     if (g[0] == '1') {
       if (const char* e = std::getenv("LINS_LAUNCH_ORDER")) ctx->use_order = e[0] != '0';
+      if (const char* e = std::getenv("LINS_SPLIT_STREAMS")) ctx->split_mode = std::atoi(e) == 0 ? 0 : (std::atoi(e) >= 2 ? 3 : 1);  // (0: one launch; 1: when runs are queued; 2: always)
+      if (std::getenv("LINS_RELAY_AT") || std::getenv("LINS_RELAY_MASK") || std::getenv("LINS_RELAY_CUTS")) ctx->split_mode = 0;  // (the one-launch form's knobs)
       if (const char* e = std::getenv("LINS_RELAY_AT")) ctx->relay_at = std::max(0, std::atoi(e));  // (0: whole updates)
       if (const char* e = std::getenv("LINS_RELAY_CUTS")) ctx->relay_cuts = std::max(1, std::min(14, std::atoi(e)));
       if (const char* e = std::getenv("LINS_RELAY_MASK")) {  // (cuts that are not evenly spaced: bit i = a part ends before iteration i)
@@ -835,6 +864,7 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
 void lins_destroy(lins_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   (void)hipHostFree(ctx->h_arena);
   (void)hipHostFree(ctx->h_desc);
@@ -871,7 +901,12 @@ void lins_destroy(lins_ctx* ctx) {
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_split) (void)hipEventDestroy(ctx->ev_split);
   for (int k = 0; k < lins_ctx::kHist; ++k) {
+    if (ctx->hist0b[k]) (void)hipEventDestroy(ctx->hist0b[k]);
+    if (ctx->hist1b[k]) (void)hipEventDestroy(ctx->hist1b[k]);
     if (ctx->hist0[k]) (void)hipEventDestroy(ctx->hist0[k]);
     if (ctx->hist1[k]) (void)hipEventDestroy(ctx->hist1[k]);
   }
@@ -995,14 +1030,66 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   // only with ICP_FREQ 1: with a larger one the iterations in between read the triplets an earlier part of the scan left in
   // idx_store — plain stores of another workgroup, possibly on another XCD.
   const bool cut_ok = use_mr && ctx->n_uploaded > ctx->queue_grid && !ctx->d_prof && ctx->prm.icp_freq == 1 && ctx->d_relay_hdr;
-  const bool relay = cut_ok && ctx->relay_at != 0 && relay_max_parts(ctx->prm.num_iter, ctx->relay_at, ctx->relay_cuts) > 1;
+  // Two launch queues (lins_ctx::stream2): launches of <= queue_grid scans, whole updates, dealt alternately to the two
+  // streams.  Not with the phase profile (one launch) or the pipelined gather mode (its events follow ONE stream);
+  // split_mode 0 (lins_set_launch_queues, LINS_SPLIT_STREAMS=0) selects the one-launch form with its several-part updates.
+  // ... and in the default mode (2) only when the caller is QUEUING runs — the run before this one is still in flight: a run
+  // issued into an idle context is one launch with several-part updates, the shorter of the two forms for a run that is
+  // waited for (room batch, 1024 scans x 10 iterations: 0.57 against 0.63 ms; queued back to back: 0.56 against 0.505 ms
+  // per run — tools/split_launch_time.py).  Mode 3 (LINS_SPLIT_STREAMS=2) always takes the two queues.
+  bool queued = ctx->split_mode >= 3;
+  if (!queued && ctx->split_mode && ctx->hist_n > 0) {
+    const int hp = (int)((ctx->hist_n - 1) % lins_ctx::kHist);
+    queued = hipEventQuery(ctx->hist1[hp]) == hipErrorNotReady || (ctx->hist_split[hp] && hipEventQuery(ctx->hist1b[hp]) == hipErrorNotReady);
+    (void)hipGetLastError();  // (hipErrorNotReady is an answer, not an error to keep)
+  }
+  const bool split = use_mr && queued && ctx->n_uploaded > ctx->queue_grid && !ctx->d_prof && !q.on;
+  const bool relay = !split && cut_ok && ctx->relay_at != 0 && relay_max_parts(ctx->prm.num_iter, ctx->relay_at, ctx->relay_cuts) > 1;
   RelayArgs ra;
   if (relay) {
     const int rcq = relay_prepare(ctx, ctx->n_uploaded, ctx->use_order, ra);
     if (rcq) return rcq;
   }
   ctx->last_parts = relay ? ra.parts : 1;
-  if (use_mr || use_lds) {
+  ctx->hist_split[h] = split;
+  if (split) {
+    if (!ctx->stream2) {
+      // A priority of its own: HIP multiplexes the streams of a process onto a handful of hardware queues (four by default) in
+      // creation order, and two streams that share one are served in order — measured: a context whose two streams collided
+      // ran its queued steps at 0.646 instead of 0.50 ms, depending on how many other contexts the process had created
+      // (gpurun r06w).  Streams of different priority never share a hardware queue.  LOW, so that the work a caller puts on
+      // streams of his own is not pushed back by it.
+      int pr_least = 0, pr_greatest = 0;
+      HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+      HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, pr_least));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_split, hipEventDisableTiming));
+      for (int k = 0; k < lins_ctx::kHist; ++k) {
+        HIP_TRY(ctx, hipEventCreate(&ctx->hist0b[k]));
+        HIP_TRY(ctx, hipEventCreate(&ctx->hist1b[k]));
+      }
+    }
+    if (ctx->split_dirty) {  // (uploads, index builds, downloads since the last fork: the second queue starts behind them)
+      HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+      HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+      ctx->split_dirty = false;
+    }
+    const int n = ctx->n_uploaded, n_launch = (n + ctx->queue_grid - 1) / ctx->queue_grid, per = (n + n_launch - 1) / n_launch;
+    RangeFlags fl;
+    fl.lds_ok = ctx->lds_ok, fl.mr_ok = ctx->mr_ok, fl.lds3_ok = ctx->lds3_ok;
+    HIP_TRY(ctx, hipEventRecord(ctx->hist0b[h], ctx->stream2));
+    for (int c = 0; c < n_launch; ++c) {
+      const int lo = c * per, cnt = std::min(per, n - lo);
+      const int rcr = run_range(ctx, lo, cnt, n, fl, (lins_pose_record*)d_poses, scan_id_base, (c & 1) ? ctx->stream2 : ctx->stream);
+      if (rcr) return rcr;
+    }
+    ctx->last_parts = 1;
+    HIP_TRY(ctx, hipEventRecord(ctx->hist1[h], ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->hist1b[h], ctx->stream2));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_split, ctx->stream2));
+    ctx->split_pending = true;
+  } else if (use_mr || use_lds) {
+    ctx->split_dirty = true;  // (a launch on the context's stream the second queue is not ordered behind)
     if (use_mr)
       launch_lds_mr(ctx->stream, ctx->n_uploaded, ctx->dprm, ctx->d_desc,
                     relay ? ctx->d_order + ctx->max_batch : (ctx->use_order ? ctx->d_order : nullptr), ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in,
@@ -1019,6 +1106,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
     // and at lowest stream priority — lets its 1024 small workgroups sit on the LDS and wave slots the NEXT run's update
     // kernel needs for its second resident workgroup: that kernel then takes 0.86 instead of 0.71 ms.)
   } else {
+    ctx->split_dirty = true;
     DevParams dp = ctx->dprm;
     dp.search = want_lds ? (int)SEARCH_BINNED : search;  // a scan does not fit LDS: global-memory grid
     launch_persistent(ctx->stream, ctx->n_uploaded, dp, ctx->d_desc, ctx->d_arena, ctx->d_state_in, ctx->d_cov_in,
@@ -1056,6 +1144,53 @@ int lins_set_pipelined(lins_ctx* ctx, int on) {
   return LINS_OK;
 }
 
+int lins_set_launch_queues(lins_ctx* ctx, int queues) {
+  if (!ctx || (queues != 1 && queues != 2)) return LINS_E_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (int rc = pipe_join(ctx)) return rc;
+  ctx->split_mode = queues == 2 ? 1 : 0;
+  return LINS_OK;
+}
+
+/* GPU time (ms) from the start of the first to the end of the last of the last n lins_batch_run() calls (both launch
+ * queues): what n queued runs took on the device, launches overlapping or not.  Waits for the newest of them.        */
+int lins_runs_span_ms(lins_ctx* ctx, int n, float* ms) {
+  if (!ctx || !ms || n < 1 || n > lins_ctx::kHist || (unsigned)n > ctx->hist_n) return LINS_E_ARG;
+  const int h0 = (int)((ctx->hist_n - n) % lins_ctx::kHist);
+  float best = 0.f;
+  for (int k = 0; k < n; ++k) {  // (ends are not ordered across the two queues: the latest of all)
+    const int h = (int)((ctx->hist_n - n + k) % lins_ctx::kHist);
+    float t = 0.f;
+    HIP_TRY(ctx, hipEventSynchronize(ctx->hist1[h]));
+    HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->hist0[h0], ctx->hist1[h]));
+    best = std::max(best, t);
+    if (ctx->hist_split[h]) {
+      HIP_TRY(ctx, hipEventSynchronize(ctx->hist1b[h]));
+      HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->hist0[h0], ctx->hist1b[h]));
+      best = std::max(best, t);
+    }
+  }
+  *ms = best;
+  return LINS_OK;
+}
+
+/* per launch of the last n runs: its duration by the events of its own queue (ms; 2 per run with two queues, the second
+ * 0 for a one-launch run): out[2 k], out[2 k + 1] */
+int lins_launch_ms_history(lins_ctx* ctx, int n, float* ms) {
+  if (!ctx || !ms || n < 1 || n > lins_ctx::kHist || (unsigned)n > ctx->hist_n) return LINS_E_ARG;
+  for (int k = 0; k < n; ++k) {
+    const int h = (int)((ctx->hist_n - n + k) % lins_ctx::kHist);
+    HIP_TRY(ctx, hipEventSynchronize(ctx->hist1[h]));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms[2 * k], ctx->hist0[h], ctx->hist1[h]));
+    ms[2 * k + 1] = 0.f;
+    if (ctx->hist_split[h]) {
+      HIP_TRY(ctx, hipEventSynchronize(ctx->hist1b[h]));
+      HIP_TRY(ctx, hipEventElapsedTime(&ms[2 * k + 1], ctx->hist0b[h], ctx->hist1b[h]));
+    }
+  }
+  return LINS_OK;
+}
+
 /* HIP-event times (ms) of the update kernels of the last n lins_batch_run() calls, oldest first (n <= 64 and <= the
  * runs so far); waits for the newest of them.                                                                       */
 int lins_kernel_ms_history(lins_ctx* ctx, int n, float* ms) {
@@ -1064,6 +1199,12 @@ int lins_kernel_ms_history(lins_ctx* ctx, int n, float* ms) {
     const int h = (int)((ctx->hist_n - n + k) % lins_ctx::kHist);
     HIP_TRY(ctx, hipEventSynchronize(ctx->hist1[h]));
     HIP_TRY(ctx, hipEventElapsedTime(&ms[k], ctx->hist0[h], ctx->hist1[h]));
+    if (ctx->hist_split[h]) {  // (two launch queues: the run = from its first launch's start to its last launch's end)
+      float b = 0.f;
+      HIP_TRY(ctx, hipEventSynchronize(ctx->hist1b[h]));
+      HIP_TRY(ctx, hipEventElapsedTime(&b, ctx->hist0[h], ctx->hist1b[h]));
+      ms[k] = std::max(ms[k], b);
+    }
   }
   return LINS_OK;
 }
@@ -1143,6 +1284,7 @@ int lins_pose_allgather(lins_ctx* ctx, const void* d_local, int n_records, void*
   if (!ctx || !d_local || !d_all || n_records < 0) return LINS_E_ARG;
   if (!ctx->rccl.comm) return LINS_E_STATE;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (int rcs = split_join(ctx)) return rcs;  // (results of the second launch queue: ordered before what follows)
   auto& q = ctx->pipe;
   hipStream_t st = ctx->stream;
   int set = 0;
@@ -1224,6 +1366,7 @@ int lins_debug_math(lins_ctx* ctx, int op, int n, const double* in, int n_in, do
 int lins_debug_phase_profile(lins_ctx* ctx, int enable, long long* out, int n_scans) {
   if (!ctx) return LINS_E_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (int rcs = split_join(ctx)) return rcs;
   if (enable && !ctx->d_prof) {
     // (16 words per scan, then — behind the records of the launch — 32 words per scan of per-wave phase ticks, written by
     // libraries built with -DLINS_PROF2=k: lins_debug_wave_phases)
@@ -1510,6 +1653,7 @@ int lins_segment_batch(lins_ctx* ctx, int n, const lins_point* const* raw, const
   if (!ctx || n < 0 || (n && (!raw || !n_raw || !out))) return LINS_E_ARG;
   if (n == 0) return LINS_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (int rcs = split_join(ctx)) return rcs;
   for (int k = 0; k < n; ++k)
     if (!out[k].cloud || !out[k].range || !out[k].col || !out[k].ground) return LINS_E_ARG;
   std::vector<long long> offs((size_t)n * 4, 0);
@@ -1550,6 +1694,7 @@ int lins_extract_features_batch(lins_ctx* ctx, int n, const lins_segmented_scan*
   if (!ctx || n < 0 || (n && (!in || !out))) return LINS_E_ARG;
   if (n == 0) return LINS_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (int rcs = split_join(ctx)) return rcs;
   for (int k = 0; k < n; ++k)
     if (!out[k].corner_sharp || !out[k].corner_less_sharp || !out[k].surf_flat || !out[k].surf_less_flat)
       return LINS_E_ARG;
@@ -1593,6 +1738,7 @@ int lins_streams_init(lins_ctx* ctx, int n_streams) {
   if (!ctx || n_streams < 1) return LINS_E_ARG;
   if (n_streams > ctx->max_batch) return LINS_E_CAPACITY;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (int rcs = split_join(ctx)) return rcs;
   streams_free(ctx);
   auto& t = ctx->st;
   const size_t pts = (size_t)n_streams * 2 * kSlotSize;
@@ -1644,6 +1790,7 @@ static int streams_step_impl(lins_ctx* ctx, const lins_segmented_scan* scans, co
   } guard{t.failed};
   const CallTrace trace;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (int rcs = split_join(ctx)) return rcs;
   const int n = t.n, cur = t.cur, last = cur ^ 1;
   ctx->n_uploaded = 0, ctx->ran = false;  // the batch buffers are reused below
   // 1. feature front-end, straight into this scan's slots
@@ -1865,6 +2012,7 @@ int lins_transform_to_end_batch(lins_ctx* ctx, int n_jobs, const lins_reproject_
   static_assert(sizeof(ReprojectJobHost) == 80, "ReprojectJob layout");
   if (reproject_job_size() != sizeof(ReprojectJobHost)) return LINS_E_STATE;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (int rcs = split_join(ctx)) return rcs;
   std::vector<ReprojectJobHost> hj(n_jobs);
   size_t off = 0;
   int max_n = 0;
@@ -1976,6 +2124,7 @@ int lins_batch_total_iters(lins_ctx* ctx, uint64_t* iters) {
   if (!ctx || !iters) return LINS_E_ARG;
   if (!ctx->ran) return LINS_E_STATE;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (int rcs = split_join(ctx)) return rcs;  // (results of the second launch queue: ordered before what follows)
   int n = ctx->n_uploaded;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)n * sizeof(OutRecHost), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

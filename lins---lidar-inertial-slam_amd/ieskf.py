@@ -23,7 +23,7 @@ EXPORTS = [
     "lins_last_reproject_stats", "lins_icp_update_batch", "lins_extract_features_batch", "lins_last_frontend_stats",
     "lins_streams_init", "lins_streams_step", "lins_streams_stats", "lins_streams_peek", "lins_segment_batch",
     "lins_last_segment_ms", "lins_streams_step_raw", "lins_map_correspondences", "lins_scan2map_batch",
-    "lins_last_map_stats", "lins_last_search", "lins_kernel_ms_history", "lins_set_pipelined",
+    "lins_last_map_stats", "lins_last_search", "lins_kernel_ms_history", "lins_set_pipelined", "lins_set_launch_queues", "lins_runs_span_ms", "lins_launch_ms_history",
     "lins_rccl_unique_id", "lins_rccl_init", "lins_pose_allgather", "lins_rccl_destroy", "lins_last_index_ms", "lins_last_cut",
     "lins_batch_map",
 ]
@@ -70,6 +70,9 @@ def lib():
         L.lins_kernel_ms_history.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
         L.lins_last_index_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.lins_set_pipelined.argtypes = [vp, C.c_int]
+        L.lins_set_launch_queues.argtypes = [vp, C.c_int]
+        L.lins_runs_span_ms.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
+        L.lins_launch_ms_history.argtypes = [vp, C.c_int, C.POINTER(C.c_float)]
         L.lins_rccl_unique_id.argtypes = [vp, C.c_void_p]
         L.lins_rccl_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
         L.lins_pose_allgather.argtypes = [vp, vp, C.c_int, vp]
@@ -391,6 +394,22 @@ class IeskfContext:
     def set_pipelined(self, on=True):
         """Pipelined staged mode: Joseph kernel / pose gather of run k beside the update kernel of run k + 1."""
         self._check(lib().lins_set_pipelined(self._h, 1 if on else 0))
+
+    def runs_span_ms(self, n):
+        """GPU time the last n runs took together (first launch's start to last launch's end, both launch queues)."""
+        v = C.c_float(0)
+        self._check(lib().lins_runs_span_ms(self._h, int(n), C.byref(v)))
+        return float(v.value)
+
+    def launch_ms_history(self, n):
+        """durations of the launches of the last n runs, each by its own queue's events: [(first, second or 0.0), ...]"""
+        a = (C.c_float * (2 * n))()
+        self._check(lib().lins_launch_ms_history(self._h, int(n), a))
+        return [(float(a[2 * k]), float(a[2 * k + 1])) for k in range(n)]
+
+    def set_launch_queues(self, queues):
+        """2 (default): a batch beyond the device's slots runs as whole-update launches on two streams; 1: one launch, several-part updates."""
+        self._check(lib().lins_set_launch_queues(self._h, int(queues)))
 
     # -- multi-GPU: RCCL all-gather of the pose records through the C ABI (include/lins_ieskf.h) ------
     def rccl_unique_id(self):

@@ -312,6 +312,44 @@ def test_default_cut_of_a_large_batch(pkg, ieskf, host):
     assert all(x.iters == 10 for x in r)
 
 
+def _bits(res):
+    return np.concatenate([np.concatenate([np.asarray(r.state), np.asarray(r.cov).ravel(),
+                                           [r.iters, r.converged, r.diverged, r.m_surf, r.m_corner]]) for r in res])
+
+
+def test_two_launch_queues_return_the_one_launch_bits(pkg, ieskf, host):
+    """Runs queued back to back on a batch beyond the device's slots go out as whole-update launches on the context's two
+    launch queues (lins_set_launch_queues 2, the default; lins_ctx::stream2): the same bits as the one-launch form with its
+    several-part updates, for a batch that does not divide evenly (three launches), under fixed iterations and the stop rule;
+    an upload issued right behind queued runs is ordered behind BOTH queues (its results are its own), and so is the download."""
+    for prm in (pkg.default_params(num_iter=10, fixed_iters=1), pkg.default_params(num_iter=30)):
+        batch = host.synth_batch(1300, start=21000)
+        other = host.synth_batch(700, start=23000)
+        with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384, search="mr") as c:
+            c.set_launch_queues(1)
+            c.upload(batch); c.run(); c.sync()
+            want = _bits(c.download())
+            assert c.launch_ms_history(1)[0][1] == 0.0  # (one launch)
+            c.upload(other); c.run(); c.sync()
+            want_other = _bits(c.download())
+        with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384, search="mr") as c:
+            c.upload(batch)
+            for _ in range(4):
+                c.run()  # (no wait in between: the runs behind the first find the context busy)
+            got = _bits(c.download())  # (waits for both queues)
+            second = [b for _, b in c.launch_ms_history(4)]
+            assert second[0] == 0.0 and all(b > 0.0 for b in second[1:]), second  # the first run: one launch; the queued ones: two queues
+            assert c.runs_span_ms(4) > 0.0
+            assert np.array_equal(got, want, equal_nan=True)
+            for _ in range(3):
+                c.run()
+            c.upload(other)  # (behind runs still in flight on both queues)
+            c.run(); c.run()
+            c.sync()
+            assert np.array_equal(_bits(c.download()), want_other, equal_nan=True)
+            assert c.total_iters() > 0
+
+
 def test_a_competing_context_saturating_the_device_changes_no_bit(pkg, ieskf, host, monkeypatch):
     """HIP promises nothing about the order workgroups are handed out in, and a production process shares the device.
     While a second context on its own stream keeps every CU busy with several-part launches of its own, this context's

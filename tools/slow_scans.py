@@ -12,7 +12,7 @@ pkg = importlib.import_module(PKG); host = importlib.import_module(PKG + ".host"
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 search = sys.argv[2] if len(sys.argv) > 2 else "mr"
 with ThreadPoolExecutor(16) as ex:
-    pairs = list(ex.map(host.synth_pair, range(batch)))
+    pairs = list(ex.map((lambda i: host.synth_pair(i, scene=1)) if os.environ.get("SLOW_SCENE_B") else host.synth_pair, range(50000, 50000 + batch) if os.environ.get("SLOW_SCENE_B") else range(batch)))
 ctx = ieskf.IeskfContext(pkg.default_params(num_iter=10, fixed_iters=1), max_batch=batch, max_targets=16384, search=search)
 L = ieskf.lib()
 L.lins_debug_phase_profile.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
