@@ -688,7 +688,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic[0]["bytes_hi"] if traffic[0] else None,  # fabric-side upper bound, see traffic_detail
+                "traffic": traffic[0]["bytes_hi"] if traffic[0] else None,  # per step (the counter runs take a step as ONE launch); fabric-side upper bound, see traffic_detail
                 "traffic_detail": {k: v for k, v in traffic[0].items() if k != "valu"} if traffic[0] else None,
                 # VALU side ("report both the HBM fraction and the VALU fraction"): SQ counters of the
                 # same PMC record — busy_frac of the 1024 SIMDs' issue cycles, active lanes per VALU instruction (of 64)

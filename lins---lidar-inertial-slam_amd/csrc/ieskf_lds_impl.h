@@ -155,7 +155,7 @@ struct LdsStore {
   IterConst ic;
   double filt[19];
   double sums[28];
-  double partial[kMaxLWaves * 28];  // one partial 28-vector per wave
+  double partial[kMaxLWaves * 28 > kIcpWorkspace ? kMaxLWaves * 28 : kIcpWorkspace];  // one partial 28-vector per wave (and the ICP step's workspace)
   double aug[3][42];  // one staging copy of [N | z] per solving wave
   double res_prev, res_last, upd_norm;
   int scan_tmp[kMaxLWaves + 4];

@@ -32,7 +32,9 @@ def counters(cmd, counter, tag):
     names = [counter] if isinstance(counter, str) else list(counter)
     d = os.path.join(OUT, f"_pmc_{tag}_{names[0]}")
     subprocess.run(["rm", "-rf", d])
-    env = dict(os.environ, TMPDIR="/tmp")
+    # (counters are summed per LAUNCH: the runs under the counters pin the one-launch form of a step — lins_set_launch_queues 1 —
+    # so that "per launch" is "per step of the whole batch", as in every earlier round's record)
+    env = dict(os.environ, TMPDIR="/tmp", LINS_ENABLE_DEBUG_KNOBS="1", LINS_SPLIT_STREAMS="0")
     p = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + names + ["-d", d, "--"] + cmd, cwd="/tmp", env=env,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)

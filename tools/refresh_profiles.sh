@@ -2,7 +2,7 @@
 # Regenerates the line-of-record artifacts for round $1 (default r05) on the GPU box into gpurun_out/; copy what is
 # to be judged into profiles/ afterwards (tools/README.md).  PMC passes are separate rocprofv3 runs with
 # --kernel-trace only (never combined with other trace domains).
-tag=${1:-r05}
+tag=${1:-r06}
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out
 mkdir -p $out
@@ -51,6 +51,10 @@ cat $out/${tag}_aux_rates.txt
     LINS_IESKF_LIB=$PWD/ab/qtrace.so python tools/queue_trace.py 1024 10 1 2>&1 | tail -9
     LINS_IESKF_LIB=$PWD/ab/qtrace.so python tools/queue_trace.py 1024 30 0 2>&1 | tail -9
   fi
+  echo "== tools/split_launch_time.py  (one launch per run against two launch queues; queued runs and one run + wait)"
+  python tools/split_launch_time.py 2>&1 | tail -4
+  echo "== tools/slow_scans.py 1024 mr  (the slowest updates of the batch, PROF variant, whole updates)"
+  python tools/slow_scans.py 1024 mr 2>&1 | tail -13
   echo "== tools/index_time.py 1024  (grid_index_kernel at lins_batch_upload)"
   python tools/index_time.py 1024 2>&1 | tail -1
   if [ -f ab/prof2.so ]; then
