@@ -449,17 +449,14 @@ __device__ __forceinline__ ColWin reach_cols(const LCloud& c, float rho, float s
 template <int LANES>
 __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float sx, float sy, float sz,
                                        const QueryPolar& qp, float thr, float margin, int rq, int ln, int role,
-                                       int lane_base, int warm_pos, int warm_ring, bool valid = true) {
-  // `valid` (the three-lane shape): the function is entered by EVERY lane of the wave whenever one of its queries searches, so
-  // that the lane merges below run under wave-uniform control flow; a lane whose query does not search (valid = false: all
-  // three lanes of that query) scans nothing and carries neutral values through the merges.
+                                       int lane_base, int warm_pos, int warm_ring) {
   const int LN = LANES ? LANES : ln;  // lanes of this query (LANES = 0: a run-time power of two, wave-uniform)
   Best b = best_init(thr);
   // Warm start (iterations >= 1): last iteration's nearest neighbour is still a candidate, and its
   // distance to the re-de-skewed query bounds the search from the start — the seed scan is skipped
   // and the windows are minimal.  It only tightens bounds; the exact arg-min is still taken over
   // every cell that could beat it, so the result is the same as a cold search.
-  const bool warm = valid && warm_pos >= 0;
+  const bool warm = warm_pos >= 0;
   if (warm)
     consider(b, pt_sqdist(L, c, warm_pos, sx, sy, sz), pt_idx(L, c, warm_pos), warm_pos, warm_ring);
   const float rho = qp.rho, qn3 = qp.qn3, el_q = qp.el;
@@ -469,26 +466,23 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
   auto f = [&](float x, float y, float z, int j, int p, bool ok) {
     consider_scan(b, ok, sqdist3(x, y, z, sx, sy, sz), j, p, rcur);
   };
-  const bool own = valid && ring_nonempty(c, rq);
+  const bool own = ring_nonempty(c, rq);
   // cold seed: columns a0-1..a0+1 of the query's own ring and of its two neighbours, one ring per
   // lane, merged before the bound is fixed — a query that sits between rings (or whose own ring is
   // empty there) still starts from a real neighbour instead of sweeping the whole search radius
   {
     const int rs = LN == 1 ? rq : rq + (role == 0 ? 0 : (role == 1 ? 1 : -1));
-    const bool seed = valid && !warm && role < 3 && ring_nonempty(c, rs);
+    const bool seed = !warm && role < 3 && ring_nonempty(c, rs);
     rcur = rs;
     scan_cols(L, c, rs, seed ? a0 - 1 : 1, seed ? a0 + 1 : 0, f);
     if (LN == 1) {
 #pragma unroll 1
       for (int dr = -1; dr <= 1; dr += 2) {
-        const bool sd2 = valid && !warm && ring_nonempty(c, rq + dr);
+        const bool sd2 = !warm && ring_nonempty(c, rq + dr);
         rcur = rq + dr;
         scan_cols(L, c, rq + dr, sd2 ? a0 - 1 : 1, sd2 ? a0 + 1 : 0, f);
       }
-    } else if (LANES == 3 ? __ballot(valid && !warm) != 0ull : !warm) {
-      // (LANES == 0: the lanes of a query agree on `warm`.  LANES == 3: the whole wave merges as soon as ONE of its queries
-      // seeded — a wave-uniform decision; a warm query's three lanes hold the same single candidate, merging them changes
-      // nothing — so that the shuffles are not inside a branch the queries of a wave take differently)
+    } else if (!warm) {  // (the lanes of a query agree on `warm`)
       merge_query_lanes<LANES>(b, lane_base, role, ln);
     }
     rcur = rq;
@@ -527,7 +521,6 @@ __device__ __forceinline__ Best nn_lds(const LdsStore& L, const LCloud& c, float
       todo |= go ? (1u << i) : 0u;
     }
   }
-  if (!valid) todo = 0;
 #pragma unroll 1
   while (todo) {
     const int i = __ffs(todo) - 1;
@@ -613,8 +606,8 @@ __device__ __forceinline__ WalkCtx make_walk_ctx(const LCloud& c, int nq, int j1
 // were already scanned (by the all-lane class-2 seed) — otherwise the extensions include them.
 __device__ __forceinline__ void walk_task(const LdsStore& L, const LCloud& c, const WalkCtx& w, int r, bool seed_first,
                                           bool centre_done, int a0, float sx, float sy, float sz, float rho_q,
-                                          float qn3, float el_q, float margin, Best& cur, bool valid = true) {
-  bool go = valid && walk_ring_has_candidates(c, w, r);
+                                          float qn3, float el_q, float margin, Best& cur) {
+  bool go = walk_ring_has_candidates(c, w, r);
   if (go) go = ring_in_reach(c, r, el_q, reach_elev(qn3, bound_sqrtf(cur.d()) + margin));
   auto f = [&](float x, float y, float z, int j, int p, bool ok) {
     int rank;
@@ -649,7 +642,7 @@ template <int LANES>
 __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, bool is_surf, int nq, float thr, int j1,
                                          int rho, float sx, float sy, float sz, const QueryPolar& qp, float margin,
                                          int ln, int role, int lane_base, int warm2, int warm3, bool check_class,
-                                         Best& c2, Best& c3, bool valid = true) {  // (valid: see nn_lds)
+                                         Best& c2, Best& c3) {
   const int LN = LANES ? LANES : ln;
   const WalkCtx w = make_walk_ctx(c, nq, j1, rho);
   c2 = best_init(thr);
@@ -661,7 +654,7 @@ __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, boo
   // (check_class) they still qualify when they lie in the new intervals and on a ring of the right class.
   auto warm_cand = [&](Best& b, int pos, bool on_ring_rho) {
     int rank;
-    if (!valid || pos < 0) return;
+    if (pos < 0) return;
     const int j = pt_idx(L, c, pos);
     if (!walk_rank(w, j, rank)) return;
     if (check_class) {
@@ -677,7 +670,7 @@ __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, boo
   warm_cand(c3, warm3, false);    // third point (planes only): another ring
   const bool w2 = c2.pos >= 0, w3 = c3.pos >= 0;
   if (is_surf && !w2) {  // class-2 seed on ring rho: all lanes of the query
-    bool go = valid && walk_ring_has_candidates(c, w, rho);
+    bool go = walk_ring_has_candidates(c, w, rho);
     auto f = [&](float x, float y, float z, int j, int p, bool ok) {
       int rank;
       const bool in_walk = walk_rank(w, j, rank);
@@ -705,7 +698,7 @@ __device__ __forceinline__ void walk_lds(const LdsStore& L, const LCloud& c, boo
     const bool seed_first = !have_bound && (!is_surf || dr != 0);
     const bool centre_done = is_surf && dr == 0 && !w2;
     Best cur = use2 ? c2 : c3;
-    walk_task(L, c, w, rho + dr, seed_first, centre_done, a0, sx, sy, sz, rho_q, qn3, el_q, margin, cur, valid);
+    walk_task(L, c, w, rho + dr, seed_first, centre_done, a0, sx, sy, sz, rho_q, qn3, el_q, margin, cur);
     if (use2)
       c2 = cur;
     else
@@ -816,11 +809,13 @@ __device__ __forceinline__ LCloud make_cloud(const LdsStore& L, bool is_surf, co
 // Every move is unconditional on a CLAMPED index (the threads past the end re-copy the last word: same value to the
 // same address), so that nothing ties a read to a branch: written with guards, the compiler sinks each read into its
 // guard and waits for it there — nine dependent HBM round trips instead of one.
-// Inlined since round 5 (-2 %).  Rounds 3-4 kept it out of line: inlined, the three-lane correspondence pass returned a wrong
-// second point — a wave shuffle of the walk's lane merges, executed inside a branch the queries of a wave took differently, read
-// a switched-off lane.  Since round 6 those merges run under wave-uniform control flow (the several-lanes block of
-// ieskf_lds_update, nn_lds / walk_lds `valid`); both inlining choices pass the whole GPU suite and the canary is gone
-// (history: profiles/history/kernel_notes.md #gridinline, tools/repro/README.md).
+// Inlined since round 5 (-2 %).  Rounds 3-4 kept it out of line because, inlined, the 1024 x 3 correspondence-pass
+// instantiation returned grid position 0 as the second point of every line query.  Root cause (round 6, tools/repro/README.md):
+// a register-allocator fault of this compiler — the copies of a live-range split and spill stores placed at the top of the
+// block where a divergent branch ends IN FRONT of its `s_or_b64 exec`, so the lanes that skipped the branch keep stale
+// registers (there: the partner lane of merge_query_lanes<3>).  Where the allocator splits depends on register pressure —
+// inlining this function is one of the things that move it.  tools/check_exec_prologue.py finds the shape in the shipped
+// library; __graft_entry__.build() and tests/test_build_check.py refuse a library that has it.
 template <int BLOCK>
 #ifndef LINS_GRID_INLINE
 #define LINS_GRID_INLINE 1
@@ -1050,8 +1045,14 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
     WrLay y;
     y.k = rnd * kWaves + wave;
     if (spread_ok) {
-      y.n_wr = kWs + kWc, y.kind_s = y.k < kWs;
-      const int j = y.kind_s ? y.k : y.k - kWs, nw = y.kind_s ? kWs : kWc, n = y.kind_s ? sd.n_surf_q : sd.n_corner_q;
+#ifdef LINS_SPREAD_ROLES  // (experiment of round 6, +-0: which share a wave takes — a map from the wave to its place in the list "plane shares near to far, then line shares", e.g. -DLINS_SPREAD_ROLES=0,5,1,6,2,7,3,4)
+      constexpr int kRole[] = {LINS_SPREAD_ROLES, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+      const int role_k = (kWeighted && y.k < kWs + kWc && y.k < 8) ? kRole[y.k] : y.k;
+#else
+      const int role_k = y.k;
+#endif
+      y.n_wr = kWs + kWc, y.kind_s = role_k < kWs;
+      const int j = y.kind_s ? role_k : role_k - kWs, nw = y.kind_s ? kWs : kWc, n = y.kind_s ? sd.n_surf_q : sd.n_corner_q;
       const int q0 = share_start(y.kind_s ? kWtS : kWtC, nw, n, j), q1 = share_start(y.kind_s ? kWtS : kWtC, nw, n, j + 1);
       y.slot = (y.kind_s ? 0 : sd.n_surf_q) + q0 + lane, y.active = y.k < y.n_wr && lane < q1 - q0;
     } else {
@@ -1421,24 +1422,16 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
         if (prof && tid == 0) L.prof_acc[9] += clock64() - s3;
 #endif
         if (prof) PROF2_ADD(3, clock64() - s3);
-      } else {
-        // ---- several lanes per query (the three-lane single-scan shape) ----------------------------------------------------
-        // Round 6: the block is entered by every lane of the wave and its two searches are called under WAVE-UNIFORM
-        // control flow (a ballot decides whether the wave searches at all; a lane whose query does not — or that holds no
-        // query — goes through them with valid = false): the lane merges inside nn_lds / walk_lds are wave shuffles, and a
-        // shuffle inside a branch the lanes take differently reads what the compiler's reconvergence leaves there (the
-        // round-3/4 miscompile of this instantiation: tools/repro/README.md).  Same arithmetic, same results.
+      } else if (active) {
         const bool is_surf = slot < sd.n_surf_q;
         const int qi = is_surf ? slot : slot - sd.n_surf_q;
-        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (active) q = arena[(is_surf ? sd.off_surf_q : sd.off_corner_q) + qi];
+        const float4 q = arena[(is_surf ? sd.off_surf_q : sd.off_corner_q) + qi];
         const LCloud& c = is_surf ? cs : cc;
         V3 phi = L.ic.phi;
         V3 t{L.ic.lin[0], L.ic.lin[1], L.ic.lin[2]};
         QueryOut o;
-        o.sel[0] = o.sel[1] = o.sel[2] = 0.f;
         long long s0 = prof ? clock64() : 0, s1 = s0, s2 = s0;
-        if (active) transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2], g_lds.trig);
+        transform_to_start(prm, phi, t, q, o.sel[0], o.sel[1], o.sel[2], g_lds.trig);
         if (prof) {
           s1 = clock64();
 #ifndef LINS_PROF_WAVES
@@ -1448,7 +1441,7 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
         o.accepted = 0;
         o.c[0] = o.c[1] = o.c[2] = o.c[3] = 0.f;
         int p1 = -1, p2 = -1, p3 = -1;  // grid positions of the three target points
-        if (do_search) {  // (uniform)
+        if (do_search) {
           const bool single_round = span <= kQPerRound;
           if (!single_round) a1 = b1c = a2 = b2c = a3 = b3c = sel1 = -1, have_cert = false;
           QueryPolar qp;
@@ -1472,73 +1465,62 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
           // warm-started from A.
           const unsigned long long kNone = ~0ull;
           const bool verify = (pad & 8) != 0;  // test aid: search anyway and count disagreements
-          // --- nearest neighbour: certificate (per lane; the lanes of a query agree) ------------------------
-          bool need_nn = false, said = false, flip = false;
-          int pred = -1;
-          if (active) {
+          // --- nearest neighbour -----------------------------------------------------------------------
+          {
             const float da = a1 >= 0 ? dist_to(a1) : INFINITY, db = b1c >= 0 ? dist_to(b1c) : INFINITY;
             bool ok = have_cert && !(pad & 16) && certified(fminf(fminf(da, db), thr), lb1, drift_from(certA));
             const unsigned long long ka = da < thr ? pack_key(da, pt_idx(L, c, a1)) : kNone;
             const unsigned long long kb = db < thr ? pack_key(db, pt_idx(L, c, b1c)) : kNone;
-            flip = kb < ka;
-            pred = (flip ? kb : ka) == kNone ? -1 : (flip ? b1c : a1);
-            said = ok;
+            const bool flip = kb < ka;
+            const int pred = (flip ? kb : ka) == kNone ? -1 : (flip ? b1c : a1);
+            const bool said = ok;
             if (verify) ok = false;
-            need_nn = !ok;
-          }
-          if (active && !need_nn) {  // a certified lane is finished before the search: nothing of its decision stays live across it
-            p1 = pred;
-            if (flip) {  // the runner-up took over: swap the two tracked candidates
-              const int tp = a1, tr = ra1;
-              a1 = b1c, ra1 = rb1, b1c = tp, rb1 = tr;
-            }
-            if (role == 0) atomicAdd(&L.dbg[1], 1);
-          }
-          // --- nearest neighbour: the search, entered by the whole wave ---------------------------------------
-          {
-            const unsigned long long m_nn = __ballot(need_nn);
-            Best bb = best_init(thr);
-            if (m_nn) {  // (uniform)
-              if ((pad & 32) && __ffsll(m_nn) - 1 == lane) atomicAdd(&L.dbg[3], 1 + (iter >= 3 ? 1000 : 0));
+            if (!ok) {
+              if ((pad & 32) && __ffsll(__ballot(1)) - 1 == lane) atomicAdd(&L.dbg[3], 1 + (iter >= 3 ? 1000 : 0));
+              Best bb = best_init(thr);
               if (!(pad & 2))  // (profiling aid: LINS_DEBUG_SKIP=2 skips the search, 1 skips the walk)
                 bb = nn_lds<LANES>(L, c, o.sel[0], o.sel[1], o.sel[2], qp, thr, margin, ring_of(q.w), LANES, role, lane_base,
-                                   a1, ra1, need_nn);
-            }
-            if (need_nn) {
+                                   a1, ra1);
               p1 = bb.pos;  // (a winner beat the threshold sentinel, so its distance is < thr, SE:851)
-              if (KNOBS && said && p1 != pred && role == 0) atomicAdd(&L.dbg[0], 1);
+              if (said && p1 != pred && role == 0) atomicAdd(&L.dbg[0], 1);
               a1 = bb.pos, ra1 = bb.ring, b1c = bb.pos2, rb1 = bb.ring2;
               lb1 = cert_lb(bb, thr, margin);
               certA[0] = o.sel[0], certA[1] = o.sel[1], certA[2] = o.sel[2];
+            } else {
+              p1 = pred;
+              if (flip) {  // the runner-up took over: swap the two tracked candidates
+                const int tp = a1, tr = ra1;
+                a1 = b1c, ra1 = rb1, b1c = tp, rb1 = tr;
+              }
+              if (role == 0) atomicAdd(&L.dbg[1], 1);
             }
           }
-          const bool nn_changed = active && p1 != sel1;
-          if (active) sel1 = p1;
+          const bool nn_changed = p1 != sel1;
+          sel1 = p1;
           if (prof) {
             s2 = clock64();
 #ifndef LINS_PROF_WAVES
             if (tid == 0) L.prof_acc[7] += s2 - s1;
 #endif
           }
-          // --- second / third point: certificate (per lane) ------------------------------------------------------
-          bool need_walk = false, flip2 = false, flip3 = false, said23 = false;
-          int pred2 = -1, pred3 = -1, j1 = -1;
-          const int rho1 = ra1;  // (p1 >= 0 => p1 is candidate A, on ring ra1)
-          if (active && p1 >= 0) {
-            j1 = pt_idx(L, c, p1);
-            need_walk = nn_changed || !have_cert;
+          // --- second / third point ------------------------------------------------------------------
+          if (p1 >= 0) {
+            const int j1 = pt_idx(L, c, p1), rho1 = ra1;  // (p1 >= 0 => p1 is candidate A)
+            bool need_walk = nn_changed || !have_cert;
+            int pred2 = -1, pred3 = -1;
+            bool flip2 = false, flip3 = false, said23 = false;
             if (!need_walk) {
               const WalkCtx w = make_walk_ctx(c, is_surf ? sd.n_surf_q : sd.n_corner_q, j1, rho1);
               const float dB = drift_from(certB);
-              auto judge = [&](int pa, int pb, float lb, int& pd, bool& fl) {
+              auto judge = [&](int pa, int pb, float lb, int& pred, bool& flip) {
                 const float da = pa >= 0 ? dist_to(pa) : INFINITY, db = pb >= 0 ? dist_to(pb) : INFINITY;
                 int rka = 0, rkb = 0;
                 if (pa >= 0) walk_rank(w, pt_idx(L, c, pa), rka);
                 if (pb >= 0) walk_rank(w, pt_idx(L, c, pb), rkb);
                 const unsigned long long ka = da < thr ? pack_key(da, rka) : kNone;
                 const unsigned long long kb = db < thr ? pack_key(db, rkb) : kNone;
-                fl = kb < ka;
-                pd = (fl ? kb : ka) == kNone ? -1 : (fl ? pb : pa);
+                flip = kb < ka;
+                pred = (flip ? kb : ka) == kNone ? -1 : (flip ? pb : pa);
                 return certified(fminf(fminf(da, db), thr), lb, dB);
               };
               bool ok23 = judge(a2, b2c, lb2, pred2, flip2);
@@ -1546,7 +1528,18 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
               said23 = ok23;
               need_walk = !ok23 || verify;
             }
-            if (!need_walk) {  // finished before the walk
+            if (need_walk) {
+              if ((pad & 32) && __ffsll(__ballot(1)) - 1 == lane) atomicAdd(&L.dbg[0], 1 + (iter >= 3 ? 1000 : 0));
+              Best c2 = best_init(thr), c3 = c2;
+              if (!(pad & 1))
+                walk_lds<LANES>(L, c, is_surf, is_surf ? sd.n_surf_q : sd.n_corner_q, thr, j1, rho1, o.sel[0], o.sel[1],
+                                o.sel[2], qp, margin, LANES, role, lane_base, a2, a3, nn_changed, c2, c3);
+              if (said23 && (c2.pos != pred2 || (is_surf && c3.pos != pred3)) && role == 0) atomicAdd(&L.dbg[0], 1);
+              p2 = c2.pos, p3 = c3.pos;
+              a2 = c2.pos, b2c = c2.pos2, a3 = c3.pos, b3c = c3.pos2;
+              lb2 = cert_lb(c2, thr, margin), lb3 = cert_lb(c3, thr, margin);
+              certB[0] = o.sel[0], certB[1] = o.sel[1], certB[2] = o.sel[2];
+            } else {
               p2 = pred2, p3 = pred3;
               if (flip2) {
                 const int tp = a2;
@@ -1559,29 +1552,11 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
               if (role == 0) atomicAdd(&L.dbg[2], 1);
             }
           }
-          // --- second / third point: the walk, entered by the whole wave -------------------------------------------
-          {
-            const unsigned long long m_wk = __ballot(need_walk);
-            Best c2 = best_init(thr), c3 = c2;
-            if (m_wk) {  // (uniform)
-              if ((pad & 32) && __ffsll(m_wk) - 1 == lane) atomicAdd(&L.dbg[0], 1 + (iter >= 3 ? 1000 : 0));
-              if (!(pad & 1))
-                walk_lds<LANES>(L, c, is_surf, is_surf ? sd.n_surf_q : sd.n_corner_q, thr, j1, rho1, o.sel[0], o.sel[1],
-                                o.sel[2], qp, margin, LANES, role, lane_base, a2, a3, nn_changed, c2, c3, need_walk);
-            }
-            if (need_walk) {
-              if (KNOBS && said23 && (c2.pos != pred2 || (is_surf && c3.pos != pred3)) && role == 0) atomicAdd(&L.dbg[0], 1);
-              p2 = c2.pos, p3 = c3.pos;
-              a2 = c2.pos, b2c = c2.pos2, a3 = c3.pos, b3c = c3.pos2;
-              lb2 = cert_lb(c2, thr, margin), lb3 = cert_lb(c3, thr, margin);
-              certB[0] = o.sel[0], certB[1] = o.sel[1], certB[2] = o.sel[2];
-            }
-          }
           have_cert = single_round;
 #ifndef LINS_PROF_WAVES
           if (prof && tid == 0) L.prof_acc[8] += clock64() - s2;
 #endif
-          if (active && prm.icp_freq > 1 && role == 0) {
+          if (prm.icp_freq > 1 && role == 0) {
             // ICP mode: estimateTransform searches the corners only after >= 10 plane rows were accepted
             // (SE:1175-1178) — a corner triplet is committed after the reduction, once that count is known
             if (ICP && !is_surf)
@@ -1589,21 +1564,21 @@ __device__ __forceinline__ bool ieskf_lds_update(const KernelArgs ka, const floa
             else
               idx_store[sd.slot_base + slot] = make_int4(p1, p2, p3, 0);
           }
-        } else if (active) {
+        } else {
           int4 s = idx_store[sd.slot_base + slot];
           p1 = s.x, p2 = s.y, p3 = s.z;
         }
         long long s3 = prof ? clock64() : 0;
         asm volatile("" ::: "memory");  // (R^T, G^T are read from LDS here, not hoisted and spilled: see the one-lane path)
-        if (active && role == 0) {
+        if (role == 0) {
           auto pt4 = [&](int pos) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             pt_xyz(L, c, pos, v.x, v.y, v.z);
             return v;
           };
           if (is_surf) {
-            if (p1 >= 0 && p2 >= 0 && p3 >= 0) surf_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], pt4(p1), pt4(p2), pt4(p3), o);
-          } else if (p1 >= 0 && p2 >= 0) {
+            if (p2 >= 0 && p3 >= 0) surf_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], pt4(p1), pt4(p2), pt4(p3), o);
+          } else if (p2 >= 0) {
             corner_row(prm, iter, o.sel[0], o.sel[1], o.sel[2], pt4(p1), pt4(p2), o);
           }
           if (o.accepted) {

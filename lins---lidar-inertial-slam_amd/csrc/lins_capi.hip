@@ -227,6 +227,8 @@ struct lins_ctx {
     bool on = false;
     hipStream_t s_comm = nullptr;
     hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_comm[2] = {nullptr, nullptr};
+    hipEvent_t ev_main_b[2] = {nullptr, nullptr};  // ... of the run's launches on the second launch queue (lins_ctx::stream2)
+    bool run_split[2] = {false, false};
     bool comm_pending[2] = {false, false};
     unsigned runs = 0;  // staged runs so far (parity = set)
   } pipe;
@@ -295,6 +297,7 @@ void pipe_free(lins_ctx* ctx) {
   if (q.s_comm) (void)hipStreamSynchronize(q.s_comm), (void)hipStreamDestroy(q.s_comm);
   for (int k = 0; k < 2; ++k) {
     if (q.ev_main[k]) (void)hipEventDestroy(q.ev_main[k]);
+    if (q.ev_main_b[k]) (void)hipEventDestroy(q.ev_main_b[k]);
     if (q.ev_comm[k]) (void)hipEventDestroy(q.ev_comm[k]);
   }
   q = lins_ctx::Pipe{};
@@ -1013,10 +1016,12 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   const int set = q.on ? (int)(q.runs & 1u) : 0;
   double* const a6 = ctx->d_a6;
   void* const out = ctx->d_out;
-  if (q.on && q.comm_pending[set]) {  // this run rewrites the pose buffer the gather of run k - 2 read
+  const bool wait_comm = q.on && q.comm_pending[set];
+  if (wait_comm) {  // this run rewrites the pose buffer the gather of run k - 2 read
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, q.ev_comm[set], 0));
     q.comm_pending[set] = false;
   }
+  if (q.on) q.run_split[set] = false;
   const int h = (int)(ctx->hist_n % lins_ctx::kHist);
   HIP_TRY(ctx, hipEventRecord(ctx->hist0[h], ctx->stream));
   const int search = effective_search(ctx, ctx->n_uploaded);
@@ -1043,7 +1048,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
     queued = hipEventQuery(ctx->hist1[hp]) == hipErrorNotReady || (ctx->hist_split[hp] && hipEventQuery(ctx->hist1b[hp]) == hipErrorNotReady);
     (void)hipGetLastError();  // (hipErrorNotReady is an answer, not an error to keep)
   }
-  const bool split = use_mr && queued && ctx->n_uploaded > ctx->queue_grid && !ctx->d_prof && !q.on;
+  const bool split = use_mr && queued && ctx->n_uploaded > ctx->queue_grid && !ctx->d_prof;
   const bool relay = !split && cut_ok && ctx->relay_at != 0 && relay_max_parts(ctx->prm.num_iter, ctx->relay_at, ctx->relay_cuts) > 1;
   RelayArgs ra;
   if (relay) {
@@ -1077,6 +1082,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
     const int n = ctx->n_uploaded, n_launch = (n + ctx->queue_grid - 1) / ctx->queue_grid, per = (n + n_launch - 1) / n_launch;
     RangeFlags fl;
     fl.lds_ok = ctx->lds_ok, fl.mr_ok = ctx->mr_ok, fl.lds3_ok = ctx->lds3_ok;
+    if (wait_comm) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, q.ev_comm[set], 0));  // (the second queue writes that pose buffer too)
     HIP_TRY(ctx, hipEventRecord(ctx->hist0b[h], ctx->stream2));
     for (int c = 0; c < n_launch; ++c) {
       const int lo = c * per, cnt = std::min(per, n - lo);
@@ -1088,6 +1094,11 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
     HIP_TRY(ctx, hipEventRecord(ctx->hist1b[h], ctx->stream2));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_split, ctx->stream2));
     ctx->split_pending = true;
+    if (q.on) {  // (pipelined gather mode: the pose records of this run are complete when BOTH queues are through)
+      HIP_TRY(ctx, hipEventRecord(q.ev_main[set], ctx->stream));
+      HIP_TRY(ctx, hipEventRecord(q.ev_main_b[set], ctx->stream2));
+      q.run_split[set] = true;
+    }
   } else if (use_mr || use_lds) {
     ctx->split_dirty = true;  // (a launch on the context's stream the second queue is not ordered behind)
     if (use_mr)
@@ -1135,6 +1146,7 @@ int lins_set_pipelined(lins_ctx* ctx, int on) {
     HIP_TRY(ctx, hipStreamCreateWithFlags(&q.s_comm, hipStreamNonBlocking));
     for (int k = 0; k < 2; ++k) {
       HIP_TRY(ctx, hipEventCreateWithFlags(&q.ev_main[k], hipEventDisableTiming));
+      HIP_TRY(ctx, hipEventCreateWithFlags(&q.ev_main_b[k], hipEventDisableTiming));
       HIP_TRY(ctx, hipEventCreateWithFlags(&q.ev_comm[k], hipEventDisableTiming));
     }
   }
@@ -1284,7 +1296,6 @@ int lins_pose_allgather(lins_ctx* ctx, const void* d_local, int n_records, void*
   if (!ctx || !d_local || !d_all || n_records < 0) return LINS_E_ARG;
   if (!ctx->rccl.comm) return LINS_E_STATE;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (int rcs = split_join(ctx)) return rcs;  // (results of the second launch queue: ordered before what follows)
   auto& q = ctx->pipe;
   hipStream_t st = ctx->stream;
   int set = 0;
@@ -1292,7 +1303,10 @@ int lins_pose_allgather(lins_ctx* ctx, const void* d_local, int n_records, void*
     if (q.runs == 0) return LINS_E_STATE;
     set = (int)((q.runs - 1) & 1u);  // the run whose records these are
     HIP_TRY(ctx, hipStreamWaitEvent(q.s_comm, q.ev_main[set], 0));
+    if (q.run_split[set]) HIP_TRY(ctx, hipStreamWaitEvent(q.s_comm, q.ev_main_b[set], 0));  // (both launch queues; the queues themselves are not joined)
     st = q.s_comm;
+  } else if (int rcs = split_join(ctx)) {  // (the gather runs on the context's stream: behind the second launch queue too)
+    return rcs;
   }
   ncclResult_t e = ctx->rccl.all_gather(d_local, d_all, (size_t)n_records * sizeof(lins_pose_record), ncclChar, ctx->rccl.comm, st);
   if (e != ncclSuccess) return rccl_fail(ctx, e, "ncclAllGather");
@@ -1455,6 +1469,37 @@ int lins_debug_stream_copy(lins_ctx* ctx, uint64_t bytes, int reps, double* gbs)
     if (r && ms < best) best = ms;
   }
   *gbs = 2.0 * (double)(n4 * sizeof(float4)) / ((double)best * 1e-3) / 1e9;
+  return LINS_OK;
+}
+
+/* measurement aid (tools/pull_copy_rate.py): `bytes` of the pinned staging arena to the device arena — mode 0: hipMemcpyAsync
+ * (what the uploads do), mode 1: a copy KERNEL reading the host memory over PCIe (launch_stream_copy on the mapped pointer) —
+ * best of `reps`, GB/s one way. */
+int lins_debug_pull_copy(lins_ctx* ctx, uint64_t bytes, int reps, int mode, double* gbs) {
+  if (!ctx || !gbs || reps < 1) return LINS_E_ARG;
+  const size_t cap = ctx->arena_cap * sizeof(float4);
+  if (bytes > cap) bytes = cap;
+  const size_t n4 = bytes / sizeof(float4);
+  if (!n4) return LINS_E_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (int rc = pipe_join(ctx)) return rc;
+  float4* mapped = nullptr;
+  HIP_TRY(ctx, hipHostGetDevicePointer((void**)&mapped, ctx->h_arena, 0));
+  float best = 1e30f;
+  for (int r = 0; r < reps + 1; ++r) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (mode == 0)
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->d_binned, ctx->h_arena, n4 * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    else
+      launch_stream_copy(ctx->stream, mapped, ctx->d_binned, n4);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev2, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev2));
+    float ms = 0;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev2));
+    if (r && ms < best) best = ms;
+  }
+  *gbs = (double)(n4 * sizeof(float4)) / ((double)best * 1e-3) / 1e9;
   return LINS_OK;
 }
 

@@ -63,7 +63,7 @@ PKG = "lins---lidar-inertial-slam_amd"
 pkg = importlib.import_module(PKG); host = importlib.import_module(PKG + ".host"); ieskf = importlib.import_module(PKG + ".ieskf")
 defs = importlib.import_module(PKG + "._ctypes_defs")
 prm = pkg.default_params(num_iter=10, fixed_iters=1)
-batch = host.synth_batch(300, start=5000)
+batch = host.synth_batch(%d, start=5000)
 with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384, search="mr") as c:
     c.upload(batch)
     c.run(); c.sync()
@@ -89,12 +89,18 @@ print("RCCL_GATHER_OK")
 """
 
 
-def test_pose_allgather_through_the_c_abi_world_of_one():
+@pytest.mark.parametrize("n_scans,queues", [(300, "one launch"), (700, "two launch queues")])
+def test_pose_allgather_through_the_c_abi_world_of_one(n_scans, queues):
     """lins_rccl_unique_id / _init / lins_pose_allgather / _destroy (include/lins_ieskf.h) in the pipelined staged mode:
-    the records RCCL delivers are the records the update kernel wrote, for the LAST of four back-to-back runs."""
+    the records RCCL delivers are the records the update kernel wrote, for the LAST of four back-to-back runs — for a batch
+    within the device's workgroup slots (one launch per run) and for one beyond them with every run dealt to the context's
+    two launch queues (lins_set_launch_queues; forced with the debug knob so that it does not hang on timing): the gather
+    then waits for both queues without joining them."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    p = subprocess.run([sys.executable, "-c", RCCL_SCRIPT % ROOT], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    if queues != "one launch":
+        env.update(LINS_ENABLE_DEBUG_KNOBS="1", LINS_SPLIT_STREAMS="2")
+    p = subprocess.run([sys.executable, "-c", RCCL_SCRIPT % (ROOT, n_scans)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert p.returncode == 0 and b"RCCL_GATHER_OK" in p.stdout, p.stderr.decode()[-3000:]
 
 
