@@ -126,6 +126,15 @@ struct lins_ctx {
   ScanDesc* h_desc = nullptr;
   double* h_state = nullptr;
   double* h_cov = nullptr;
+  // The per-scan records of a batch live in ONE pinned block and two device blocks of the same layout —
+  //   host      [state | cov | out records | descriptors]      (h_state, h_cov, h_out, h_desc point into it)
+  //   device in [state | cov |   (unused)  | descriptors]      (d_state_in, d_cov_in, d_desc)
+  //   device out[state | cov | out records]                    (d_state_out, d_cov_out, d_out)
+  // so that a batch that fills the context (n == max_batch: the single-scan context of a live filter, the bench's batch)
+  // goes up in ONE copy besides the clouds and comes back in ONE: every hipMemcpyAsync is ~8 us of host time and as much
+  // in-order latency on the stream (round 6: lins_ieskf_update of one scan 245 -> see DESIGN.md section 7).
+  char *h_meta = nullptr, *d_meta_in = nullptr, *d_meta_out = nullptr;
+  size_t meta_in_bytes = 0, meta_out_bytes = 0;
   OutRecHost* h_out = nullptr;
   // device
   float4* d_arena = nullptr;
@@ -595,9 +604,35 @@ int h2d_range(lins_ctx* ctx, int lo, int hi, size_t arena_end, hipStream_t st) {
   const size_t a0 = (size_t)ctx->h_desc[lo].off_surf_q;
   if (arena_end > a0)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_arena + a0, ctx->h_arena + a0, (arena_end - a0) * sizeof(float4), hipMemcpyHostToDevice, st));
+  if (lo == 0 && hi == ctx->max_batch) {  // the whole context: priors and descriptors are one block (lins_ctx::h_meta)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_meta_in, ctx->h_meta, ctx->meta_in_bytes, hipMemcpyHostToDevice, st));
+    return LINS_OK;
+  }
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_desc + lo, ctx->h_desc + lo, (size_t)(hi - lo) * sizeof(ScanDesc), hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_state_in + (size_t)lo * 19, ctx->h_state + (size_t)lo * 19, (size_t)(hi - lo) * 19 * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_cov_in + (size_t)lo * 324, ctx->h_cov + (size_t)lo * 324, (size_t)(hi - lo) * 324 * 8, hipMemcpyHostToDevice, st));
+  return LINS_OK;
+}
+
+// The second launch queue of a context (lins_set_launch_queues): created when a batch beyond the workgroup slots is uploaded —
+// not inside the first run that uses it, where the stream and its 2 x 64 timing events cost that run a millisecond or more
+// (round 6: the bench's queued stop-rule figure read 1.12 instead of 0.89 ms for it) — and, as a fallback, by that run.
+int split_prepare(lins_ctx* ctx) {
+  if (ctx->stream2) return LINS_OK;
+  // A priority of its own: HIP multiplexes the streams of a process onto a handful of hardware queues (four by default) in
+  // creation order, and two streams that share one are served in order — measured: a context whose two streams collided
+  // ran its queued steps at 0.646 instead of 0.50 ms, depending on how many other contexts the process had created
+  // (gpurun r06w).  Streams of different priority never share a hardware queue.  LOW, so that the work a caller puts on
+  // streams of his own is not pushed back by it.
+  int pr_least = 0, pr_greatest = 0;
+  HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+  HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, pr_least));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_split, hipEventDisableTiming));
+  for (int k = 0; k < lins_ctx::kHist; ++k) {
+    HIP_TRY(ctx, hipEventCreate(&ctx->hist0b[k]));
+    HIP_TRY(ctx, hipEventCreate(&ctx->hist1b[k]));
+  }
   return LINS_OK;
 }
 
@@ -686,8 +721,11 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in, bool wait = true) {
   HIP_TRY(ctx, hipEventRecord(ctx->ev_idx1, ctx->stream));
   ctx->idx_timed = true;
   launch_order(ctx, n);
-  if (n > 0) HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->h_order, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->max_batch > 1)  // (a one-scan context: the order is [0], which is what the array holds since lins_create)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->h_order, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   if (wait) HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->split_mode && n > ctx->queue_grid)  // (a batch whose queued runs go out on two launch queues: the second one exists before the first run)
+    if (int rcq = split_prepare(ctx)) return rcq;
   set_batch_state(ctx, n, fl, slots, bytes);
   return LINS_OK;
 }
@@ -819,12 +857,15 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   }
   const size_t nb = (size_t)max_batch;
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_arena, ctx->arena_cap * sizeof(float4)));
-  CREATE_TRY(hipHostMalloc((void**)&ctx->h_desc, nb * sizeof(ScanDesc)));
+  const auto up64 = [](size_t v) { return (v + 63) & ~(size_t)63; };
+  const size_t m_cov = up64(nb * 19 * 8), m_out = m_cov + up64(nb * 324 * 8), m_desc = m_out + up64(nb * std::max(sizeof(OutRecHost), out_rec_size()));
+  ctx->meta_out_bytes = m_desc, ctx->meta_in_bytes = m_desc + up64(nb * sizeof(ScanDesc));
+  CREATE_TRY(hipHostMalloc((void**)&ctx->h_meta, ctx->meta_in_bytes));
+  ctx->h_state = (double*)ctx->h_meta, ctx->h_cov = (double*)(ctx->h_meta + m_cov);
+  ctx->h_out = (OutRecHost*)(ctx->h_meta + m_out), ctx->h_desc = (ScanDesc*)(ctx->h_meta + m_desc);
   CREATE_TRY(hipHostMalloc((void**)&ctx->h_order, 16 * nb * sizeof(int)));  // (n entries: launch order; from max_batch on: parts x n items)
   CREATE_TRY(hipMalloc((void**)&ctx->d_order, 16 * nb * sizeof(int)));
-  CREATE_TRY(hipHostMalloc((void**)&ctx->h_state, nb * 19 * 8));
-  CREATE_TRY(hipHostMalloc((void**)&ctx->h_cov, nb * 324 * 8));
-  CREATE_TRY(hipHostMalloc((void**)&ctx->h_out, nb * sizeof(OutRecHost)));
+  CREATE_TRY(hipMemsetAsync(ctx->d_order, 0, 16 * nb * sizeof(int), ctx->stream));
   CREATE_TRY(hipMalloc((void**)&ctx->d_arena, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_binned, ctx->arena_cap * sizeof(float4)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_gsorted, ctx->arena_cap * sizeof(float4)));
@@ -844,14 +885,12 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   }
   CREATE_TRY(hipEventCreate(&ctx->ev_idx0));
   CREATE_TRY(hipEventCreate(&ctx->ev_idx1));
-  CREATE_TRY(hipMalloc((void**)&ctx->d_desc, nb * sizeof(ScanDesc)));
-  CREATE_TRY(hipMalloc((void**)&ctx->d_state_in, nb * 19 * 8));
-  CREATE_TRY(hipMalloc((void**)&ctx->d_cov_in, nb * 324 * 8));
-  CREATE_TRY(hipMalloc((void**)&ctx->d_state_out, nb * 19 * 8));
-  CREATE_TRY(hipMalloc((void**)&ctx->d_cov_out, nb * 324 * 8));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_meta_in, ctx->meta_in_bytes));
+  CREATE_TRY(hipMalloc((void**)&ctx->d_meta_out, ctx->meta_out_bytes));
+  ctx->d_state_in = (double*)ctx->d_meta_in, ctx->d_cov_in = (double*)(ctx->d_meta_in + m_cov), ctx->d_desc = (ScanDesc*)(ctx->d_meta_in + m_desc);
+  ctx->d_state_out = (double*)ctx->d_meta_out, ctx->d_cov_out = (double*)(ctx->d_meta_out + m_cov), ctx->d_out = ctx->d_meta_out + m_out;
   CREATE_TRY(hipMalloc((void**)&ctx->d_lin, nb * 19 * 8));
   CREATE_TRY(hipMalloc((void**)&ctx->d_a6, nb * 21 * 8));
-  CREATE_TRY(hipMalloc((void**)&ctx->d_out, nb * out_rec_size()));
   CREATE_TRY(hipMalloc((void**)&ctx->d_idx, ctx->slot_cap * sizeof(int4)));
   CREATE_TRY(hipMalloc((void**)&ctx->d_walk_cache, ctx->slot_cap * 32));
   CREATE_TRY(hipMemset(ctx->d_walk_cache, 0xFF, ctx->slot_cap * 32));
@@ -870,11 +909,8 @@ void lins_destroy(lins_ctx* ctx) {
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   (void)hipHostFree(ctx->h_arena);
-  (void)hipHostFree(ctx->h_desc);
+  (void)hipHostFree(ctx->h_meta);  // (h_state, h_cov, h_out, h_desc)
   (void)hipHostFree(ctx->h_order), (void)hipFree(ctx->d_order);
-  (void)hipHostFree(ctx->h_state);
-  (void)hipHostFree(ctx->h_cov);
-  (void)hipHostFree(ctx->h_out);
   (void)hipFree(ctx->d_arena);
   (void)hipFree(ctx->d_binned);
   (void)hipFree(ctx->d_gsorted);
@@ -882,11 +918,7 @@ void lins_destroy(lins_ctx* ctx) {
   (void)hipFree(ctx->d_relay_hdr), (void)hipFree(ctx->d_relay_lane), (void)hipFree(ctx->d_queue), (void)hipHostFree(ctx->h_relay_err);
   if (ctx->ev_idx0) (void)hipEventDestroy(ctx->ev_idx0);
   if (ctx->ev_idx1) (void)hipEventDestroy(ctx->ev_idx1);
-  (void)hipFree(ctx->d_desc);
-  (void)hipFree(ctx->d_state_in);
-  (void)hipFree(ctx->d_cov_in);
-  (void)hipFree(ctx->d_state_out);
-  (void)hipFree(ctx->d_cov_out);
+  (void)hipFree(ctx->d_meta_in), (void)hipFree(ctx->d_meta_out);  // (d_state_in, d_cov_in, d_desc; d_state_out, d_cov_out, d_out)
   (void)hipFree(ctx->d_lin);
   (void)hipFree(ctx->d_a6);
   (void)hipFree(ctx->d_prof);
@@ -895,7 +927,6 @@ void lins_destroy(lins_ctx* ctx) {
   fe_free(ctx);
   streams_free(ctx);
   if (ctx->map_state && ctx->map_state_free) ctx->map_state_free(ctx->map_state);
-  (void)hipFree(ctx->d_out);
   (void)hipFree(ctx->d_idx);
   (void)hipFree(ctx->d_walk_cache);
   (void)hipFree(ctx->d_dump);
@@ -1058,22 +1089,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   ctx->last_parts = relay ? ra.parts : 1;
   ctx->hist_split[h] = split;
   if (split) {
-    if (!ctx->stream2) {
-      // A priority of its own: HIP multiplexes the streams of a process onto a handful of hardware queues (four by default) in
-      // creation order, and two streams that share one are served in order — measured: a context whose two streams collided
-      // ran its queued steps at 0.646 instead of 0.50 ms, depending on how many other contexts the process had created
-      // (gpurun r06w).  Streams of different priority never share a hardware queue.  LOW, so that the work a caller puts on
-      // streams of his own is not pushed back by it.
-      int pr_least = 0, pr_greatest = 0;
-      HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
-      HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, pr_least));
-      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-      HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_split, hipEventDisableTiming));
-      for (int k = 0; k < lins_ctx::kHist; ++k) {
-        HIP_TRY(ctx, hipEventCreate(&ctx->hist0b[k]));
-        HIP_TRY(ctx, hipEventCreate(&ctx->hist1b[k]));
-      }
-    }
+    if (int rcq = split_prepare(ctx)) return rcq;
     if (ctx->split_dirty) {  // (uploads, index builds, downloads since the last fork: the second queue starts behind them)
       HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
       HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
@@ -2131,9 +2147,13 @@ int lins_batch_download(lins_ctx* ctx, int n, lins_result* out) {
     int rc = pipe_join(ctx);
     if (rc) return rc;
   }
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state_out, (size_t)n * 19 * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cov, ctx->d_cov_out, (size_t)n * 324 * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)n * sizeof(OutRecHost), hipMemcpyDeviceToHost, ctx->stream));
+  if (n == ctx->max_batch) {  // the whole context: posteriors and out records are one block (lins_ctx::h_meta)
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_meta, ctx->d_meta_out, ctx->meta_out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  } else {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state_out, (size_t)n * 19 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_cov, ctx->d_cov_out, (size_t)n * 324 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)n * sizeof(OutRecHost), hipMemcpyDeviceToHost, ctx->stream));
+  }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (int rc = relay_check(ctx)) return rc;  // (a scan whose hand-over never arrived holds an earlier launch's values)
   uint64_t tot = 0;
