@@ -191,7 +191,8 @@ int lins_batch_upload(lins_ctx* ctx, int n, const lins_scan_pair* in);
  * lins_batch_upload / lins_ieskf_update(_batch) call (same n, same sizes) skips the library's copy into the arena:
  * the points are validated where they lie and sent by DMA.  Any other pointer is copied as before.                  */
 int lins_batch_map(lins_ctx* ctx, int n, const int32_t* counts, lins_point** clouds);
-/* HIP-event time (ms) of the index build of the last upload; 0 when the batch cannot take the grid kernels.          */
+/* HIP-event time (ms) of the index build of the last lins_batch_upload; 0 when the batch cannot take the grid kernels.
+ * (The single-call entry points lins_ieskf_update(_batch) do not time it: LINS_E_STATE after them.)                   */
 int lins_last_index_ms(lins_ctx* ctx, float* ms);
 /* Runs the full IESKF loop for the uploaded batch on the context's stream.
  * d_poses: optional DEVICE pointer to n lins_pose_record (e.g. a torch tensor

@@ -706,20 +706,28 @@ int upload(lins_ctx* ctx, int n, const lins_scan_pair* in, bool wait = true) {
     int rcj = pipe_join(ctx);
     if (rcj) return rcj;
   }
+  const CallTrace tr;  // (stage times on stderr: LINS_ENABLE_DEBUG_KNOBS=1 LINS_BATCH_TRACE=1)
   size_t off = 0, slots = 0;
   uint64_t bytes = 0;
   int rc = layout_batch(ctx, n, in, &off, &slots, &bytes);
   if (rc) return rc;
+  tr.mark("upload: layout");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if ((rc = parallel_scans(n, [&](int s) { return pack_one(ctx, in, s); }))) return rc;
+  tr.mark("upload: validate + pack");
   const RangeFlags fl = range_flags(ctx, 0, n);
+  tr.mark("upload: range flags");
   if ((rc = h2d_range(ctx, 0, n, off, ctx->stream))) return rc;
+  tr.mark("upload: copies queued");
   // the target clouds have arrived: their search index (the reference builds its kd-trees where it produces the
   // clouds, SE:1156-1160, not in performIESKF)
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_idx0, ctx->stream));
+  // (timed by its own events for lins_last_index_ms — at the staged lins_batch_upload only: in the single-call entry points,
+  // which a live filter waits for, two event records are ~10 us of in-order latency on the stream, tools/experiments/graph_latency.hip)
+  if (wait) HIP_TRY(ctx, hipEventRecord(ctx->ev_idx0, ctx->stream));
   if ((rc = build_index_range(ctx, 0, n, fl))) return rc;
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_idx1, ctx->stream));
-  ctx->idx_timed = true;
+  if (wait) HIP_TRY(ctx, hipEventRecord(ctx->ev_idx1, ctx->stream));
+  ctx->idx_timed = wait;
+  tr.mark("upload: index queued");
   launch_order(ctx, n);
   if (ctx->max_batch > 1)  // (a one-scan context: the order is [0], which is what the array holds since lins_create)
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_order, ctx->h_order, (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -1074,7 +1082,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   // waited for (room batch, 1024 scans x 10 iterations: 0.57 against 0.63 ms; queued back to back: 0.56 against 0.505 ms
   // per run — tools/split_launch_time.py).  Mode 3 (LINS_SPLIT_STREAMS=2) always takes the two queues.
   bool queued = ctx->split_mode >= 3;
-  if (!queued && ctx->split_mode && ctx->hist_n > 0) {
+  if (!queued && ctx->split_mode && ctx->hist_n > 0 && use_mr && ctx->n_uploaded > ctx->queue_grid) {  // (asked only where the answer matters)
     const int hp = (int)((ctx->hist_n - 1) % lins_ctx::kHist);
     queued = hipEventQuery(ctx->hist1[hp]) == hipErrorNotReady || (ctx->hist_split[hp] && hipEventQuery(ctx->hist1b[hp]) == hipErrorNotReady);
     (void)hipGetLastError();  // (hipErrorNotReady is an answer, not an error to keep)
@@ -2216,11 +2224,16 @@ int lins_ieskf_update_batch(lins_ctx* ctx, int n, const lins_scan_pair* in, lins
   const auto t_begin = std::chrono::steady_clock::now();
   auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
   if (n < 2 * kChunk || ctx->d_prof) {
+    const CallTrace tr;
     int rc = upload(ctx, n, in, /*wait*/ false);  // (lins_batch_download below waits for the whole chain)
     if (rc) return rc;
     if (n == 0) return LINS_OK;
+    tr.mark("update: uploaded");
     if ((rc = lins_batch_run(ctx, nullptr, 0))) return rc;
-    return lins_batch_download(ctx, n, out);
+    tr.mark("update: run queued");
+    rc = lins_batch_download(ctx, n, out);
+    tr.mark("update: downloaded");
+    return rc;
   }
   size_t arena_used = 0, slots = 0;
   uint64_t bytes = 0;
