@@ -161,6 +161,9 @@ struct LdsStore {
   int scan_tmp[kMaxLWaves + 4];
   int m_surf, m_corner, iter, conv, div, pad;
   long long prof_acc[16];  // phase profile accumulators of the PROF variant (written by thread 0)
+#ifdef LINS_PROF_TAIL
+  long long prof_tail[2];  // stamps inside solve_wave0 (system built, solved)
+#endif
 #ifdef LINS_PROF2
   int prof2[64];  // per wave x phase ticks of the iterations >= LINS_PROF2 (lane 0 of each wave; lins_debug_wave_phases)
   int prof3[32];  // per wave: [0] wave-iterations with a nearest-neighbour search [1] ... with a walk [2] searches [3] walks

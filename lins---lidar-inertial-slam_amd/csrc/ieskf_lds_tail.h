@@ -55,7 +55,14 @@ __device__ __noinline__ long long solve_wave0(double prm_r2, int prm_fixed_iters
       dl = L.ic.d[lane];
     }
     double wsol[6];
+#ifdef LINS_PROF_TAIL
+    if (prof && lane == 0) L.prof_tail[0] = clock64();
+#endif
     wave_gj_solve6(v, lane, wsol);
+#ifdef LINS_PROF_TAIL
+    asm volatile("" ::"v"(wsol[0]) : "memory");
+    if (prof && lane == 0) L.prof_tail[1] = clock64();
+#endif
     double dxi = 0;
     if (lane < 18) {
       double sacc = 0;
@@ -154,16 +161,35 @@ __device__ __forceinline__ long long solve_and_update(double prm_r2, int prm_fix
   }
   const double* const stage = &L.aug[0][0];  // 22 doubles: linState_ (19), |r|, |r| kept, |dx|
   const int* const stage_flags = reinterpret_cast<const int*>(&L.aug[1][0]);  // diverged, converged
+#ifdef LINS_PROF_TAIL  // (build with -DLINS_PROF_WAVES=99 -DLINS_PROF_TAIL=1: slots 6..11 of the phase profile = the tail's sub-phases on thread 0, tools/tail_phases.py)
+  const long long a0 = prof ? clock64() : 0;
+#endif
   if (wave == 0) t3 = solve_wave0(prm_r2, prm_fixed_iters, lane, prof);
+#ifdef LINS_PROF_TAIL
+  const long long a1 = prof ? clock64() : 0;
+#endif
   __syncthreads();  // every reader of the old linearisation state is done; the staged one is visible
+#ifdef LINS_PROF_TAIL
+  const long long a2 = prof ? clock64() : 0;
+#endif
   const int div = stage_flags[0];
   if (wave < 3 && !div) next_iter_consts(wave, lane);
+#ifdef LINS_PROF_TAIL
+  const long long a3 = prof ? clock64() : 0;
+#endif
   if (tid == 0) {
     L.res_last = stage[19], L.res_prev = stage[20], L.upd_norm = stage[21];
     L.conv = stage_flags[1], L.div = div;
     L.iter = iter + 1;
   }
   __syncthreads();
+#ifdef LINS_PROF_TAIL
+  if (prof && tid == 0) {
+    const long long a4 = clock64();
+    L.prof_acc[6] += L.prof_tail[0] - a0, L.prof_acc[7] += L.prof_tail[1] - L.prof_tail[0], L.prof_acc[8] += a1 - L.prof_tail[1];
+    L.prof_acc[9] += a2 - a1, L.prof_acc[10] += a3 - a2, L.prof_acc[11] += a4 - a3;
+  }
+#endif
   return t3;
 }
 

@@ -235,8 +235,11 @@ struct lins_ctx {
   struct Pipe {
     bool on = false;
     hipStream_t s_comm = nullptr;
-    hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_comm[2] = {nullptr, nullptr};
-    hipEvent_t ev_main_b[2] = {nullptr, nullptr};  // ... of the run's launches on the second launch queue (lins_ctx::stream2)
+    hipEvent_t ev_comm[2] = {nullptr, nullptr};
+    // (what a gather waits for are the run's own end-of-launch events — lins_ctx::hist1[h], and hist1b[h] of the second launch
+    // queue when the run went out on both: an event record is ~5 us of in-order latency on its stream, so a run records no
+    // event that says what another one already does)
+    int h_of[2] = {0, 0};
     bool run_split[2] = {false, false};
     bool comm_pending[2] = {false, false};
     unsigned runs = 0;  // staged runs so far (parity = set)
@@ -251,11 +254,13 @@ struct lins_ctx {
   // other queue's launch, of this run or of the next (runs are not joined: each queue is in order, the two own disjoint
   // scan ranges).  Everything else the context enqueues goes to `stream` behind a join (split_join).
   hipStream_t stream2 = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_split = nullptr;
+  hipEvent_t ev_fork = nullptr;
+  int split_h = 0;  // hist1b[split_h]: the end of the last run that used the second launch queue
   hipEvent_t hist0b[kHist] = {}, hist1b[kHist] = {};  // start / end of a run's launches on stream2 (null timing when it had none)
   bool hist_split[kHist] = {};
   bool split_pending = false;  // stream2 holds work the context's stream has not been ordered behind
   bool split_dirty = true;     // the context's stream holds work (uploads, other calls) stream2 has not been ordered behind
+  bool comm_default_prio = false;  // (debug knob LINS_COMM_PRIO=0: the gather's stream at the default priority, as before round 6)
   int split_mode = 1;          // 0: one launch per run (several-part updates when the batch exceeds the slots)
   // RCCL (dlopen): one communicator per context
   struct Rccl {
@@ -305,8 +310,6 @@ void pipe_free(lins_ctx* ctx) {
   auto& q = ctx->pipe;
   if (q.s_comm) (void)hipStreamSynchronize(q.s_comm), (void)hipStreamDestroy(q.s_comm);
   for (int k = 0; k < 2; ++k) {
-    if (q.ev_main[k]) (void)hipEventDestroy(q.ev_main[k]);
-    if (q.ev_main_b[k]) (void)hipEventDestroy(q.ev_main_b[k]);
     if (q.ev_comm[k]) (void)hipEventDestroy(q.ev_comm[k]);
   }
   q = lins_ctx::Pipe{};
@@ -327,7 +330,7 @@ void rccl_free(lins_ctx* ctx) {
 int split_join(lins_ctx* ctx) {
   ctx->split_dirty = true;
   if (ctx->split_pending) {
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_split, 0));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->hist1b[ctx->split_h], 0));
     ctx->split_pending = false;
   }
   return LINS_OK;
@@ -628,7 +631,6 @@ int split_prepare(lins_ctx* ctx) {
   HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
   HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, pr_least));
   HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-  HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_split, hipEventDisableTiming));
   for (int k = 0; k < lins_ctx::kHist; ++k) {
     HIP_TRY(ctx, hipEventCreate(&ctx->hist0b[k]));
     HIP_TRY(ctx, hipEventCreate(&ctx->hist1b[k]));
@@ -821,6 +823,7 @@ int lins_create(const lins_params* params, int device, int max_batch, int max_ta
   if (const char* g = std::getenv("LINS_ENABLE_DEBUG_KNOBS"))
     if (g[0] == '1') {
       if (const char* e = std::getenv("LINS_LAUNCH_ORDER")) ctx->use_order = e[0] != '0';
+      if (const char* e = std::getenv("LINS_COMM_PRIO")) ctx->comm_default_prio = std::atoi(e) == 0;
       if (const char* e = std::getenv("LINS_SPLIT_STREAMS")) ctx->split_mode = std::atoi(e) == 0 ? 0 : (std::atoi(e) >= 2 ? 3 : 1);  // (0: one launch; 1: when runs are queued; 2: always)
       if (std::getenv("LINS_RELAY_AT") || std::getenv("LINS_RELAY_MASK") || std::getenv("LINS_RELAY_CUTS")) ctx->split_mode = 0;  // (the one-launch form's knobs)
       if (const char* e = std::getenv("LINS_RELAY_AT")) ctx->relay_at = std::max(0, std::atoi(e));  // (0: whole updates)
@@ -945,7 +948,6 @@ void lins_destroy(lins_ctx* ctx) {
   if (ctx->ev2) (void)hipEventDestroy(ctx->ev2);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-  if (ctx->ev_split) (void)hipEventDestroy(ctx->ev_split);
   for (int k = 0; k < lins_ctx::kHist; ++k) {
     if (ctx->hist0b[k]) (void)hipEventDestroy(ctx->hist0b[k]);
     if (ctx->hist1b[k]) (void)hipEventDestroy(ctx->hist1b[k]);
@@ -1116,13 +1118,8 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
     ctx->last_parts = 1;
     HIP_TRY(ctx, hipEventRecord(ctx->hist1[h], ctx->stream));
     HIP_TRY(ctx, hipEventRecord(ctx->hist1b[h], ctx->stream2));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_split, ctx->stream2));
-    ctx->split_pending = true;
-    if (q.on) {  // (pipelined gather mode: the pose records of this run are complete when BOTH queues are through)
-      HIP_TRY(ctx, hipEventRecord(q.ev_main[set], ctx->stream));
-      HIP_TRY(ctx, hipEventRecord(q.ev_main_b[set], ctx->stream2));
-      q.run_split[set] = true;
-    }
+    ctx->split_pending = true, ctx->split_h = h;
+    if (q.on) q.run_split[set] = true, q.h_of[set] = h;  // (pipelined gather mode: the pose records of this run are complete when BOTH queues are through)
   } else if (use_mr || use_lds) {
     ctx->split_dirty = true;  // (a launch on the context's stream the second queue is not ordered behind)
     if (use_mr)
@@ -1135,7 +1132,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
                  ctx->d_arena, ctx->d_gsorted, ctx->d_gridtab, ctx->d_state_in, ctx->d_cov_in, ctx->d_state_out, a6, ctx->d_cov_out, out, ctx->d_idx,
                  (lins_pose_record*)d_poses, scan_id_base, ctx->d_prof, ctx->d_relay_lane);
     HIP_TRY(ctx, hipEventRecord(ctx->hist1[h], ctx->stream));
-    if (q.on) HIP_TRY(ctx, hipEventRecord(q.ev_main[set], ctx->stream));  // (the pose records of this run are complete)
+    if (q.on) q.h_of[set] = h;  // (the pose records of this run are complete at hist1[h])
     // (The Joseph update, SE:594-598, is the update kernel's epilogue since round 3: ieskf_lds_impl.h joseph_epilogue.
     // Rounds 1-2 launched ieskf_joseph_kernel here, ~20 us + a launch per run; a side stream for it — measured at normal
     // and at lowest stream priority — lets its 1024 small workgroups sit on the LDS and wave slots the NEXT run's update
@@ -1148,7 +1145,7 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
                       ctx->d_state_out, ctx->d_cov_out, a6, out, ctx->d_idx,
                       (lins_pose_record*)d_poses, scan_id_base, ctx->d_binned, ctx->d_prof);
     HIP_TRY(ctx, hipEventRecord(ctx->hist1[h], ctx->stream));
-    if (q.on) HIP_TRY(ctx, hipEventRecord(q.ev_main[set], ctx->stream));
+    if (q.on) q.h_of[set] = h;
   }
   HIP_TRY(ctx, hipGetLastError());
   ctx->hist_n++;
@@ -1167,10 +1164,14 @@ int lins_set_pipelined(lins_ctx* ctx, int on) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   auto& q = ctx->pipe;
   if (on && !q.s_comm) {
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&q.s_comm, hipStreamNonBlocking));
+    // A priority of its own (the highest; the second launch queue has the lowest, the context's stream the default): streams of
+    // one priority may share a hardware queue, and a gather that waits for BOTH launch queues of run k on the queue that also
+    // carries run k + 1's first launch holds that launch back until run k is through — the two launch queues then overlap
+    // nothing (forced on one GPU: 18.9 M it/s against 19.5 without the gather, gpurun r06p).  The gather is ~10 us of work.
+    int pr_least = 0, pr_greatest = 0;
+    HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+    HIP_TRY(ctx, hipStreamCreateWithPriority(&q.s_comm, hipStreamNonBlocking, (ctx->comm_default_prio ? 0 : pr_greatest)));
     for (int k = 0; k < 2; ++k) {
-      HIP_TRY(ctx, hipEventCreateWithFlags(&q.ev_main[k], hipEventDisableTiming));
-      HIP_TRY(ctx, hipEventCreateWithFlags(&q.ev_main_b[k], hipEventDisableTiming));
       HIP_TRY(ctx, hipEventCreateWithFlags(&q.ev_comm[k], hipEventDisableTiming));
     }
   }
@@ -1326,8 +1327,8 @@ int lins_pose_allgather(lins_ctx* ctx, const void* d_local, int n_records, void*
   if (q.on) {
     if (q.runs == 0) return LINS_E_STATE;
     set = (int)((q.runs - 1) & 1u);  // the run whose records these are
-    HIP_TRY(ctx, hipStreamWaitEvent(q.s_comm, q.ev_main[set], 0));
-    if (q.run_split[set]) HIP_TRY(ctx, hipStreamWaitEvent(q.s_comm, q.ev_main_b[set], 0));  // (both launch queues; the queues themselves are not joined)
+    HIP_TRY(ctx, hipStreamWaitEvent(q.s_comm, ctx->hist1[q.h_of[set]], 0));
+    if (q.run_split[set]) HIP_TRY(ctx, hipStreamWaitEvent(q.s_comm, ctx->hist1b[q.h_of[set]], 0));  // (both launch queues; the queues themselves are not joined)
     st = q.s_comm;
   } else if (int rcs = split_join(ctx)) {  // (the gather runs on the context's stream: behind the second launch queue too)
     return rcs;
