@@ -1098,6 +1098,10 @@ int lins_batch_run(lins_ctx* ctx, void* d_poses, int32_t scan_id_base) {
   }
   ctx->last_parts = relay ? ra.parts : 1;
   ctx->hist_split[h] = split;
+  // (a run that goes out on the context's stream alone after one that used the second queue — lins_set_launch_queues(1) or
+  // another kernel family chosen between two queued runs — is ordered behind that queue: same scans, same scratch records)
+  if (!split && ctx->split_pending)
+    if (int rcs = split_join(ctx)) return rcs;
   if (split) {
     if (int rcq = split_prepare(ctx)) return rcq;
     if (ctx->split_dirty) {  // (uploads, index builds, downloads since the last fork: the second queue starts behind them)

@@ -348,6 +348,25 @@ def test_two_launch_queues_return_the_one_launch_bits(pkg, ieskf, host):
             c.sync()
             assert np.array_equal(_bits(c.download()), want_other, equal_nan=True)
             assert c.total_iters() > 0
+            # the launch form switched between queued runs: the one-launch run is ordered behind the second queue's last launch
+            # (same scans, same scratch records), and a run of another kernel family behind it likewise
+            c.upload(batch)
+            for _ in range(3):
+                c.run()
+            c.set_launch_queues(1)
+            c.run()
+            assert np.array_equal(_bits(c.download()), want, equal_nan=True)
+            c.set_launch_queues(2)
+            for _ in range(3):
+                c.run()
+            c.set_search("lds1")
+            c.run()
+            c.sync()
+            assert c.last_search() == "lds1"
+            lds1 = c.download()
+            c.run(); c.sync()
+            assert np.array_equal(_bits(c.download()), _bits(lds1), equal_nan=True)  # (the undisturbed run of that family)
+            c.set_search("mr")
 
 
 def test_a_competing_context_saturating_the_device_changes_no_bit(pkg, ieskf, host, monkeypatch):
