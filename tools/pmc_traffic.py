@@ -35,8 +35,25 @@ def counters(cmd, counter, tag):
     # (counters are summed per LAUNCH: the runs under the counters pin the one-launch form of a step — lins_set_launch_queues 1 —
     # so that "per launch" is "per step of the whole batch", as in every earlier round's record)
     env = dict(os.environ, TMPDIR="/tmp", LINS_ENABLE_DEBUG_KNOBS="1", LINS_SPLIT_STREAMS="0")
-    p = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + names + ["-d", d, "--"] + cmd, cwd="/tmp", env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    # (bounded: bench.py runs these passes inside the driver's run — a profiler that hangs must cost a fallback to the
+    # committed record, not the bench line; the pass runs in a process group of its own so that the limit ends all of it)
+    proc = subprocess.Popen(["rocprofv3", "--kernel-trace", "--pmc"] + names + ["-d", d, "--"] + cmd, cwd="/tmp", env=env,
+                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=int(os.environ.get("LINS_PMC_TIMEOUT", "180")))
+    except subprocess.TimeoutExpired:
+        import signal
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)  # (the group this call created: rocprofv3 and the run under it)
+        except OSError:
+            pass
+        proc.communicate()
+        subprocess.run(["rm", "-rf", d])
+        raise RuntimeError(f"rocprofv3 pass {names[0]} did not finish in time")
+
+    class _P:
+        stdout = out
+    p = _P()
     dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
     res = {}
     if dbs:
