@@ -36,10 +36,14 @@ def competitor():
 th = threading.Thread(target=competitor, daemon=True)
 th.start()
 total_timeouts = 0
-print(f"# several-part updates under repetition, a second context launching 640-scan batches all the while; {launches} lins_batch_run per line, a host wait + download every 100")
-for label, prm in (("fixed 10", pkg.default_params(num_iter=10, fixed_iters=1)), ("stop rule", pkg.default_params(num_iter=30, fixed_iters=0))):
+print(f"# the batch kernel's two launch forms under repetition, a second context launching 640-scan batches all the while; {launches} lins_batch_run per line, a host wait + download every 100")
+# (both launch forms: lins_set_launch_queues 1 = every run ONE launch with several-part updates — the hand-over protocol; 2, the
+# default = the runs behind the first of each hundred go out as whole-update launches on the context's two launch queues)
+for queues, label, prm in [(q, l, p) for q in (1, 2) for l, p in (("fixed 10", pkg.default_params(num_iter=10, fixed_iters=1)), ("stop rule", pkg.default_params(num_iter=30, fixed_iters=0)))]:
+    label = f"queues {queues} {label}"
     for n in (1024, 777, 1500):
         with ieskf.IeskfContext(prm, max_batch=n, max_targets=16384, search="mr") as c:
+            c.set_launch_queues(queues)
             c.upload(pairs[:n])
             c.run(); c.sync()
             first = bits(c.download())
