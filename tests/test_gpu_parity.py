@@ -317,7 +317,7 @@ def _bits(res):
                                            [r.iters, r.converged, r.diverged, r.m_surf, r.m_corner]]) for r in res])
 
 
-def test_two_launch_queues_return_the_one_launch_bits(pkg, ieskf, host):
+def test_two_launch_queues_return_the_one_launch_bits(pkg, ieskf, host, monkeypatch):
     """Runs queued back to back on a batch beyond the device's slots go out as whole-update launches on the context's two
     launch queues (lins_set_launch_queues 2, the default; lins_ctx::stream2): the same bits as the one-launch form with its
     several-part updates, for a batch that does not divide evenly (three launches), under fixed iterations and the stop rule;
@@ -332,15 +332,27 @@ def test_two_launch_queues_return_the_one_launch_bits(pkg, ieskf, host):
             assert c.launch_ms_history(1)[0][1] == 0.0  # (one launch)
             c.upload(other); c.run(); c.sync()
             want_other = _bits(c.download())
+        # (which form a run takes is decided by whether the run before it is still in flight — a matter of timing the test must
+        # not rest on: the first context below takes the two queues for EVERY run, debug knob LINS_SPLIT_STREAMS=2; the second
+        # runs the default policy and is held to the bits only)
+        monkeypatch.setenv("LINS_ENABLE_DEBUG_KNOBS", "1")
+        monkeypatch.setenv("LINS_SPLIT_STREAMS", "2")
         with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384, search="mr") as c:
             c.upload(batch)
             for _ in range(4):
-                c.run()  # (no wait in between: the runs behind the first find the context busy)
+                c.run()
             got = _bits(c.download())  # (waits for both queues)
             second = [b for _, b in c.launch_ms_history(4)]
-            assert second[0] == 0.0 and all(b > 0.0 for b in second[1:]), second  # the first run: one launch; the queued ones: two queues
+            assert all(b > 0.0 for b in second), second  # every run went out on both queues
             assert c.runs_span_ms(4) > 0.0
             assert np.array_equal(got, want, equal_nan=True)
+        monkeypatch.delenv("LINS_SPLIT_STREAMS")
+        monkeypatch.delenv("LINS_ENABLE_DEBUG_KNOBS")
+        with ieskf.IeskfContext(prm, max_batch=len(batch), max_targets=16384, search="mr") as c:
+            c.upload(batch)
+            for _ in range(4):
+                c.run()  # (no wait in between: the runs behind the first normally find the context busy and take the two queues)
+            assert np.array_equal(_bits(c.download()), want, equal_nan=True)
             for _ in range(3):
                 c.run()
             c.upload(other)  # (behind runs still in flight on both queues)
